@@ -1,0 +1,91 @@
+#!/usr/bin/env python3
+"""Regenerates tests/golden/*.npz and golden.json from the CPU oracle (oracle/dsabf_oracle.c).
+
+Run from the repo root in the build container:  python tests/golden/make_golden.py
+
+What pins what
+--------------
+* ``config/*.txt`` are the reference's own data files (config/ in devincody/DSAbeamformer), copied as
+  fixtures: antenna positions, beam directions and source catalogues (radians / metres).
+* ``golden.json`` holds FNV-1a-64 hashes and sums of the a5 weights and the a6 generator batch for the
+  ``config/linear_*`` inputs.  In the round-1 session the reference's own CPU code
+  (src/beamformer.cu:230-241 pasted into a main(), src/beamformer.hh, src/test_data_generator.hh, compiled
+  with g++ -DDEBUG=1 -O3 -fopenmp behind a throw-away 10-line CUDA-type shim in /tmp) produced BYTE-IDENTICAL
+  output to the oracle for all 8 MiB of weights and all 256 MiB of the batch; that probe is not committed
+  (the build rules forbid stand-ins for CUDA), the hashes of its output are.  SURVEY.md 8c's independent
+  known answers -- sum(re) = 1,688,496, sum(im) = 0, first 16 generator bytes 5c a3 7e 91 ..., dedispersed
+  source 0 beams 0..2 = 103931896, 3003815, 1711951.38 -- are asserted in tests/test_oracle.py.
+* ``linear_debug.npz``: packed column 0 of five sources, weight slices, detected output 0 of two sources and
+  the full dedispersed [1024][256] table (the reference's bin/data.py equivalent) -- oracle outputs.
+* ``random_small.npz``: a seeded-random nibble block that exercises what the reference's own data cannot
+  (all 16 nibble codes incl. -8, distinct columns, every output index), inputs and oracle outputs.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+import oracle as orc  # noqa: E402
+
+CFG = os.path.join(HERE, "config")
+SOURCES = [0, 100, 511, 512, 1023]
+
+
+def main():
+    g = orc.DEBUG_GEOM
+    pos = orc.read_positions(os.path.join(CFG, "linear_positions.txt"), g.n_ant)
+    dirs = orc.read_directions(os.path.join(CFG, "linear_directions.txt"), g.n_beams)
+    src = orc.read_directions(os.path.join(CFG, "linear_source_directions_1024.txt"))
+    w = orc.make_weights(g, pos, dirs, 0)
+    batch = orc.generate_test_data(g, pos, src, 0, 0, 1024)
+    meta = {
+        "weights_fnv1a64": "%016x" % orc.fnv1a64(w),
+        "weights_sum_re": int(w[..., 0].astype(np.int64).sum()),
+        "weights_sum_im": int(w[..., 1].astype(np.int64).sum()),
+        "batch_fnv1a64": "%016x" % orc.fnv1a64(batch),
+        "batch_nbytes": int(batch.nbytes),
+        "batch_first16": " ".join("%02x" % x for x in batch.ravel()[:16]),
+    }
+    # dedispersed table = the bin/data.py equivalent (src/beamformer.cu:498-510,568-571)
+    ded = np.empty((1024, g.n_beams), np.float32)
+    det = {}
+    for lo in range(0, 1024, 64):
+        out = orc.beamform(g, w, batch[lo:lo + 64])
+        for u in range(64):
+            ded[lo + u] = orc.dedisperse(g, out[u])
+            if lo + u in (0, 511):
+                det[lo + u] = out[u, 0].copy()
+    meta["dedispersed_fnv1a64"] = "%016x" % orc.fnv1a64(ded)
+    np.savez_compressed(
+        os.path.join(HERE, "linear_debug.npz"),
+        sources=np.array(SOURCES),
+        packed_col0=np.stack([batch[s, :, 0, :] for s in SOURCES]),
+        weights_f0=w[0], weights_f255=w[255],
+        detected_src0_out0=det[0], detected_src511_out0=det[511],
+        dedispersed=ded,
+    )
+    # seeded random small block, production-style n_ipo = 32 and DEBUG-style n_ipo = 2
+    rng = np.random.default_rng(0xD5A)
+    small = {}
+    for tag, geom in (("p", orc.Geom(n_beams=64, n_ant=64, n_freq=4, n_avg=16, n_out_per_gemm=2)),
+                      ("d", orc.Geom(n_beams=64, n_ant=64, n_freq=4, n_avg=1, n_out_per_gemm=8))):
+        ws = rng.integers(-127, 128, size=(geom.n_freq, geom.n_ant, geom.n_beams, 2), dtype=np.int8)
+        ps = rng.integers(0, 256, size=(2, geom.n_freq, geom.n_time, geom.n_ant), dtype=np.uint8)
+        ps.ravel()[:16] = np.arange(16, dtype=np.uint8) * 17  # every nibble code present, incl. 0x88 (-8,-8)
+        small[tag + "_w"] = ws
+        small[tag + "_packed"] = ps
+        small[tag + "_out"] = orc.beamform(geom, ws, ps)
+        small[tag + "_geom"] = np.array([geom.n_beams, geom.n_ant, geom.n_freq, geom.n_pol, geom.n_avg,
+                                         geom.n_out_per_gemm])
+    np.savez_compressed(os.path.join(HERE, "random_small.npz"), **small)
+    with open(os.path.join(HERE, "golden.json"), "w") as fp:
+        json.dump(meta, fp, indent=1, sort_keys=True)
+        fp.write("\n")
+    print(json.dumps(meta, indent=1))
+
+
+if __name__ == "__main__":
+    main()
