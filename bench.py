@@ -1,0 +1,243 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the beamformer hot path (fused 4-bit expand -> int8 MFMA GEMM -> power detect).
+
+Contract (driver):  python bench.py --gpus N --steps K --warmup W   (N > 1: one rank per GPU under
+torch.distributed.run; RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment).  Rank 0 prints ONE JSON line.
+
+Workload (BASELINE.json configs[2] geometry, "C3" in SURVEY.md section 8d): 64 antennas x 2 pol, 256 frequencies,
+256 beams, N_TIME = 512 voltage columns per gemm-unit (16 detected outputs x n_ipo 32), input = uniform random
+nibbles (all 16 codes) already resident in HBM.  One *step* = one launch over `--units` gemm-units (default 32 =
+one PSRDADA block of the reference, src/beamformer.hh:114) = units*16 beam-blocks.  The metric unit is the
+beam-block: one detected [256 freq][256 beams] float32 output.
+
+N > 1 (strong scaling, BASELINE.json configs[3]): rank r owns frequencies [r*256/N, (r+1)*256/N) of every
+gemm-unit; the only collective is the detected-power gather (RCCL all_to_all_single: every rank becomes the owner of
+the full band for 1/N of the outputs; `--gather root` gathers everything on rank 0 instead, `--gather none` skips it).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+INT8_DENSE_PEAK_TOPS = 5000.0  # MI355X_MICROARCH.md: I8 MFMA = 2x the BF16 rate (~2.5 PF dense) -> ~5 POP/s
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=25)  # mirrors BURNIN 25, src/beamformer.hh:45
+    ap.add_argument("--units", type=int, default=32, help="gemm-units per step (one launch)")
+    ap.add_argument("--nbuf", type=int, default=3, help="distinct input step-buffers cycled (defeats L2/MALL reuse)")
+    ap.add_argument("--workload", default="c3", choices=["c3", "prod", "c2"],
+                    help="c3: N_TIME 512 (16 outputs x n_ipo 32); prod: reference production N_TIME 256; "
+                         "c2: DEBUG geometry N_TIME 16 (n_ipo 2, parity config; HBM-write bound)")
+    ap.add_argument("--gather", default="alltoall", choices=["alltoall", "root", "none"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def geometry(workload):
+    # (n_avg, n_out_per_gemm): n_ipo = 2*n_avg, N_TIME = n_out*n_ipo
+    return {"c3": (16, 16), "prod": (16, 8), "c2": (1, 8)}[workload]
+
+
+def product_weights(torch, cfg, f0):
+    """Steering weights for the linear DSA geometry, computed by the product's own host code (a5)."""
+    import ctypes as C
+
+    import numpy as np
+
+    from dsabeamformer_amd import host
+
+    w = host.make_weights_default(n_beams=cfg.n_beams, n_ant=cfg.n_ant, n_freq_total=256, gpu=0)
+    return np.ascontiguousarray(w[f0:f0 + cfg.n_freq])
+
+
+def cpu_baseline(args, n_avg, n_out, seconds):
+    """Oracle (C restatement, OpenMP, all host cores) on a bounded sample of the SAME workload."""
+    import numpy as np
+
+    import oracle as orc
+
+    g = orc.Geom(n_avg=n_avg, n_out_per_gemm=n_out)
+    pos, dirs = orc.default_positions(g.n_ant), orc.default_directions(g.n_beams)
+    w = orc.make_weights(g, pos, dirs, 0)
+    rng = np.random.default_rng(1)
+    unit = rng.integers(0, 256, size=(1, g.n_freq, g.n_time, g.n_ant), dtype=np.uint8)
+    orc.beamform(g, w, unit)  # warm-up (thread pool, page faults)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        orc.beamform(g, w, unit)
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= seconds or n >= 4096:
+            break
+    return {"value": n * g.n_out_per_gemm / el, "unit": "beam-blocks/s", "cores": orc.get_threads(), "kind": "port",
+            "sample": "%d gemm-unit(s) of the bench workload (%d beam-blocks), oracle/dsabf_oracle.c -O3 -mavx2 "
+                      "-fopenmp, %.1f s" % (n, n * g.n_out_per_gemm, el)}
+
+
+def main():
+    args = parse()
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
+                     % (args.gpus, args.gpus))
+        args.gpus = world
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    import dsabeamformer_amd as bfm
+
+    n_avg, n_out = geometry(args.workload)
+    n_freq_total = 256
+    assert n_freq_total % world == 0
+    n_freq = n_freq_total // world
+    cfg = bfm.production_config(n_avg=n_avg, n_out_per_gemm=n_out, n_freq=n_freq)
+    n_ipo, n_time = cfg.n_pol * cfg.n_avg, n_out * cfg.n_pol * cfg.n_avg
+    bf = bfm.Beamformer(cfg, device=local)
+    bf.set_weights(product_weights(torch, cfg, rank * n_freq))
+
+    units = args.units
+    blocks_per_step = units * n_out                      # beam-blocks per step (whole job)
+    in_bytes = units * n_freq * n_time * cfg.n_ant       # this rank's packed bytes per step
+    out_floats = units * n_out * n_freq * cfg.n_beams    # this rank's detected floats per step
+    gen = torch.Generator(device="cuda").manual_seed(0xD5A + rank)
+    d_in = [torch.randint(0, 256, (in_bytes,), dtype=torch.uint8, device="cuda", generator=gen)
+            for _ in range(max(1, args.nbuf))]
+    d_out = [torch.empty(out_floats, dtype=torch.float32, device="cuda") for _ in range(2)]
+    stream = torch.cuda.current_stream()
+    sptr = stream.cuda_stream
+
+    # ---- gather plumbing (N > 1) -----------------------------------------------------------------------
+    gather_bufs, pending = None, [None, None]
+    og = units * n_out
+    if world > 1 and args.gather != "none":
+        assert og % world == 0
+        if args.gather == "alltoall":
+            gather_bufs = [torch.empty(out_floats, dtype=torch.float32, device="cuda") for _ in range(2)]
+            full = [torch.empty((og // world, n_freq_total, cfg.n_beams), dtype=torch.float32, device="cuda")
+                    for _ in range(2)]
+        else:
+            gather_bufs = [[torch.empty(out_floats, dtype=torch.float32, device="cuda") for _ in range(world)]
+                           if rank == 0 else None for _ in range(2)]
+
+    def finish_gather(slot):
+        if pending[slot] is None:
+            return
+        pending[slot].wait()
+        if args.gather == "alltoall":
+            # [shard][o][f_local][b] -> reference layout [o][f][b] for the outputs this rank owns
+            src = gather_bufs[slot].view(world, og // world, n_freq, cfg.n_beams)
+            full[slot].view(og // world, world, n_freq, cfg.n_beams).copy_(src.permute(1, 0, 2, 3))
+        pending[slot] = None
+
+    def step(i, ev_pair=None):
+        slot = i & 1
+        finish_gather(slot)  # the buffer about to be overwritten must have left
+        if ev_pair:
+            ev_pair[0].record(stream)
+        bf.beamform(d_in[i % len(d_in)], units, d_out[slot], sptr)
+        if ev_pair:
+            ev_pair[1].record(stream)
+        if gather_bufs is not None:
+            if args.gather == "alltoall":
+                pending[slot] = dist.all_to_all_single(gather_bufs[slot], d_out[slot], async_op=True)
+            else:
+                pending[slot] = dist.gather(d_out[slot], gather_bufs[slot] if rank == 0 else None, dst=0, async_op=True)
+
+    def drain():
+        finish_gather(0)
+        finish_gather(1)
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    drain()
+
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i, events[i])
+    drain()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    kern_ms = sorted(a.elapsed_time(b) for a, b in events)
+    kern_avg_ms = sum(kern_ms) / len(kern_ms)
+
+    if rank == 0:
+        total_blocks = args.steps * blocks_per_step
+        value = total_blocks / elapsed
+        # algorithmic work per beam-block: ops = 8*B*A*n_ipo*F ; bytes = A*n_ipo*F + 4*B*F
+        ops_per_block = 8 * cfg.n_beams * cfg.n_ant * n_ipo * n_freq_total
+        bytes_per_block = cfg.n_ant * n_ipo * n_freq_total + 4 * cfg.n_beams * n_freq_total
+        launch_ops = ops_per_block * blocks_per_step / world    # per launch (this rank's kernel)
+        launch_bytes = bytes_per_block * blocks_per_step / world
+        mfma_bound = args.workload != "c2"
+        if mfma_bound:
+            achieved = launch_ops / (kern_avg_ms * 1e-3) / 1e12
+            roof = {"bound": "mfma", "achieved": achieved, "peak": INT8_DENSE_PEAK_TOPS, "unit": "TFLOP/s",
+                    "frac": achieved / INT8_DENSE_PEAK_TOPS, "traffic": None}
+        else:
+            achieved = launch_bytes / (kern_avg_ms * 1e-3) / 1e9
+            roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": None}
+        roof.update({"kernel": "dsabf::fused_kernel<NKS=%d,NIPO=%d>" % (cfg.n_ant // 16, n_ipo),
+                     "kernel_ms_avg": kern_avg_ms, "kernel_ms_median": kern_ms[len(kern_ms) // 2],
+                     "kernel_ms_min": kern_ms[0], "algorithmic_ops_per_launch": launch_ops,
+                     "algorithmic_bytes_per_launch": launch_bytes, "note": "int8 ops (1 complex MAC = 8 ops)"})
+        info = bf.kernel_info(units)
+        out = {
+            "metric": "beam-blocks/sec (256 beams x 256 freq x N_TIME)", "value": value, "unit": "beam-blocks/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_block": elapsed / total_blocks * 1e3, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "int8 (int32 accumulate, fp32 detect)",
+            "data": "synthetic: uniform random 4-bit complex voltages resident in HBM (%d step buffers), steering "
+                    "weights of the linear 64-antenna / 256-beam DSA geometry" % len(d_in),
+            "config": {"workload": {"c3": "C3: 64 ant x 2 pol, 256 freq, 256 beams, N_TIME=512 (16 outputs x n_ipo 32)",
+                                    "prod": "reference production: N_TIME=256 (8 outputs x n_ipo 32)",
+                                    "c2": "C2 DEBUG geometry: N_TIME=16 (8 outputs x n_ipo 2)"}[args.workload],
+                       "gemm_units_per_step": units, "beam_blocks_per_step": blocks_per_step,
+                       "freq_per_gpu": n_freq, "gather": args.gather if world > 1 else "n/a",
+                       "launch": info},
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, n_avg, n_out, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    bf.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

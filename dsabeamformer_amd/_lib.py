@@ -1,0 +1,131 @@
+"""ctypes loader for libdsabf.so.  Fails loudly: there is no CPU or PyTorch fallback for the hot path."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG, "libdsabf.so")
+
+BF_OK = 0
+BF_NOT_READY = 1
+
+
+class BfConfig(C.Structure):
+    """Mirror of ``bf_config`` (include/dsabf.h)."""
+
+    _fields_ = [(n, C.c_int) for n in ("n_beams", "n_ant", "n_freq", "n_pol", "n_avg", "n_out_per_gemm",
+                                       "n_gemms_per_block", "n_blocks_on_gpu", "n_streams", "verbose")]
+
+
+class DsabfError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__("libdsabf error %d: %s" % (code, msg))
+        self.code = code
+
+
+_lib = None
+
+# name -> (restype, argtypes); every symbol include/dsabf.h declares
+SIGNATURES = {
+    "bf_last_error": (C.c_char_p, []),
+    "bf_version": (C.c_char_p, []),
+    "bf_config_default": (C.c_int, [C.POINTER(BfConfig), C.c_int]),
+    "bf_n_inputs_per_output": (C.c_int, [C.POINTER(BfConfig)]),
+    "bf_n_timesteps_per_gemm": (C.c_int, [C.POINTER(BfConfig)]),
+    "bf_bytes_per_gemm": (C.c_size_t, [C.POINTER(BfConfig)]),
+    "bf_bytes_per_block": (C.c_size_t, [C.POINTER(BfConfig)]),
+    "bf_floats_per_detect": (C.c_size_t, [C.POINTER(BfConfig)]),
+    "bf_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "bf_device_name": (C.c_int, [C.c_int, C.c_char_p, C.c_size_t]),
+    "bf_create": (C.c_int, [C.POINTER(BfConfig), C.c_int, C.POINTER(C.c_void_p)]),
+    "bf_destroy": (C.c_int, [C.c_void_p]),
+    "bf_get_config": (C.c_int, [C.c_void_p, C.POINTER(BfConfig)]),
+    "bf_set_weights": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "bf_set_weights_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "bf_alloc_pinned": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t]),
+    "bf_free_pinned": (C.c_int, [C.c_void_p]),
+    "bf_event_create": (C.c_int, [C.POINTER(C.c_void_p)]),
+    "bf_event_destroy": (C.c_int, [C.c_void_p]),
+    "bf_event_query": (C.c_int, [C.c_void_p]),
+    "bf_event_synchronize": (C.c_int, [C.c_void_p]),
+    "bf_submit_block": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "bf_record_transfer_event": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "bf_enqueue_gemm_unit": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "bf_enqueue_dedisperse": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "bf_record_analysis_event": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "bf_stream_sync": (C.c_int, [C.c_void_p, C.c_int]),
+    "bf_timer_start": (C.c_int, [C.c_void_p]),
+    "bf_timer_stop": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+    "bf_beamform_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "bf_expand_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "bf_gemm_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "bf_dedisperse_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "bf_kernel_info": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                 C.POINTER(C.c_int)]),
+    # ---- include/dsabf_host.h ----
+    "bfh_default_positions": (C.c_int, [C.c_int, C.c_void_p]),
+    "bfh_default_directions": (C.c_int, [C.c_int, C.c_void_p]),
+    "bfh_read_positions": (C.c_int, [C.c_char_p, C.c_int, C.c_void_p]),
+    "bfh_read_directions": (C.c_int, [C.c_char_p, C.c_int, C.c_void_p]),
+    "bfh_count_entries": (C.c_int, [C.c_char_p]),
+    "bfh_write_python_file": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_char_p]),
+    "bfh_channel_frequency": (C.c_float, [C.c_int, C.c_int, C.c_int]),
+    "bfh_make_weights": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "bfh_gen_create": (C.c_int, [C.POINTER(BfConfig), C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "bfh_gen_destroy": (C.c_int, [C.c_void_p]),
+    "bfh_gen_read_sources": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "bfh_gen_set_sources": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    "bfh_gen_generate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    "bfh_gen_data": (C.c_void_p, [C.c_void_p]),
+    "bfh_gen_size": (C.c_size_t, [C.c_void_p]),
+    "bfh_gen_n_pt_sources": (C.c_int, [C.c_void_p]),
+    "bfh_gen_need_more": (C.c_int, [C.c_void_p, C.c_int]),
+    "bfh_gen_ready": (C.c_int, [C.c_void_p, C.c_int]),
+    "bfh_obs_create": (C.c_int, [C.c_uint64, C.c_uint64, C.POINTER(BfConfig), C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
+    "bfh_obs_destroy": (C.c_int, [C.c_void_p]),
+    "bfh_obs_generate_transfer_event": (C.c_int, [C.c_void_p]),
+    "bfh_obs_generate_analysis_event": (C.c_int, [C.c_void_p]),
+    "bfh_obs_check_transfer_events": (C.c_int, [C.c_void_p]),
+    "bfh_obs_check_analysis_events": (C.c_int, [C.c_void_p]),
+    "bfh_obs_counters": (C.c_int, [C.c_void_p] + [C.POINTER(C.c_uint64)] * 4),
+    "bfh_obs_check_ready_for_transfer": (C.c_int, [C.c_void_p]),
+    "bfh_obs_check_ready_for_analysis": (C.c_int, [C.c_void_p]),
+    "bfh_obs_check_ready_for_dh2_transfer": (C.c_int, [C.c_void_p, C.c_int]),
+    "bfh_obs_check_observations_complete": (C.c_int, [C.c_void_p]),
+    "bfh_obs_check_transfers_complete": (C.c_int, [C.c_void_p]),
+    "bfh_obs_set_transfers_complete": (C.c_int, [C.c_void_p, C.c_int]),
+    "bfh_obs_set_n_pt_sources": (C.c_int, [C.c_void_p, C.c_int]),
+    "bfh_obs_get_current_analysis_gemm": (C.c_uint64, [C.c_void_p, C.c_int]),
+    "bfh_obs_get_current_transfer_gemm": (C.c_uint64, [C.c_void_p]),
+    "bfh_obs_get_next_gpu_analysis_block": (C.c_uint64, [C.c_void_p]),
+    "bfh_obs_get_next_gpu_transfer_block": (C.c_uint64, [C.c_void_p]),
+    "bfh_obs_describe": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t]),
+    "bfh_obs_fake_complete": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "bfh_run_debug_observation": (C.c_int, [C.POINTER(BfConfig), C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p,
+                                            C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_int),
+                                            C.POINTER(C.c_float)]),
+}
+
+
+def load() -> C.CDLL:
+    """Load libdsabf.so (built by ``dsabeamformer_amd.build.build()`` / ``__graft_entry__.build()``)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "%s is missing: build it with `python -m dsabeamformer_amd.build` (hipcc, gfx950). "
+                "There is no CPU fallback for the beamformer hot path." % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError here = header/library mismatch: fail loudly
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(rc: int) -> int:
+    if rc < 0:
+        raise DsabfError(rc, load().bf_last_error().decode(errors="replace"))
+    return rc

@@ -1,0 +1,165 @@
+"""Object wrapper over the C-ABI (include/dsabf.h) for Python callers that own device memory through torch.
+
+Names follow the reference: a *gemm-unit* is the work of one cublasGemmStridedBatchedEx call
+(src/beamformer.cu:470-477), a *block* is a PSRDADA block of ``n_gemms_per_block`` gemm-units, a *beam-block* is
+one detected ``[n_freq][n_beams]`` float32 output.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+from ._lib import BfConfig, check, load
+
+
+def debug_config(**over) -> BfConfig:
+    """The reference's ``make debug`` geometry (N_AVERAGING = 1, src/beamformer.hh:55-57)."""
+    cfg = BfConfig()
+    check(load().bf_config_default(C.byref(cfg), 1))
+    for k, v in over.items():
+        setattr(cfg, k, v)
+    return cfg
+
+
+def production_config(**over) -> BfConfig:
+    """The reference's production geometry (N_AVERAGING = 16, src/beamformer.hh:59)."""
+    cfg = BfConfig()
+    check(load().bf_config_default(C.byref(cfg), 0))
+    for k, v in over.items():
+        setattr(cfg, k, v)
+    return cfg
+
+
+def _ptr(x) -> C.c_void_p:
+    """Accept ints, ctypes pointers, numpy arrays (host) and torch tensors (device or host)."""
+    if x is None:
+        return C.c_void_p(0)
+    if isinstance(x, int):
+        return C.c_void_p(x)
+    if hasattr(x, "data_ptr"):
+        return C.c_void_p(x.data_ptr())
+    if hasattr(x, "ctypes"):
+        return C.c_void_p(x.ctypes.data)
+    return x
+
+
+class Beamformer:
+    """One handle = one GPU = one frequency shard (the reference runs one process per GPU, README.md:168)."""
+
+    def __init__(self, cfg: BfConfig, device: int = 0):
+        self._lib = load()
+        self._h = C.c_void_p()
+        self.cfg = cfg
+        check(self._lib.bf_create(C.byref(cfg), device, C.byref(self._h)))
+
+    # -- geometry -----------------------------------------------------------------------------------------
+    @property
+    def n_ipo(self) -> int:
+        return self._lib.bf_n_inputs_per_output(C.byref(self.cfg))
+
+    @property
+    def n_time(self) -> int:
+        return self._lib.bf_n_timesteps_per_gemm(C.byref(self.cfg))
+
+    @property
+    def bytes_per_gemm(self) -> int:
+        return self._lib.bf_bytes_per_gemm(C.byref(self.cfg))
+
+    @property
+    def bytes_per_block(self) -> int:
+        return self._lib.bf_bytes_per_block(C.byref(self.cfg))
+
+    @property
+    def floats_per_detect(self) -> int:
+        return self._lib.bf_floats_per_detect(C.byref(self.cfg))
+
+    # -- setup --------------------------------------------------------------------------------------------
+    def set_weights(self, w_host) -> None:
+        """``w_host``: int8 host array [freq][ant][beam][2] (reference layout)."""
+        check(self._lib.bf_set_weights(self._h, _ptr(w_host)))
+
+    def set_weights_device(self, d_w, stream: int = 0) -> None:
+        check(self._lib.bf_set_weights_device(self._h, _ptr(d_w), C.c_void_p(stream)))
+
+    # -- device-pointer entry points -------------------------------------------------------------------------
+    def beamform(self, d_packed, n_units: int, d_out, stream: int = 0) -> None:
+        check(self._lib.bf_beamform_device(self._h, _ptr(d_packed), int(n_units), _ptr(d_out), C.c_void_p(stream)))
+
+    def expand(self, d_in, nbytes: int, d_out, stream: int = 0) -> None:
+        check(self._lib.bf_expand_device(self._h, _ptr(d_in), int(nbytes), _ptr(d_out), C.c_void_p(stream)))
+
+    def gemm(self, d_packed_unit, d_c, stream: int = 0) -> None:
+        check(self._lib.bf_gemm_device(self._h, _ptr(d_packed_unit), _ptr(d_c), C.c_void_p(stream)))
+
+    def dedisperse(self, d_out_unit, d_ded, stream: int = 0) -> None:
+        check(self._lib.bf_dedisperse_device(self._h, _ptr(d_out_unit), _ptr(d_ded), C.c_void_p(stream)))
+
+    # -- streaming entry points (the reference's observation loop) ---------------------------------------------
+    def submit_block(self, slot: int, host, nbytes: int, event=None) -> None:
+        check(self._lib.bf_submit_block(self._h, slot, _ptr(host), nbytes, _ptr(event)))
+
+    def enqueue_gemm_unit(self, stream_idx: int, slot: int, time_slice: int, host_out=None) -> None:
+        check(self._lib.bf_enqueue_gemm_unit(self._h, stream_idx, slot, time_slice, _ptr(host_out)))
+
+    def enqueue_dedisperse(self, stream_idx: int, host_out_row=None) -> None:
+        check(self._lib.bf_enqueue_dedisperse(self._h, stream_idx, _ptr(host_out_row)))
+
+    def record_analysis_event(self, event) -> None:
+        check(self._lib.bf_record_analysis_event(self._h, _ptr(event)))
+
+    def sync(self, stream_idx: int = -1) -> None:
+        check(self._lib.bf_stream_sync(self._h, stream_idx))
+
+    def timer_start(self) -> None:
+        check(self._lib.bf_timer_start(self._h))
+
+    def timer_stop(self) -> float:
+        ms = C.c_float()
+        check(self._lib.bf_timer_stop(self._h, C.byref(ms)))
+        return ms.value
+
+    def kernel_info(self, n_units: int = 1) -> dict:
+        g, b, l, v = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        check(self._lib.bf_kernel_info(self._h, n_units, C.byref(g), C.byref(b), C.byref(l), C.byref(v)))
+        return {"grid": g.value, "block": b.value, "lds_bytes": l.value, "vgprs": v.value}
+
+    def close(self) -> None:
+        if self._h:
+            self._lib.bf_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+
+# events / pinned memory as free functions (they are not tied to a handle in the C-ABI)
+def event_create() -> C.c_void_p:
+    ev = C.c_void_p()
+    check(load().bf_event_create(C.byref(ev)))
+    return ev
+
+
+def event_query(ev) -> int:
+    return check(load().bf_event_query(ev))
+
+
+def event_destroy(ev) -> None:
+    check(load().bf_event_destroy(ev))
+
+
+def alloc_pinned(nbytes: int) -> int:
+    p = C.c_void_p()
+    check(load().bf_alloc_pinned(C.byref(p), nbytes))
+    return p.value
+
+
+def free_pinned(ptr: int) -> None:
+    check(load().bf_free_pinned(C.c_void_p(ptr)))

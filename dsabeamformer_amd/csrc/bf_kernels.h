@@ -1,0 +1,52 @@
+// bf_kernels.h -- internal launch interface between the C-ABI runtime (bf_runtime.cpp) and the gfx950
+// kernels (bf_kernels.hip).  Not installed; the public surface is include/dsabf.h.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace dsabf {
+
+constexpr int kWgThreads = 512;      // 8 wave64 per workgroup
+constexpr int kWavesPerWg = 8;       // one 32-beam tile per wave -> 256 beams per workgroup
+constexpr int kTilesPerChunk = 4;    // MFMA row-tiles (32 time samples each) staged per LDS buffer
+constexpr int kRowsPerChunk = 128;   // time samples per LDS buffer
+constexpr int kRunsPerChunk = 8;     // contiguous 16-sample runs per LDS buffer
+
+struct Geometry {
+    int n_beams, n_ant, n_freq, n_ipo, n_out, n_time;  // n_time = n_out * n_ipo (per gemm-unit)
+    int nks;                                            // k-steps of 16 antennas: ceil(n_ant / 16)
+    int n_btiles;                                       // n_beams / 32
+    int n_bgroups;                                      // ceil(n_btiles / 8)
+};
+
+// Bytes of the MFMA-fragment weight image: [freq][btile][re|im][kstep][lane] x 16 B.
+size_t weight_image_bytes(const Geometry& g);
+
+// True if the fused kernel has an instantiation for this geometry; `why` (optional) explains a refusal.
+bool fused_supported(const Geometry& g, const char** why);
+
+struct LaunchShape {
+    int grid, block, lds_bytes, n_tsplit, chunks_total;
+};
+LaunchShape fused_launch_shape(const Geometry& g, int n_units, int n_cus);
+
+// Reference-layout weights [f][a][b]{re,im} (device) -> fragment image (device).  Sets *d_bad to non-zero if
+// any imaginary part is -128 (its negation does not fit int8).
+hipError_t launch_weight_relayout(const Geometry& g, const int8_t* d_w, void* d_image, int* d_bad, hipStream_t s);
+
+// Fused expand -> int8 MFMA -> detect over n_units gemm-units.
+hipError_t launch_fused(const Geometry& g, const void* d_image, const void* d_packed, int n_units, float* d_out,
+                        int n_cus, hipStream_t s);
+
+// Same pipeline but stores the scaled complex GEMM result c[f][t][b]{re,im} for ONE gemm-unit (stage parity).
+hipError_t launch_gemm_only(const Geometry& g, const void* d_image, const void* d_packed, float* d_c, int n_cus,
+                            hipStream_t s);
+
+hipError_t launch_expand(const void* d_in, size_t nbytes, void* d_out, hipStream_t s);
+hipError_t launch_dedisperse(const Geometry& g, const float* d_out_unit, float* d_ded, hipStream_t s);
+
+int fused_vgprs(const Geometry& g);  // from hipFuncGetAttributes, for reports
+
+}  // namespace dsabf

@@ -1,0 +1,488 @@
+// bf_runtime.cpp -- the C-ABI of libdsabf.so (include/dsabf.h): handle, device memory, HIP queues and events.
+//
+// This is the thin host layer the reference keeps inline in main() (src/beamformer.cu:159-320,560-618):
+// one transfer queue + n_streams compute queues, a device ring of n_blocks_on_gpu PSRDADA-sized blocks, one
+// detected-power buffer per compute queue.  There is no CPU fallback: without a gfx950 device every compute
+// entry point fails with BF_ERR_NO_DEVICE / BF_ERR_DEVICE.
+#include "../../include/dsabf.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "bf_kernels.h"
+
+struct bf_event {
+    hipEvent_t ev = nullptr;
+    bool recorded = false;
+};
+
+struct bf_handle {
+    bf_config cfg{};
+    dsabf::Geometry geom{};
+    int device = 0;
+    int n_cus = 256;
+    bool weights_set = false;
+    void* d_wimage = nullptr;     // MFMA fragment image of the weights
+    int* d_flag = nullptr;        // relayout validity flag
+    uint8_t* d_data = nullptr;    // ring: n_blocks_on_gpu x bytes_per_block
+    float* d_out = nullptr;       // n_streams x floats_per_detect
+    float* d_ded = nullptr;       // n_streams x n_beams
+    hipStream_t h2d = nullptr;
+    std::vector<hipStream_t> streams;
+    std::vector<hipEvent_t> join;  // one per compute queue, for bf_record_analysis_event
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+};
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                       \
+    do {                                                                                                    \
+        hipError_t e_ = (expr);                                                                             \
+        if (e_ != hipSuccess)                                                                               \
+            return fail(BF_ERR_DEVICE, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+int check_cfg(const bf_config* c)
+{
+    if (!c) return fail(BF_ERR_INVALID, "config is NULL");
+    if (c->n_beams <= 0 || c->n_ant <= 0 || c->n_freq <= 0 || c->n_pol <= 0 || c->n_avg <= 0 ||
+        c->n_out_per_gemm <= 0 || c->n_gemms_per_block <= 0 || c->n_blocks_on_gpu <= 0 || c->n_streams <= 0)
+        return fail(BF_ERR_INVALID, "every geometry field must be positive");
+    if (c->n_beams % 4) return fail(BF_ERR_INVALID, "N_BEAMS must be divisible by 4");       // src/beamformer.hh:155
+    if (c->n_ant % 4) return fail(BF_ERR_INVALID, "N_ANTENNAS must be divisible by 4");      // src/beamformer.hh:156
+    return BF_OK;
+}
+
+dsabf::Geometry make_geom(const bf_config& c)
+{
+    dsabf::Geometry g{};
+    g.n_beams = c.n_beams;
+    g.n_ant = c.n_ant;
+    g.n_freq = c.n_freq;
+    g.n_ipo = c.n_pol * c.n_avg;
+    g.n_out = c.n_out_per_gemm;
+    g.n_time = g.n_out * g.n_ipo;
+    g.nks = (c.n_ant + 15) / 16;
+    g.n_btiles = c.n_beams / 32;
+    g.n_bgroups = (g.n_btiles + dsabf::kWavesPerWg - 1) / dsabf::kWavesPerWg;
+    return g;
+}
+
+hipStream_t as_stream(void* s) { return static_cast<hipStream_t>(s); }
+
+}  // namespace
+
+extern "C" {
+
+const char* bf_last_error(void) { return g_err.c_str(); }
+const char* bf_version(void) { return "dsabf 0.1 (gfx950, fused expand+int8 MFMA+detect)"; }
+
+int bf_config_default(bf_config* cfg, int debug)
+{
+    if (!cfg) return fail(BF_ERR_INVALID, "config is NULL");
+    cfg->n_beams = 256;
+    cfg->n_ant = 64;
+    cfg->n_freq = 256;
+    cfg->n_pol = 2;
+    cfg->n_avg = debug ? 1 : 16;
+    cfg->n_out_per_gemm = 8;
+    cfg->n_gemms_per_block = 32;
+    cfg->n_blocks_on_gpu = 8;
+    cfg->n_streams = 8;
+    cfg->verbose = 0;
+    return BF_OK;
+}
+
+int bf_n_inputs_per_output(const bf_config* c) { return c ? c->n_pol * c->n_avg : 0; }
+int bf_n_timesteps_per_gemm(const bf_config* c) { return c ? c->n_out_per_gemm * c->n_pol * c->n_avg : 0; }
+size_t bf_bytes_per_gemm(const bf_config* c)
+{
+    return c ? (size_t)c->n_ant * c->n_freq * (size_t)bf_n_timesteps_per_gemm(c) : 0;
+}
+size_t bf_bytes_per_block(const bf_config* c) { return c ? bf_bytes_per_gemm(c) * (size_t)c->n_gemms_per_block : 0; }
+size_t bf_floats_per_detect(const bf_config* c)
+{
+    return c ? (size_t)c->n_out_per_gemm * c->n_freq * (size_t)c->n_beams : 0;
+}
+
+int bf_device_count(int* count)
+{
+    if (!count) return fail(BF_ERR_INVALID, "count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count = 0;
+        return fail(BF_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    }
+    *count = n;
+    return BF_OK;
+}
+
+int bf_device_name(int device, char* buf, size_t buflen)
+{
+    if (!buf || !buflen) return fail(BF_ERR_INVALID, "buffer is NULL");
+    hipDeviceProp_t p;
+    HIP_TRY(hipGetDeviceProperties(&p, device));
+    snprintf(buf, buflen, "%s (%s, %d CUs)", p.name, p.gcnArchName, p.multiProcessorCount);
+    return BF_OK;
+}
+
+int bf_create(const bf_config* cfg, int device, bf_handle** out)
+{
+    if (!out) return fail(BF_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (int rc = check_cfg(cfg)) return rc;
+    dsabf::Geometry g = make_geom(*cfg);
+    const char* why = nullptr;
+    if (!dsabf::fused_supported(g, &why)) return fail(BF_ERR_INVALID, "unsupported geometry: %s", why);
+
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return fail(BF_ERR_NO_DEVICE, "no HIP device visible (libdsabf has no CPU fallback)");
+    if (device < 0 || device >= n) return fail(BF_ERR_INVALID, "device %d out of range (0..%d)", device, n - 1);
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(BF_ERR_NO_DEVICE, "device %d is %s; libdsabf is built for gfx950 only", device, prop.gcnArchName);
+
+    bf_handle* h = new (std::nothrow) bf_handle();
+    if (!h) return fail(BF_ERR_DEVICE, "out of host memory");
+    h->cfg = *cfg;
+    h->geom = g;
+    h->device = device;
+    h->n_cus = prop.multiProcessorCount;
+    *out = h;  // from here on bf_destroy cleans up partial state
+
+#define CREATE_TRY(expr)                                                                                     \
+    do {                                                                                                     \
+        hipError_t e_ = (expr);                                                                              \
+        if (e_ != hipSuccess) {                                                                              \
+            int rc_ = fail(BF_ERR_DEVICE, "%s failed: %s", #expr, hipGetErrorString(e_));                    \
+            std::string keep = g_err;                                                                        \
+            bf_destroy(h);                                                                                   \
+            *out = nullptr;                                                                                  \
+            g_err = keep;                                                                                    \
+            return rc_;                                                                                      \
+        }                                                                                                    \
+    } while (0)
+
+    CREATE_TRY(hipMalloc(&h->d_wimage, dsabf::weight_image_bytes(g)));
+    CREATE_TRY(hipMalloc((void**)&h->d_flag, sizeof(int)));
+    CREATE_TRY(hipMalloc((void**)&h->d_data, bf_bytes_per_block(cfg) * (size_t)cfg->n_blocks_on_gpu));
+    CREATE_TRY(hipMalloc((void**)&h->d_out, bf_floats_per_detect(cfg) * sizeof(float) * (size_t)cfg->n_streams));
+    CREATE_TRY(hipMalloc((void**)&h->d_ded, (size_t)cfg->n_beams * sizeof(float) * (size_t)cfg->n_streams));
+    // src/beamformer.cu:291-298: the reference zeroes its buffers
+    CREATE_TRY(hipMemset(h->d_data, 0, bf_bytes_per_block(cfg) * (size_t)cfg->n_blocks_on_gpu));
+    CREATE_TRY(hipMemset(h->d_out, 0, bf_floats_per_detect(cfg) * sizeof(float) * (size_t)cfg->n_streams));
+    CREATE_TRY(hipMemset(h->d_ded, 0, (size_t)cfg->n_beams * sizeof(float) * (size_t)cfg->n_streams));
+    CREATE_TRY(hipStreamCreateWithFlags(&h->h2d, hipStreamNonBlocking));
+    h->streams.resize(cfg->n_streams, nullptr);
+    h->join.resize(cfg->n_streams, nullptr);
+    for (int i = 0; i < cfg->n_streams; i++) {
+        CREATE_TRY(hipStreamCreateWithFlags(&h->streams[i], hipStreamNonBlocking));
+        CREATE_TRY(hipEventCreateWithFlags(&h->join[i], hipEventDisableTiming));
+    }
+#undef CREATE_TRY
+    return BF_OK;
+}
+
+int bf_destroy(bf_handle* h)
+{
+    if (!h) return BF_OK;
+    (void)hipSetDevice(h->device);
+    for (auto s : h->streams)
+        if (s) (void)hipStreamSynchronize(s);
+    if (h->h2d) (void)hipStreamSynchronize(h->h2d);
+    for (auto e : h->join)
+        if (e) (void)hipEventDestroy(e);
+    for (auto s : h->streams)
+        if (s) (void)hipStreamDestroy(s);
+    if (h->h2d) (void)hipStreamDestroy(h->h2d);
+    if (h->t0) (void)hipEventDestroy(h->t0);
+    if (h->t1) (void)hipEventDestroy(h->t1);
+    (void)hipFree(h->d_wimage);
+    (void)hipFree(h->d_flag);
+    (void)hipFree(h->d_data);
+    (void)hipFree(h->d_out);
+    (void)hipFree(h->d_ded);
+    delete h;
+    return BF_OK;
+}
+
+int bf_get_config(const bf_handle* h, bf_config* cfg)
+{
+    if (!h || !cfg) return fail(BF_ERR_INVALID, "NULL argument");
+    *cfg = h->cfg;
+    return BF_OK;
+}
+
+static int finish_weights(bf_handle* h, const int8_t* d_w, hipStream_t s)
+{
+    HIP_TRY(hipMemsetAsync(h->d_flag, 0, sizeof(int), s));
+    HIP_TRY(dsabf::launch_weight_relayout(h->geom, d_w, h->d_wimage, h->d_flag, s));
+    int bad = 0;
+    HIP_TRY(hipMemcpyAsync(&bad, h->d_flag, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (bad) {
+        h->weights_set = false;
+        return fail(BF_ERR_INVALID, "weights contain an imaginary part of -128 (must be >= -127)");
+    }
+    h->weights_set = true;
+    return BF_OK;
+}
+
+int bf_set_weights(bf_handle* h, const int8_t* w)
+{
+    if (!h || !w) return fail(BF_ERR_INVALID, "NULL argument");
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t n = (size_t)h->cfg.n_freq * h->cfg.n_ant * h->cfg.n_beams * 2;
+    int8_t* d_w = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_w, n));
+    hipError_t e = hipMemcpy(d_w, w, n, hipMemcpyHostToDevice);
+    int rc = BF_OK;
+    if (e != hipSuccess)
+        rc = fail(BF_ERR_DEVICE, "weight upload failed: %s", hipGetErrorString(e));
+    else
+        rc = finish_weights(h, d_w, h->streams[0]);
+    (void)hipFree(d_w);
+    return rc;
+}
+
+int bf_set_weights_device(bf_handle* h, const int8_t* d_w, void* hip_stream)
+{
+    if (!h || !d_w) return fail(BF_ERR_INVALID, "NULL argument");
+    HIP_TRY(hipSetDevice(h->device));
+    return finish_weights(h, d_w, as_stream(hip_stream));
+}
+
+int bf_alloc_pinned(void** ptr, size_t nbytes)
+{
+    if (!ptr) return fail(BF_ERR_INVALID, "ptr is NULL");
+    *ptr = nullptr;
+    HIP_TRY(hipHostMalloc(ptr, nbytes, hipHostMallocDefault));
+    return BF_OK;
+}
+
+int bf_free_pinned(void* ptr)
+{
+    if (!ptr) return BF_OK;
+    HIP_TRY(hipHostFree(ptr));
+    return BF_OK;
+}
+
+int bf_event_create(bf_event** ev)
+{
+    if (!ev) return fail(BF_ERR_INVALID, "ev is NULL");
+    *ev = nullptr;
+    bf_event* e = new (std::nothrow) bf_event();
+    if (!e) return fail(BF_ERR_DEVICE, "out of host memory");
+    hipError_t rc = hipEventCreateWithFlags(&e->ev, hipEventDisableTiming);  // src/observation_loop.hh:59-60
+    if (rc != hipSuccess) {
+        delete e;
+        return fail(BF_ERR_DEVICE, "hipEventCreateWithFlags: %s", hipGetErrorString(rc));
+    }
+    *ev = e;
+    return BF_OK;
+}
+
+int bf_event_destroy(bf_event* ev)
+{
+    if (!ev) return BF_OK;
+    hipError_t rc = hipEventDestroy(ev->ev);
+    delete ev;
+    if (rc != hipSuccess) return fail(BF_ERR_DEVICE, "hipEventDestroy: %s", hipGetErrorString(rc));
+    return BF_OK;
+}
+
+int bf_event_query(bf_event* ev)
+{
+    if (!ev) return fail(BF_ERR_INVALID, "ev is NULL");
+    hipError_t rc = hipEventQuery(ev->ev);  // an event never recorded reports "done", as in CUDA
+    if (rc == hipSuccess) return BF_OK;
+    if (rc == hipErrorNotReady) return BF_NOT_READY;
+    return fail(BF_ERR_DEVICE, "hipEventQuery: %s", hipGetErrorString(rc));
+}
+
+int bf_event_synchronize(bf_event* ev)
+{
+    if (!ev) return fail(BF_ERR_INVALID, "ev is NULL");
+    HIP_TRY(hipEventSynchronize(ev->ev));
+    return BF_OK;
+}
+
+int bf_submit_block(bf_handle* h, int slot, const void* host, size_t nbytes, bf_event* ev)
+{
+    if (!h || !host) return fail(BF_ERR_INVALID, "NULL argument");
+    if (slot < 0 || slot >= h->cfg.n_blocks_on_gpu) return fail(BF_ERR_INVALID, "slot %d out of range", slot);
+    const size_t block = bf_bytes_per_block(&h->cfg);
+    if (nbytes > block) return fail(BF_ERR_INVALID, "nbytes %zu exceeds the block size %zu", nbytes, block);
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipMemcpyAsync(h->d_data + block * (size_t)slot, host, nbytes, hipMemcpyHostToDevice, h->h2d));
+    if (ev) {
+        HIP_TRY(hipEventRecord(ev->ev, h->h2d));
+        ev->recorded = true;
+    }
+    return BF_OK;
+}
+
+int bf_record_transfer_event(bf_handle* h, bf_event* ev)
+{
+    if (!h || !ev) return fail(BF_ERR_INVALID, "NULL argument");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipEventRecord(ev->ev, h->h2d));
+    ev->recorded = true;
+    return BF_OK;
+}
+
+int bf_enqueue_gemm_unit(bf_handle* h, int stream_idx, int slot, int time_slice, float* host_out)
+{
+    if (!h) return fail(BF_ERR_INVALID, "handle is NULL");
+    if (!h->weights_set) return fail(BF_ERR_STATE, "bf_set_weights has not been called");
+    if (stream_idx < 0 || stream_idx >= h->cfg.n_streams) return fail(BF_ERR_INVALID, "stream %d out of range", stream_idx);
+    if (slot < 0 || slot >= h->cfg.n_blocks_on_gpu) return fail(BF_ERR_INVALID, "slot %d out of range", slot);
+    if (time_slice < 0 || time_slice >= h->cfg.n_gemms_per_block)
+        return fail(BF_ERR_INVALID, "time_slice %d out of range", time_slice);
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t per_gemm = bf_bytes_per_gemm(&h->cfg);
+    const size_t per_det = bf_floats_per_detect(&h->cfg);
+    // src/beamformer.cu:464: &d_data[N_BYTES_PRE_EXPANSION_PER_GEMM*(N_GEMMS_PER_BLOCK*block + timeSlice)]
+    const uint8_t* in = h->d_data + per_gemm * ((size_t)h->cfg.n_gemms_per_block * slot + time_slice);
+    float* out = h->d_out + per_det * (size_t)stream_idx;
+    hipStream_t s = h->streams[stream_idx];
+    HIP_TRY(dsabf::launch_fused(h->geom, h->d_wimage, in, 1, out, h->n_cus, s));
+    if (host_out) HIP_TRY(hipMemcpyAsync(host_out, out, per_det * sizeof(float), hipMemcpyDeviceToHost, s));
+    return BF_OK;
+}
+
+int bf_enqueue_dedisperse(bf_handle* h, int stream_idx, float* host_out_row)
+{
+    if (!h) return fail(BF_ERR_INVALID, "handle is NULL");
+    if (stream_idx < 0 || stream_idx >= h->cfg.n_streams) return fail(BF_ERR_INVALID, "stream %d out of range", stream_idx);
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t s = h->streams[stream_idx];
+    const float* out = h->d_out + bf_floats_per_detect(&h->cfg) * (size_t)stream_idx;
+    float* ded = h->d_ded + (size_t)h->cfg.n_beams * stream_idx;
+    HIP_TRY(dsabf::launch_dedisperse(h->geom, out, ded, s));
+    if (host_out_row)
+        HIP_TRY(hipMemcpyAsync(host_out_row, ded, (size_t)h->cfg.n_beams * sizeof(float), hipMemcpyDeviceToHost, s));
+    return BF_OK;
+}
+
+int bf_record_analysis_event(bf_handle* h, bf_event* ev)
+{
+    if (!h || !ev) return fail(BF_ERR_INVALID, "NULL argument");
+    HIP_TRY(hipSetDevice(h->device));
+    const int last = h->cfg.n_streams - 1;
+    for (int i = 0; i < last; i++) {
+        HIP_TRY(hipEventRecord(h->join[i], h->streams[i]));
+        HIP_TRY(hipStreamWaitEvent(h->streams[last], h->join[i], 0));
+    }
+    HIP_TRY(hipEventRecord(ev->ev, h->streams[last]));
+    ev->recorded = true;
+    return BF_OK;
+}
+
+int bf_stream_sync(bf_handle* h, int stream_idx)
+{
+    if (!h) return fail(BF_ERR_INVALID, "handle is NULL");
+    HIP_TRY(hipSetDevice(h->device));
+    if (stream_idx < 0) {
+        HIP_TRY(hipStreamSynchronize(h->h2d));
+        for (auto s : h->streams) HIP_TRY(hipStreamSynchronize(s));
+        return BF_OK;
+    }
+    if (stream_idx >= h->cfg.n_streams) return fail(BF_ERR_INVALID, "stream %d out of range", stream_idx);
+    HIP_TRY(hipStreamSynchronize(h->streams[stream_idx]));
+    return BF_OK;
+}
+
+int bf_timer_start(bf_handle* h)
+{
+    if (!h) return fail(BF_ERR_INVALID, "handle is NULL");
+    HIP_TRY(hipSetDevice(h->device));
+    if (!h->t0) HIP_TRY(hipEventCreate(&h->t0));
+    if (!h->t1) HIP_TRY(hipEventCreate(&h->t1));
+    HIP_TRY(hipEventRecord(h->t0, nullptr));
+    return BF_OK;
+}
+
+int bf_timer_stop(bf_handle* h, float* ms)
+{
+    if (!h || !ms) return fail(BF_ERR_INVALID, "NULL argument");
+    if (!h->t0) return fail(BF_ERR_STATE, "bf_timer_start has not been called");
+    HIP_TRY(hipEventRecord(h->t1, nullptr));
+    HIP_TRY(hipEventSynchronize(h->t1));
+    HIP_TRY(hipEventElapsedTime(ms, h->t0, h->t1));
+    return BF_OK;
+}
+
+int bf_beamform_device(bf_handle* h, const void* d_packed, int n_units, float* d_out, void* hip_stream)
+{
+    if (!h || !d_packed || !d_out) return fail(BF_ERR_INVALID, "NULL argument");
+    if (n_units <= 0) return fail(BF_ERR_INVALID, "n_units must be positive");
+    if (!h->weights_set) return fail(BF_ERR_STATE, "bf_set_weights has not been called");
+    if (((uintptr_t)d_packed & 15) || ((uintptr_t)d_out & 3)) return fail(BF_ERR_INVALID, "misaligned device pointer");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(dsabf::launch_fused(h->geom, h->d_wimage, d_packed, n_units, d_out, h->n_cus, as_stream(hip_stream)));
+    return BF_OK;
+}
+
+int bf_expand_device(bf_handle* h, const void* d_in, size_t nbytes, void* d_out, void* hip_stream)
+{
+    if (!h || !d_in || !d_out) return fail(BF_ERR_INVALID, "NULL argument");
+    if (nbytes % 16 || ((uintptr_t)d_in & 15) || ((uintptr_t)d_out & 15))
+        return fail(BF_ERR_INVALID, "expand needs 16-byte aligned pointers and a multiple of 16 bytes");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(dsabf::launch_expand(d_in, nbytes, d_out, as_stream(hip_stream)));
+    return BF_OK;
+}
+
+int bf_gemm_device(bf_handle* h, const void* d_packed_unit, float* d_c, void* hip_stream)
+{
+    if (!h || !d_packed_unit || !d_c) return fail(BF_ERR_INVALID, "NULL argument");
+    if (!h->weights_set) return fail(BF_ERR_STATE, "bf_set_weights has not been called");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(dsabf::launch_gemm_only(h->geom, h->d_wimage, d_packed_unit, d_c, h->n_cus, as_stream(hip_stream)));
+    return BF_OK;
+}
+
+int bf_dedisperse_device(bf_handle* h, const float* d_out_unit, float* d_ded, void* hip_stream)
+{
+    if (!h || !d_out_unit || !d_ded) return fail(BF_ERR_INVALID, "NULL argument");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(dsabf::launch_dedisperse(h->geom, d_out_unit, d_ded, as_stream(hip_stream)));
+    return BF_OK;
+}
+
+int bf_kernel_info(const bf_handle* h, int n_units, int* grid, int* block, int* lds_bytes, int* vgprs)
+{
+    if (!h) return fail(BF_ERR_INVALID, "handle is NULL");
+    const dsabf::LaunchShape ls = dsabf::fused_launch_shape(h->geom, n_units > 0 ? n_units : 1, h->n_cus);
+    if (grid) *grid = ls.grid;
+    if (block) *block = ls.block;
+    if (lds_bytes) *lds_bytes = ls.lds_bytes;
+    if (vgprs) *vgprs = dsabf::fused_vgprs(h->geom);
+    return BF_OK;
+}
+
+}  // extern "C"

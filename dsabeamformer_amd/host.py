@@ -1,0 +1,207 @@
+"""ctypes access to the C++ host mirror (include/dsabf_host.h): weights, config readers, the data.py writer,
+test_data_generator and observation_loop_state.  Thin wrappers only; the logic is C++ (csrc/bf_host.cpp)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from ._lib import BfConfig, check, load
+
+
+def _p(a: np.ndarray) -> C.c_void_p:
+    assert a.flags["C_CONTIGUOUS"]
+    return C.c_void_p(a.ctypes.data)
+
+
+def default_positions(n_ant: int) -> np.ndarray:
+    pos = np.zeros((n_ant, 3), np.float32)
+    check(load().bfh_default_positions(n_ant, _p(pos)))
+    return pos
+
+
+def default_directions(n_beams: int) -> np.ndarray:
+    d = np.zeros((n_beams, 2), np.float32)
+    check(load().bfh_default_directions(n_beams, _p(d)))
+    return d
+
+
+def read_positions(path: str, n_ant: int) -> np.ndarray:
+    pos = np.zeros((n_ant, 3), np.float32)
+    check(load().bfh_read_positions(path.encode(), n_ant, _p(pos)))
+    return pos
+
+
+def read_directions(path: str, expected: int | None = None) -> np.ndarray:
+    if expected is None:
+        expected = check(load().bfh_count_entries(path.encode()))
+    d = np.zeros((expected, 2), np.float32)
+    check(load().bfh_read_directions(path.encode(), expected, _p(d)))
+    return d
+
+
+def write_python_file(data: np.ndarray, path: str) -> None:
+    data = np.ascontiguousarray(data, np.float32)
+    check(load().bfh_write_python_file(_p(data), data.shape[0], data.shape[1], path.encode()))
+
+
+def channel_frequency(gpu: int, chan: int, generator_variant: bool = False) -> float:
+    return float(load().bfh_channel_frequency(1 if generator_variant else 0, gpu, chan))
+
+
+def make_weights(pos: np.ndarray, dirs: np.ndarray, n_freq: int, chan0: int = 0, gpu: int = 0) -> np.ndarray:
+    """src/beamformer.cu:230-241 -> int8 [n_freq][n_ant][n_beams][2] for channels chan0.. of sub-band gpu."""
+    pos = np.ascontiguousarray(pos, np.float32)
+    dirs = np.ascontiguousarray(dirs, np.float32)
+    w = np.empty((n_freq, pos.shape[0], dirs.shape[0], 2), np.int8)
+    check(load().bfh_make_weights(dirs.shape[0], pos.shape[0], n_freq, chan0, gpu, _p(pos), _p(dirs), _p(w)))
+    return w
+
+
+def make_weights_default(n_beams: int = 256, n_ant: int = 64, n_freq_total: int = 256, gpu: int = 0) -> np.ndarray:
+    return make_weights(default_positions(n_ant), default_directions(n_beams), n_freq_total, 0, gpu)
+
+
+class TestDataGenerator:
+    """test_data_generator (src/test_data_generator.hh:11-108)."""
+
+    __test__ = False
+
+    def __init__(self, cfg: BfConfig, n_sources_per_batch: int = 1024, pin: bool = True):
+        self._lib = load()
+        self._g = C.c_void_p()
+        self.cfg = cfg
+        check(self._lib.bfh_gen_create(C.byref(cfg), n_sources_per_batch, 1 if pin else 0, C.byref(self._g)))
+
+    def read_in_source_directions(self, path: str) -> None:
+        check(self._lib.bfh_gen_read_sources(self._g, path.encode()))
+
+    def set_source_directions(self, src: np.ndarray) -> None:
+        src = np.ascontiguousarray(src, np.float32).reshape(-1, 2)
+        check(self._lib.bfh_gen_set_sources(self._g, _p(src), src.shape[0]))
+
+    def generate_test_data(self, pos: np.ndarray, gpu: int = 0) -> None:
+        check(self._lib.bfh_gen_generate(self._g, _p(np.ascontiguousarray(pos, np.float32)), gpu))
+
+    def get_n_pt_sources(self) -> int:
+        return check(self._lib.bfh_gen_n_pt_sources(self._g))
+
+    def data_ptr(self) -> int:
+        return self._lib.bfh_gen_data(self._g)
+
+    def size(self) -> int:
+        return self._lib.bfh_gen_size(self._g)
+
+    def data(self) -> np.ndarray:
+        """View (no copy) of the generator's batch buffer as uint8."""
+        buf = (C.c_uint8 * self.size()).from_address(self.data_ptr())
+        return np.frombuffer(buf, dtype=np.uint8)
+
+    def check_need_to_generate_more_input_data(self, blocks_transferred: int) -> bool:
+        return bool(check(self._lib.bfh_gen_need_more(self._g, blocks_transferred)))
+
+    def check_data_ready_for_transfer(self, blocks_transfer_queue: int) -> bool:
+        return bool(check(self._lib.bfh_gen_ready(self._g, blocks_transfer_queue)))
+
+    def close(self) -> None:
+        if self._g:
+            self._lib.bfh_gen_destroy(self._g)
+            self._g = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class ObservationLoopState:
+    """observation_loop_state (src/observation_loop.hh:1-177).  handle=None -> fake events (CPU tests)."""
+
+    def __init__(self, cfg: BfConfig, handle=None, max_transfer_sep: int = 2, max_total_sep: int = 4, debug: bool = True):
+        self._lib = load()
+        self._o = C.c_void_p()
+        check(self._lib.bfh_obs_create(max_transfer_sep, max_total_sep, C.byref(cfg), handle, 1 if debug else 0,
+                                       C.byref(self._o)))
+
+    def counters(self) -> dict:
+        v = [C.c_uint64() for _ in range(4)]
+        check(self._lib.bfh_obs_counters(self._o, *[C.byref(x) for x in v]))
+        return dict(zip(("A", "AQ", "T", "TQ"), (x.value for x in v)))
+
+    def generate_transfer_event(self):
+        check(self._lib.bfh_obs_generate_transfer_event(self._o))
+
+    def generate_analysis_event(self):
+        check(self._lib.bfh_obs_generate_analysis_event(self._o))
+
+    def check_transfer_events(self):
+        check(self._lib.bfh_obs_check_transfer_events(self._o))
+
+    def check_analysis_events(self):
+        check(self._lib.bfh_obs_check_analysis_events(self._o))
+
+    def check_ready_for_transfer(self) -> bool:
+        return bool(check(self._lib.bfh_obs_check_ready_for_transfer(self._o)))
+
+    def check_ready_for_analysis(self) -> bool:
+        return bool(check(self._lib.bfh_obs_check_ready_for_analysis(self._o)))
+
+    def check_ready_for_dh2_transfer(self, time_slice: int) -> bool:
+        return bool(check(self._lib.bfh_obs_check_ready_for_dh2_transfer(self._o, time_slice)))
+
+    def check_observations_complete(self) -> bool:
+        return bool(check(self._lib.bfh_obs_check_observations_complete(self._o)))
+
+    def check_transfers_complete(self) -> bool:
+        return bool(check(self._lib.bfh_obs_check_transfers_complete(self._o)))
+
+    def set_transfers_complete(self, v: bool):
+        check(self._lib.bfh_obs_set_transfers_complete(self._o, 1 if v else 0))
+
+    def set_n_pt_sources(self, n: int):
+        check(self._lib.bfh_obs_set_n_pt_sources(self._o, n))
+
+    def get_current_analysis_gemm(self, time_slice: int) -> int:
+        return self._lib.bfh_obs_get_current_analysis_gemm(self._o, time_slice)
+
+    def get_current_transfer_gemm(self) -> int:
+        return self._lib.bfh_obs_get_current_transfer_gemm(self._o)
+
+    def get_next_gpu_analysis_block(self) -> int:
+        return self._lib.bfh_obs_get_next_gpu_analysis_block(self._o)
+
+    def get_next_gpu_transfer_block(self) -> int:
+        return self._lib.bfh_obs_get_next_gpu_transfer_block(self._o)
+
+    def describe(self) -> str:
+        buf = C.create_string_buffer(512)
+        check(self._lib.bfh_obs_describe(self._o, buf, 512))
+        return buf.value.decode()
+
+    def fake_complete(self, n_transfers: int = 0, n_analyses: int = 0):
+        check(self._lib.bfh_obs_fake_complete(self._o, n_transfers, n_analyses))
+
+    def close(self):
+        if self._o:
+            self._lib.bfh_obs_destroy(self._o)
+            self._o = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def run_debug_observation(cfg: BfConfig, gpu: int = 0, positions: str | None = None, directions: str | None = None,
+                          sources: str | None = None, output: str | None = None, device: int = 0,
+                          verbose: bool = False, max_sources: int = 4096):
+    """The reference's `make debug` main() end to end; returns (dedispersed [n_src][n_beams], observation_ms)."""
+    ded = np.zeros((max_sources, cfg.n_beams), np.float32)
+    n = C.c_int()
+    ms = C.c_float()
+    enc = lambda s: s.encode() if s else None  # noqa: E731
+    check(load().bfh_run_debug_observation(C.byref(cfg), gpu, enc(positions), enc(directions), enc(sources), enc(output),
+                                           device, 1 if verbose else 0, _p(ded), ded.size, C.byref(n), C.byref(ms)))
+    return ded[:n.value].copy(), ms.value

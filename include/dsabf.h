@@ -1,0 +1,160 @@
+/* dsabf.h -- C-ABI of libdsabf.so, the MI355X-native (gfx950) DSA beamformer hot path.
+ *
+ * The reference (devincody/DSAbeamformer) has no plugin/FFI layer: its device code is inlined into main()
+ * of one CUDA translation unit.  This header is the drop-in boundary for that implicit interface -- one entry
+ * point per cluster of CUDA/cuBLAS calls made by main(), observation_loop_state and test_data_generator
+ * (SURVEY.md section 8b).  Every entry point cites the reference call sites it replaces (file:line under
+ * the reference repository).  Plain pointers and sizes only; no C++ or torch types.
+ *
+ * Conventions
+ *   - every function returns int: 0 = BF_OK, negative = error; bf_last_error() gives the message of the
+ *     calling thread's most recent failure.  The library never calls exit() (the reference's gpuErrchk does,
+ *     src/beamformer.cuh:19-29; a driver may keep that policy on top of the return codes).
+ *   - one host thread drives one handle (as in the reference, src/beamformer.cu:364-534); the library is
+ *     re-entrant per handle but a handle is not thread-safe.
+ *   - "gemm-unit": the work of one cublasGemmStridedBatchedEx call in the reference = n_freq batches of
+ *     [n_beams x n_ant] . [n_ant x n_time], n_time = n_out_per_gemm * n_pol * n_avg, producing n_out_per_gemm
+ *     detected [n_freq][n_beams] float32 "beam-blocks".
+ *
+ * Data layouts (identical to the reference's)
+ *   packed voltages  uint8  [unit][freq][time][ant]      one byte per complex sample, high nibble = real,
+ *                                                         low nibble = imaginary, two's complement 4-bit
+ *   weights          int8   [freq][ant][beam]{re,im}     src/beamformer.cu:230-241
+ *   detected power   float  [unit][output][freq][beam]   src/beamformer.cuh:147
+ */
+#ifndef DSABF_H
+#define DSABF_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BF_OK 0
+#define BF_NOT_READY 1          /* bf_event_query: work still in flight (cudaErrorNotReady) */
+#define BF_ERR_INVALID (-1)     /* bad argument / unsupported geometry */
+#define BF_ERR_DEVICE (-2)      /* HIP runtime error (message in bf_last_error) */
+#define BF_ERR_NO_DEVICE (-3)   /* no gfx950 device visible */
+#define BF_ERR_STATE (-4)       /* call out of order (e.g. beamform before bf_set_weights) */
+
+/* Geometry.  The reference fixes these at compile time (src/beamformer.hh:45-152); they are runtime here
+ * because BASELINE config 5 needs 100 ant / 512 beams / 1024 freq.  bf_config_default fills the reference's
+ * values (debug != 0: `make debug`, n_avg = 1; debug == 0: production, n_avg = 16). */
+typedef struct bf_config {
+    int n_beams;           /* N_BEAMS            src/beamformer.hh:47   multiple of 32 */
+    int n_ant;             /* N_ANTENNAS         src/beamformer.hh:48   multiple of 4 (:156) */
+    int n_freq;            /* N_FREQUENCIES      src/beamformer.hh:49   frequencies owned by THIS handle/GPU */
+    int n_pol;             /* N_POL              src/beamformer.hh:52 */
+    int n_avg;             /* N_AVERAGING        src/beamformer.hh:55-60 */
+    int n_out_per_gemm;    /* N_OUTPUTS_PER_GEMM src/beamformer.hh:111 */
+    int n_gemms_per_block; /* N_GEMMS_PER_BLOCK  src/beamformer.hh:114 */
+    int n_blocks_on_gpu;   /* N_BLOCKS_ON_GPU    src/beamformer.hh:124 */
+    int n_streams;         /* N_STREAMS          src/beamformer.hh:83 */
+    int verbose;           /* -DVERBOSE as a runtime flag */
+} bf_config;
+
+typedef struct bf_handle bf_handle; /* owns device memory, 1 transfer queue + n_streams compute queues */
+typedef struct bf_event bf_event;
+
+const char *bf_last_error(void);
+const char *bf_version(void);
+
+int bf_config_default(bf_config *cfg, int debug);
+/* Derived sizes (src/beamformer.hh:117,120,144,147,137): */
+int bf_n_inputs_per_output(const bf_config *cfg);  /* N_INPUTS_PER_OUTPUT */
+int bf_n_timesteps_per_gemm(const bf_config *cfg); /* N_TIMESTEPS_PER_GEMM */
+size_t bf_bytes_per_gemm(const bf_config *cfg);    /* N_BYTES_PRE_EXPANSION_PER_GEMM */
+size_t bf_bytes_per_block(const bf_config *cfg);   /* N_BYTES_PRE_EXPANSION_PER_BLOCK */
+size_t bf_floats_per_detect(const bf_config *cfg); /* N_F_PER_DETECT */
+
+/* Device selection.  Replaces CUDA_select_GPU (src/beamformer.cuh:171-192): device index instead of a name
+ * match; bf_device_name reports what was found. */
+int bf_device_count(int *count);
+int bf_device_name(int device, char *buf, size_t buflen);
+
+/* Replaces: allocations src/beamformer.cu:249-266, memsets :291-298, streams/handles :305-320 and the
+ * teardown :560-605.  d_B and d_C of the reference do not exist here (expand, GEMM and detect are fused). */
+int bf_create(const bf_config *cfg, int device, bf_handle **out);
+int bf_destroy(bf_handle *h);
+int bf_get_config(const bf_handle *h, bf_config *cfg);
+
+/* Replaces the weight upload src/beamformer.cu:251,272.  `w` is a HOST array in the reference layout
+ * [freq][ant][beam]{re,im} int8; the library re-lays it out once for the MFMA operand fragments.
+ * Imaginary parts must be >= -127 (the reference's round(127*sin) never produces -128). */
+int bf_set_weights(bf_handle *h, const int8_t *w);
+/* Same, from a DEVICE array (caller-owned HBM, e.g. weights computed on the GPU or a sharded slice). */
+int bf_set_weights_device(bf_handle *h, const int8_t *d_w, void *hip_stream);
+
+/* Replaces cudaHostAlloc/cudaFreeHost in src/test_data_generator.hh:35,40 and src/beamformer.cu:212,249,
+ * 605,613 (pinned input batch, beam_out, dedispersed_out). */
+int bf_alloc_pinned(void **ptr, size_t nbytes);
+int bf_free_pinned(void *ptr);
+
+/* Events.  Replace the cudaEvent ring of observation_loop_state (src/observation_loop.hh:58-61,65-68,73,
+ * 79,86,95-96,105,112-113).  bf_event_query returns BF_OK (done), BF_NOT_READY, or a negative error. */
+int bf_event_create(bf_event **ev);
+int bf_event_destroy(bf_event *ev);
+int bf_event_query(bf_event *ev);
+int bf_event_synchronize(bf_event *ev);
+
+/* Replaces cudaMemcpyAsync H2D of one PSRDADA block + generate_transfer_event, src/beamformer.cu:389-396,
+ * 425-431 and src/observation_loop.hh:71-75.  Copies `nbytes` (<= bf_bytes_per_block) from host memory into
+ * ring slot `slot` (0 .. n_blocks_on_gpu-1) on the transfer queue and records `ev` (may be NULL) behind it.
+ * The host buffer must stay valid until the event fires. */
+int bf_submit_block(bf_handle *h, int slot, const void *host, size_t nbytes, bf_event *ev);
+
+/* Replaces generate_transfer_event's cudaEventRecord(..., HtoDstream), src/observation_loop.hh:73, when the
+ * copy and the event are issued separately (bf_submit_block with ev == NULL, then this). */
+int bf_record_transfer_event(bf_handle *h, bf_event *ev);
+
+/* Replaces K1-K4 for one gemm-unit, src/beamformer.cu:464-488: expand_input, cublasGemmStridedBatchedEx,
+ * detect_sum and the D2H copy of the detected powers.  Reads gemm-unit `time_slice` (0 .. n_gemms_per_block-1)
+ * of ring slot `slot`, runs on compute queue `stream_idx`, leaves [n_out_per_gemm][n_freq][n_beams] float32 in
+ * the handle's per-queue device buffer and, if host_out != NULL, copies it there asynchronously (host_out should
+ * be pinned). */
+int bf_enqueue_gemm_unit(bf_handle *h, int stream_idx, int slot, int time_slice, float *host_out);
+
+/* Replaces K5, the DEBUG dedisperse, src/beamformer.cu:498-510: sums output 0 of the unit last enqueued on
+ * `stream_idx` over frequency (ascending f, fp32) and copies the n_beams floats to host_out_row. */
+int bf_enqueue_dedisperse(bf_handle *h, int stream_idx, float *host_out_row);
+
+/* Replaces generate_analysis_event, src/beamformer.cu:525 / src/observation_loop.hh:77-81.  The reference
+ * records on stream[N_STREAMS-1] only (a latent race); this records `ev` behind ALL
+ * compute queues. */
+int bf_record_analysis_event(bf_handle *h, bf_event *ev);
+
+/* Replaces cudaStreamSynchronize x N_STREAMS, src/beamformer.cu:560-562 (stream_idx < 0: all queues incl.
+ * the transfer queue). */
+int bf_stream_sync(bf_handle *h, int stream_idx);
+
+/* Replaces START_TIMER / STOP_RECORD_TIMER, src/beamformer.cuh:43-58 (events on the default queue order). */
+int bf_timer_start(bf_handle *h);
+int bf_timer_stop(bf_handle *h, float *ms);
+
+/* ---- Device-pointer entry points: operands already resident in HBM (caller-owned memory and queue). ----
+ * These are what bench.py and the multi-GPU path call; `hip_stream` is a hipStream_t (NULL = default). */
+
+/* Fused a1+a2+a3 over n_units gemm-units: d_packed [n_units][freq][time][ant] -> d_out
+ * [n_units][output][freq][beam].  One kernel launch. */
+int bf_beamform_device(bf_handle *h, const void *d_packed, int n_units, float *d_out, void *hip_stream);
+
+/* a1 alone (expand_input, src/beamformer.cuh:66-109): nbytes packed bytes -> 2*nbytes int8 (re, im pairs in
+ * order).  nbytes must be a multiple of 16, pointers 16-byte aligned. */
+int bf_expand_device(bf_handle *h, const void *d_in, size_t nbytes, void *d_out, void *hip_stream);
+
+/* a2 alone, for stage-level parity checks (the reference's d_C, src/beamformer.cu:470-477): one gemm-unit of
+ * packed voltages -> complex float32 [freq][time][beam]{re,im} = (1/127) * W * V. */
+int bf_gemm_device(bf_handle *h, const void *d_packed_unit, float *d_c, void *hip_stream);
+
+/* a8 alone: d_out_unit [output][freq][beam] -> d_ded [beam] = sum over freq of output 0. */
+int bf_dedisperse_device(bf_handle *h, const float *d_out_unit, float *d_ded, void *hip_stream);
+
+/* Introspection for benchmarks/roofline reports. */
+int bf_kernel_info(const bf_handle *h, int n_units, int *grid, int *block, int *lds_bytes, int *vgprs);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DSABF_H */

@@ -1,0 +1,76 @@
+/* dsabf_host.h -- C-ABI wrappers over the C++ host mirror (include/dsabf_host.hpp) so that non-C++ callers
+ * (ctypes tests, other FFIs) can drive the reference's host-side entry points:
+ *   weights           src/beamformer.cu:230-241          config readers  src/beamformer.hh:250-284
+ *   python writer     src/beamformer.hh:287-311          generator       src/test_data_generator.hh:11-108
+ *   scheduler         src/observation_loop.hh:1-177      DEBUG main()    src/beamformer.cu:12-621
+ * Same conventions as dsabf.h: int return, 0 = ok, negative = error, bf_last_error() for the message.
+ */
+#ifndef DSABF_HOST_H
+#define DSABF_HOST_H
+
+#include "dsabf.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* pos: n_ant x {x,y,z} float32; dir: n x {theta,phi} float32 (radians) */
+int bfh_default_positions(int n_ant, float *pos);
+int bfh_default_directions(int n_beams, float *dir);
+int bfh_read_positions(const char *path, int n_ant, float *pos);
+int bfh_read_directions(const char *path, int expected, float *dir);
+int bfh_count_entries(const char *path); /* first token of a config file; < 0 if unreadable */
+int bfh_write_python_file(const float *data, int rows, int cols, const char *path);
+float bfh_channel_frequency(int generator_variant, int gpu, int chan);
+int bfh_make_weights(int n_beams, int n_ant, int n_freq, int chan0, int gpu, const float *pos, const float *dir,
+                     int8_t *out);
+
+/* test_data_generator */
+typedef struct bfh_generator bfh_generator;
+int bfh_gen_create(const bf_config *cfg, int n_sources_per_batch, int pin, bfh_generator **out);
+int bfh_gen_destroy(bfh_generator *g);
+int bfh_gen_read_sources(bfh_generator *g, const char *path);
+int bfh_gen_set_sources(bfh_generator *g, const float *src, int n);
+int bfh_gen_generate(bfh_generator *g, const float *pos, int gpu);
+void *bfh_gen_data(bfh_generator *g);
+size_t bfh_gen_size(bfh_generator *g);
+int bfh_gen_n_pt_sources(bfh_generator *g);
+int bfh_gen_need_more(bfh_generator *g, int blocks_transferred);
+int bfh_gen_ready(bfh_generator *g, int blocks_transfer_queue);
+
+/* observation_loop_state.  backend: handle == NULL -> fake events completed by bfh_obs_fake_complete (tests);
+ * handle != NULL -> HIP events on that handle's queues. */
+typedef struct bfh_obs bfh_obs;
+int bfh_obs_create(uint64_t max_transfer_sep, uint64_t max_total_sep, const bf_config *cfg, bf_handle *h, int debug_mode,
+                   bfh_obs **out);
+int bfh_obs_destroy(bfh_obs *o);
+int bfh_obs_generate_transfer_event(bfh_obs *o);
+int bfh_obs_generate_analysis_event(bfh_obs *o);
+int bfh_obs_check_transfer_events(bfh_obs *o);
+int bfh_obs_check_analysis_events(bfh_obs *o);
+int bfh_obs_counters(bfh_obs *o, uint64_t *A, uint64_t *AQ, uint64_t *T, uint64_t *TQ);
+int bfh_obs_check_ready_for_transfer(bfh_obs *o);
+int bfh_obs_check_ready_for_analysis(bfh_obs *o);
+int bfh_obs_check_ready_for_dh2_transfer(bfh_obs *o, int time_slice);
+int bfh_obs_check_observations_complete(bfh_obs *o);
+int bfh_obs_check_transfers_complete(bfh_obs *o);
+int bfh_obs_set_transfers_complete(bfh_obs *o, int v);
+int bfh_obs_set_n_pt_sources(bfh_obs *o, int n);
+uint64_t bfh_obs_get_current_analysis_gemm(bfh_obs *o, int time_slice);
+uint64_t bfh_obs_get_current_transfer_gemm(bfh_obs *o);
+uint64_t bfh_obs_get_next_gpu_analysis_block(bfh_obs *o);
+uint64_t bfh_obs_get_next_gpu_transfer_block(bfh_obs *o);
+int bfh_obs_describe(bfh_obs *o, char *buf, size_t buflen); /* operator<<, src/observation_loop.hh:172-176 */
+int bfh_obs_fake_complete(bfh_obs *o, int n_transfers, int n_analyses); /* fake backend only */
+
+/* The reference's `make debug` run end to end (generate -> H2D -> beamform -> dedisperse -> data.py).
+ * Paths may be NULL (defaults src/beamformer.cu:135-147 and BOGUS_DATA).  ded_out (optional) receives
+ * [n_pt_sources][n_beams] floats (capacity in floats given by ded_capacity). */
+int bfh_run_debug_observation(const bf_config *cfg, int gpu, const char *positions, const char *directions,
+                              const char *sources, const char *output, int device, int verbose, float *ded_out,
+                              size_t ded_capacity, int *n_pt_sources, float *observation_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

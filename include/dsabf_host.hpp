@@ -1,0 +1,198 @@
+// dsabf_host.hpp -- C++ host-side mirror of the reference's host classes and helpers, on top of the C-ABI
+// (include/dsabf.h).  A reference-style main() can include this header, link libdsabf.so and keep its structure:
+// same class names, method names, argument meaning and loop semantics as
+//   observation_loop_state   src/observation_loop.hh:1-177
+//   test_data_generator      src/test_data_generator.hh:11-108
+//   antenna / beam_direction src/beamformer.hh:170-213, readers :250-284, python writer :287-311
+//   steering weights         src/beamformer.cu:230-241 (inline in the reference's main)
+// Differences, on purpose: geometry is runtime (bf_config) instead of #defines; errors are return codes /
+// exceptions instead of exit(); the analysis-complete event is recorded behind ALL compute queues (the
+// reference records on stream[7] only -- SURVEY.md section 5, latent race 2).
+#pragma once
+
+#include <cstdint>
+#include <iosfwd>
+#include <string>
+#include <vector>
+
+#include "dsabf.h"
+
+namespace dsabf {
+
+// ---- reference constants (src/beamformer.hh:45-85) -----------------------------------------------------
+constexpr int kBurnIn = 25;            // BURNIN
+constexpr double kHalfFov = 3.5;       // HALF_FOV, degrees
+constexpr int kNGpus = 8;              // N_GPUS
+constexpr int kTotChannels = 2048;     // TOT_CHANNELS
+constexpr double kStartF = 1.28;       // START_F (GHz)
+constexpr double kEndF = 1.53;         // END_F
+constexpr int kZeroPt = 0;             // ZERO_PT
+constexpr double kCSpeed = 299792458.0;
+constexpr double kPi = 3.14159265358979;
+constexpr int kMaxVal = 127;           // MAX_VAL
+constexpr int kSigMaxVal = 7;          // SIG_MAX_VAL
+constexpr int kMaxTransferSep = 2;     // MAX_TRANSFER_SEP
+constexpr int kMaxTotalSep = 4;        // MAX_TOTAL_SEP
+constexpr int kSourcesPerBatch = 1024; // N_SOURCES_PER_BATCH
+constexpr unsigned char kBogusData = 0x70;  // BOGUS_DATA, src/test_data_generator.hh:8
+
+// src/beamformer.hh:170-213
+class antenna {
+public:
+    float x = 0, y = 0, z = 0;
+};
+std::istream& operator>>(std::istream& in, antenna& a);
+std::ostream& operator<<(std::ostream& out, const antenna& a);
+
+class beam_direction {
+public:
+    float theta = 0, phi = 0;
+    beam_direction() {}
+    beam_direction(float th, float ph) : theta(th), phi(ph) {}
+};
+std::istream& operator>>(std::istream& in, beam_direction& a);
+std::ostream& operator<<(std::ostream& out, const beam_direction& a);
+
+// src/beamformer.hh:250-284.  Return 0, or -1 if the file cannot be opened (the reference does not check).
+int read_in_beam_directions(const char* file_name, int expected_beams, beam_direction* dir);
+int read_in_position_locations(const char* file_name, int n_antennas, antenna* pos);
+// src/beamformer.hh:287-311
+int write_array_to_disk_as_python_file(const float* data_out, int rows, int cols, const char* output_filename);
+// src/beamformer.hh:314-350 (runtime values)
+void print_all_defines(const bf_config& cfg, std::ostream& out);
+// src/beamformer.hh:222-243
+void usage(bool debug_mode, std::ostream& out);
+
+// src/beamformer.cu:135-147: default linear array / beam fan when no -p / -d file is given
+void default_positions(int n_antennas, antenna* pos);
+void default_directions(int n_beams, beam_direction* dir);
+
+// Channel centre frequencies (GHz), both of the reference's variants (float bw in main(), double macro in the
+// generator); integer division gpu*2048/7 kept verbatim.
+float channel_frequency_weights(int gpu, int chan);    // src/beamformer.cu:173,233
+float channel_frequency_generator(int gpu, int chan);  // src/test_data_generator.hh:72
+
+// src/beamformer.cu:230-241: int8 steering weights, layout [freq][ant][beam]{re,im}; channels chan0 ..
+// chan0+n_freq-1 of sub-band `gpu` (chan0 > 0 is how a frequency shard of a multi-GPU job gets its slice).
+void generate_fourier_coefficients(int n_beams, int n_antennas, int n_freq, int chan0, int gpu, const antenna* pos,
+                                   const beam_direction* dir, int8_t* out);
+
+// ---- test_data_generator (src/test_data_generator.hh:11-108) --------------------------------------------
+class test_data_generator {
+private:
+    bf_config cfg;
+    int n_pt_sources = 1024;
+    int n_source_batches = 1;
+    int source_batch_counter = 0;
+    std::vector<beam_direction> sources;
+    bool use_source_catalog = false;
+    char* data = nullptr;      // pinned (bf_alloc_pinned) when a GPU runtime is present, else plain host memory
+    bool pinned = false;
+    int n_sources_per_batch;
+
+public:
+    explicit test_data_generator(const bf_config& cfg, int n_sources_per_batch = kSourcesPerBatch, bool pin = true);
+    ~test_data_generator();
+    test_data_generator(const test_data_generator&) = delete;
+    test_data_generator& operator=(const test_data_generator&) = delete;
+
+    int get_n_pt_sources() const { return n_pt_sources; }
+    char* get_data() const { return data; }
+    size_t input_data_size() const;  // INPUT_DATA_SIZE, src/beamformer.hh:150
+    int get_source_batch_counter() const { return source_batch_counter; }
+
+    void generate_test_data(const antenna pos[], int gpu);
+    int read_in_source_directions(const char* file_name);
+    void set_source_directions(const beam_direction* src, int n);  // same effect as the file reader
+    bool check_need_to_generate_more_input_data(int blocks_transfered);
+    bool check_data_ready_for_transfer(int blocks_transfer_queue);
+};
+
+// ---- observation_loop_state (src/observation_loop.hh:1-177) ----------------------------------------------
+// Event backend: the real one records/queries bf_event (HIP events); tests inject a fake to exercise the
+// scheduler on a machine with no GPU.
+struct event_backend {
+    virtual ~event_backend() {}
+    virtual void* create() = 0;
+    virtual void destroy(void* ev) = 0;
+    virtual void record_transfer(void* ev) = 0;  // behind the last bf_submit_block
+    virtual void record_analysis(void* ev) = 0;  // behind all compute queues
+    virtual int query(void* ev) = 0;             // BF_OK done, BF_NOT_READY, < 0 error
+};
+event_backend* make_hip_event_backend(bf_handle* h);  // caller deletes
+
+class observation_loop_state {
+private:
+    uint64_t blocks_analyzed = 0;
+    uint64_t blocks_transferred = 0;
+    uint64_t blocks_analysis_queue = 0;
+    uint64_t blocks_transfer_queue = 0;
+    uint64_t maximum_transfer_seperation;
+    uint64_t maximum_total_seperation;
+    bool transfers_complete = false;
+    std::vector<void*> BlockTransferredSync;  // N_EVENTS_ON_GPU = 5 * N_BLOCKS_ON_GPU, src/beamformer.hh:128
+    std::vector<void*> BlockAnalyzedSync;
+    int most_recent_gemm = 0;
+    int n_pt_sources = 0;
+    bool debug_mode;
+    bool verbose;
+    int n_gemms_per_block, n_blocks_on_gpu, n_events;
+    event_backend* ev;
+
+public:
+    observation_loop_state(uint64_t maximum_transfer_seperation, uint64_t maximum_total_seperation,
+                           const bf_config& cfg, event_backend* backend, bool debug_mode);
+    ~observation_loop_state();
+    observation_loop_state(const observation_loop_state&) = delete;
+    observation_loop_state& operator=(const observation_loop_state&) = delete;
+
+    void generate_transfer_event();  // the reference passes the stream; the backend knows the queue
+    void generate_analysis_event();
+    void check_transfer_events();
+    void check_analysis_events();
+
+    uint64_t get_blocks_analyzed() const { return blocks_analyzed; }
+    uint64_t get_blocks_transferred() const { return blocks_transferred; }
+    uint64_t get_blocks_analysis_queue() const { return blocks_analysis_queue; }
+    uint64_t get_blocks_transfer_queue() const { return blocks_transfer_queue; }
+
+    uint64_t get_current_analysis_gemm(int time_slice);
+    uint64_t get_current_transfer_gemm() const;
+    uint64_t get_next_gpu_analysis_block() const { return blocks_analysis_queue % n_blocks_on_gpu; }
+    uint64_t get_next_gpu_transfer_block() const { return blocks_transfer_queue % n_blocks_on_gpu; }
+
+    void set_transfers_complete(bool value) { transfers_complete = value; }
+    bool get_transfers_complete() const { return transfers_complete; }
+
+    bool check_ready_for_transfer() const;
+    bool check_ready_for_analysis() const;
+    bool check_ready_for_dh2_transfer(int time_slice);
+
+    bool check_observations_complete();
+    void set_n_pt_sources(int val) { n_pt_sources = val; }  // DEBUG only in the reference
+    bool check_transfers_complete();                        // DEBUG only in the reference
+
+    friend std::ostream& operator<<(std::ostream& out, const observation_loop_state& a);
+};
+
+// ---- the reference's DEBUG main() as a callable (src/beamformer.cu:12-621, `make debug` flow) -------------
+struct debug_run_options {
+    int gpu = 0;                 // -g
+    const char* positions = nullptr;   // -p
+    const char* directions = nullptr;  // -d
+    const char* sources = nullptr;     // -s
+    const char* output = "bin/data.py";
+    int device = 0;
+    bool verbose = false;
+};
+struct debug_run_result {
+    float observation_time_ms = 0;
+    int n_pt_sources = 0;
+    long long data_chunks = 0;  // n_pt_sources * N_OUTPUTS_PER_GEMM, src/beamformer.cu:544
+};
+// Runs generate -> H2D -> fused beamform -> dedisperse -> data.py for every source; dedispersed_out (optional)
+// receives the [n_pt_sources][n_beams] table that is also written to opt.output.
+int run_debug_observation(const bf_config& cfg, const debug_run_options& opt, debug_run_result* res,
+                          std::vector<float>* dedispersed_out, std::ostream& log);
+
+}  // namespace dsabf

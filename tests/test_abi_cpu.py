@@ -1,0 +1,89 @@
+"""CPU-side checks of the C-ABI boundary: the library loads, exports every symbol include/dsabf.h declares,
+and the geometry helpers reproduce the reference's compile-time constants.  No compute calls (no GPU here)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from dsabeamformer_amd import build as b
+    from dsabeamformer_amd import _lib
+
+    b.build()
+    return _lib.load()
+
+
+def _declared_symbols():
+    names = set()
+    for hdr in ("dsabf.h", "dsabf_host.h"):
+        text = open(os.path.join(ROOT, "include", hdr)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        names |= set(re.findall(r"\b(bfh?_[a-z0-9_]+)\s*\(", text))
+    return sorted(names)
+
+
+def test_library_exports_every_declared_symbol(lib):
+    from dsabeamformer_amd import _lib
+
+    names = _declared_symbols()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(lib, n), "libdsabf.so does not export %s" % n
+    # and the ctypes signature table covers exactly the header
+    assert sorted(_lib.SIGNATURES) == names
+
+
+def test_default_configs_match_reference_constants(lib):
+    from dsabeamformer_amd import BfConfig
+
+    dbg, prod = BfConfig(), BfConfig()
+    assert lib.bf_config_default(C.byref(dbg), 1) == 0 and lib.bf_config_default(C.byref(prod), 0) == 0
+    # SURVEY.md section 0 table (src/beamformer.hh:47-152)
+    for cfg, n_avg, n_ipo, n_time, per_gemm, per_block in ((dbg, 1, 2, 16, 256 << 10, 8 << 20),
+                                                           (prod, 16, 32, 256, 4 << 20, 128 << 20)):
+        assert (cfg.n_beams, cfg.n_ant, cfg.n_freq, cfg.n_pol, cfg.n_avg) == (256, 64, 256, 2, n_avg)
+        assert (cfg.n_out_per_gemm, cfg.n_gemms_per_block, cfg.n_blocks_on_gpu, cfg.n_streams) == (8, 32, 8, 8)
+        assert lib.bf_n_inputs_per_output(C.byref(cfg)) == n_ipo
+        assert lib.bf_n_timesteps_per_gemm(C.byref(cfg)) == n_time
+        assert lib.bf_bytes_per_gemm(C.byref(cfg)) == per_gemm
+        assert lib.bf_bytes_per_block(C.byref(cfg)) == per_block
+        assert lib.bf_floats_per_detect(C.byref(cfg)) == 524288
+
+
+def test_error_convention_without_gpu(lib):
+    """Return codes + bf_last_error instead of exit() (src/beamformer.cuh:19-29 exits)."""
+    from dsabeamformer_amd import BfConfig
+
+    cfg = BfConfig()
+    lib.bf_config_default(C.byref(cfg), 1)
+    h = C.c_void_p()
+    cfg.n_beams = 250  # not a multiple of 32 -> invalid before any device work
+    assert lib.bf_create(C.byref(cfg), 0, C.byref(h)) == -1
+    assert b"n_beams" in lib.bf_last_error() or b"N_BEAMS" in lib.bf_last_error()
+    cfg.n_beams = 256
+    cfg.n_avg = 3  # n_ipo = 6: no kernel instantiation
+    assert lib.bf_create(C.byref(cfg), 0, C.byref(h)) == -1
+    assert not h.value
+    assert lib.bf_beamform_device(None, None, 1, None, None) == -1
+    assert lib.bf_destroy(None) == 0
+
+
+def test_product_does_not_reference_the_oracle():
+    """The product path must never import, link or fall back to oracle/."""
+    pkg = os.path.join(ROOT, "dsabeamformer_amd")
+    for dirpath, _, files in os.walk(pkg):
+        if os.path.basename(dirpath) in ("build", "__pycache__"):
+            continue
+        for fn in files:
+            if fn.endswith((".py", ".cpp", ".hip", ".h", ".hpp")):
+                src = open(os.path.join(dirpath, fn)).read()
+                assert "liborc" not in src and "import oracle" not in src and "dsabf_oracle" not in src, fn
+    import subprocess
+
+    out = subprocess.run(["ldd", os.path.join(pkg, "libdsabf.so")], capture_output=True, text=True).stdout
+    assert "liborc" not in out

@@ -1,0 +1,244 @@
+"""GPU parity tests (run with -m gpu on an MI355X): every call goes through the C-ABI of libdsabf.so and is
+checked against the CPU oracle and the committed golden fixtures.
+
+Bar: BIT-EXACT everywhere -- 4-bit expand (integer), complex GEMM output (exact integer sums, one fp32 rounding),
+detected powers (the kernel keeps the reference's sequential fp32 accumulation order in registers, so this holds
+for n_ipo = 32 as well as the DEBUG n_ipo = 2) and dedispersed rows (ascending-f fp32 sum)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch as t
+
+    assert t.cuda.is_available(), "these tests need a GPU"
+    return t
+
+
+@pytest.fixture(scope="module")
+def bfmod():
+    import dsabeamformer_amd as m
+
+    return m
+
+
+def _cfg(bfmod, g, **over):
+    kw = dict(n_beams=g.n_beams, n_ant=g.n_ant, n_freq=g.n_freq, n_pol=g.n_pol, n_avg=g.n_avg,
+              n_out_per_gemm=g.n_out_per_gemm)
+    kw.update(over)
+    return bfmod.debug_config(**kw)
+
+
+def _run(torch, bf, packed_np, n_out_floats):
+    d_in = torch.from_numpy(packed_np).cuda()
+    d_out = torch.full((n_out_floats,), float("nan"), dtype=torch.float32, device="cuda")
+    bf.beamform(d_in, packed_np.shape[0], d_out, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    return d_out.cpu().numpy()
+
+
+def test_expand_bit_exact(torch, bfmod, orc):
+    bf = bfmod.Beamformer(bfmod.debug_config())
+    rng = np.random.default_rng(7)
+    packed = rng.integers(0, 256, size=1 << 20, dtype=np.uint8)
+    packed[:256] = np.arange(256, dtype=np.uint8)
+    packed[256:260] = [0xD7, 0x25, 0xA8, 0x70]  # reference KATs (sandbox/kernelTest.cu:128, bitshift.cpp:5-6)
+    d_in = torch.from_numpy(packed).cuda()
+    d_out = torch.zeros(packed.size * 2, dtype=torch.int8, device="cuda")
+    bf.expand(d_in, packed.size, d_out, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    got = d_out.cpu().numpy().reshape(-1, 2)
+    assert got[256:260].tolist() == [[-3, 7], [2, 5], [-6, -8], [7, 0]]
+    assert np.array_equal(got, orc.expand(packed))
+
+
+@pytest.mark.parametrize("tag", ["p", "d"])
+def test_fused_random_small_golden(torch, bfmod, orc, tag):
+    gold = np.load(os.path.join(GOLDEN, "random_small.npz"))
+    g = orc.Geom(*[int(x) for x in gold[tag + "_geom"]])
+    bf = bfmod.Beamformer(_cfg(bfmod, g))
+    bf.set_weights(np.ascontiguousarray(gold[tag + "_w"]))
+    packed = np.ascontiguousarray(gold[tag + "_packed"])
+    got = _run(torch, bf, packed, gold[tag + "_out"].size).reshape(gold[tag + "_out"].shape)
+    assert np.array_equal(got, gold[tag + "_out"])
+    assert np.array_equal(got, orc.beamform(g, gold[tag + "_w"], packed))
+
+
+@pytest.mark.parametrize("n_ant,n_avg,n_units", [(64, 1, 1), (64, 1, 3), (64, 16, 2), (64, 2, 2), (64, 4, 1),
+                                                  (64, 8, 1), (64, 32, 1), (16, 1, 2), (32, 16, 1), (128, 1, 3),
+                                                  (128, 16, 2)])
+def test_fused_geometries_bit_exact(torch, bfmod, orc, n_ant, n_avg, n_units):
+    g = orc.Geom(n_beams=96, n_ant=n_ant, n_freq=5, n_avg=n_avg, n_out_per_gemm=8 if n_avg == 1 else 2)
+    rng = np.random.default_rng(1000 + n_ant + n_avg)
+    w = rng.integers(-127, 128, size=(g.n_freq, g.n_ant, g.n_beams, 2), dtype=np.int8)
+    packed = rng.integers(0, 256, size=(n_units, g.n_freq, g.n_time, g.n_ant), dtype=np.uint8)
+    bf = bfmod.Beamformer(_cfg(bfmod, g))
+    bf.set_weights(w)
+    want = orc.beamform(g, w, packed)
+    got = _run(torch, bf, packed, want.size).reshape(want.shape)
+    assert np.array_equal(got, want)
+
+
+def test_gemm_stage_bit_exact(torch, bfmod, orc):
+    g = orc.Geom(n_beams=64, n_ant=64, n_freq=3, n_avg=1, n_out_per_gemm=8)
+    rng = np.random.default_rng(11)
+    w = rng.integers(-127, 128, size=(g.n_freq, g.n_ant, g.n_beams, 2), dtype=np.int8)
+    packed = rng.integers(0, 256, size=(g.n_freq, g.n_time, g.n_ant), dtype=np.uint8)
+    bf = bfmod.Beamformer(_cfg(bfmod, g))
+    bf.set_weights(w)
+    d_in = torch.from_numpy(packed).cuda()
+    d_c = torch.zeros(g.n_freq * g.n_time * g.n_beams * 2, dtype=torch.float32, device="cuda")
+    bf.gemm(d_in, d_c, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    want = orc.gemm(g, w, orc.expand(packed))
+    assert np.array_equal(d_c.cpu().numpy().reshape(want.shape), want)
+
+
+def test_linear_config_debug_geometry_bit_identical(torch, bfmod, orc, linear_inputs, linear_weights):
+    """BASELINE config 2: 64 ant x 256 freq x 256 beams, N_TIME = 16, config/linear_* inputs."""
+    pos, _, src = linear_inputs
+    g = orc.DEBUG_GEOM
+    gold = np.load(os.path.join(GOLDEN, "linear_debug.npz"))
+    pick = [0, 100, 511, 512, 1023, 77, 900]
+    units = orc.generate_test_data(g, pos, src[pick], 0, 0, len(pick))
+    bf = bfmod.Beamformer(bfmod.debug_config())
+    bf.set_weights(linear_weights)
+    got = _run(torch, bf, units, len(pick) * g.out_per_gemm).reshape(len(pick), 8, 256, 256)
+    assert np.array_equal(got[0, 0], gold["detected_src0_out0"])
+    assert np.array_equal(got[2, 0], gold["detected_src511_out0"])
+    assert np.array_equal(got, orc.beamform(g, linear_weights, units))
+    # dedisperse (K5) on the device, output 0 of each unit
+    d_out = torch.from_numpy(got).cuda()
+    d_ded = torch.zeros(256, dtype=torch.float32, device="cuda")
+    for i, s in enumerate(pick):
+        bf.dedisperse(d_out[i], d_ded, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert np.array_equal(d_ded.cpu().numpy(), gold["dedispersed"][s])
+
+
+def test_production_geometry_full_size_bit_exact(torch, bfmod, orc, linear_weights):
+    """BASELINE config 3 shape: N_TIME = 512 (16 outputs x n_ipo 32), random nibbles incl. -8, 2 gemm-units."""
+    g = orc.Geom(n_avg=16, n_out_per_gemm=16)
+    rng = np.random.default_rng(0xD5A)
+    packed = rng.integers(0, 256, size=(2, g.n_freq, g.n_time, g.n_ant), dtype=np.uint8)
+    bf = bfmod.Beamformer(_cfg(bfmod, g))
+    bf.set_weights(linear_weights)
+    want = orc.beamform(g, linear_weights, packed)
+    got = _run(torch, bf, packed, want.size).reshape(want.shape)
+    assert np.array_equal(got, want)
+
+
+def test_large_batch_properties_and_sampled_parity(torch, bfmod, orc, linear_weights):
+    """32 gemm-units of production-shaped input (the bench workload): sampled frequencies bit-exact vs the oracle,
+    plus size-independent properties: negating every voltage leaves the power unchanged, zero input gives zero,
+    and a launch over all units equals unit-by-unit launches."""
+    g = orc.Geom(n_avg=16, n_out_per_gemm=16)
+    n_units = 32
+    bf = bfmod.Beamformer(_cfg(bfmod, g))
+    bf.set_weights(linear_weights)
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    d_in = torch.randint(0, 256, (n_units, g.n_freq, g.n_time, g.n_ant), dtype=torch.uint8, device="cuda", generator=gen)
+    # avoid the -8 code so that negation is representable: map nibble 8 -> 9 in both halves
+    hi, lo = d_in >> 4, d_in & 15
+    hi = torch.where(hi == 8, torch.full_like(hi, 9), hi)
+    lo = torch.where(lo == 8, torch.full_like(lo, 9), lo)
+    d_in = ((hi << 4) | lo).contiguous()
+    d_neg = ((((16 - hi) & 15) << 4) | ((16 - lo) & 15)).to(torch.uint8).contiguous()
+    n_out = n_units * g.out_per_gemm
+    stream = torch.cuda.current_stream().cuda_stream
+    d_a = torch.empty(n_out, dtype=torch.float32, device="cuda")
+    d_b = torch.empty_like(d_a)
+    bf.beamform(d_in, n_units, d_a, stream)
+    bf.beamform(d_neg, n_units, d_b, stream)
+    torch.cuda.synchronize()
+    assert torch.equal(d_a, d_b)
+    assert float(d_a.min()) >= 0.0 and bool(torch.isfinite(d_a).all())
+    # unit-by-unit == batched
+    d_c = torch.empty_like(d_a)
+    for u in range(n_units):
+        bf.beamform(d_in[u], 1, d_c[u * g.out_per_gemm:(u + 1) * g.out_per_gemm], stream)
+    torch.cuda.synchronize()
+    assert torch.equal(d_a, d_c)
+    # zero input
+    bf.beamform(torch.zeros_like(d_in), n_units, d_b, stream)
+    torch.cuda.synchronize()
+    assert float(d_b.abs().max()) == 0.0
+    # sampled parity: frequencies 3, 130, 255 of units 0, 17, 31
+    fs, us = [3, 130, 255], [0, 17, 31]
+    gs = orc.Geom(n_avg=16, n_out_per_gemm=16, n_freq=len(fs))
+    sub = d_in[us][:, fs].contiguous().cpu().numpy()
+    want = orc.beamform(gs, np.ascontiguousarray(linear_weights[fs]), sub)
+    got = d_a.view(n_units, g.n_out_per_gemm, g.n_freq, g.n_beams)[us][:, :, fs].cpu().numpy()
+    assert np.array_equal(got, want)
+
+
+def test_streaming_api_debug_flow(torch, bfmod, orc, linear_inputs, linear_weights):
+    """The reference's DEBUG observation flow through the streaming entry points: pinned host batch ->
+    bf_submit_block -> per-stream bf_enqueue_gemm_unit + bf_enqueue_dedisperse -> events (src/beamformer.cu:
+    421-431,461-526).  First two PSRDADA-sized blocks (64 sources) reproduce the golden data.py rows."""
+    from dsabeamformer_amd import api
+
+    pos, _, src = linear_inputs
+    g = orc.DEBUG_GEOM
+    gold = np.load(os.path.join(GOLDEN, "linear_debug.npz"))
+    cfg = bfmod.debug_config()
+    bf = bfmod.Beamformer(cfg)
+    bf.set_weights(linear_weights)
+    n_blocks, per_block = 2, cfg.n_gemms_per_block
+    nbytes = bf.bytes_per_block
+    host = api.alloc_pinned(nbytes * n_blocks)
+    batch = orc.generate_test_data(g, pos, src, 0, 0, per_block * n_blocks)
+    C.memmove(host, batch.ctypes.data, batch.nbytes)
+    ded_ptr = api.alloc_pinned(per_block * n_blocks * 256 * 4)
+    out_ptr = api.alloc_pinned(bf.floats_per_detect * 4 * cfg.n_streams)
+    evs = [api.event_create() for _ in range(n_blocks)]
+    aev = [api.event_create() for _ in range(n_blocks)]
+    for blk in range(n_blocks):
+        bf.submit_block(blk, host + blk * nbytes, nbytes, evs[blk])
+    for blk in range(n_blocks):
+        while api.event_query(evs[blk]) != 0:
+            pass
+        for part in range(per_block // cfg.n_streams):
+            for st in range(cfg.n_streams):
+                ts = part * cfg.n_streams + st
+                bf.enqueue_gemm_unit(st, blk, ts, out_ptr + st * bf.floats_per_detect * 4)
+                bf.enqueue_dedisperse(st, ded_ptr + (blk * per_block + ts) * 256 * 4)
+        bf.record_analysis_event(aev[blk])
+    for blk in range(n_blocks):
+        while api.event_query(aev[blk]) != 0:
+            pass
+    bf.sync()
+    ded = np.ctypeslib.as_array(C.cast(ded_ptr, C.POINTER(C.c_float)), shape=(per_block * n_blocks, 256)).copy()
+    assert np.array_equal(ded, gold["dedispersed"][:per_block * n_blocks])
+    for e in evs + aev:
+        api.event_destroy(e)
+    for p in (host, ded_ptr, out_ptr):
+        api.free_pinned(p)
+
+
+def test_error_paths_on_device(torch, bfmod, orc):
+    from dsabeamformer_amd._lib import DsabfError
+
+    bf = bfmod.Beamformer(bfmod.debug_config(n_freq=2, n_beams=32))
+    d = torch.zeros(2 * 16 * 64, dtype=torch.uint8, device="cuda")
+    o = torch.zeros(8 * 2 * 32, dtype=torch.float32, device="cuda")
+    with pytest.raises(DsabfError) as e:
+        bf.beamform(d, 1, o)  # before set_weights
+    assert e.value.code == -4
+    w = np.zeros((2, 64, 32, 2), np.int8)
+    w[1, 3, 5, 1] = -128
+    with pytest.raises(DsabfError) as e:
+        bf.set_weights(w)
+    assert e.value.code == -1 and "-128" in str(e.value)
+    w[1, 3, 5, 1] = -127
+    bf.set_weights(w)
+    bf.beamform(d, 1, o)
+    torch.cuda.synchronize()

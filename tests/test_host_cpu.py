@@ -1,0 +1,220 @@
+"""CPU tests of the C++ host mirror (dsabeamformer_amd/csrc/bf_host.cpp) -- the product's own weight generator,
+config readers, data.py writer, test_data_generator and observation_loop_state -- against the oracle and the
+reference's documented scheduler rules (README.md:122-140, src/observation_loop.hh)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import CFG, GOLDEN
+
+
+@pytest.fixture(scope="module")
+def host():
+    from dsabeamformer_amd import build as b
+
+    b.build()
+    from dsabeamformer_amd import host as h
+
+    return h
+
+
+@pytest.fixture(scope="module")
+def bfm():
+    import dsabeamformer_amd as m
+
+    return m
+
+
+def test_defaults_and_frequency_table_match_oracle(host, orc):
+    assert np.array_equal(host.default_positions(64), orc.default_positions(64))
+    assert np.array_equal(host.default_directions(256), orc.default_directions(256))
+    assert np.array_equal(host.default_positions(100), orc.default_positions(100))
+    for gpu in range(8):
+        for chan in (0, 1, 17, 255, 1023):
+            assert host.channel_frequency(gpu, chan) == orc.freq_weights(gpu, chan)
+            assert host.channel_frequency(gpu, chan, generator_variant=True) == orc.freq_generator(gpu, chan)
+
+
+def test_config_readers_match_oracle(host, orc):
+    for name, n in (("linear_positions.txt", 64), ("grid_positions.txt", 64), ("random_positions.txt", 64),
+                    ("grid_positions.txt", 100)):
+        p = os.path.join(CFG, name)
+        assert np.array_equal(host.read_positions(p, n), orc.read_positions(p, n))
+    for name, n in (("linear_directions.txt", 256), ("grid_beam_directions.txt", 256), ("grid_beam_directions.txt", 512),
+                    ("linear_source_directions_1024.txt", None), ("grid_source_directions_3721.txt", None)):
+        p = os.path.join(CFG, name)
+        assert np.array_equal(host.read_directions(p, n), orc.read_directions(p, n))
+    with pytest.raises(Exception):
+        host.read_positions(os.path.join(CFG, "does_not_exist.txt"), 64)
+
+
+def test_weights_bit_exact_vs_oracle_and_reference_hash(host, orc, linear_inputs, linear_weights):
+    meta = json.load(open(os.path.join(GOLDEN, "golden.json")))
+    pos, dirs, _ = linear_inputs
+    w = host.make_weights(pos, dirs, 256, 0, 0)
+    assert np.array_equal(w, linear_weights)
+    assert "%016x" % orc.fnv1a64(w) == meta["weights_fnv1a64"]
+    assert np.array_equal(host.make_weights_default(), linear_weights)
+    # a frequency shard (rank 3 of 8: channels 96..127) is the matching slice
+    assert np.array_equal(host.make_weights(pos, dirs, 32, 96, 0), linear_weights[96:128])
+    # other sub-band and a 2-D array
+    gpos = orc.read_positions(os.path.join(CFG, "grid_positions.txt"), 64)
+    gdir = orc.read_directions(os.path.join(CFG, "grid_beam_directions.txt"), 256)
+    g = orc.Geom(n_freq=6)
+    assert np.array_equal(host.make_weights(gpos, gdir, 6, 0, 5), orc.make_weights(g, gpos, gdir, 5))
+
+
+def test_python_file_writer(host, orc, tmp_path):
+    x = np.array([[1.03932e8, 3003815.0, 1711951.38], [0.5, 1e-7, 12345678.0]], np.float32)
+    p1, p2 = str(tmp_path / "a.py"), str(tmp_path / "b.py")
+    host.write_python_file(x, p1)
+    orc.write_python_file(x, p2)
+    assert open(p1).read() == open(p2).read() == "A = [[1.03932e+08,3.00382e+06,1.71195e+06],\n[0.5,1e-07,1.23457e+07]]\n"
+    gold = np.load(os.path.join(GOLDEN, "linear_debug.npz"))["dedispersed"][:16]
+    host.write_python_file(gold, p1)
+    orc.write_python_file(gold, p2)
+    assert open(p1).read() == open(p2).read()
+
+
+def test_generator_batch_bit_exact(host, orc, bfm, linear_inputs):
+    meta = json.load(open(os.path.join(GOLDEN, "golden.json")))
+    pos, _, _ = linear_inputs
+    gen = host.TestDataGenerator(bfm.debug_config(), pin=False)
+    assert gen.size() == 268435456
+    assert gen.get_n_pt_sources() == 1024
+    data = gen.data()
+    assert data[0] == 0x70 and data[-1] == 0x70 and data[12345678] == 0x70  # BOGUS_DATA memset
+    gen.read_in_source_directions(os.path.join(CFG, "linear_source_directions_1024.txt"))
+    gen.generate_test_data(pos, 0)
+    assert "%016x" % orc.fnv1a64(data) == meta["batch_fnv1a64"]
+    gen.close()
+
+
+def test_generator_batches_gating_and_overrun(host, orc, bfm, linear_inputs):
+    pos, _, src = linear_inputs
+    cfg = bfm.debug_config(n_freq=4)
+    g = orc.Geom(n_freq=4)
+    gen = host.TestDataGenerator(cfg, n_sources_per_batch=64, pin=False)
+    # without a catalogue: nothing to generate, data is "ready" for the first batch only (hh:98-108)
+    assert not gen.check_need_to_generate_more_input_data(0)
+    assert gen.check_data_ready_for_transfer(0) and gen.check_data_ready_for_transfer(1)
+    assert not gen.check_data_ready_for_transfer(2)  # 64 sources / 32 gemms per block = 2 blocks
+    gen.close()
+    gen = host.TestDataGenerator(cfg, n_sources_per_batch=64, pin=False)
+    gen.set_source_directions(src[:100])
+    assert gen.get_n_pt_sources() == 100
+    assert gen.check_need_to_generate_more_input_data(0) and not gen.check_data_ready_for_transfer(0)
+    gen.generate_test_data(pos, 0)
+    assert np.array_equal(gen.data(), orc.generate_test_data(g, pos, src[:100], 0, 0, 64).ravel())
+    assert not gen.check_need_to_generate_more_input_data(1) and gen.check_need_to_generate_more_input_data(2)
+    assert gen.check_data_ready_for_transfer(1) and not gen.check_data_ready_for_transfer(2)
+    gen.generate_test_data(pos, 0)  # second batch: sources 64..99 then zero bytes (hh:84-86)
+    want = orc.generate_test_data(g, pos, src[:100], 0, 1, 64)
+    assert np.array_equal(gen.data(), want.ravel())
+    assert want[36:].max() == 0 and want[:36].max() > 0
+    gen.close()
+
+
+def _simulate(obs, gen_blocks, per_block=32, n_streams=8, transfer_lag=1, analysis_lag=2, max_iter=100000):
+    """The reference's DEBUG while-loop (src/beamformer.cu:364-534) with fake device completion."""
+    time_slice = list(range(n_streams))
+    log = []
+    pend_t, pend_a = [], []
+    it = 0
+    while not obs.check_observations_complete():
+        it += 1
+        assert it < max_iter, "scheduler did not terminate"
+        c = obs.counters()
+        # invariants (README.md:130-134)
+        assert c["A"] <= c["AQ"] <= c["T"] <= c["TQ"]
+        assert c["TQ"] - c["A"] <= 4 and c["TQ"] - c["T"] <= 2
+        if obs.check_ready_for_transfer():
+            if c["TQ"] < gen_blocks:
+                log.append(("H2D", obs.get_next_gpu_transfer_block(), c["TQ"]))
+                assert obs.get_next_gpu_transfer_block() == c["TQ"] % 8
+                obs.generate_transfer_event()
+                pend_t.append(it)
+            obs.check_transfers_complete()
+        # device progress: a transfer completes `transfer_lag` iterations after it was queued
+        done_t = len([x for x in pend_t if it - x >= transfer_lag])
+        obs.fake_complete(done_t, 0)
+        pend_t = pend_t[done_t:]
+        obs.check_transfer_events()
+        if obs.check_ready_for_analysis():
+            blk = obs.get_next_gpu_analysis_block()
+            for part in range(per_block // n_streams):
+                for st in range(n_streams):
+                    gemm = obs.get_current_analysis_gemm(time_slice[st])
+                    log.append(("GEMM", blk, time_slice[st], gemm, obs.check_ready_for_dh2_transfer(time_slice[st])))
+                    time_slice[st] += n_streams
+                    if time_slice[st] >= per_block:
+                        time_slice[st] -= per_block
+            obs.generate_analysis_event()
+            pend_a.append(it)
+        done_a = len([x for x in pend_a if it - x >= analysis_lag])
+        obs.fake_complete(0, done_a)
+        pend_a = pend_a[done_a:]
+        obs.check_analysis_events()
+    return log
+
+
+@pytest.mark.parametrize("n_src,tl,al", [(1024, 1, 2), (1024, 3, 1), (100, 1, 5), (33, 2, 2)])
+def test_observation_loop_scheduler(host, bfm, n_src, tl, al):
+    cfg = bfm.debug_config()
+    obs = host.ObservationLoopState(cfg, handle=None, debug=True)
+    obs.set_n_pt_sources(n_src)
+    assert obs.describe() == "A: 0, AQ: 0, T: 0, TQ: 0\ncurrent_gemm: 0, transfers_complete: 0"
+    assert obs.check_ready_for_transfer() and not obs.check_ready_for_analysis()
+    log = _simulate(obs, gen_blocks=10 ** 9, transfer_lag=tl, analysis_lag=al)
+    n_blocks = -(-n_src // 32)
+    c = obs.counters()
+    assert c == {"A": n_blocks, "AQ": n_blocks, "T": n_blocks, "TQ": n_blocks}
+    gemms = [e for e in log if e[0] == "GEMM"]
+    # every gemm-unit of every block exactly once, in the reference's (part, stream) order, ring slot = block % 8
+    assert [e[3] for e in gemms] == [b * 32 + p * 8 + s for b in range(n_blocks) for p in range(4) for s in range(8)]
+    assert all(e[1] == (e[3] // 32) % 8 for e in gemms)
+    # dedisperse/D2H only for gemm < n_pt_sources (src/beamformer.cu:492)
+    assert [e[3] for e in gemms if e[4]] == list(range(n_src))
+    assert [e[2] for e in log if e[0] == "H2D"] == list(range(n_blocks))
+    assert "transfers_complete: 1" in obs.describe()
+    obs.close()
+
+
+def test_observation_loop_backpressure_rules(host, bfm):
+    obs = host.ObservationLoopState(bfm.debug_config(), handle=None, debug=False)
+    # transfer separation: at most 2 un-transferred blocks in flight
+    obs.generate_transfer_event()
+    assert obs.check_ready_for_transfer()
+    obs.generate_transfer_event()
+    assert not obs.check_ready_for_transfer()
+    obs.check_transfer_events()
+    assert obs.counters()["T"] == 0 and not obs.check_ready_for_analysis()
+    obs.fake_complete(1, 0)
+    obs.check_transfer_events()
+    assert obs.counters()["T"] == 1 and obs.check_ready_for_analysis() and obs.check_ready_for_transfer()
+    # events complete in order only: a later finished event does not overtake an earlier pending one
+    obs.fake_complete(1, 0)
+    obs.check_transfer_events()
+    for _ in range(2):
+        obs.generate_transfer_event()
+        obs.fake_complete(1, 0)
+        obs.check_transfer_events()
+    assert obs.counters()["TQ"] == 4 and obs.counters()["T"] == 4
+    assert not obs.check_ready_for_transfer()  # total separation: TQ - A < 4 violated
+    obs.generate_analysis_event()
+    obs.fake_complete(0, 1)
+    obs.check_analysis_events()
+    assert obs.counters()["A"] == 1 and obs.check_ready_for_transfer()
+    # production completion rule (src/observation_loop.hh:153-157)
+    assert not obs.check_observations_complete()
+    obs.set_transfers_complete(True)
+    assert not obs.check_ready_for_transfer() and not obs.check_observations_complete()
+    for _ in range(3):
+        obs.generate_analysis_event()
+    obs.fake_complete(0, 3)
+    obs.check_analysis_events()
+    assert obs.check_observations_complete()
+    assert obs.get_current_transfer_gemm() == 4 * 32
+    obs.close()
