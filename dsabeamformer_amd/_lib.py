@@ -108,6 +108,36 @@ SIGNATURES = {
 }
 
 
+_hip = None
+
+
+def _preload_hip_runtime():
+    """libdsabf.so carries no DT_NEEDED for the HIP runtime (see build.py): make exactly ONE libamdhip64 visible
+    process-wide before loading it -- torch's bundled copy when torch is installed (so that torch streams, events
+    and allocations belong to the same runtime as our launches), else the system ROCm one."""
+    global _hip
+    if _hip is not None:
+        return _hip
+    cands = []
+    try:
+        import torch  # noqa: F401  (plumbing only: device memory, streams, torch.distributed)
+
+        cands.append(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+    except ImportError:
+        pass
+    cands += [os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib", "libamdhip64.so"), "libamdhip64.so"]
+    errs = []
+    for c in cands:
+        if os.path.sep in c and not os.path.exists(c):
+            continue
+        try:
+            _hip = C.CDLL(c, mode=C.RTLD_GLOBAL)
+            return _hip
+        except OSError as e:  # pragma: no cover
+            errs.append("%s: %s" % (c, e))
+    raise ImportError("no HIP runtime (libamdhip64.so) could be loaded: %s" % "; ".join(errs))
+
+
 def load() -> C.CDLL:
     """Load libdsabf.so (built by ``dsabeamformer_amd.build.build()`` / ``__graft_entry__.build()``)."""
     global _lib
@@ -116,6 +146,7 @@ def load() -> C.CDLL:
             raise ImportError(
                 "%s is missing: build it with `python -m dsabeamformer_amd.build` (hipcc, gfx950). "
                 "There is no CPU fallback for the beamformer hot path." % LIB_PATH)
+        _preload_hip_runtime()
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError here = header/library mismatch: fail loudly

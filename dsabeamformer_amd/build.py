@@ -59,7 +59,14 @@ def build(force: bool = False, verbose: bool = False) -> str:
             raise RuntimeError("hipcc failed: %s\n%s" % (" ".join(cmd), out))
         if verbose and out.strip():
             print(out)
-    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    # Link WITHOUT a DT_NEEDED on libamdhip64: hip* symbols stay undefined and bind to the HIP runtime that is
+    # already in the process (a C++ application links -lamdhip64 itself; Python callers get torch's bundled runtime
+    # preloaded by _lib.load()).  Linking /opt/rocm's libamdhip64.so.7 here would put a SECOND HIP runtime next to
+    # torch's, and streams/events created by one are meaningless to the other.
+    cxx = os.path.join(os.path.dirname(os.path.realpath(HIPCC)), "..", "lib", "llvm", "bin", "clang++")
+    if not os.path.exists(cxx):
+        cxx = shutil.which("g++") or "g++"
+    cmd = [cxx, "-shared", "-fPIC", "-o", LIB] + objs + ["-lpthread"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

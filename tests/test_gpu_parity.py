@@ -76,7 +76,7 @@ def test_fused_random_small_golden(torch, bfmod, orc, tag):
                                                   (64, 8, 1), (64, 32, 1), (16, 1, 2), (32, 16, 1), (128, 1, 3),
                                                   (128, 16, 2)])
 def test_fused_geometries_bit_exact(torch, bfmod, orc, n_ant, n_avg, n_units):
-    g = orc.Geom(n_beams=96, n_ant=n_ant, n_freq=5, n_avg=n_avg, n_out_per_gemm=8 if n_avg == 1 else 2)
+    g = orc.Geom(n_beams=96, n_ant=n_ant, n_freq=5, n_avg=n_avg, n_out_per_gemm=max(2, 16 // (2 * n_avg)))
     rng = np.random.default_rng(1000 + n_ant + n_avg)
     w = rng.integers(-127, 128, size=(g.n_freq, g.n_ant, g.n_beams, 2), dtype=np.int8)
     packed = rng.integers(0, 256, size=(n_units, g.n_freq, g.n_time, g.n_ant), dtype=np.uint8)
