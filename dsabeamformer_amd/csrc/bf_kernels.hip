@@ -60,12 +60,38 @@ struct FusedArgs {
     int n_tsplit;                    // workgroups along time
 };
 
-// MFMA D-row r (0..31) <-> (lane half, accumulator register): rows held by half h, reg j are
-// (j&3) + 8*(j>>2) + 4*h.  We want half h / reg j to mean "sample j of run h", so LDS row of D-row r is:
-__device__ __forceinline__ int lds_row_of_mfma_row(int r) { return ((r >> 2) & 1) * 16 + (r >> 3) * 4 + (r & 3); }
+// ---- time-sample <-> MFMA-row mapping ------------------------------------------------------------------------
+// v_mfma_*_32x32: lane (column c = lane&31, half h = lane>>5) holds D rows (reg&3) + 8*(reg>>2) + 4*h in
+// accumulator registers reg = 0..15.  Packed fp32 VALU ops (v_pk_fma/mul/add_f32) work on the register PAIRS
+// (2i, 2i+1), so the mapping is chosen such that the two elements e = 0,1 of pair i always belong to two DIFFERENT
+// outputs at the SAME position in their accumulation windows: every step of the detect -- scale, square, add,
+// running sum -- is then one packed instruction for two outputs, and each output's fp32 sum still runs in the
+// reference's sequential order (src/beamformer.cuh:150-152).
+//
+//   NIPO >= 16 (L = NIPO samples per output): a lane half carries TWO output streams; a tile advances each stream
+//     by 8 samples (pair i = sample 8q+i of output 4*grp + 2h + e); an output needs R = L/8 tiles.
+//     Staging unit ("run") = 8 contiguous samples; LDS row of (tile j, stream sidx = 2h+e, i) = 32j + 8*sidx + i.
+//   NIPO < 16: a lane half carries one run of 16 contiguous samples = 16/NIPO whole outputs; pair i, element e is
+//     sample k = i % NIPO of output u = 2*(i / NIPO) + e of that run.  Run = 16 samples; LDS row = 32j + 16h + sigma.
+template <int NIPO>
+__device__ __forceinline__ int sample_in_half(int i, int e)  // NIPO < 16: position of (pair i, elem e) in the run
+{
+    return (2 * (i / NIPO) + e) * NIPO + (i % NIPO);
+}
+
+template <int NIPO>
+__device__ __forceinline__ int lds_row_of_mfma_row(int r)  // r = D row = lane&31 of the A operand
+{
+    const int reg = (r & 3) + 4 * (r >> 3), h = (r >> 2) & 1, i = reg >> 1, e = reg & 1;
+    if constexpr (NIPO >= 16)
+        return (2 * h + e) * 8 + i;
+    else
+        return 16 * h + sample_in_half<NIPO>(i, e);
+}
 
 // XOR swizzle of the 16-byte chunk index inside an LDS row so that both the ds_write_b128 of the staging pass
-// and the ds_read_b128 of the fragment pass are bank-conflict free.
+// and the ds_read_b128 of the fragment pass are bank-conflict free (modelled exhaustively
+// in tests/test_numerics_tricks.py).
 template <int RBC>
 __device__ __forceinline__ int swz(int chunk, int row)
 {
@@ -77,12 +103,15 @@ __global__ __launch_bounds__(kWgThreads, (NKS <= 4 ? 4 : 2)) void fused_kernel(F
 {
     constexpr int RBC = (NKS <= 4) ? 8 : 16;            // 16-byte chunks per LDS row
     constexpr int RB = RBC * 16;                         // LDS row bytes: [16*re of ant 0.. | 16*im of ant 0..]
-    constexpr int L = NIPO < 16 ? 16 : NIPO;             // samples per lane-half stream
-    constexpr int R = L / 16;                            // row-tiles per output group
+    constexpr bool LONG = NIPO >= 16;                    // an output spans several tiles
+    constexpr int L = LONG ? NIPO : 16;                  // samples per output stream (LONG) / per run (short)
+    constexpr int R = LONG ? L / 8 : 1;                  // tiles per output group
+    constexpr int RUN = LONG ? 8 : 16;                   // contiguous samples per staging run
+    constexpr int RUNS_PER_TILE = 32 / RUN;
     constexpr int A = 16 * NKS;                          // packed bytes per time sample (= n_ant)
     constexpr int PIECES = kRowsPerChunk * NKS;          // 16-byte packed pieces per chunk
     constexpr int PPT = (PIECES + kWgThreads - 1) / kWgThreads;
-    static_assert(kTilesPerChunk % R == 0, "chunk must hold whole output groups");
+    static_assert(R <= kTilesPerChunk ? (kTilesPerChunk % R == 0) : (R % kTilesPerChunk == 0), "bad NIPO");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 x 128 rows x RB
 
@@ -99,8 +128,11 @@ __global__ __launch_bounds__(kWgThreads, (NKS <= 4 ? 4 : 2)) void fused_kernel(F
     bid /= a.n_freq;
     const int bg = bid % a.n_bgroups;
     const int ts = bid / a.n_bgroups;
-    const int c_begin = (int)(((long long)a.chunks_total * ts) / a.n_tsplit);
-    const int c_end = (int)(((long long)a.chunks_total * (ts + 1)) / a.n_tsplit);
+    // split in units of whole output groups (R tiles; a chunk is 4 tiles)
+    constexpr int CPG = R > kTilesPerChunk ? R / kTilesPerChunk : 1;  // chunks per group
+    const int units_total = a.chunks_total / CPG;
+    const int c_begin = (int)(((long long)units_total * ts) / a.n_tsplit) * CPG;
+    const int c_end = (int)(((long long)units_total * (ts + 1)) / a.n_tsplit) * CPG;
 
     const int bt = bg * kWavesPerWg + wave;  // this wave's 32-beam tile
     const bool wave_active = bt < a.n_btiles;
@@ -128,19 +160,31 @@ __global__ __launch_bounds__(kWgThreads, (NKS <= 4 ? 4 : 2)) void fused_kernel(F
     for (int i = 0; i < 16; i++) kc[i] = (int)kMagicBits;
     asm volatile("" : "+v"(kc));  // keep the seed in registers; do not rematerialise 16 v_mov per tile
 
+    // first global sample of run rr of chunk c (and whether it exists)
+    auto run_start = [&](int c, int rr, unsigned& s0) -> bool {
+        const unsigned tile = (unsigned)c * kTilesPerChunk + (unsigned)(rr / RUNS_PER_TILE);
+        if constexpr (LONG) {
+            const unsigned o = 4u * (tile / R) + (unsigned)(rr % RUNS_PER_TILE);  // output stream
+            s0 = o * (unsigned)L + 8u * (tile % R);
+            return o * (unsigned)L < a.S;
+        } else {
+            s0 = (2u * tile + (unsigned)(rr % RUNS_PER_TILE)) * 16u;
+            return s0 < a.S;
+        }
+    };
+
     // ---- staging helpers ---------------------------------------------------------------------------------
     v4i stage[PPT];
     auto load_chunk = [&](int c) {
 #pragma unroll
         for (int k = 0; k < PPT; k++) {
             const int pc = tid + k * kWgThreads;
-            const int rr = pc / (16 * NKS);   // run within chunk (0..7): tile rr>>1, half rr&1
-            const int pi = pc % (16 * NKS);   // 16-byte piece within the run
-            const unsigned tile = (unsigned)c * kTilesPerChunk + (rr >> 1);
-            const unsigned hs = 2u * (tile / R) + (rr & 1);
-            const unsigned s0 = hs * L + 16u * (tile % R);
+            const int rr = pc / (RUN * NKS);   // run within chunk
+            const int pi = pc % (RUN * NKS);   // 16-byte piece within the run
+            unsigned s0;
+            const bool ok = run_start(c, rr, s0);
             stage[k] = v4i{0, 0, 0, 0};
-            if (pc < PIECES && s0 < a.S) {
+            if (pc < PIECES && ok) {
                 const unsigned u = a.t_shift >= 0 ? (s0 >> a.t_shift) : (s0 / (unsigned)a.T);
                 const unsigned t = s0 - u * (unsigned)a.T;
                 const uint8_t* src = a.in + ((size_t)((size_t)u * a.n_freq + f) * a.T + t) * A + (size_t)pi * 16;
@@ -153,9 +197,9 @@ __global__ __launch_bounds__(kWgThreads, (NKS <= 4 ? 4 : 2)) void fused_kernel(F
         for (int k = 0; k < PPT; k++) {
             const int pc = tid + k * kWgThreads;
             if (pc < PIECES) {
-                const int rr = pc / (16 * NKS);
-                const int pi = pc % (16 * NKS);
-                const int row = rr * 16 + pi / NKS;
+                const int rr = pc / (RUN * NKS);
+                const int pi = pc % (RUN * NKS);
+                const int row = rr * RUN + pi / NKS;
                 const int ks = pi % NKS;
                 v4i re, im;
 #pragma unroll
@@ -171,13 +215,16 @@ __global__ __launch_bounds__(kWgThreads, (NKS <= 4 ? 4 : 2)) void fused_kernel(F
     };
 
     // ---- per-lane constants for the fragment reads and the epilogue --------------------------------------
-    const int arow = lds_row_of_mfma_row(lc);
+    const int arow = lds_row_of_mfma_row<NIPO>(lc);
     int aoff[NKS];
 #pragma unroll
     for (int ks = 0; ks < NKS; ks++) aoff[ks] = arow * RB + 16 * swz<RBC>(hl * (RBC / 2) + ks, arow);
 
     const size_t FB = (size_t)a.n_freq * a.n_beams;
-    float carry = 0.0f;  // running sum of the current output when NIPO > 16
+    float* const out_lane = a.out + (size_t)f * a.n_beams + beam;  // + output_index * FB
+    const v2f alpha2 = {kAlpha16, kAlpha16};
+    const v2f bias2 = {kNegMagicAlpha16, kNegMagicAlpha16};
+    v2f carry = {0.0f, 0.0f};  // running sums of this lane's two output streams (LONG)
 
     if (c_begin >= c_end) return;
 
@@ -212,53 +259,84 @@ __global__ __launch_bounds__(kWgThreads, (NKS <= 4 ? 4 : 2)) void fused_kernel(F
                     aim = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[ks], bim[ks], aim, 0, 0, 0);
                 }
 
-                // -- epilogue: lane (beam, half hl) holds samples s0 .. s0+15 of its half-stream --
-                const unsigned tile = (unsigned)c * kTilesPerChunk + j;
-                const unsigned hs = 2u * (tile / R) + hl;
-                const unsigned s0 = hs * L + 16u * (tile % R);
-                const bool valid = (s0 < a.S) && (beam < a.n_beams);
-
+                // -- epilogue ------------------------------------------------------------------------------
                 // NOTE: bit-cast the WHOLE vector; __builtin_bit_cast(float, vec[i]) is miscompiled by ROCm 7.2
                 // clang (it reads element 0 for every i).
                 const v16f fre = __builtin_bit_cast(v16f, are);
                 const v16f fim = __builtin_bit_cast(v16f, aim);
-                float p[16];
+                const unsigned tile = (unsigned)c * kTilesPerChunk + j;
+
+                v2f pp[8];  // detected power of (pair i, element e)
+                v2f xr[8], xi[8];
 #pragma unroll
-                for (int i = 0; i < 16; i++) {
-                    const float xr = __builtin_fmaf(fre[i], kAlpha16, kNegMagicAlpha16);
-                    const float xi = __builtin_fmaf(fim[i], kAlpha16, kNegMagicAlpha16);
-                    if constexpr (WRITE_C) {
-                        if (valid) {
-                            v2f cv = {xr, xi};
-                            *reinterpret_cast<v2f*>(a.out + 2 * (((size_t)f * a.T + (s0 + i)) * a.n_beams + beam)) = cv;
-                        }
-                    } else {
-                        const float xx = xr * xr;
-                        const float yy = xi * xi;
-                        p[i] = xx + yy;
+                for (int i = 0; i < 8; i++) {
+                    const v2f mr = {fre[2 * i], fre[2 * i + 1]};
+                    const v2f mi = {fim[2 * i], fim[2 * i + 1]};
+                    xr[i] = __builtin_elementwise_fma(mr, alpha2, bias2);  // fl(n * alpha), exact single rounding
+                    xi[i] = __builtin_elementwise_fma(mi, alpha2, bias2);
+                    if constexpr (!WRITE_C) {
+                        const v2f xx = xr[i] * xr[i];
+                        const v2f yy = xi[i] * xi[i];
+                        pp[i] = xx + yy;  // two multiplies, one add (compiled with -ffp-contract=off)
                     }
                 }
-                if constexpr (!WRITE_C) {
-                    if constexpr (NIPO < 16) {
-                        constexpr int OPR = 16 / NIPO;  // outputs per run
-                        float* op = a.out + ((size_t)hs * OPR) * FB + (size_t)f * a.n_beams + beam;
+
+                if constexpr (WRITE_C) {
+                    // stage-parity path: store the scaled complex beam voltages c[f][t][b]{re,im} (one gemm-unit)
 #pragma unroll
-                        for (int g = 0; g < OPR; g++) {
-                            float s = p[g * NIPO];
+                    for (int i = 0; i < 8; i++) {
 #pragma unroll
-                            for (int i = 1; i < NIPO; i++) s = s + p[g * NIPO + i];
-                            asm volatile("" : "+v"(s));  // keep the detect outside the store predicate (see below)
-                            if (valid) op[(size_t)g * FB] = s;
+                        for (int e = 0; e < 2; e++) {
+                            unsigned s;
+                            bool ok;
+                            if constexpr (LONG) {
+                                const unsigned o = 4u * (tile / R) + 2u * hl + e;
+                                s = o * (unsigned)L + 8u * (tile % R) + i;
+                                ok = o * (unsigned)L < a.S;
+                            } else {
+                                s = (2u * tile + hl) * 16u + sample_in_half<NIPO>(i, e);
+                                ok = (2u * tile + hl) * 16u < a.S;
+                            }
+                            if (ok && beam < a.n_beams) {
+                                v2f cv = {xr[i][e], xi[i][e]};
+                                *reinterpret_cast<v2f*>(a.out + 2 * (((size_t)f * a.T + s) * a.n_beams + beam)) = cv;
+                            }
                         }
-                    } else {
-                        float s = (j % R == 0) ? p[0] : (carry + p[0]);
+                    }
+                } else if constexpr (LONG) {
+                    // two output streams per lane (e = 0, 1), 8 more samples each, sequential fp32 order
+                    const unsigned q = (R <= kTilesPerChunk) ? (unsigned)(j % R) : (tile % R);
+                    v2f s2 = (q == 0) ? pp[0] : (carry + pp[0]);
 #pragma unroll
-                        for (int i = 1; i < 16; i++) s = s + p[i];
-                        // Pin the value here: otherwise the compiler sinks the whole detect under `if (valid)`,
-                        // hoists the MFMAs of the next tile above that branch and doubles the live accumulators.
-                        asm volatile("" : "+v"(s));
-                        carry = s;
-                        if ((j % R == R - 1) && valid) a.out[(size_t)hs * FB + (size_t)f * a.n_beams + beam] = s;
+                    for (int i = 1; i < 8; i++) s2 = s2 + pp[i];
+                    // Pin the value here: otherwise the compiler sinks the whole detect under the store predicate,
+                    // hoists the MFMAs of the next tile above that branch and doubles the live accumulators.
+                    asm volatile("" : "+v"(s2));
+                    carry = s2;
+                    if (q == R - 1) {
+                        const unsigned o = 4u * (tile / R) + 2u * hl;
+                        if (o * (unsigned)L < a.S && beam < a.n_beams) {
+                            float* op = out_lane + (size_t)o * FB;
+                            op[0] = s2[0];
+                            if ((o + 1) * (unsigned)L < a.S) op[FB] = s2[1];
+                        }
+                    }
+                } else {
+                    // 16/NIPO whole outputs per lane half: pair-packed sequential sums
+                    constexpr int OPR = 16 / NIPO;  // outputs per run (even)
+                    const unsigned hs = 2u * tile + hl;
+                    const bool valid = (hs * 16u < a.S) && (beam < a.n_beams);
+                    float* op = out_lane + ((size_t)hs * OPR) * FB;
+#pragma unroll
+                    for (int m = 0; m < OPR / 2; m++) {
+                        v2f s2 = pp[m * NIPO];
+#pragma unroll
+                        for (int k = 1; k < NIPO; k++) s2 = s2 + pp[m * NIPO + k];
+                        asm volatile("" : "+v"(s2));
+                        if (valid) {
+                            op[(size_t)(2 * m) * FB] = s2[0];
+                            op[(size_t)(2 * m + 1) * FB] = s2[1];
+                        }
                     }
                 }
                 // One tile at a time per wave: 4 waves/SIMD overlap each other's MFMA and VALU phases; letting the
@@ -394,8 +472,7 @@ bool fused_supported(const Geometry& g, const char** why)
     if (!why) why = &dummy;
     if (g.n_beams <= 0 || g.n_beams % 32) { *why = "n_beams must be a positive multiple of 32"; return false; }
     if (g.n_ant != 16 * g.nks) { *why = "n_ant must be a multiple of 16 (16, 32, 64 or 128) in this build"; return false; }
-    if (g.n_time % 16) { *why = "n_out_per_gemm * n_pol * n_avg must be a multiple of 16"; return false; }
-    if (g.n_ipo > 16 && g.n_time % g.n_ipo) { *why = "n_time must be a multiple of n_ipo"; return false; }
+    if (g.n_ipo < 16 && g.n_time % 16) { *why = "n_out_per_gemm * n_pol * n_avg must be a multiple of 16"; return false; }
 #define X(nks_, nipo_) \
     if (g.nks == nks_ && g.n_ipo == nipo_) return true;
     DSABF_FOR_EACH_VARIANT(X)
@@ -408,18 +485,24 @@ bool fused_supported(const Geometry& g, const char** why)
 LaunchShape fused_launch_shape(const Geometry& g, int n_units, int n_cus)
 {
     LaunchShape ls{};
-    const int L = g.n_ipo < 16 ? 16 : g.n_ipo;
-    const int R = L / 16;
     const long long S = (long long)n_units * g.n_time;
-    const long long halfstreams = S / L;
-    const long long groups = (halfstreams + 1) / 2;
-    const long long tiles = groups * R;
+    long long tiles;
+    int cpg = 1;  // chunks per output group: a workgroup's chunk range must cover whole groups
+    if (g.n_ipo >= 16) {
+        const int R = g.n_ipo / 8;                       // tiles per group of 4 outputs
+        const long long groups = (S / g.n_ipo + 3) / 4;
+        tiles = groups * R;
+        if (R > kTilesPerChunk) cpg = R / kTilesPerChunk;
+    } else {
+        tiles = (S / 16 + 1) / 2;                        // two 16-sample runs per tile
+    }
     ls.chunks_total = (int)((tiles + kTilesPerChunk - 1) / kTilesPerChunk);
+    ls.chunks_total = (ls.chunks_total + cpg - 1) / cpg * cpg;
     const int base = g.n_freq * g.n_bgroups;
     // aim for ~2 resident workgroups per CU, but never less than 1 chunk per workgroup
     int want = (2 * n_cus + base - 1) / base;
     if (want < 1) want = 1;
-    if (want > ls.chunks_total) want = ls.chunks_total;
+    if (want > ls.chunks_total / cpg) want = ls.chunks_total / cpg;
     ls.n_tsplit = want;
     ls.grid = base * ls.n_tsplit;
     ls.block = kWgThreads;

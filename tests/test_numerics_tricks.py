@@ -66,17 +66,43 @@ def test_standalone_expand_bit_tricks():
     assert np.array_equal(got, want)
 
 
-def _lds_row_of_mfma_row(r):
-    return ((r >> 2) & 1) * 16 + (r >> 3) * 4 + (r & 3)
+def _sample_in_half(i, e, nipo):
+    return (2 * (i // nipo) + e) * nipo + (i % nipo)
 
 
-def test_mfma_row_mapping_puts_a_contiguous_run_in_each_lane_half():
-    # D row held by (half h, reg j) of v_mfma_*_32x32: (j&3) + 8*(j>>2) + 4*h  (cdna guide section 3)
-    for h in range(2):
-        for j in range(16):
-            d_row = (j & 3) + 8 * (j >> 2) + 4 * h
-            assert _lds_row_of_mfma_row(d_row) == 16 * h + j
-    assert sorted(_lds_row_of_mfma_row(r) for r in range(32)) == list(range(32))
+def _lds_row_of_mfma_row(r, nipo):
+    """Mirror of lds_row_of_mfma_row<NIPO> in bf_kernels.hip: D row r -> row of the tile's LDS image."""
+    reg, h = (r & 3) + 4 * (r >> 3), (r >> 2) & 1
+    i, e = reg >> 1, reg & 1
+    if nipo >= 16:
+        return (2 * h + e) * 8 + i
+    return 16 * h + _sample_in_half(i, e, nipo)
+
+
+def test_mfma_row_mapping_pairs_two_outputs_per_register_pair():
+    """D row of (half h, reg) is (reg&3) + 8*(reg>>2) + 4*h (cdna guide section 3).  The mapping must (a) be a
+    bijection on the 32 rows of a tile, (b) put the SAME window position of two different outputs in the two
+    elements of every register pair, (c) walk each output's window in increasing time order over the pairs."""
+    for nipo in (2, 4, 8, 16, 32, 64):
+        rows = {}
+        for h in range(2):
+            for reg in range(16):
+                d_row = (reg & 3) + 8 * (reg >> 2) + 4 * h
+                rows[(h, reg >> 1, reg & 1)] = _lds_row_of_mfma_row(d_row, nipo)
+        assert sorted(rows.values()) == list(range(32))
+        for h in range(2):
+            if nipo >= 16:
+                # stream (h, e) = 8 contiguous samples, pair i = sample i
+                for e in range(2):
+                    assert [rows[(h, i, e)] for i in range(8)] == list(range((2 * h + e) * 8, (2 * h + e) * 8 + 8))
+            else:
+                for i in range(8):
+                    s0, s1 = rows[(h, i, 0)] - 16 * h, rows[(h, i, 1)] - 16 * h
+                    assert s0 // nipo != s1 // nipo and s0 % nipo == s1 % nipo == i % nipo   # (b)
+                    assert s1 // nipo == s0 // nipo + 1 and (s0 // nipo) % 2 == 0
+                for u in range(16 // nipo):                                                    # (c)
+                    pos = [(i, e) for i in range(8) for e in range(2) if (rows[(h, i, e)] - 16 * h) // nipo == u]
+                    assert [rows[(h, i, e)] - 16 * h - u * nipo for i, e in pos] == list(range(nipo))
 
 
 def test_lds_swizzle_is_bank_conflict_free():
@@ -85,26 +111,30 @@ def test_lds_swizzle_is_bank_conflict_free():
     groups_r = [list(range(0, 4)) + list(range(12, 16)) + list(range(20, 28)),
                 list(range(4, 12)) + list(range(16, 20)) + list(range(28, 32))]
     groups_r += [[l + 32 for l in g] for g in groups_r]
-    for rbc, nks in ((8, 4), (16, 8)):
-        rb = rbc * 16
-        swz = (lambda c, row: c ^ (((row >> 1) & 7) ^ ((row & 1) << 2))) if rbc == 8 else (lambda c, row: c ^ (row & 15))
-        for tile in range(4):
-            for ks in range(nks):
-                for g in groups_r:
+    for nipo in (2, 4, 8, 16, 32, 64):
+        run = 8 if nipo >= 16 else 16
+        for rbc, nks in ((8, 4), (8, 2), (16, 8)):
+            rb = rbc * 16
+            swz = (lambda c, row: c ^ (((row >> 1) & 7) ^ ((row & 1) << 2))) if rbc == 8 else (lambda c, row: c ^ (row & 15))
+            for tile in range(4):
+                for ks in range(nks):
+                    for g in groups_r:
+                        slots = set()
+                        for lane in g:
+                            hl, lc = lane >> 5, lane & 31
+                            row = tile * 32 + _lds_row_of_mfma_row(lc, nipo)
+                            addr = row * rb + 16 * swz(hl * (rbc // 2) + ks, row)
+                            slots.add((addr // 16) % 16)
+                        assert len(slots) == 16, (nipo, rbc, tile, ks)
+            # staging writes: thread tid writes piece pc: row = rr*run + (pi // nks), ks = pi % nks
+            if nks == 2:
+                continue  # half-empty rows: 8 consecutive pieces span 4 rows (2-way at most, irrelevant sizes)
+            for pc0 in range(0, 128 * nks, 8):
+                for comp in range(2):
                     slots = set()
-                    for lane in g:
-                        hl, lc = lane >> 5, lane & 31
-                        row = tile * 32 + _lds_row_of_mfma_row(lc)
-                        addr = row * rb + 16 * swz(hl * (rbc // 2) + ks, row)
-                        slots.add((addr // 16) % 16)
-                    assert len(slots) == 16, (rbc, tile, ks)
-        # staging writes: thread tid writes piece pc = tid (+512): row = rr*16 + pi//nks, ks = pi % nks
-        for pc0 in range(0, 128 * nks, 8):
-            for comp in range(2):
-                slots = set()
-                for pc in range(pc0, pc0 + 8):
-                    rr, pi = divmod(pc, 16 * nks)
-                    row, ks = rr * 16 + pi // nks, pi % nks
-                    addr = row * rb + 16 * swz(comp * (rbc // 2) + ks, row)
-                    slots.add((addr // 16) % 8)
-                assert len(slots) == 8, (rbc, pc0, comp)
+                    for pc in range(pc0, pc0 + 8):
+                        rr, pi = divmod(pc, run * nks)
+                        row, ks = rr * run + pi // nks, pi % nks
+                        addr = row * rb + 16 * swz(comp * (rbc // 2) + ks, row)
+                        slots.add((addr // 16) % 8)
+                    assert len(slots) == 8, (nipo, rbc, pc0, comp)
