@@ -41,6 +41,8 @@ def parse():
                     help="c3: N_TIME 512 (16 outputs x n_ipo 32); prod: reference production N_TIME 256; "
                          "c2: DEBUG geometry N_TIME 16 (n_ipo 2, parity config; HBM-write bound)")
     ap.add_argument("--gather", default="alltoall", choices=["alltoall", "root", "none"])
+    ap.add_argument("--input", default="random", choices=["random", "zeros", "const"],
+                    help="experiment only: voltage bit patterns (MFMA power depends on operand toggling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -61,6 +63,23 @@ def product_weights(torch, cfg, f0):
 
     w = host.make_weights_default(n_beams=cfg.n_beams, n_ant=cfg.n_ant, n_freq_total=256, gpu=0)
     return np.ascontiguousarray(w[f0:f0 + cfg.n_freq])
+
+
+def pmc_traffic(args, world):
+    """HBM bytes per launch of the fused kernel from the committed rocprofv3 PMC passes (tools/pmc.sh: FETCH_SIZE
+    and WRITE_SIZE collected in separate passes, KiB units; FETCH_SIZE doubled per MI355X_MICROARCH.md section HBM --
+    gfx950 tallies 128-B read requests at 64 B).  Only valid for the exact launch it was measured on."""
+    path = os.path.join(ROOT, "profiles", "r01_c3_pmc_summary.txt")
+    if not (args.workload == "c3" and args.units == 32 and world == 1 and os.path.exists(path)):
+        return None
+    vals = {}
+    for line in open(path):
+        parts = line.split()
+        if len(parts) >= 3 and parts[1] == "mean":
+            vals[parts[0]] = float(parts[2])
+    if "FETCH_SIZE" not in vals or "WRITE_SIZE" not in vals:
+        return None
+    return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
 
 
 def cpu_baseline(args, n_avg, n_out, seconds):
@@ -124,6 +143,9 @@ def main():
     gen = torch.Generator(device="cuda").manual_seed(0xD5A + rank)
     d_in = [torch.randint(0, 256, (in_bytes,), dtype=torch.uint8, device="cuda", generator=gen)
             for _ in range(max(1, args.nbuf))]
+    if args.input != "random":
+        for t in d_in:
+            t.fill_(0 if args.input == "zeros" else 0x31)
     d_out = [torch.empty(out_floats, dtype=torch.float32, device="cuda") for _ in range(2)]
     stream = torch.cuda.current_stream()
     sptr = stream.cuda_stream
@@ -206,7 +228,7 @@ def main():
         if mfma_bound:
             achieved = launch_ops / (kern_avg_ms * 1e-3) / 1e12
             roof = {"bound": "mfma", "achieved": achieved, "peak": INT8_DENSE_PEAK_TOPS, "unit": "TFLOP/s",
-                    "frac": achieved / INT8_DENSE_PEAK_TOPS, "traffic": None}
+                    "frac": achieved / INT8_DENSE_PEAK_TOPS, "traffic": pmc_traffic(args, world)}
         else:
             achieved = launch_bytes / (kern_avg_ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -214,7 +236,9 @@ def main():
         roof.update({"kernel": "dsabf::fused_kernel<NKS=%d,NIPO=%d>" % (cfg.n_ant // 16, n_ipo),
                      "kernel_ms_avg": kern_avg_ms, "kernel_ms_median": kern_ms[len(kern_ms) // 2],
                      "kernel_ms_min": kern_ms[0], "algorithmic_ops_per_launch": launch_ops,
-                     "algorithmic_bytes_per_launch": launch_bytes, "note": "int8 ops (1 complex MAC = 8 ops)"})
+                     "algorithmic_bytes_per_launch": launch_bytes,
+                     "note": "unit is int8 TOP/s (1 complex MAC = 8 ops); traffic = HBM bytes per launch from the "
+                             "committed PMC passes (profiles/r01_c3_pmc_summary.txt), null if this launch differs"})
         info = bf.kernel_info(units)
         out = {
             "metric": "beam-blocks/sec (256 beams x 256 freq x N_TIME)", "value": value, "unit": "beam-blocks/s",

@@ -16,8 +16,10 @@ ROOT = os.path.dirname(PKG)
 
 HIPCC = os.environ.get("HIPCC") or shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 # -ffp-contract=off: the detect stage's x*x + y*y must be two multiplies and one add (bit-exact contract).
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function",
-         "-I" + os.path.join(ROOT, "include")]
+# -fno-slp-vectorize: keep the detect epilogue on plain fp32 VALU ops (packed v_pk_*_f32 do not co-execute with MFMA).
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize", "-Wall",
+         "-Wno-unused-function",
+         "-I" + os.path.join(ROOT, "include")] + os.environ.get("DSABF_EXTRA_FLAGS", "").split()
 
 
 def sources() -> list[str]:

@@ -8,8 +8,11 @@
 
 namespace dsabf {
 
-constexpr int kWgThreads = 512;      // 8 wave64 per workgroup
-constexpr int kWavesPerWg = 8;       // one 32-beam tile per wave -> 256 beams per workgroup
+#ifndef DSABF_WAVES
+#define DSABF_WAVES 8
+#endif
+constexpr int kWavesPerWg = DSABF_WAVES;      // one 32-beam tile per wave -> 32*waves beams per workgroup
+constexpr int kWgThreads = 64 * kWavesPerWg;
 constexpr int kTilesPerChunk = 4;    // MFMA row-tiles (32 time samples each) staged per LDS buffer
 constexpr int kRowsPerChunk = 128;   // time samples per LDS buffer
 constexpr int kRunsPerChunk = 8;     // contiguous 16-sample runs per LDS buffer

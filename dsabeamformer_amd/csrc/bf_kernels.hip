@@ -31,6 +31,19 @@
 
 #include <hip/hip_runtime.h>
 
+#ifndef DSABF_OCC
+#define DSABF_OCC 4   // waves per SIMD requested for NKS <= 4
+#endif
+#ifndef DSABF_STAGGER
+#define DSABF_STAGGER 0
+#endif
+#ifndef DSABF_PRIO
+#define DSABF_PRIO 0
+#endif
+#ifndef DSABF_ABLATE
+#define DSABF_ABLATE 0  // perf experiments only (tools/ablate.sh): 1 no loop barrier, 2 no LDS fragment reads,
+#endif                  // 3 no stores, 4 no staging in the loop, 5 no detect VALU.  0 = product.
+
 namespace dsabf {
 
 typedef int v4i __attribute__((ext_vector_type(4)));
@@ -62,11 +75,13 @@ struct FusedArgs {
 
 // ---- time-sample <-> MFMA-row mapping ------------------------------------------------------------------------
 // v_mfma_*_32x32: lane (column c = lane&31, half h = lane>>5) holds D rows (reg&3) + 8*(reg>>2) + 4*h in
-// accumulator registers reg = 0..15.  Packed fp32 VALU ops (v_pk_fma/mul/add_f32) work on the register PAIRS
-// (2i, 2i+1), so the mapping is chosen such that the two elements e = 0,1 of pair i always belong to two DIFFERENT
-// outputs at the SAME position in their accumulation windows: every step of the detect -- scale, square, add,
-// running sum -- is then one packed instruction for two outputs, and each output's fp32 sum still runs in the
-// reference's sequential order (src/beamformer.cuh:150-152).
+// accumulator registers reg = 0..15.  The A-operand row <-> time-sample mapping is free, so it is chosen such that
+// the registers of one lane hold, in increasing register order, consecutive samples of the accumulation windows of
+// TWO different outputs (even registers: one output, odd registers: the next): each output's fp32 sum runs in the
+// reference's sequential order (src/beamformer.cuh:150-152) entirely inside one lane -- no cross-lane reduction --
+// and the two interleaved chains give the in-order wave two independent dependency chains to overlap.
+// (The pairing also makes every step expressible as v_pk_*_f32 on register pairs; measured, packed fp32 does not
+// co-execute with MFMA on gfx950 and is 5 % slower here, so the product uses plain ops.)
 //
 //   NIPO >= 16 (L = NIPO samples per output): a lane half carries TWO output streams; a tile advances each stream
 //     by 8 samples (pair i = sample 8q+i of output 4*grp + 2h + e); an output needs R = L/8 tiles.
@@ -99,7 +114,7 @@ __device__ __forceinline__ int swz(int chunk, int row)
 }
 
 template <int NKS, int NIPO, bool WRITE_C>
-__global__ __launch_bounds__(kWgThreads, (NKS <= 4 ? 4 : 2)) void fused_kernel(FusedArgs a)
+__global__ __launch_bounds__(kWgThreads, (NKS <= 4 ? DSABF_OCC : 2)) void fused_kernel(FusedArgs a)
 {
     constexpr int RBC = (NKS <= 4) ? 8 : 16;            // 16-byte chunks per LDS row
     constexpr int RB = RBC * 16;                         // LDS row bytes: [16*re of ant 0.. | 16*im of ant 0..]
@@ -222,11 +237,38 @@ __global__ __launch_bounds__(kWgThreads, (NKS <= 4 ? 4 : 2)) void fused_kernel(F
 
     const size_t FB = (size_t)a.n_freq * a.n_beams;
     float* const out_lane = a.out + (size_t)f * a.n_beams + beam;  // + output_index * FB
-    const v2f alpha2 = {kAlpha16, kAlpha16};
-    const v2f bias2 = {kNegMagicAlpha16, kNegMagicAlpha16};
     v2f carry = {0.0f, 0.0f};  // running sums of this lane's two output streams (LONG)
 
+    // Deferred output stores (LONG): the sums finished in chunk c are stored at the top of chunk c+1, BEFORE the
+    // prefetch load of chunk c+2 is issued.  The compiler guards the prefetched registers with s_waitcnt vmcnt(0);
+    // with in-order vmcnt that wait then only covers operations a whole chunk old instead of stores issued a few
+    // cycles earlier (which stalled every wave for a store round trip per chunk: -11 % kernel time).
+    constexpr int PEND = LONG ? (R <= kTilesPerChunk ? kTilesPerChunk / R : 1) : 1;
+    v2f pend[PEND];
+    int pend_chunk = -1;  // chunk whose finished sums are in pend[]
+    auto flush_pending = [&]() {
+        if constexpr (LONG && !WRITE_C) {
+            if (pend_chunk >= 0 && wave_active) {
+#pragma unroll
+                for (int g = 0; g < PEND; g++) {
+                    // last tile of output group g of that chunk
+                    const unsigned tile = (unsigned)pend_chunk * kTilesPerChunk + (R <= kTilesPerChunk ? (g + 1) * R - 1 : kTilesPerChunk - 1);
+                    const unsigned o = 4u * (tile / R) + 2u * hl;
+                    if (o * (unsigned)L < a.S && beam < a.n_beams && DSABF_ABLATE != 3) {
+                        float* op = out_lane + (size_t)o * FB;
+                        op[0] = pend[g][0];
+                        if ((o + 1) * (unsigned)L < a.S) op[FB] = pend[g][1];
+                    }
+                }
+            }
+            pend_chunk = -1;
+        }
+    };
+
     if (c_begin >= c_end) return;
+#if DSABF_STAGGER
+    if (wave >= kWavesPerWg / 2) __builtin_amdgcn_s_sleep(DSABF_STAGGER);
+#endif
 
     // ---- prologue ------------------------------------------------------------------------------------------
     load_chunk(c_begin);
@@ -239,8 +281,13 @@ __global__ __launch_bounds__(kWgThreads, (NKS <= 4 ? 4 : 2)) void fused_kernel(F
         char* nxt = smem + ((c - c_begin + 1) & 1) * (kRowsPerChunk * RB);
 
         // stage chunk c+1 (its global loads were issued one iteration ago) and issue the loads of chunk c+2
+#if DSABF_ABLATE != 4
         if (c + 1 < c_end) write_chunk(nxt);
+        flush_pending();
         if (c + 2 < c_end) load_chunk(c + 2);
+#else
+        flush_pending();
+#endif
 
         if (wave_active) {
 #pragma unroll
@@ -248,9 +295,17 @@ __global__ __launch_bounds__(kWgThreads, (NKS <= 4 ? 4 : 2)) void fused_kernel(F
                 // -- A fragments: 32 time rows x (16*NKS re | 16*NKS im) int8 --
                 v4i af[NKS];
 #pragma unroll
-                for (int ks = 0; ks < NKS; ks++)
+                for (int ks = 0; ks < NKS; ks++) {
+#if DSABF_ABLATE == 2
+                    af[ks] = v4i{aoff[ks], j, (int)c, ks};
+#else
                     af[ks] = *reinterpret_cast<const v4i*>(cur + j * 32 * RB + aoff[ks]);
+#endif
+                }
 
+#if DSABF_PRIO
+                __builtin_amdgcn_s_setprio(DSABF_PRIO);  // MFMA issue wins arbitration over other waves' detect VALU
+#endif
                 v16i are = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[0], bre[0], kc, 0, 0, 0);
                 v16i aim = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[0], bim[0], kc, 0, 0, 0);
 #pragma unroll
@@ -259,83 +314,90 @@ __global__ __launch_bounds__(kWgThreads, (NKS <= 4 ? 4 : 2)) void fused_kernel(F
                     aim = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[ks], bim[ks], aim, 0, 0, 0);
                 }
 
+#if DSABF_PRIO
+                __builtin_amdgcn_s_setprio(0);
+#endif
                 // -- epilogue ------------------------------------------------------------------------------
+                // Plain (unpacked) fp32 VALU on purpose: v_pk_* f32 ops do not co-execute with the MFMAs of the
+                // other waves on this SIMD (SQ_VALU_MFMA_COEXEC_CYCLES drops 7x, kernel +5 %); the build uses
+                // -fno-slp-vectorize so that the compiler does not re-pack these.
                 // NOTE: bit-cast the WHOLE vector; __builtin_bit_cast(float, vec[i]) is miscompiled by ROCm 7.2
                 // clang (it reads element 0 for every i).
                 const v16f fre = __builtin_bit_cast(v16f, are);
                 const v16f fim = __builtin_bit_cast(v16f, aim);
                 const unsigned tile = (unsigned)c * kTilesPerChunk + j;
 
-                v2f pp[8];  // detected power of (pair i, element e)
-                v2f xr[8], xi[8];
-#pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    const v2f mr = {fre[2 * i], fre[2 * i + 1]};
-                    const v2f mi = {fim[2 * i], fim[2 * i + 1]};
-                    xr[i] = __builtin_elementwise_fma(mr, alpha2, bias2);  // fl(n * alpha), exact single rounding
-                    xi[i] = __builtin_elementwise_fma(mi, alpha2, bias2);
-                    if constexpr (!WRITE_C) {
-                        const v2f xx = xr[i] * xr[i];
-                        const v2f yy = xi[i] * xi[i];
-                        pp[i] = xx + yy;  // two multiplies, one add (compiled with -ffp-contract=off)
-                    }
-                }
-
                 if constexpr (WRITE_C) {
                     // stage-parity path: store the scaled complex beam voltages c[f][t][b]{re,im} (one gemm-unit)
 #pragma unroll
-                    for (int i = 0; i < 8; i++) {
-#pragma unroll
-                        for (int e = 0; e < 2; e++) {
-                            unsigned s;
-                            bool ok;
-                            if constexpr (LONG) {
-                                const unsigned o = 4u * (tile / R) + 2u * hl + e;
-                                s = o * (unsigned)L + 8u * (tile % R) + i;
-                                ok = o * (unsigned)L < a.S;
-                            } else {
-                                s = (2u * tile + hl) * 16u + sample_in_half<NIPO>(i, e);
-                                ok = (2u * tile + hl) * 16u < a.S;
-                            }
-                            if (ok && beam < a.n_beams) {
-                                v2f cv = {xr[i][e], xi[i][e]};
-                                *reinterpret_cast<v2f*>(a.out + 2 * (((size_t)f * a.T + s) * a.n_beams + beam)) = cv;
-                            }
+                    for (int r = 0; r < 16; r++) {
+                        const int i = r >> 1, e = r & 1;
+                        unsigned s;
+                        bool ok;
+                        if constexpr (LONG) {
+                            const unsigned o = 4u * (tile / R) + 2u * hl + e;
+                            s = o * (unsigned)L + 8u * (tile % R) + i;
+                            ok = o * (unsigned)L < a.S;
+                        } else {
+                            s = (2u * tile + hl) * 16u + sample_in_half<NIPO>(i, e);
+                            ok = (2u * tile + hl) * 16u < a.S;
                         }
-                    }
-                } else if constexpr (LONG) {
-                    // two output streams per lane (e = 0, 1), 8 more samples each, sequential fp32 order
-                    const unsigned q = (R <= kTilesPerChunk) ? (unsigned)(j % R) : (tile % R);
-                    v2f s2 = (q == 0) ? pp[0] : (carry + pp[0]);
-#pragma unroll
-                    for (int i = 1; i < 8; i++) s2 = s2 + pp[i];
-                    // Pin the value here: otherwise the compiler sinks the whole detect under the store predicate,
-                    // hoists the MFMAs of the next tile above that branch and doubles the live accumulators.
-                    asm volatile("" : "+v"(s2));
-                    carry = s2;
-                    if (q == R - 1) {
-                        const unsigned o = 4u * (tile / R) + 2u * hl;
-                        if (o * (unsigned)L < a.S && beam < a.n_beams) {
-                            float* op = out_lane + (size_t)o * FB;
-                            op[0] = s2[0];
-                            if ((o + 1) * (unsigned)L < a.S) op[FB] = s2[1];
+                        if (ok && beam < a.n_beams) {
+                            v2f cv = {__builtin_fmaf(fre[r], kAlpha16, kNegMagicAlpha16),
+                                      __builtin_fmaf(fim[r], kAlpha16, kNegMagicAlpha16)};
+                            *reinterpret_cast<v2f*>(a.out + 2 * (((size_t)f * a.T + s) * a.n_beams + beam)) = cv;
                         }
                     }
                 } else {
-                    // 16/NIPO whole outputs per lane half: pair-packed sequential sums
-                    constexpr int OPR = 16 / NIPO;  // outputs per run (even)
-                    const unsigned hs = 2u * tile + hl;
-                    const bool valid = (hs * 16u < a.S) && (beam < a.n_beams);
-                    float* op = out_lane + ((size_t)hs * OPR) * FB;
+                    // detected power of accumulator register r: x = fl(n * alpha) by ONE fma (exact, see header),
+                    // then x*x + y*y as two multiplies and one add (no contraction)
+                    float p[16];
 #pragma unroll
-                    for (int m = 0; m < OPR / 2; m++) {
-                        v2f s2 = pp[m * NIPO];
+                    for (int r = 0; r < 16; r++) {
+#if DSABF_ABLATE == 5
+                        p[r] = fre[r] + fim[r];
+#else
+                        const float x = __builtin_fmaf(fre[r], kAlpha16, kNegMagicAlpha16);
+                        const float y = __builtin_fmaf(fim[r], kAlpha16, kNegMagicAlpha16);
+                        const float xx = x * x;
+                        const float yy = y * y;
+                        p[r] = xx + yy;
+#endif
+                    }
+                    if constexpr (LONG) {
+                        // two output streams per lane (registers 2i+e, e = 0, 1), 8 more samples each, summed in
+                        // the reference's sequential order (src/beamformer.cuh:150-152)
+                        const unsigned q = (R <= kTilesPerChunk) ? (unsigned)(j % R) : (tile % R);
+                        float s0 = (q == 0) ? p[0] : (carry[0] + p[0]);
+                        float s1 = (q == 0) ? p[1] : (carry[1] + p[1]);
 #pragma unroll
-                        for (int k = 1; k < NIPO; k++) s2 = s2 + pp[m * NIPO + k];
-                        asm volatile("" : "+v"(s2));
-                        if (valid) {
-                            op[(size_t)(2 * m) * FB] = s2[0];
-                            op[(size_t)(2 * m + 1) * FB] = s2[1];
+                        for (int i = 1; i < 8; i++) {
+                            s0 = s0 + p[2 * i];
+                            s1 = s1 + p[2 * i + 1];
+                        }
+                        // Pin the values here: otherwise the compiler sinks the whole detect under the store
+                        // predicate, hoists the MFMAs of the next tile above that branch and doubles the live
+                        // accumulators.
+                        asm volatile("" : "+v"(s0), "+v"(s1));
+                        carry = v2f{s0, s1};
+                        if (q == R - 1) {  // output pair complete: park it, flush_pending() stores it next chunk
+                            pend[R <= kTilesPerChunk ? j / R : 0] = carry;
+                            pend_chunk = c;
+                        }
+                    } else {
+                        // 16/NIPO whole outputs per lane half; output u = 2m+e lives in registers 2*(m*NIPO+k)+e
+                        constexpr int OPR = 16 / NIPO;  // outputs per run (even)
+                        const unsigned hs = 2u * tile + hl;
+                        const bool valid = (hs * 16u < a.S) && (beam < a.n_beams) && DSABF_ABLATE != 3;
+                        float* op = out_lane + ((size_t)hs * OPR) * FB;
+#pragma unroll
+                        for (int u = 0; u < OPR; u++) {
+                            const int m = u >> 1, e = u & 1;
+                            float sacc = p[2 * (m * NIPO) + e];
+#pragma unroll
+                            for (int k = 1; k < NIPO; k++) sacc = sacc + p[2 * (m * NIPO + k) + e];
+                            asm volatile("" : "+v"(sacc));
+                            if (valid) op[(size_t)u * FB] = sacc;
                         }
                     }
                 }
@@ -344,8 +406,11 @@ __global__ __launch_bounds__(kWgThreads, (NKS <= 4 ? 4 : 2)) void fused_kernel(F
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+#if DSABF_ABLATE != 1
         __syncthreads();
+#endif
     }
+    flush_pending();
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -499,8 +564,8 @@ LaunchShape fused_launch_shape(const Geometry& g, int n_units, int n_cus)
     ls.chunks_total = (int)((tiles + kTilesPerChunk - 1) / kTilesPerChunk);
     ls.chunks_total = (ls.chunks_total + cpg - 1) / cpg * cpg;
     const int base = g.n_freq * g.n_bgroups;
-    // aim for ~2 resident workgroups per CU, but never less than 1 chunk per workgroup
-    int want = (2 * n_cus + base - 1) / base;
+    // aim for ~16 resident waves per CU, but never less than 1 output group per workgroup
+    int want = ((16 / kWavesPerWg) * n_cus + base - 1) / base;
     if (want < 1) want = 1;
     if (want > ls.chunks_total / cpg) want = ls.chunks_total / cpg;
     ls.n_tsplit = want;
