@@ -150,46 +150,30 @@ def main():
     stream = torch.cuda.current_stream()
     sptr = stream.cuda_stream
 
-    # ---- gather plumbing (N > 1) -----------------------------------------------------------------------
-    gather_bufs, pending = None, [None, None]
+    # ---- gather plumbing (N > 1): dsabeamformer_amd/shard.py, covered by tests/test_shard_gloo.py ------------
     og = units * n_out
+    gather = None
     if world > 1 and args.gather != "none":
-        assert og % world == 0
-        if args.gather == "alltoall":
-            gather_bufs = [torch.empty(out_floats, dtype=torch.float32, device="cuda") for _ in range(2)]
-            full = [torch.empty((og // world, n_freq_total, cfg.n_beams), dtype=torch.float32, device="cuda")
-                    for _ in range(2)]
-        else:
-            gather_bufs = [[torch.empty(out_floats, dtype=torch.float32, device="cuda") for _ in range(world)]
-                           if rank == 0 else None for _ in range(2)]
+        from dsabeamformer_amd.shard import DetectedGather
 
-    def finish_gather(slot):
-        if pending[slot] is None:
-            return
-        pending[slot].wait()
-        if args.gather == "alltoall":
-            # [shard][o][f_local][b] -> reference layout [o][f][b] for the outputs this rank owns
-            src = gather_bufs[slot].view(world, og // world, n_freq, cfg.n_beams)
-            full[slot].view(og // world, world, n_freq, cfg.n_beams).copy_(src.permute(1, 0, 2, 3))
-        pending[slot] = None
+        gather = DetectedGather(torch, dist, args.gather, og, n_freq, cfg.n_beams, torch.device("cuda", local))
 
     def step(i, ev_pair=None):
         slot = i & 1
-        finish_gather(slot)  # the buffer about to be overwritten must have left
+        if gather is not None:
+            gather.finish(slot)  # the output buffer about to be overwritten must have left (and been re-laid out)
         if ev_pair:
             ev_pair[0].record(stream)
         bf.beamform(d_in[i % len(d_in)], units, d_out[slot], sptr)
         if ev_pair:
             ev_pair[1].record(stream)
-        if gather_bufs is not None:
-            if args.gather == "alltoall":
-                pending[slot] = dist.all_to_all_single(gather_bufs[slot], d_out[slot], async_op=True)
-            else:
-                pending[slot] = dist.gather(d_out[slot], gather_bufs[slot] if rank == 0 else None, dst=0, async_op=True)
+        if gather is not None:
+            gather.start(slot, d_out[slot])  # RCCL runs on its own stream, overlapping the next step's kernel
 
     def drain():
-        finish_gather(0)
-        finish_gather(1)
+        if gather is not None:
+            gather.finish(0)
+            gather.finish(1)
         torch.cuda.synchronize()
 
     for i in range(args.warmup):

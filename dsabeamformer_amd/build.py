@@ -22,15 +22,23 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
          "-I" + os.path.join(ROOT, "include")] + os.environ.get("DSABF_EXTRA_FLAGS", "").split()
 
 
+BEAM = os.path.join(PKG, "beam")                      # the `beam` CLI driver (reference: bin/beam)
+BEAM_SRC = os.path.join(CSRC, "beam_main.cpp")
+
+
 def sources() -> list[str]:
-    return sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.cpp")))
+    """Sources of libdsabf.so (everything under csrc/ except the CLI driver)."""
+    return sorted(p for p in glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.cpp"))
+                  if os.path.abspath(p) != os.path.abspath(BEAM_SRC))
 
 
 def _stale() -> bool:
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.hpp")) + \
+    if not os.path.exists(BEAM):
+        return True
+    deps = [BEAM_SRC] + sources() + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.hpp")) + \
         glob.glob(os.path.join(ROOT, "include", "*.h")) + [os.path.abspath(__file__)]
     return any(os.path.getmtime(p) > t for p in deps)
 
@@ -69,6 +77,12 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not os.path.exists(cxx):
         cxx = shutil.which("g++") or "g++"
     cmd = [cxx, "-shared", "-fPIC", "-o", LIB] + objs + ["-lpthread"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    # the CLI driver is an ordinary HIP application: it links libdsabf.so AND the HIP runtime
+    cmd = [HIPCC, "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "include"), BEAM_SRC, "-o", BEAM, "-L" + PKG, "-ldsabf",
+           "-Wl,-rpath,$ORIGIN"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -242,3 +242,43 @@ def test_error_paths_on_device(torch, bfmod, orc):
     bf.set_weights(w)
     bf.beamform(d, 1, o)
     torch.cuda.synchronize()
+
+
+def test_beam_cli_writes_reference_data_py(tmp_path, orc):
+    """The `beam` driver end to end = the reference's `make debug` run (src/beamformer.cu:12-621):
+    bin/beam -p linear_positions -d linear_directions -s linear_source_directions_1024 -> data.py.
+    The file must be byte-identical to the oracle's dedispersed table written by the reference's writer format."""
+    import subprocess
+
+    from conftest import CFG, ROOT
+
+    out = tmp_path / "data.py"
+    cmd = [os.path.join(ROOT, "dsabeamformer_amd", "beam"), "-g", "0", "-p", os.path.join(CFG, "linear_positions.txt"),
+           "-d", os.path.join(CFG, "linear_directions.txt"), "-s", os.path.join(CFG, "linear_source_directions_1024.txt"),
+           "-o", str(out)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "obs Complete" in r.stdout and "Time per data chunk" in r.stdout
+    assert "Code produced outputs for 8192 data chunks." in r.stdout  # 1024 sources x N_OUTPUTS_PER_GEMM
+    gold = np.load(os.path.join(GOLDEN, "linear_debug.npz"))["dedispersed"]
+    want = tmp_path / "want.py"
+    orc.write_python_file(gold, str(want))
+    assert out.read_text() == want.read_text()
+    ns = {}
+    exec(out.read_text(), ns)  # "written such that it can be imported into any python file" (beamformer.hh:291)
+    assert np.array_equal(np.array(ns["A"], np.float32), np.array(eval(want.read_text()[4:]), np.float32))
+
+
+def test_debug_observation_bogus_data(bfmod, orc):
+    """No -s file: the generator's buffer stays BOGUS_DATA 0x70 = (7 + 0j) everywhere (test_data_generator.hh:8,36),
+    n_pt_sources = 1024; every row of the dedispersed table is the same oracle-computable vector."""
+    from dsabeamformer_amd import host
+
+    cfg = bfmod.debug_config()
+    ded, ms = host.run_debug_observation(cfg, gpu=0)
+    assert ded.shape == (1024, 256) and ms > 0
+    g = orc.DEBUG_GEOM
+    w = orc.make_weights(g, orc.default_positions(64), orc.default_directions(256), 0)
+    unit = np.full((1, g.n_freq, g.n_time, g.n_ant), 0x70, np.uint8)
+    row = orc.dedisperse(g, orc.beamform(g, w, unit)[0])
+    assert np.array_equal(ded, np.broadcast_to(row, ded.shape))

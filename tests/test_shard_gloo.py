@@ -1,0 +1,79 @@
+"""world_size-2 CPU test (gloo) of the multi-GPU path: frequency sharding + the detected-power gather must
+reassemble exactly the single-device result (no arithmetic happens in the collective)."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+WORKER = r'''
+import os, sys
+sys.path.insert(0, os.environ["REPO_ROOT"])
+import numpy as np, torch, torch.distributed as dist
+import oracle as orc
+from dsabeamformer_amd import shard
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+g = orc.Geom(n_beams=32, n_ant=16, n_freq=8, n_avg=16, n_out_per_gemm=2)
+rng = np.random.default_rng(5)
+w = rng.integers(-127, 128, size=(g.n_freq, g.n_ant, g.n_beams, 2), dtype=np.int8)
+packed = rng.integers(0, 256, size=(4, g.n_freq, g.n_time, g.n_ant), dtype=np.uint8)
+full = orc.beamform(g, w, packed).reshape(-1, g.n_freq, g.n_beams)          # [og][F][B], the single-device answer
+# what THIS rank's GPU would compute: its frequency shard (the oracle stands in for the device in this CPU test)
+gl = orc.Geom(n_beams=g.n_beams, n_ant=g.n_ant, n_freq=g.n_freq // world, n_avg=g.n_avg, n_out_per_gemm=g.n_out_per_gemm)
+f0, f1 = shard.freq_range(rank, world, g.n_freq)
+lw = np.ascontiguousarray(shard.shard_weights(w, rank, world))
+lp = shard.shard_packed(packed, rank, world)
+assert lw.shape[0] == f1 - f0 and lp.shape == (4, f1 - f0, g.n_time, g.n_ant)
+local = torch.from_numpy(orc.beamform(gl, lw, lp).reshape(-1, gl.n_freq, g.n_beams))
+assert np.array_equal(local.numpy(), full[:, f0:f1])
+og = local.shape[0]
+for mode in ("alltoall", "root"):
+    gat = shard.DetectedGather(torch, dist, mode, og, gl.n_freq, g.n_beams, "cpu")
+    for it in range(3):                       # double-buffered reuse
+        slot = it & 1
+        gat.finish(slot)
+        gat.start(slot, local * (it + 1))
+    for slot, it in ((0, 2), (1, 1)):
+        res = gat.finish(slot)
+        if mode == "alltoall":
+            want = full[rank * og // world:(rank + 1) * og // world] * np.float32(it + 1)
+            assert res.shape == (og // world, g.n_freq, g.n_beams)
+            assert np.array_equal(res.numpy(), want), (mode, rank)
+        elif rank == 0:
+            assert np.array_equal(res.numpy(), full * np.float32(it + 1)), (mode, rank)
+        else:
+            assert res is None
+dist.barrier()
+dist.destroy_process_group()
+print("rank %d ok" % rank)
+'''
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_frequency_shard_and_gather_world2(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, REPO_ROOT=ROOT, OMP_NUM_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), str(script)]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert "rank 0 ok" in out.stdout and "rank 1 ok" in out.stdout
+
+
+def test_freq_range_rules():
+    from dsabeamformer_amd import shard
+
+    assert [shard.freq_range(r, 8, 256) for r in (0, 3, 7)] == [(0, 32), (96, 128), (224, 256)]
+    with pytest.raises(ValueError):
+        shard.freq_range(0, 3, 256)
