@@ -37,9 +37,10 @@ def parse():
     ap.add_argument("--warmup", type=int, default=25)  # mirrors BURNIN 25, src/beamformer.hh:45
     ap.add_argument("--units", type=int, default=32, help="gemm-units per step (one launch)")
     ap.add_argument("--nbuf", type=int, default=3, help="distinct input step-buffers cycled (defeats L2/MALL reuse)")
-    ap.add_argument("--workload", default="c3", choices=["c3", "prod", "c2"],
+    ap.add_argument("--workload", default="c3", choices=["c3", "prod", "c2", "c5"],
                     help="c3: N_TIME 512 (16 outputs x n_ipo 32); prod: reference production N_TIME 256; "
-                         "c2: DEBUG geometry N_TIME 16 (n_ipo 2, parity config; HBM-write bound)")
+                         "c2: DEBUG geometry N_TIME 16 (n_ipo 2, parity config; HBM-write bound); "
+                         "c5: DSA100 scale-up, 100 ant x 512 beams x 1024 freq, N_TIME 256 (use --units 4)")
     ap.add_argument("--gather", default="alltoall", choices=["alltoall", "root", "none"])
     ap.add_argument("--input", default="random", choices=["random", "zeros", "const"],
                     help="experiment only: voltage bit patterns (MFMA power depends on operand toggling)")
@@ -50,7 +51,7 @@ def parse():
 
 def geometry(workload):
     # (n_avg, n_out_per_gemm): n_ipo = 2*n_avg, N_TIME = n_out*n_ipo
-    return {"c3": (16, 16), "prod": (16, 8), "c2": (1, 8)}[workload]
+    return {"c3": (16, 16), "prod": (16, 8), "c2": (1, 8), "c5": (16, 8)}[workload]
 
 
 def product_weights(torch, cfg, f0):
@@ -61,6 +62,13 @@ def product_weights(torch, cfg, f0):
 
     from dsabeamformer_amd import host
 
+    if cfg.n_ant == 100:  # c5: 10x10 grid, 32x16 beam grid (notebook formulas)
+        ax = np.linspace(-250, 250, 10)
+        pos = np.zeros((100, 3), np.float32)
+        pos[:, 0], pos[:, 1] = [v.ravel() for v in np.meshgrid(ax, ax)]
+        th, ph = np.meshgrid(np.linspace(-3.5, 3.5, 32) * np.pi / 180, np.linspace(-3.5, 3.5, 16) * np.pi / 180)
+        dirs = np.stack([th.ravel(), ph.ravel()], 1).astype(np.float32)
+        return host.make_weights(pos, dirs, cfg.n_freq, chan0=f0, gpu=0)
     w = host.make_weights_default(n_beams=cfg.n_beams, n_ant=cfg.n_ant, n_freq_total=256, gpu=0)
     return np.ascontiguousarray(w[f0:f0 + cfg.n_freq])
 
@@ -128,10 +136,12 @@ def main():
     import dsabeamformer_amd as bfm
 
     n_avg, n_out = geometry(args.workload)
-    n_freq_total = 256
+    n_freq_total = 1024 if args.workload == "c5" else 256
     assert n_freq_total % world == 0
     n_freq = n_freq_total // world
     cfg = bfm.production_config(n_avg=n_avg, n_out_per_gemm=n_out, n_freq=n_freq)
+    if args.workload == "c5":
+        cfg.n_ant, cfg.n_beams = 100, 512
     n_ipo, n_time = cfg.n_pol * cfg.n_avg, n_out * cfg.n_pol * cfg.n_avg
     bf = bfm.Beamformer(cfg, device=local)
     bf.set_weights(product_weights(torch, cfg, rank * n_freq))
@@ -225,7 +235,8 @@ def main():
                              "committed PMC passes (profiles/r01_c3_pmc_summary.txt), null if this launch differs"})
         info = bf.kernel_info(units)
         out = {
-            "metric": "beam-blocks/sec (256 beams x 256 freq x N_TIME)", "value": value, "unit": "beam-blocks/s",
+            "metric": "beam-blocks/sec (%d beams x %d freq x N_TIME)" % (cfg.n_beams, n_freq_total), "value": value,
+            "unit": "beam-blocks/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "ms_per_block": elapsed / total_blocks * 1e3, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "int8 (int32 accumulate, fp32 detect)",
@@ -233,7 +244,9 @@ def main():
                     "weights of the linear 64-antenna / 256-beam DSA geometry" % len(d_in),
             "config": {"workload": {"c3": "C3: 64 ant x 2 pol, 256 freq, 256 beams, N_TIME=512 (16 outputs x n_ipo 32)",
                                     "prod": "reference production: N_TIME=256 (8 outputs x n_ipo 32)",
-                                    "c2": "C2 DEBUG geometry: N_TIME=16 (8 outputs x n_ipo 2)"}[args.workload],
+                                    "c2": "C2 DEBUG geometry: N_TIME=16 (8 outputs x n_ipo 2)",
+                                    "c5": "C5 DSA100 scale-up: 100 ant x 2 pol, 1024 freq, 512 beams, N_TIME=256; the "
+                                          "unit is a 512-beam x 1024-freq block"}[args.workload],
                        "gemm_units_per_step": units, "beam_blocks_per_step": blocks_per_step,
                        "freq_per_gpu": n_freq, "gather": args.gather if world > 1 else "n/a",
                        "launch": info},

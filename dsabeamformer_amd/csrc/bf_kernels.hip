@@ -31,8 +31,16 @@
 
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #ifndef DSABF_OCC
 #define DSABF_OCC 4   // waves per SIMD requested for NKS <= 4
+#endif
+#ifndef DSABF_STAGE_IN_SHADOW
+#define DSABF_STAGE_IN_SHADOW 1
+#endif
+#ifndef DSABF_FAST_ADDR
+#define DSABF_FAST_ADDR 1
 #endif
 #ifndef DSABF_STAGGER
 #define DSABF_STAGGER 0
@@ -113,9 +121,10 @@ __device__ __forceinline__ int swz(int chunk, int row)
     return RBC == 8 ? (chunk ^ (((row >> 1) & 7) ^ ((row & 1) << 2))) : (chunk ^ (row & 15));
 }
 
-template <int NKS, int NIPO, bool WRITE_C>
-__global__ __launch_bounds__(kWgThreads, (NKS <= 4 ? DSABF_OCC : 2)) void fused_kernel(FusedArgs a)
+template <int ANT, int NIPO, bool WRITE_C>
+__global__ __launch_bounds__(kWgThreads, ((ANT + 15) / 16 <= 4 ? DSABF_OCC : 2)) void fused_kernel(FusedArgs a)
 {
+    constexpr int NKS = (ANT + 15) / 16;                 // k-steps of 16 antennas (K' = 32 per step: re | im)
     constexpr int RBC = (NKS <= 4) ? 8 : 16;            // 16-byte chunks per LDS row
     constexpr int RB = RBC * 16;                         // LDS row bytes: [16*re of ant 0.. | 16*im of ant 0..]
     constexpr bool LONG = NIPO >= 16;                    // an output spans several tiles
@@ -123,9 +132,13 @@ __global__ __launch_bounds__(kWgThreads, (NKS <= 4 ? DSABF_OCC : 2)) void fused_
     constexpr int R = LONG ? L / 8 : 1;                  // tiles per output group
     constexpr int RUN = LONG ? 8 : 16;                   // contiguous samples per staging run
     constexpr int RUNS_PER_TILE = 32 / RUN;
-    constexpr int A = 16 * NKS;                          // packed bytes per time sample (= n_ant)
-    constexpr int PIECES = kRowsPerChunk * NKS;          // 16-byte packed pieces per chunk
+    constexpr int A = ANT;                               // packed bytes per time sample (= n_ant)
+    constexpr bool DW = (ANT % 16) != 0;                 // rows are only dword-aligned (e.g. 100 antennas)
+    constexpr int PW = DW ? 4 : 16;                      // staging piece width in bytes
+    constexpr int PPS = A / PW;                          // pieces per time sample
+    constexpr int PIECES = kRowsPerChunk * PPS;          // packed pieces per chunk
     constexpr int PPT = (PIECES + kWgThreads - 1) / kWgThreads;
+    static_assert(ANT % 4 == 0, "N_ANTENNAS must be divisible by 4 (src/beamformer.hh:156)");
     static_assert(R <= kTilesPerChunk ? (kTilesPerChunk % R == 0) : (R % kTilesPerChunk == 0), "bad NIPO");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 x 128 rows x RB
@@ -175,35 +188,63 @@ __global__ __launch_bounds__(kWgThreads, (NKS <= 4 ? DSABF_OCC : 2)) void fused_
     for (int i = 0; i < 16; i++) kc[i] = (int)kMagicBits;
     asm volatile("" : "+v"(kc));  // keep the seed in registers; do not rematerialise 16 v_mov per tile
 
-    // first global sample of run rr of chunk c (and whether it exists)
-    auto run_start = [&](int c, int rr, unsigned& s0) -> bool {
-        const unsigned tile = (unsigned)c * kTilesPerChunk + (unsigned)(rr / RUNS_PER_TILE);
-        if constexpr (LONG) {
-            const unsigned o = 4u * (tile / R) + (unsigned)(rr % RUNS_PER_TILE);  // output stream
-            s0 = o * (unsigned)L + 8u * (tile % R);
-            return o * (unsigned)L < a.S;
-        } else {
-            s0 = (2u * tile + (unsigned)(rr % RUNS_PER_TILE)) * 16u;
-            return s0 < a.S;
-        }
+    // ---- staging: global -> registers ------------------------------------------------------------------------
+    // First sample of run rr of chunk c is  chunk_base(c) + toff(rr)  with a chunk-uniform base and a per-thread
+    // constant offset (all six NIPO modes; derivation in DESIGN.md 3.1).  When a chunk never straddles two gemm-units
+    // (n_time % span == 0) the source address is  scalar base (SALU)  +  per-thread constant byte offset, so the
+    // steady-state loop spends no VALU on addressing.
+    constexpr int SPAN = (LONG && R > kTilesPerChunk) ? 32 * R : kRowsPerChunk;  // samples touched by one chunk
+    auto chunk_base = [&](int c) -> unsigned {
+        if constexpr (LONG && R > kTilesPerChunk)
+            return (unsigned)(c / CPG) * (4u * L) + (unsigned)(c % CPG) * 32u;
+        else
+            return (unsigned)c * kRowsPerChunk;
     };
-
-    // ---- staging helpers ---------------------------------------------------------------------------------
-    v4i stage[PPT];
-    auto load_chunk = [&](int c) {
+    unsigned toff[PPT];       // per-thread sample offset of its run inside the chunk
+    unsigned tbyte[PPT];      // per-thread byte offset inside the chunk's unit (fast path)
 #pragma unroll
-        for (int k = 0; k < PPT; k++) {
-            const int pc = tid + k * kWgThreads;
-            const int rr = pc / (RUN * NKS);   // run within chunk
-            const int pi = pc % (RUN * NKS);   // 16-byte piece within the run
-            unsigned s0;
-            const bool ok = run_start(c, rr, s0);
-            stage[k] = v4i{0, 0, 0, 0};
-            if (pc < PIECES && ok) {
-                const unsigned u = a.t_shift >= 0 ? (s0 >> a.t_shift) : (s0 / (unsigned)a.T);
-                const unsigned t = s0 - u * (unsigned)a.T;
-                const uint8_t* src = a.in + ((size_t)((size_t)u * a.n_freq + f) * a.T + t) * A + (size_t)pi * 16;
-                stage[k] = *reinterpret_cast<const v4i*>(src);
+    for (int k = 0; k < PPT; k++) {
+        const int pc = tid + k * kWgThreads;
+        const int rr = pc / (RUN * PPS), pi = pc % (RUN * PPS);
+        const int jt = rr / RUNS_PER_TILE, sidx = rr % RUNS_PER_TILE;
+        if constexpr (LONG) {
+            if constexpr (R > kTilesPerChunk)
+                toff[k] = (unsigned)(sidx * L + 8 * jt);
+            else
+                toff[k] = (unsigned)(((jt / R) * 4 + sidx) * L + 8 * (jt % R));
+        } else {
+            toff[k] = (unsigned)(32 * jt + 16 * sidx);
+        }
+        tbyte[k] = toff[k] * A + (unsigned)pi * PW;
+    }
+    const bool fast_addr = DSABF_FAST_ADDR && (a.T % SPAN) == 0;
+
+    typedef typename std::conditional<DW, int, v4i>::type piece_t;
+    piece_t stage[PPT];
+    auto load_chunk = [&](int c) {
+        const unsigned base = chunk_base(c);
+        if (fast_addr) {
+            const unsigned u = a.t_shift >= 0 ? (base >> a.t_shift) : (base / (unsigned)a.T);
+            const unsigned tb = base - u * (unsigned)a.T;
+            const uint8_t* cb = a.in + ((size_t)((size_t)u * a.n_freq + f) * a.T + tb) * A;  // wave-uniform
+#pragma unroll
+            for (int k = 0; k < PPT; k++) {
+                stage[k] = piece_t{};
+                if (tid + k * kWgThreads < PIECES && base + toff[k] < a.S)
+                    stage[k] = *reinterpret_cast<const piece_t*>(cb + tbyte[k]);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < PPT; k++) {
+                const unsigned s0 = base + toff[k];
+                stage[k] = piece_t{};
+                if (tid + k * kWgThreads < PIECES && s0 < a.S) {
+                    const unsigned u = a.t_shift >= 0 ? (s0 >> a.t_shift) : (s0 / (unsigned)a.T);
+                    const unsigned t = s0 - u * (unsigned)a.T;
+                    const int pi = (tid + k * kWgThreads) % (RUN * PPS);
+                    const uint8_t* src = a.in + ((size_t)((size_t)u * a.n_freq + f) * a.T + t) * A + (size_t)pi * PW;
+                    stage[k] = *reinterpret_cast<const piece_t*>(src);
+                }
             }
         }
     };
@@ -212,19 +253,30 @@ __global__ __launch_bounds__(kWgThreads, (NKS <= 4 ? DSABF_OCC : 2)) void fused_
         for (int k = 0; k < PPT; k++) {
             const int pc = tid + k * kWgThreads;
             if (pc < PIECES) {
-                const int rr = pc / (RUN * NKS);
-                const int pi = pc % (RUN * NKS);
-                const int row = rr * RUN + pi / NKS;
-                const int ks = pi % NKS;
-                v4i re, im;
+                const int rr = pc / (RUN * PPS);
+                const int pi = pc % (RUN * PPS);
+                const int row = rr * RUN + pi / PPS;
+                const int pp = pi % PPS;  // piece within the sample
+                if constexpr (DW) {
+                    // 4 antennas per piece: ks = antenna / 16, byte position inside that 16-byte chunk = antenna % 16.
+                    // Bytes of antennas >= ANT inside the last chunk are never written; they multiply zero weights.
+                    const int ks = (pp * 4) / 16, sub = (pp * 4) % 16;
+                    const unsigned w = (unsigned)stage[k];
+                    *reinterpret_cast<int*>(buf + row * RB + 16 * swz<RBC>(ks, row) + sub) = (int)(w & 0xF0F0F0F0u);
+                    *reinterpret_cast<int*>(buf + row * RB + 16 * swz<RBC>(RBC / 2 + ks, row) + sub) =
+                        (int)((w << 4) & 0xF0F0F0F0u);
+                } else {
+                    const int ks = pp;
+                    v4i re, im;
 #pragma unroll
-                for (int d = 0; d < 4; d++) {
-                    const unsigned w = (unsigned)stage[k][d];
-                    re[d] = (int)(w & 0xF0F0F0F0u);          // 16 * real nibble, as int8 x4
-                    im[d] = (int)((w << 4) & 0xF0F0F0F0u);   // 16 * imag nibble
+                    for (int d = 0; d < 4; d++) {
+                        const unsigned w = (unsigned)stage[k][d];
+                        re[d] = (int)(w & 0xF0F0F0F0u);          // 16 * real nibble, as int8 x4
+                        im[d] = (int)((w << 4) & 0xF0F0F0F0u);   // 16 * imag nibble
+                    }
+                    *reinterpret_cast<v4i*>(buf + row * RB + 16 * swz<RBC>(ks, row)) = re;
+                    *reinterpret_cast<v4i*>(buf + row * RB + 16 * swz<RBC>(RBC / 2 + ks, row)) = im;
                 }
-                *reinterpret_cast<v4i*>(buf + row * RB + 16 * swz<RBC>(ks, row)) = re;
-                *reinterpret_cast<v4i*>(buf + row * RB + 16 * swz<RBC>(RBC / 2 + ks, row)) = im;
             }
         }
     };
@@ -246,18 +298,20 @@ __global__ __launch_bounds__(kWgThreads, (NKS <= 4 ? DSABF_OCC : 2)) void fused_
     constexpr int PEND = LONG ? (R <= kTilesPerChunk ? kTilesPerChunk / R : 1) : 1;
     v2f pend[PEND];
     int pend_chunk = -1;  // chunk whose finished sums are in pend[]
+    const unsigned lane_out = (unsigned)(2 * hl) * (unsigned)FB + (unsigned)beam;  // lane part of the output index
     auto flush_pending = [&]() {
         if constexpr (LONG && !WRITE_C) {
             if (pend_chunk >= 0 && wave_active) {
 #pragma unroll
                 for (int g = 0; g < PEND; g++) {
-                    // last tile of output group g of that chunk
+                    // last tile of output group g of that chunk; ob = first of the group's 4 outputs (wave-uniform)
                     const unsigned tile = (unsigned)pend_chunk * kTilesPerChunk + (R <= kTilesPerChunk ? (g + 1) * R - 1 : kTilesPerChunk - 1);
-                    const unsigned o = 4u * (tile / R) + 2u * hl;
+                    const unsigned ob = 4u * (tile / R);
+                    float* ub = a.out + (size_t)ob * FB + (size_t)f * a.n_beams;  // scalar (SALU) part of the address
+                    const unsigned o = ob + 2u * hl;
                     if (o * (unsigned)L < a.S && beam < a.n_beams && DSABF_ABLATE != 3) {
-                        float* op = out_lane + (size_t)o * FB;
-                        op[0] = pend[g][0];
-                        if ((o + 1) * (unsigned)L < a.S) op[FB] = pend[g][1];
+                        ub[lane_out] = pend[g][0];
+                        if ((o + 1) * (unsigned)L < a.S) ub[lane_out + (unsigned)FB] = pend[g][1];
                     }
                 }
             }
@@ -281,13 +335,31 @@ __global__ __launch_bounds__(kWgThreads, (NKS <= 4 ? DSABF_OCC : 2)) void fused_
         char* nxt = smem + ((c - c_begin + 1) & 1) * (kRowsPerChunk * RB);
 
         // stage chunk c+1 (its global loads were issued one iteration ago) and issue the loads of chunk c+2
+        // Staging of chunk c+1 (its global loads were issued one chunk ago), the deferred stores of chunk c-1 and the
+        // prefetch of chunk c+2 are all independent of this chunk's MFMA results: they are issued right AFTER the
+        // MFMA clusters of tiles 0 and 1, i.e. in the shadow of this wave's own 256-cycle MFMA burst, instead of in
+        // a separate phase at the top of the chunk where the matrix pipe would idle.
+        auto stage_part0 = [&]() {
 #if DSABF_ABLATE != 4
-        if (c + 1 < c_end) write_chunk(nxt);
-        flush_pending();
-        if (c + 2 < c_end) load_chunk(c + 2);
-#else
-        flush_pending();
+            if (c + 1 < c_end) write_chunk(nxt);
 #endif
+        };
+        auto stage_part1 = [&]() {
+            flush_pending();
+#if DSABF_ABLATE != 4
+            if (c + 2 < c_end) load_chunk(c + 2);
+#endif
+        };
+#if !DSABF_STAGE_IN_SHADOW
+        stage_part0();
+        stage_part1();
+#endif
+        if (!wave_active) {
+#if DSABF_STAGE_IN_SHADOW
+            stage_part0();
+            stage_part1();
+#endif
+        }
 
         if (wave_active) {
 #pragma unroll
@@ -316,6 +388,13 @@ __global__ __launch_bounds__(kWgThreads, (NKS <= 4 ? DSABF_OCC : 2)) void fused_
 
 #if DSABF_PRIO
                 __builtin_amdgcn_s_setprio(0);
+#endif
+#if DSABF_STAGE_IN_SHADOW
+                if (j == 0 || j == 1) {
+                    __builtin_amdgcn_sched_barrier(0);  // MFMAs first, then the independent staging work
+                    if (j == 0) stage_part0(); else stage_part1();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
 #endif
                 // -- epilogue ------------------------------------------------------------------------------
                 // Plain (unpacked) fp32 VALU on purpose: v_pk_* f32 ops do not co-execute with the MFMAs of the
@@ -492,10 +571,10 @@ __global__ void dedisperse_kernel(const float* __restrict__ out_unit, float* __r
     ded[b] = acc;
 }
 
-template <int NKS, int NIPO, bool WRITE_C>
+template <int ANT, int NIPO, bool WRITE_C>
 hipError_t launch_fused_t(const FusedArgs& args, const LaunchShape& ls, hipStream_t s)
 {
-    auto kern = fused_kernel<NKS, NIPO, WRITE_C>;
+    auto kern = fused_kernel<ANT, NIPO, WRITE_C>;
     if (ls.lds_bytes > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            ls.lds_bytes);
@@ -513,15 +592,16 @@ int ilog2_exact(int v)
     return s;
 }
 
-// (NKS, NIPO) instantiation table.
+// (n_ant, n_ipo) instantiation table.
 #define DSABF_FOR_EACH_VARIANT(X) \
-    X(1, 2) X(1, 32) X(2, 2) X(2, 32) X(4, 2) X(4, 4) X(4, 8) X(4, 16) X(4, 32) X(4, 64) X(8, 2) X(8, 32)
+    X(16, 2) X(16, 32) X(32, 2) X(32, 32) X(64, 2) X(64, 4) X(64, 8) X(64, 16) X(64, 32) X(64, 64) X(100, 2) \
+    X(100, 32) X(128, 2) X(128, 32)
 
 template <bool WRITE_C>
 hipError_t dispatch_fused(const Geometry& g, const FusedArgs& args, const LaunchShape& ls, hipStream_t s)
 {
-#define X(nks_, nipo_) \
-    if (g.nks == nks_ && g.n_ipo == nipo_) return launch_fused_t<nks_, nipo_, WRITE_C>(args, ls, s);
+#define X(ant_, nipo_) \
+    if (g.n_ant == ant_ && g.n_ipo == nipo_) return launch_fused_t<ant_, nipo_, WRITE_C>(args, ls, s);
     DSABF_FOR_EACH_VARIANT(X)
 #undef X
     return hipErrorInvalidValue;
@@ -536,13 +616,13 @@ bool fused_supported(const Geometry& g, const char** why)
     const char* dummy;
     if (!why) why = &dummy;
     if (g.n_beams <= 0 || g.n_beams % 32) { *why = "n_beams must be a positive multiple of 32"; return false; }
-    if (g.n_ant != 16 * g.nks) { *why = "n_ant must be a multiple of 16 (16, 32, 64 or 128) in this build"; return false; }
+    if (g.n_ant % 4) { *why = "N_ANTENNAS must be divisible by 4"; return false; }
     if (g.n_ipo < 16 && g.n_time % 16) { *why = "n_out_per_gemm * n_pol * n_avg must be a multiple of 16"; return false; }
-#define X(nks_, nipo_) \
-    if (g.nks == nks_ && g.n_ipo == nipo_) return true;
+#define X(ant_, nipo_) \
+    if (g.n_ant == ant_ && g.n_ipo == nipo_) return true;
     DSABF_FOR_EACH_VARIANT(X)
 #undef X
-    *why = "no kernel instantiation for this (n_ant, n_pol*n_avg); supported: n_ant 16/32/64/128 with n_ipo 2/32, "
+    *why = "no kernel instantiation for this (n_ant, n_pol*n_avg); supported: n_ant 16/32/100/128 with n_ipo 2/32, "
            "n_ant 64 with n_ipo 2/4/8/16/32/64";
     return false;
 }
@@ -645,8 +725,8 @@ int fused_vgprs(const Geometry& g)
 {
     hipFuncAttributes attr{};
     const void* fn = nullptr;
-#define X(nks_, nipo_) \
-    if (g.nks == nks_ && g.n_ipo == nipo_) fn = reinterpret_cast<const void*>(fused_kernel<nks_, nipo_, false>);
+#define X(ant_, nipo_) \
+    if (g.n_ant == ant_ && g.n_ipo == nipo_) fn = reinterpret_cast<const void*>(fused_kernel<ant_, nipo_, false>);
     DSABF_FOR_EACH_VARIANT(X)
 #undef X
     if (!fn || hipFuncGetAttributes(&attr, fn) != hipSuccess) return -1;

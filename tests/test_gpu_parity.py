@@ -74,12 +74,36 @@ def test_fused_random_small_golden(torch, bfmod, orc, tag):
 
 @pytest.mark.parametrize("n_ant,n_avg,n_units", [(64, 1, 1), (64, 1, 3), (64, 16, 2), (64, 2, 2), (64, 4, 1),
                                                   (64, 8, 1), (64, 32, 1), (16, 1, 2), (32, 16, 1), (128, 1, 3),
-                                                  (128, 16, 2)])
+                                                  (128, 16, 2), (100, 1, 3), (100, 16, 2)])
 def test_fused_geometries_bit_exact(torch, bfmod, orc, n_ant, n_avg, n_units):
     g = orc.Geom(n_beams=96, n_ant=n_ant, n_freq=5, n_avg=n_avg, n_out_per_gemm=max(2, 16 // (2 * n_avg)))
     rng = np.random.default_rng(1000 + n_ant + n_avg)
     w = rng.integers(-127, 128, size=(g.n_freq, g.n_ant, g.n_beams, 2), dtype=np.int8)
     packed = rng.integers(0, 256, size=(n_units, g.n_freq, g.n_time, g.n_ant), dtype=np.uint8)
+    bf = bfmod.Beamformer(_cfg(bfmod, g))
+    bf.set_weights(w)
+    want = orc.beamform(g, w, packed)
+    got = _run(torch, bf, packed, want.size).reshape(want.shape)
+    assert np.array_equal(got, want)
+
+
+def test_dsa100_scale_up_shape_bit_exact(torch, bfmod, orc):
+    """BASELINE config 5 geometry on one frequency shard: 100 antennas (rows only dword aligned), 512 beams (two
+    beam groups per frequency), production n_ipo 32; 10x10 grid positions / 32x16 grid beams synthesised with the
+    notebook formulas (the shipped files are 64-antenna / 256-beam)."""
+    from dsabeamformer_amd import host
+
+    ax = np.linspace(-250, 250, 10)
+    pos = np.zeros((100, 3), np.float32)
+    pos[:, 0], pos[:, 1] = [v.ravel() for v in np.meshgrid(ax, ax)]
+    th, ph = np.meshgrid(np.linspace(-3.5, 3.5, 32) * np.pi / 180, np.linspace(-3.5, 3.5, 16) * np.pi / 180)
+    dirs = np.stack([th.ravel(), ph.ravel()], 1).astype(np.float32)
+    g = orc.Geom(n_beams=512, n_ant=100, n_freq=6, n_avg=16, n_out_per_gemm=8)
+    w = host.make_weights(pos, dirs, g.n_freq, chan0=128 * 3, gpu=0)  # shard of rank 3 of 8 of a 1024-channel band
+    assert np.array_equal(w, np.stack([orc.make_weights(orc.Geom(n_beams=512, n_ant=100, n_freq=128 * 3 + 6), pos, dirs, 0)[128 * 3 + i]
+                                       for i in range(6)]))
+    rng = np.random.default_rng(100)
+    packed = rng.integers(0, 256, size=(2, g.n_freq, g.n_time, g.n_ant), dtype=np.uint8)
     bf = bfmod.Beamformer(_cfg(bfmod, g))
     bf.set_weights(w)
     want = orc.beamform(g, w, packed)
