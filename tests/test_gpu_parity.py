@@ -306,3 +306,55 @@ def test_debug_observation_bogus_data(bfmod, orc):
     unit = np.full((1, g.n_freq, g.n_time, g.n_ant), 0x70, np.uint8)
     row = orc.dedisperse(g, orc.beamform(g, w, unit)[0])
     assert np.array_equal(ded, np.broadcast_to(row, ded.shape))
+
+
+def test_whole_reference_batch_in_one_launch(torch, bfmod, orc, linear_inputs, linear_weights):
+    """Maximum size of the reference's DEBUG flow: all 1024 gemm-units of one generator batch (256 MiB packed,
+    2 GiB of detected output) in ONE launch; every unit's dedispersed row must equal the golden data.py table,
+    and all 8 outputs of a unit must be identical (the reference's columns are)."""
+    from dsabeamformer_amd import host
+
+    pos, _, src = linear_inputs
+    g = orc.DEBUG_GEOM
+    gold = np.load(os.path.join(GOLDEN, "linear_debug.npz"))["dedispersed"]
+    cfg = bfmod.debug_config()
+    gen = host.TestDataGenerator(cfg)  # pinned 256 MiB, the product's own generator
+    gen.set_source_directions(src)
+    gen.generate_test_data(pos, 0)
+    bf = bfmod.Beamformer(cfg)
+    bf.set_weights(linear_weights)
+    d_in = torch.from_numpy(gen.data()).cuda()
+    n_units = 1024
+    d_out = torch.empty(n_units * g.out_per_gemm, dtype=torch.float32, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    bf.beamform(d_in, n_units, d_out, s)
+    d_ded = torch.empty((n_units, g.n_beams), dtype=torch.float32, device="cuda")
+    v = d_out.view(n_units, g.n_out_per_gemm, g.n_freq, g.n_beams)
+    for u in range(n_units):
+        bf.dedisperse(v[u], d_ded[u], s)
+    torch.cuda.synchronize()
+    assert np.array_equal(d_ded.cpu().numpy(), gold)
+    assert bool((v[:, 1:] == v[:, :1]).all())
+    gen.close()
+
+
+def test_edge_geometries_and_arguments(torch, bfmod, orc):
+    from dsabeamformer_amd._lib import DsabfError
+
+    # one 32-beam tile (7 of the 8 waves of a workgroup idle), one frequency, one gemm-unit
+    for n_avg, n_out in ((1, 8), (16, 1), (16, 3)):
+        g = orc.Geom(n_beams=32, n_ant=64, n_freq=1, n_avg=n_avg, n_out_per_gemm=n_out)
+        rng = np.random.default_rng(9)
+        w = rng.integers(-127, 128, size=(1, 64, 32, 2), dtype=np.int8)
+        packed = rng.integers(0, 256, size=(1, 1, g.n_time, 64), dtype=np.uint8)
+        bf = bfmod.Beamformer(_cfg(bfmod, g))
+        bf.set_weights(w)
+        want = orc.beamform(g, w, packed)
+        assert np.array_equal(_run(torch, bf, packed, want.size).reshape(want.shape), want)
+        d = torch.zeros(16, dtype=torch.uint8, device="cuda")
+        o = torch.zeros(16, dtype=torch.float32, device="cuda")
+        with pytest.raises(DsabfError) as e:
+            bf.beamform(d, 0, o)  # empty input is an error, not a silent no-op
+        assert e.value.code == -1
+        with pytest.raises(DsabfError):
+            bf.beamform(d[1:], 1, o)  # misaligned input pointer
