@@ -36,6 +36,21 @@
 #ifndef DSABF_OCC
 #define DSABF_OCC 4   // waves per SIMD requested for NKS <= 4
 #endif
+#ifndef DSABF_USE16
+#define DSABF_USE16 1     // 64-antenna geometries run fused16_kernel (v_mfma_i32_16x16x64_i8); 0 = 32x32x32 everywhere
+#endif
+#ifndef DSABF_OCC16
+#define DSABF_OCC16 3     // 147 VGPRs, no spills; 4 would spill 15 registers for no gain (the kernel is energy-bound)
+#endif
+#ifndef DSABF_FLUSH_TILE
+#define DSABF_FLUSH_TILE 1   // tile after whose MFMA cluster the deferred stores are issued (experiment: 3)
+#endif
+#ifndef DSABF_NT_STORE
+#define DSABF_NT_STORE 0
+#endif
+#ifndef DSABF_NT_LOAD
+#define DSABF_NT_LOAD 0
+#endif
 #ifndef DSABF_STAGE_IN_SHADOW
 #define DSABF_STAGE_IN_SHADOW 1
 #endif
@@ -58,6 +73,7 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v16f __attribute__((ext_vector_type(16)));
+typedef float v4f __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -230,8 +246,13 @@ __global__ __launch_bounds__(kWgThreads, ((ANT + 15) / 16 <= 4 ? DSABF_OCC : 2))
 #pragma unroll
             for (int k = 0; k < PPT; k++) {
                 stage[k] = piece_t{};
-                if (tid + k * kWgThreads < PIECES && base + toff[k] < a.S)
+                if (tid + k * kWgThreads < PIECES && base + toff[k] < a.S) {
+#if DSABF_NT_LOAD
+                    stage[k] = __builtin_nontemporal_load(reinterpret_cast<const piece_t*>(cb + tbyte[k]));
+#else
                     stage[k] = *reinterpret_cast<const piece_t*>(cb + tbyte[k]);
+#endif
+                }
             }
         } else {
 #pragma unroll
@@ -310,8 +331,13 @@ __global__ __launch_bounds__(kWgThreads, ((ANT + 15) / 16 <= 4 ? DSABF_OCC : 2))
                     float* ub = a.out + (size_t)ob * FB + (size_t)f * a.n_beams;  // scalar (SALU) part of the address
                     const unsigned o = ob + 2u * hl;
                     if (o * (unsigned)L < a.S && beam < a.n_beams && DSABF_ABLATE != 3) {
+#if DSABF_NT_STORE
+                        __builtin_nontemporal_store(pend[g][0], ub + lane_out);
+                        if ((o + 1) * (unsigned)L < a.S) __builtin_nontemporal_store(pend[g][1], ub + lane_out + (unsigned)FB);
+#else
                         ub[lane_out] = pend[g][0];
                         if ((o + 1) * (unsigned)L < a.S) ub[lane_out + (unsigned)FB] = pend[g][1];
+#endif
                     }
                 }
             }
@@ -345,7 +371,9 @@ __global__ __launch_bounds__(kWgThreads, ((ANT + 15) / 16 <= 4 ? DSABF_OCC : 2))
 #endif
         };
         auto stage_part1 = [&]() {
+#if DSABF_FLUSH_TILE == 1
             flush_pending();
+#endif
 #if DSABF_ABLATE != 4
             if (c + 2 < c_end) load_chunk(c + 2);
 #endif
@@ -393,6 +421,9 @@ __global__ __launch_bounds__(kWgThreads, ((ANT + 15) / 16 <= 4 ? DSABF_OCC : 2))
                 if (j == 0 || j == 1) {
                     __builtin_amdgcn_sched_barrier(0);  // MFMAs first, then the independent staging work
                     if (j == 0) stage_part0(); else stage_part1();
+                }
+                if (j == DSABF_FLUSH_TILE && DSABF_FLUSH_TILE != 1) {
+                    flush_pending();
                     __builtin_amdgcn_sched_barrier(0);
                 }
 #endif
@@ -571,6 +602,292 @@ __global__ void dedisperse_kernel(const float* __restrict__ out_unit, float* __r
     ded[b] = acc;
 }
 
+// =========================================================================================================
+// fused16_kernel -- the same fused stage built on v_mfma_i32_16x16x64_i8 (64-antenna geometries).
+//
+// Why a second shape: on random int8 operands the chip holds a higher clock on the 16x16x64 instruction than on
+// 32x32x32 (tools/ubench_shape.hip: 129-142 ns vs 149-157 ns per 262,144 MACs per SIMD) and the composite tile
+// (MFMA + LDS fragment reads + canonical detect) is 7 % faster (tools/ubench_tile16.hip).  The small 4-register
+// accumulator tile also lets one wave cover 64 beams with half the accumulator/seed registers, which halves the
+// LDS fragment traffic per MFMA, and the detect of one 16x16 tile interleaves with the MFMAs of the next in the
+// wave's own in-order stream.
+//
+// Mapping (K' = 128 = 64 re | 64 im, two k-steps of 64):
+//   A operand: 16 time rows; lane l supplies row l&15, bytes 16*(l>>4).. of the k-step (LDS chunk 4*s + (l>>4)).
+//   D tile   : lane (column c = l&15, group g = l>>4) holds rows 4g..4g+3 in 4 registers.  Row 4g+r of a tile is
+//              position 4*q + r of STREAM g, so every lane accumulates one output at a time, in time order, and a
+//              128-row chunk holds 4 streams x 32 positions (n_ipo >= 32) or 2 x 4 streams x 16 positions.
+//   A wave   : 4 column tiles = 64 beams; workgroup = 4 waves = 256 beams; chunk = 8 row tiles of 16.
+template <int NIPO>
+__device__ __forceinline__ int lds_row16(int t8, int rho)  // row of the chunk image read by A-row rho of tile t8
+{
+    if constexpr (NIPO >= 32)
+        return (rho >> 2) * 32 + 4 * t8 + (rho & 3);
+    else
+        return (t8 >> 2) * 64 + (rho >> 2) * 16 + 4 * (t8 & 3) + (rho & 3);
+}
+
+template <int NIPO>
+__device__ __forceinline__ int swz16(int chunk, int row)  // 8 chunks of 16 B per 128-B row; conflict-free both ways
+{
+    constexpr int LR = NIPO >= 32 ? 32 : 16;  // rows per stream in a chunk
+    return chunk ^ ((((row >> 1) & 1) | (((row / LR) & 3) << 1)) ^ ((row & 1) << 2));
+}
+
+constexpr int kWaves16 = 4;                  // waves per workgroup of fused16_kernel
+constexpr int kThreads16 = 64 * kWaves16;
+constexpr int kColTiles16 = 4;               // 16-beam column tiles per wave
+
+template <int NIPO, bool WRITE_C>
+__global__ __launch_bounds__(kThreads16, DSABF_OCC16) void fused16_kernel(FusedArgs a)
+{
+    constexpr int A = 64, RB = 128, NB = kColTiles16;
+    constexpr bool LONG = NIPO >= 16;
+    constexpr int L = LONG ? NIPO : 16;                  // samples per stream
+    constexpr int LR = NIPO >= 32 ? 32 : 16;             // stream rows held by one chunk
+    constexpr int CPG = L > 32 ? L / 32 : 1;             // chunks per group of 4 streams
+    constexpr int PPT = (kRowsPerChunk * 4) / kThreads16; // 16-byte pieces per thread per chunk (= 2)
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 x 128 rows x 128 B
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g4 = lane >> 4;   // lane group = stream within the tile / k-block of the operands
+    const int c16 = lane & 15;  // column within a 16-beam tile / A row
+
+    int bid = blockIdx.x;
+    const int f = bid % a.n_freq;
+    bid /= a.n_freq;
+    const int bg = bid % a.n_bgroups;
+    const int ts = bid / a.n_bgroups;
+    const int units_total = a.chunks_total / CPG;
+    const int c_begin = (int)(((long long)units_total * ts) / a.n_tsplit) * CPG;
+    const int c_end = (int)(((long long)units_total * (ts + 1)) / a.n_tsplit) * CPG;
+
+    const int ct0 = (bg * kWaves16 + wave) * NB;          // first 16-beam column tile of this wave
+    const int n_ctiles = a.n_btiles * 2;
+    const bool wave_active = ct0 < n_ctiles;
+    const int beam0 = ct0 * 16 + c16;                     // + 16*ct
+
+    // ---- weight fragments -> registers: [ct][rho][s] ---------------------------------------------------------
+    v4i bw[NB][2][2];
+#pragma unroll
+    for (int ct = 0; ct < NB; ct++)
+#pragma unroll
+        for (int rho = 0; rho < 2; rho++)
+#pragma unroll
+            for (int sk = 0; sk < 2; sk++) {
+                bw[ct][rho][sk] = v4i{0, 0, 0, 0};
+                if (ct0 + ct < n_ctiles)
+                    bw[ct][rho][sk] = a.wimg[((((size_t)f * n_ctiles + ct0 + ct) * 2 + rho) * 2 + sk) * 64 + lane];
+            }
+
+    v4i kc = {(int)kMagicBits, (int)kMagicBits, (int)kMagicBits, (int)kMagicBits};
+    asm volatile("" : "+v"(kc));
+
+    // ---- staging (the chunk's 128 samples are contiguous in time for n_ipo <= 32) ------------------------------
+    auto run_sample0 = [&](int c, int run) -> unsigned {   // first global sample of stream-run `run` of chunk c
+        if constexpr (NIPO >= 32)
+            return (4u * (unsigned)(c / CPG) + (unsigned)run) * (unsigned)L + 32u * (unsigned)(c % CPG);
+        else
+            return (unsigned)c * 128u + 16u * (unsigned)run;
+    };
+    v4i stage[PPT];
+    auto load_chunk = [&](int c) {
+#pragma unroll
+        for (int k = 0; k < PPT; k++) {
+            const int pc = tid + k * kThreads16;
+            const int row = pc >> 2, ks = pc & 3;
+            const unsigned s0 = run_sample0(c, row / LR) + (unsigned)(row % LR);
+            stage[k] = v4i{0, 0, 0, 0};
+            if (s0 < a.S) {
+                const unsigned u = a.t_shift >= 0 ? (s0 >> a.t_shift) : (s0 / (unsigned)a.T);
+                const unsigned t = s0 - u * (unsigned)a.T;
+                stage[k] = *reinterpret_cast<const v4i*>(a.in + ((size_t)((size_t)u * a.n_freq + f) * a.T + t) * A + ks * 16);
+            }
+        }
+    };
+    auto write_chunk = [&](char* buf) {
+#pragma unroll
+        for (int k = 0; k < PPT; k++) {
+            const int pc = tid + k * kThreads16;
+            const int row = pc >> 2, ks = pc & 3;
+            v4i re, im;
+#pragma unroll
+            for (int d = 0; d < 4; d++) {
+                const unsigned w = (unsigned)stage[k][d];
+                re[d] = (int)(w & 0xF0F0F0F0u);
+                im[d] = (int)((w << 4) & 0xF0F0F0F0u);
+            }
+            *reinterpret_cast<v4i*>(buf + row * RB + 16 * swz16<NIPO>(ks, row)) = re;
+            *reinterpret_cast<v4i*>(buf + row * RB + 16 * swz16<NIPO>(4 + ks, row)) = im;
+        }
+    };
+
+    const size_t FB = (size_t)a.n_freq * a.n_beams;
+    float sum[NB];                         // running sum of this lane's current output, per column tile
+#pragma unroll
+    for (int ct = 0; ct < NB; ct++) sum[ct] = 0.0f;
+    constexpr int PEND = LONG ? (L >= 32 ? 1 : 2) : 1;   // outputs completed per chunk per lane (LONG)
+    float pend[PEND][NB];
+    int pend_chunk = -1;
+    auto flush_pending = [&]() {
+        if constexpr (LONG && !WRITE_C) {
+            if (pend_chunk >= 0 && wave_active) {
+#pragma unroll
+                for (int gi = 0; gi < PEND; gi++) {
+                    const unsigned grp = (NIPO >= 32) ? (unsigned)(pend_chunk / CPG) : (2u * pend_chunk + gi);
+                    float* ub = a.out + ((size_t)(4u * grp) * FB + (size_t)f * a.n_beams);  // wave-uniform part
+                    const unsigned o = 4u * grp + (unsigned)g4;
+                    if (o * (unsigned)L < a.S) {
+#pragma unroll
+                        for (int ct = 0; ct < NB; ct++)
+                            if (beam0 + 16 * ct < a.n_beams) ub[(size_t)g4 * FB + beam0 + 16 * ct] = pend[gi][ct];
+                    }
+                }
+            }
+            pend_chunk = -1;
+        }
+    };
+
+    if (c_begin >= c_end) return;
+
+    load_chunk(c_begin);
+    write_chunk(smem);
+    if (c_begin + 1 < c_end) load_chunk(c_begin + 1);
+    __syncthreads();
+
+    for (int c = c_begin; c < c_end; c++) {
+        char* cur = smem + ((c - c_begin) & 1) * (kRowsPerChunk * RB);
+        char* nxt = smem + ((c - c_begin + 1) & 1) * (kRowsPerChunk * RB);
+        if (!wave_active) {
+            if (c + 1 < c_end) write_chunk(nxt);
+            if (c + 2 < c_end) load_chunk(c + 2);
+        } else {
+#pragma unroll
+            for (int t8 = 0; t8 < 8; t8++) {
+                const int row = lds_row16<NIPO>(t8, c16);
+                const v4i a0 = *reinterpret_cast<const v4i*>(cur + row * RB + 16 * swz16<NIPO>(g4, row));
+                const v4i a1 = *reinterpret_cast<const v4i*>(cur + row * RB + 16 * swz16<NIPO>(4 + g4, row));
+                // stream position of this tile's rows and whether it starts / ends an output
+                const int gi = (NIPO >= 32) ? 0 : (t8 >> 2);          // group inside the chunk (L = 16)
+                const int q4 = (NIPO >= 32) ? (32 * (c % CPG) + 4 * t8) : 4 * (t8 & 3);  // position of register 0
+                const unsigned grp = (NIPO >= 32) ? (unsigned)(c / CPG) : (2u * (unsigned)c + gi);
+                const unsigned o = 4u * grp + (unsigned)g4;           // this lane's stream (output index if LONG)
+#pragma unroll
+                for (int ct = 0; ct < NB; ct++) {
+                    v4i cr = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, bw[ct][0][0], kc, 0, 0, 0);
+                    v4i ci = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, bw[ct][1][0], kc, 0, 0, 0);
+                    cr = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, bw[ct][0][1], cr, 0, 0, 0);
+                    ci = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, bw[ct][1][1], ci, 0, 0, 0);
+                    const v4f fr = __builtin_bit_cast(v4f, cr);
+                    const v4f fi = __builtin_bit_cast(v4f, ci);
+                    const int beam = beam0 + 16 * ct;
+                    if constexpr (WRITE_C) {
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            const unsigned sidx = o * (unsigned)L + (unsigned)(q4 + r);
+                            if (o * (unsigned)L < a.S && beam < a.n_beams) {
+                                v2f cv = {__builtin_fmaf(fr[r], kAlpha16, kNegMagicAlpha16),
+                                          __builtin_fmaf(fi[r], kAlpha16, kNegMagicAlpha16)};
+                                *reinterpret_cast<v2f*>(a.out + 2 * (((size_t)f * a.T + sidx) * a.n_beams + beam)) = cv;
+                            }
+                        }
+                    } else {
+                        float p[4];
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            const float x = __builtin_fmaf(fr[r], kAlpha16, kNegMagicAlpha16);
+                            const float y = __builtin_fmaf(fi[r], kAlpha16, kNegMagicAlpha16);
+                            const float xx = x * x;
+                            const float yy = y * y;
+                            p[r] = xx + yy;
+                        }
+                        if constexpr (LONG) {
+                            float sacc = (q4 == 0) ? p[0] : (sum[ct] + p[0]);
+                            sacc = sacc + p[1];
+                            sacc = sacc + p[2];
+                            sacc = sacc + p[3];
+                            asm volatile("" : "+v"(sacc));
+                            sum[ct] = sacc;
+                            if (q4 + 4 == L) {
+                                pend[gi][ct] = sacc;
+                                pend_chunk = c;
+                            }
+                        } else {
+                            // 16-sample stream = 16/NIPO outputs; registers r hold positions q4 + r
+                            const bool valid = (o * 16u < a.S) && (beam < a.n_beams);
+                            float* op = a.out + ((size_t)o * (16 / NIPO)) * FB + (size_t)f * a.n_beams + beam;
+                            if constexpr (NIPO == 2) {
+                                const float o0 = p[0] + p[1], o1 = p[2] + p[3];
+                                if (valid) {
+                                    op[(size_t)(q4 / 2) * FB] = o0;
+                                    op[(size_t)(q4 / 2 + 1) * FB] = o1;
+                                }
+                            } else if constexpr (NIPO == 4) {
+                                float sacc = p[0] + p[1];
+                                sacc = sacc + p[2];
+                                sacc = sacc + p[3];
+                                if (valid) op[(size_t)(q4 / 4) * FB] = sacc;
+                            } else {  // NIPO == 8
+                                float sacc = (q4 % 8 == 0) ? p[0] : (sum[ct] + p[0]);
+                                sacc = sacc + p[1];
+                                sacc = sacc + p[2];
+                                sacc = sacc + p[3];
+                                asm volatile("" : "+v"(sacc));
+                                sum[ct] = sacc;
+                                if (q4 % 8 == 4 && valid) op[(size_t)(q4 / 8) * FB] = sacc;
+                            }
+                        }
+                    }
+                }
+                // staging work in the shadow of the MFMA stream (see fused_kernel)
+                if (t8 == 1 && c + 1 < c_end) write_chunk(nxt);
+                if (t8 == 3) {
+                    flush_pending();
+                    if (c + 2 < c_end) load_chunk(c + 2);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    flush_pending();
+}
+
+// 16x16x64 weight image: image[f][ct16][rho][s][lane] (16 bytes): lane = 16*kb + c; byte i multiplies LDS chunk
+// 4*s + kb of the A row = component s (0 = re, 1 = im) of antenna 16*kb + i, for output row rho of beam 16*ct16 + c.
+__global__ void weight_relayout16_kernel(const int8_t* __restrict__ w, v4i* __restrict__ image, int n_freq, int n_ant,
+                                         int n_beams, int* __restrict__ bad)
+{
+    const int n_ct = n_beams / 16;
+    const size_t total = (size_t)n_freq * n_ct * 2 * 2 * 64;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int lane = (int)(idx & 63);
+        size_t r = idx >> 6;
+        const int sk = (int)(r & 1);
+        r >>= 1;
+        const int rho = (int)(r & 1);
+        r >>= 1;
+        const int ct = (int)(r % n_ct);
+        const int f = (int)(r / n_ct);
+        const int kb = lane >> 4, b = ct * 16 + (lane & 15);
+        unsigned d[4] = {0, 0, 0, 0};
+        for (int i = 0; i < 16; i++) {
+            const int ant = kb * 16 + i;
+            int v = 0;
+            if (ant < n_ant && b < n_beams) {
+                const int8_t* e = w + 2 * (((size_t)f * n_ant + ant) * n_beams + b);
+                const int wr = e[0], wi = e[1];
+                if (wi == -128) *bad = 1;
+                v = (rho == 0) ? (sk == 0 ? wr : -wi) : (sk == 0 ? wi : wr);
+            }
+            d[i >> 2] |= ((unsigned)v & 0xFFu) << (8 * (i & 3));
+        }
+        image[idx] = v4i{(int)d[0], (int)d[1], (int)d[2], (int)d[3]};
+    }
+}
+
 template <int ANT, int NIPO, bool WRITE_C>
 hipError_t launch_fused_t(const FusedArgs& args, const LaunchShape& ls, hipStream_t s)
 {
@@ -582,6 +899,19 @@ hipError_t launch_fused_t(const FusedArgs& args, const LaunchShape& ls, hipStrea
     }
     hipLaunchKernelGGL(kern, dim3(ls.grid), dim3(ls.block), ls.lds_bytes, s, args);
     return hipGetLastError();
+}
+
+template <int NIPO, bool WRITE_C>
+hipError_t launch_fused16_t(const FusedArgs& args, const LaunchShape& ls, hipStream_t s)
+{
+    hipLaunchKernelGGL((fused16_kernel<NIPO, WRITE_C>), dim3(ls.grid), dim3(ls.block), ls.lds_bytes, s, args);
+    return hipGetLastError();
+}
+
+bool use16(const Geometry& g)
+{
+    return DSABF_USE16 && g.n_ant == 64 &&
+           (g.n_ipo == 2 || g.n_ipo == 4 || g.n_ipo == 8 || g.n_ipo == 16 || g.n_ipo == 32 || g.n_ipo == 64);
 }
 
 int ilog2_exact(int v)
@@ -600,6 +930,16 @@ int ilog2_exact(int v)
 template <bool WRITE_C>
 hipError_t dispatch_fused(const Geometry& g, const FusedArgs& args, const LaunchShape& ls, hipStream_t s)
 {
+    if (use16(g)) {
+        switch (g.n_ipo) {
+            case 2: return launch_fused16_t<2, WRITE_C>(args, ls, s);
+            case 4: return launch_fused16_t<4, WRITE_C>(args, ls, s);
+            case 8: return launch_fused16_t<8, WRITE_C>(args, ls, s);
+            case 16: return launch_fused16_t<16, WRITE_C>(args, ls, s);
+            case 32: return launch_fused16_t<32, WRITE_C>(args, ls, s);
+            case 64: return launch_fused16_t<64, WRITE_C>(args, ls, s);
+        }
+    }
 #define X(ant_, nipo_) \
     if (g.n_ant == ant_ && g.n_ipo == nipo_) return launch_fused_t<ant_, nipo_, WRITE_C>(args, ls, s);
     DSABF_FOR_EACH_VARIANT(X)
@@ -644,15 +984,19 @@ LaunchShape fused_launch_shape(const Geometry& g, int n_units, int n_cus)
     ls.chunks_total = (int)((tiles + kTilesPerChunk - 1) / kTilesPerChunk);
     ls.chunks_total = (ls.chunks_total + cpg - 1) / cpg * cpg;
     const int base = g.n_freq * g.n_bgroups;
+    const int waves_per_wg = use16(g) ? kWaves16 : kWavesPerWg;
     // aim for ~16 resident waves per CU, but never less than 1 output group per workgroup
-    int want = ((16 / kWavesPerWg) * n_cus + base - 1) / base;
+    int want = ((16 / waves_per_wg) * n_cus + base - 1) / base;
     if (want < 1) want = 1;
     if (want > ls.chunks_total / cpg) want = ls.chunks_total / cpg;
     ls.n_tsplit = want;
     ls.grid = base * ls.n_tsplit;
-    ls.block = kWgThreads;
+    ls.block = use16(g) ? kThreads16 : kWgThreads;
     const int rbc = g.nks <= 4 ? 8 : 16;
     ls.lds_bytes = 2 * kRowsPerChunk * rbc * 16;
+#ifdef DSABF_LDS_PAD
+    ls.lds_bytes += DSABF_LDS_PAD;  // perf experiment: limit residency to one workgroup per CU
+#endif
     return ls;
 }
 
@@ -698,6 +1042,11 @@ hipError_t launch_weight_relayout(const Geometry& g, const int8_t* d_w, void* d_
     const size_t total = weight_image_bytes(g) / 16;
     int grid = (int)((total + 255) / 256);
     if (grid > 4096) grid = 4096;
+    if (use16(g)) {
+        hipLaunchKernelGGL(weight_relayout16_kernel, dim3(grid), dim3(256), 0, s, d_w, static_cast<v4i*>(d_image), g.n_freq,
+                           g.n_ant, g.n_beams, d_bad);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(weight_relayout_kernel, dim3(grid), dim3(256), 0, s, d_w, static_cast<v4i*>(d_image), g.n_freq,
                        g.n_ant, g.n_beams, g.n_btiles, g.nks, d_bad);
     return hipGetLastError();
@@ -725,6 +1074,18 @@ int fused_vgprs(const Geometry& g)
 {
     hipFuncAttributes attr{};
     const void* fn = nullptr;
+    if (use16(g)) {
+        switch (g.n_ipo) {
+            case 2: fn = reinterpret_cast<const void*>(fused16_kernel<2, false>); break;
+            case 4: fn = reinterpret_cast<const void*>(fused16_kernel<4, false>); break;
+            case 8: fn = reinterpret_cast<const void*>(fused16_kernel<8, false>); break;
+            case 16: fn = reinterpret_cast<const void*>(fused16_kernel<16, false>); break;
+            case 32: fn = reinterpret_cast<const void*>(fused16_kernel<32, false>); break;
+            case 64: fn = reinterpret_cast<const void*>(fused16_kernel<64, false>); break;
+        }
+        if (!fn || hipFuncGetAttributes(&attr, fn) != hipSuccess) return -1;
+        return attr.numRegs;
+    }
 #define X(ant_, nipo_) \
     if (g.n_ant == ant_ && g.n_ipo == nipo_) fn = reinterpret_cast<const void*>(fused_kernel<ant_, nipo_, false>);
     DSABF_FOR_EACH_VARIANT(X)
