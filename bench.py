@@ -227,13 +227,13 @@ def main():
             achieved = launch_bytes / (kern_avg_ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": None}
-        roof.update({"kernel": "dsabf::fused_kernel<NKS=%d,NIPO=%d>" % (cfg.n_ant // 16, n_ipo),
+        info = bf.kernel_info(units)
+        roof.update({"kernel": info["kernel"],
                      "kernel_ms_avg": kern_avg_ms, "kernel_ms_median": kern_ms[len(kern_ms) // 2],
                      "kernel_ms_min": kern_ms[0], "algorithmic_ops_per_launch": launch_ops,
                      "algorithmic_bytes_per_launch": launch_bytes,
                      "note": "unit is int8 TOP/s (1 complex MAC = 8 ops); traffic = HBM bytes per launch from the "
                              "committed PMC passes (profiles/r01_c3_pmc_summary.txt), null if this launch differs"})
-        info = bf.kernel_info(units)
         out = {
             "metric": "beam-blocks/sec (%d beams x %d freq x N_TIME)" % (cfg.n_beams, n_freq_total), "value": value,
             "unit": "beam-blocks/s",

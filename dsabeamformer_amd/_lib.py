@@ -63,6 +63,7 @@ SIGNATURES = {
     "bf_dedisperse_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bf_kernel_info": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
                                  C.POINTER(C.c_int)]),
+    "bf_kernel_name": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t]),
     # ---- include/dsabf_host.h ----
     "bfh_default_positions": (C.c_int, [C.c_int, C.c_void_p]),
     "bfh_default_directions": (C.c_int, [C.c_int, C.c_void_p]),

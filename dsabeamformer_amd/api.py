@@ -120,7 +120,10 @@ class Beamformer:
     def kernel_info(self, n_units: int = 1) -> dict:
         g, b, l, v = C.c_int(), C.c_int(), C.c_int(), C.c_int()
         check(self._lib.bf_kernel_info(self._h, n_units, C.byref(g), C.byref(b), C.byref(l), C.byref(v)))
-        return {"grid": g.value, "block": b.value, "lds_bytes": l.value, "vgprs": v.value}
+        name = C.create_string_buffer(160)
+        check(self._lib.bf_kernel_name(self._h, name, 160))
+        return {"kernel": name.value.decode(), "grid": g.value, "block": b.value, "lds_bytes": l.value,
+                "vgprs": v.value}
 
     def close(self) -> None:
         if self._h:

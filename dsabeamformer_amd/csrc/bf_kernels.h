@@ -51,5 +51,6 @@ hipError_t launch_expand(const void* d_in, size_t nbytes, void* d_out, hipStream
 hipError_t launch_dedisperse(const Geometry& g, const float* d_out_unit, float* d_ded, hipStream_t s);
 
 int fused_vgprs(const Geometry& g);  // from hipFuncGetAttributes, for reports
+const char* fused_kernel_name(const Geometry& g, char* buf, size_t n);
 
 }  // namespace dsabf

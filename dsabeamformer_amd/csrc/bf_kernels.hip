@@ -31,6 +31,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
+#include <cstdlib>
 #include <type_traits>
 
 #ifndef DSABF_OCC
@@ -96,6 +98,30 @@ struct FusedArgs {
     int chunks_total;                // ceil(tiles / 4)
     int n_tsplit;                    // workgroups along time
 };
+
+// blockIdx -> (frequency f, beam group bg, time split ts).  Workgroups are dealt round-robin over the 8 XCDs, each
+// with its own L2, so blocks b and b+8 share an L2: the low 3 bits of the block index select f % 8 (a frequency
+// always lands on the same XCD), and the beam groups / time splits of one frequency are the NEXT-fastest index, so
+// every workgroup that needs a frequency's 64-KiB weight panel (and, across beam groups, the same voltages) is
+// resident at the same time on the same XCD: the panel is fetched once instead of once per time split
+// (FETCH_SIZE 373 MB -> measured in profiles/).  Placement is only a speed matter; any mapping is correct.
+__device__ __forceinline__ void decode_block(const FusedArgs& a, int& f, int& bg, int& ts)
+{
+    int bid = blockIdx.x;
+    if ((a.n_freq & 7) == 0) {
+        const int lo = bid & 7;
+        bid >>= 3;
+        bg = bid % a.n_bgroups;
+        bid /= a.n_bgroups;
+        ts = bid % a.n_tsplit;
+        f = (bid / a.n_tsplit) * 8 + lo;
+    } else {
+        f = bid % a.n_freq;
+        bid /= a.n_freq;
+        bg = bid % a.n_bgroups;
+        ts = bid / a.n_bgroups;
+    }
+}
 
 // ---- time-sample <-> MFMA-row mapping ------------------------------------------------------------------------
 // v_mfma_*_32x32: lane (column c = lane&31, half h = lane>>5) holds D rows (reg&3) + 8*(reg>>2) + 4*h in
@@ -165,13 +191,8 @@ __global__ __launch_bounds__(kWgThreads, ((ANT + 15) / 16 <= 4 ? DSABF_OCC : 2))
     const int hl = lane >> 5;   // lane half
     const int lc = lane & 31;   // MFMA column (beam within tile) / MFMA row for the A operand
 
-    // blockIdx -> (f, beam group, time split); f fastest so that workgroups b and b+8 (same XCD under the
-    // round-robin dispatch) share weight panels of the same frequencies in that XCD's L2.
-    int bid = blockIdx.x;
-    const int f = bid % a.n_freq;
-    bid /= a.n_freq;
-    const int bg = bid % a.n_bgroups;
-    const int ts = bid / a.n_bgroups;
+    int f, bg, ts;
+    decode_block(a, f, bg, ts);
     // split in units of whole output groups (R tiles; a chunk is 4 tiles)
     constexpr int CPG = R > kTilesPerChunk ? R / kTilesPerChunk : 1;  // chunks per group
     const int units_total = a.chunks_total / CPG;
@@ -656,11 +677,8 @@ __global__ __launch_bounds__(kThreads16, DSABF_OCC16) void fused16_kernel(FusedA
     const int g4 = lane >> 4;   // lane group = stream within the tile / k-block of the operands
     const int c16 = lane & 15;  // column within a 16-beam tile / A row
 
-    int bid = blockIdx.x;
-    const int f = bid % a.n_freq;
-    bid /= a.n_freq;
-    const int bg = bid % a.n_bgroups;
-    const int ts = bid / a.n_bgroups;
+    int f, bg, ts;
+    decode_block(a, f, bg, ts);
     const int units_total = a.chunks_total / CPG;
     const int c_begin = (int)(((long long)units_total * ts) / a.n_tsplit) * CPG;
     const int c_end = (int)(((long long)units_total * (ts + 1)) / a.n_tsplit) * CPG;
@@ -985,8 +1003,13 @@ LaunchShape fused_launch_shape(const Geometry& g, int n_units, int n_cus)
     ls.chunks_total = (ls.chunks_total + cpg - 1) / cpg * cpg;
     const int base = g.n_freq * g.n_bgroups;
     const int waves_per_wg = use16(g) ? kWaves16 : kWavesPerWg;
-    // aim for ~16 resident waves per CU, but never less than 1 output group per workgroup
-    int want = ((16 / waves_per_wg) * n_cus + base - 1) / base;
+    // Workgroups per CU to aim for: 2x the resident count (measured best: finer time splits balance the tail;
+    // profiles/r01_variants_log.txt), but at least 2 chunks per workgroup so the weight-fragment load amortises.
+    const int target_wgs_per_cu = 2 * (16 / waves_per_wg);
+    int want = (target_wgs_per_cu * n_cus + base - 1) / base;
+    const int max_split = ls.chunks_total / cpg >= 2 ? ls.chunks_total / cpg / 2 : 1;
+    if (want > max_split) want = max_split;
+    if (const char* e = getenv("DSABF_TSPLIT")) want = atoi(e);  // perf experiments only
     if (want < 1) want = 1;
     if (want > ls.chunks_total / cpg) want = ls.chunks_total / cpg;
     ls.n_tsplit = want;
@@ -1068,6 +1091,15 @@ hipError_t launch_dedisperse(const Geometry& g, const float* d_out_unit, float* 
     hipLaunchKernelGGL(dedisperse_kernel, dim3((g.n_beams + 63) / 64), dim3(64), 0, s, d_out_unit, d_ded, g.n_freq,
                        g.n_beams);
     return hipGetLastError();
+}
+
+const char* fused_kernel_name(const Geometry& g, char* buf, size_t n)
+{
+    if (use16(g))
+        snprintf(buf, n, "dsabf::fused16_kernel<NIPO=%d> (v_mfma_i32_16x16x64_i8)", g.n_ipo);
+    else
+        snprintf(buf, n, "dsabf::fused_kernel<ANT=%d,NIPO=%d> (v_mfma_i32_32x32x32_i8)", g.n_ant, g.n_ipo);
+    return buf;
 }
 
 int fused_vgprs(const Geometry& g)

@@ -485,4 +485,11 @@ int bf_kernel_info(const bf_handle* h, int n_units, int* grid, int* block, int* 
     return BF_OK;
 }
 
+int bf_kernel_name(const bf_handle* h, char* buf, size_t buflen)
+{
+    if (!h || !buf || !buflen) return fail(BF_ERR_INVALID, "NULL argument");
+    dsabf::fused_kernel_name(h->geom, buf, buflen);
+    return BF_OK;
+}
+
 }  // extern "C"

@@ -153,6 +153,7 @@ int bf_dedisperse_device(bf_handle *h, const float *d_out_unit, float *d_ded, vo
 
 /* Introspection for benchmarks/roofline reports. */
 int bf_kernel_info(const bf_handle *h, int n_units, int *grid, int *block, int *lds_bytes, int *vgprs);
+int bf_kernel_name(const bf_handle *h, char *buf, size_t buflen); /* which fused kernel this geometry runs */
 
 #ifdef __cplusplus
 }

@@ -20,7 +20,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(out + "/pass*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        if "fused_kernel" not in k and "expand_kernel" not in k: continue
+        if "fused" not in k and "expand_kernel" not in k: continue
         agg[k.split("(")[0][-60:]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 with open(out + "/summary.txt", "w") as fp:
     for k, d in agg.items():
