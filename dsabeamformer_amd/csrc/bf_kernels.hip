@@ -44,27 +44,6 @@
 #ifndef DSABF_OCC16
 #define DSABF_OCC16 3     // 147 VGPRs, no spills; 4 would spill 15 registers for no gain (the kernel is energy-bound)
 #endif
-#ifndef DSABF_FLUSH_TILE
-#define DSABF_FLUSH_TILE 1   // tile after whose MFMA cluster the deferred stores are issued (experiment: 3)
-#endif
-#ifndef DSABF_NT_STORE
-#define DSABF_NT_STORE 0
-#endif
-#ifndef DSABF_NT_LOAD
-#define DSABF_NT_LOAD 0
-#endif
-#ifndef DSABF_STAGE_IN_SHADOW
-#define DSABF_STAGE_IN_SHADOW 1
-#endif
-#ifndef DSABF_FAST_ADDR
-#define DSABF_FAST_ADDR 1
-#endif
-#ifndef DSABF_STAGGER
-#define DSABF_STAGGER 0
-#endif
-#ifndef DSABF_PRIO
-#define DSABF_PRIO 0
-#endif
 #ifndef DSABF_ABLATE
 #define DSABF_ABLATE 0  // perf experiments only (tools/ablate.sh): 1 no loop barrier, 2 no LDS fragment reads,
 #endif                  // 3 no stores, 4 no staging in the loop, 5 no detect VALU.  0 = product.
@@ -254,7 +233,7 @@ __global__ __launch_bounds__(kWgThreads, ((ANT + 15) / 16 <= 4 ? DSABF_OCC : 2))
         }
         tbyte[k] = toff[k] * A + (unsigned)pi * PW;
     }
-    const bool fast_addr = DSABF_FAST_ADDR && (a.T % SPAN) == 0;
+    const bool fast_addr = (a.T % SPAN) == 0;
 
     typedef typename std::conditional<DW, int, v4i>::type piece_t;
     piece_t stage[PPT];
@@ -267,13 +246,8 @@ __global__ __launch_bounds__(kWgThreads, ((ANT + 15) / 16 <= 4 ? DSABF_OCC : 2))
 #pragma unroll
             for (int k = 0; k < PPT; k++) {
                 stage[k] = piece_t{};
-                if (tid + k * kWgThreads < PIECES && base + toff[k] < a.S) {
-#if DSABF_NT_LOAD
-                    stage[k] = __builtin_nontemporal_load(reinterpret_cast<const piece_t*>(cb + tbyte[k]));
-#else
+                if (tid + k * kWgThreads < PIECES && base + toff[k] < a.S)
                     stage[k] = *reinterpret_cast<const piece_t*>(cb + tbyte[k]);
-#endif
-                }
             }
         } else {
 #pragma unroll
@@ -352,13 +326,8 @@ __global__ __launch_bounds__(kWgThreads, ((ANT + 15) / 16 <= 4 ? DSABF_OCC : 2))
                     float* ub = a.out + (size_t)ob * FB + (size_t)f * a.n_beams;  // scalar (SALU) part of the address
                     const unsigned o = ob + 2u * hl;
                     if (o * (unsigned)L < a.S && beam < a.n_beams && DSABF_ABLATE != 3) {
-#if DSABF_NT_STORE
-                        __builtin_nontemporal_store(pend[g][0], ub + lane_out);
-                        if ((o + 1) * (unsigned)L < a.S) __builtin_nontemporal_store(pend[g][1], ub + lane_out + (unsigned)FB);
-#else
                         ub[lane_out] = pend[g][0];
                         if ((o + 1) * (unsigned)L < a.S) ub[lane_out + (unsigned)FB] = pend[g][1];
-#endif
                     }
                 }
             }
@@ -367,9 +336,6 @@ __global__ __launch_bounds__(kWgThreads, ((ANT + 15) / 16 <= 4 ? DSABF_OCC : 2))
     };
 
     if (c_begin >= c_end) return;
-#if DSABF_STAGGER
-    if (wave >= kWavesPerWg / 2) __builtin_amdgcn_s_sleep(DSABF_STAGGER);
-#endif
 
     // ---- prologue ------------------------------------------------------------------------------------------
     load_chunk(c_begin);
@@ -392,22 +358,14 @@ __global__ __launch_bounds__(kWgThreads, ((ANT + 15) / 16 <= 4 ? DSABF_OCC : 2))
 #endif
         };
         auto stage_part1 = [&]() {
-#if DSABF_FLUSH_TILE == 1
             flush_pending();
-#endif
 #if DSABF_ABLATE != 4
             if (c + 2 < c_end) load_chunk(c + 2);
 #endif
         };
-#if !DSABF_STAGE_IN_SHADOW
-        stage_part0();
-        stage_part1();
-#endif
         if (!wave_active) {
-#if DSABF_STAGE_IN_SHADOW
             stage_part0();
             stage_part1();
-#endif
         }
 
         if (wave_active) {
@@ -424,9 +382,6 @@ __global__ __launch_bounds__(kWgThreads, ((ANT + 15) / 16 <= 4 ? DSABF_OCC : 2))
 #endif
                 }
 
-#if DSABF_PRIO
-                __builtin_amdgcn_s_setprio(DSABF_PRIO);  // MFMA issue wins arbitration over other waves' detect VALU
-#endif
                 v16i are = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[0], bre[0], kc, 0, 0, 0);
                 v16i aim = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[0], bim[0], kc, 0, 0, 0);
 #pragma unroll
@@ -435,19 +390,11 @@ __global__ __launch_bounds__(kWgThreads, ((ANT + 15) / 16 <= 4 ? DSABF_OCC : 2))
                     aim = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[ks], bim[ks], aim, 0, 0, 0);
                 }
 
-#if DSABF_PRIO
-                __builtin_amdgcn_s_setprio(0);
-#endif
-#if DSABF_STAGE_IN_SHADOW
                 if (j == 0 || j == 1) {
                     __builtin_amdgcn_sched_barrier(0);  // MFMAs first, then the independent staging work
                     if (j == 0) stage_part0(); else stage_part1();
-                }
-                if (j == DSABF_FLUSH_TILE && DSABF_FLUSH_TILE != 1) {
-                    flush_pending();
                     __builtin_amdgcn_sched_barrier(0);
                 }
-#endif
                 // -- epilogue ------------------------------------------------------------------------------
                 // Plain (unpacked) fp32 VALU on purpose: v_pk_* f32 ops do not co-execute with the MFMAs of the
                 // other waves on this SIMD (SQ_VALU_MFMA_COEXEC_CYCLES drops 7x, kernel +5 %); the build uses
@@ -1009,7 +956,6 @@ LaunchShape fused_launch_shape(const Geometry& g, int n_units, int n_cus)
     int want = (target_wgs_per_cu * n_cus + base - 1) / base;
     const int max_split = ls.chunks_total / cpg >= 2 ? ls.chunks_total / cpg / 2 : 1;
     if (want > max_split) want = max_split;
-    if (const char* e = getenv("DSABF_TSPLIT")) want = atoi(e);  // perf experiments only
     if (want < 1) want = 1;
     if (want > ls.chunks_total / cpg) want = ls.chunks_total / cpg;
     ls.n_tsplit = want;
@@ -1017,9 +963,6 @@ LaunchShape fused_launch_shape(const Geometry& g, int n_units, int n_cus)
     ls.block = use16(g) ? kThreads16 : kWgThreads;
     const int rbc = g.nks <= 4 ? 8 : 16;
     ls.lds_bytes = 2 * kRowsPerChunk * rbc * 16;
-#ifdef DSABF_LDS_PAD
-    ls.lds_bytes += DSABF_LDS_PAD;  // perf experiment: limit residency to one workgroup per CU
-#endif
     return ls;
 }
 
