@@ -103,6 +103,8 @@ SIGNATURES = {
     "bfh_obs_get_next_gpu_transfer_block": (C.c_uint64, [C.c_void_p]),
     "bfh_obs_describe": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t]),
     "bfh_obs_fake_complete": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "bfh_run_observation_junk": (C.c_int, [C.POINTER(BfConfig), C.c_uint64, C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_int,
+                                           C.c_int, C.POINTER(C.c_float), C.c_void_p, C.c_void_p, C.c_void_p]),
     "bfh_run_debug_observation": (C.c_int, [C.POINTER(BfConfig), C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p,
                                             C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_int),
                                             C.POINTER(C.c_float)]),

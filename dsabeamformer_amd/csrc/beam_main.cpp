@@ -2,6 +2,8 @@
 // 539-571; usage() src/beamformer.hh:222-243) on top of libdsabf.so.
 //
 //   beam [-g gpu] [-p position_file] [-d direction_file] [-s source_file] [-o data.py] [-D device] [-a n_avg] [-v] [-h]
+//   beam -j n_blocks [-g gpu] [-p ...] [-d ...]     production geometry, observation loop fed by the in-memory
+//                                                   dada_junkdb stand-in (soak / data-rate run, makefile:28-29)
 //
 // With the reference's `make debug` geometry (default) it generates synthetic point-source voltages on the CPU,
 // streams them through the observation loop and writes bin/data.py (dedispersed beam responses, one row per source)
@@ -26,9 +28,10 @@ int main(int argc, char* argv[])
     debug_run_options opt;
     std::string positions, directions, sources, output = "bin/data.py";
     bool dada_requested = false;
+    long junk_blocks = -1;
 
     int arg = 0;
-    while ((arg = getopt(argc, argv, "s:g:p:d:o:D:a:c:k:vh")) != -1) {  // src/beamformer.cu:41-43 (+ -o -D -a -v)
+    while ((arg = getopt(argc, argv, "s:g:p:d:o:D:a:c:k:j:vh")) != -1) {  // src/beamformer.cu:41-43 (+ -o -D -a -v)
         switch (arg) {
             case 's': sources = optarg; break;                 // :77-89
             case 'g': opt.gpu = atoi(optarg); break;           // :92-100
@@ -37,6 +40,7 @@ int main(int argc, char* argv[])
             case 'o': output = optarg; break;
             case 'D': opt.device = atoi(optarg); break;
             case 'a': cfg.n_avg = atoi(optarg); break;
+            case 'j': junk_blocks = atol(optarg); break;
             case 'v': opt.verbose = true; cfg.verbose = 1; break;
             case 'c':
             case 'k': dada_requested = true; break;            // :59-75
@@ -60,6 +64,35 @@ int main(int argc, char* argv[])
     }
     char name[256];
     if (bf_device_name(opt.device, name, sizeof name) == BF_OK) std::cout << "Selected: " << name << std::endl;
+
+    if (junk_blocks >= 0) {  // observation (production) mode: N_AVERAGING 16, blocks from the junk source
+        bf_config pcfg;
+        bf_config_default(&pcfg, /*debug=*/0);
+        pcfg.verbose = cfg.verbose;
+        std::vector<antenna> pos((size_t)pcfg.n_ant);
+        std::vector<beam_direction> dir((size_t)pcfg.n_beams);
+        if (!opt.positions || read_in_position_locations(opt.positions, pcfg.n_ant, pos.data()) != 0)
+            default_positions(pcfg.n_ant, pos.data());
+        if (!opt.directions || read_in_beam_directions(opt.directions, pcfg.n_beams, dir.data()) != 0)
+            default_directions(pcfg.n_beams, dir.data());
+        junk_block_source src(pcfg, (uint64_t)junk_blocks);
+        if (!src.ok()) {
+            fprintf(stderr, "beam: could not allocate the junk ring\n");
+            return EXIT_FAILURE;
+        }
+        observation_options oopt;
+        oopt.gpu = opt.gpu;
+        oopt.device = opt.device;
+        oopt.verbose = opt.verbose;
+        oopt.burn_in = kBurnIn;
+        observation_result ores;
+        int orc = run_observation(pcfg, oopt, src, pos.data(), dir.data(), &ores, std::cout);
+        if (orc != BF_OK) {
+            fprintf(stderr, "GPUassert: %s (%d)\n", bf_last_error(), orc);
+            return EXIT_FAILURE;
+        }
+        return 0;
+    }
 
     debug_run_result res;
     int rc = run_debug_observation(cfg, opt, &res, nullptr, std::cout);

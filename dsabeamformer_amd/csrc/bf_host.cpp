@@ -666,6 +666,169 @@ int run_debug_observation(const bf_config& cfg, const debug_run_options& opt, de
     return BF_OK;
 }
 
+// ---- junk_block_source -------------------------------------------------------------------------------------------
+junk_block_source::junk_block_source(const bf_config& c, uint64_t nb, int rb, uint64_t seed)
+    : cfg(c), block_size(bf_bytes_per_block(&c)), n_blocks(nb), ring_blocks(rb < 1 ? 1 : rb)
+{
+    const size_t total = (size_t)block_size * ring_blocks;
+    void* p = nullptr;
+    if (bf_alloc_pinned(&p, total) == BF_OK) {  // dada_cuda_dbregister pins the shm blocks, src/dada_handler.hh:127-177
+        pinned = true;
+    } else {
+        p = ::malloc(total);
+    }
+    ring = static_cast<char*>(p);
+    if (!ring) return;
+    // every byte value (all 16 nibble codes in both halves), distinct blocks: 64-bit xorshift* per 8 bytes
+    parallel_for((long)ring_blocks * 64, [&](long lo, long hi) {
+        for (long part = lo; part < hi; part++) {
+            const size_t n8 = total / 8 / ((size_t)ring_blocks * 64);
+            uint64_t x = seed * 0x9E3779B97F4A7C15ULL + (uint64_t)(part + 1) * 0xBF58476D1CE4E5B9ULL;
+            uint64_t* q = reinterpret_cast<uint64_t*>(ring) + (size_t)part * n8;
+            for (size_t i = 0; i < n8; i++) {
+                x ^= x >> 12;
+                x ^= x << 25;
+                x ^= x >> 27;
+                q[i] = x * 0x2545F4914F6CDD1DULL;
+            }
+        }
+    });
+}
+
+junk_block_source::~junk_block_source()
+{
+    if (!ring) return;
+    if (pinned)
+        bf_free_pinned(ring);
+    else
+        ::free(ring);
+}
+
+char* junk_block_source::read()
+{
+    if (served < n_blocks) {
+        bytes_read = block_size;
+        return ring + (size_t)(served++ % (uint64_t)ring_blocks) * block_size;
+    }
+    bytes_read = 0;  // short block: end of data
+    return ring;
+}
+
+bool junk_block_source::check_transfers_complete() { return bytes_read < block_size; }  // src/dada_handler.hh:105-113
+
+// ---- production observation loop (src/beamformer.cu:364-534, #ifndef DEBUG branches) -------------------------------------
+int run_observation(const bf_config& cfg, const observation_options& opt, block_source& source, const antenna* pos,
+                    const beam_direction* dir, observation_result* res, std::ostream& log)
+{
+    const int n_streams = cfg.n_streams;
+    if (cfg.n_gemms_per_block % n_streams) return BF_ERR_INVALID;
+    bf_handle* h = nullptr;
+    int rc = bf_create(&cfg, opt.device, &h);
+    if (rc != BF_OK) {
+        log << "GPUassert: " << bf_last_error() << std::endl;
+        return rc;
+    }
+    struct guard {
+        bf_handle* h;
+        void* pinned;
+        ~guard()
+        {
+            if (h) bf_stream_sync(h, -1);
+            bf_free_pinned(pinned);
+            bf_destroy(h);
+        }
+    } g{h, nullptr};
+
+    const size_t n_f_per_detect = bf_floats_per_detect(&cfg);
+    if ((rc = bf_alloc_pinned(&g.pinned, n_f_per_detect * n_streams * sizeof(float))) != BF_OK) return rc;  // :249
+    float* beam_out = static_cast<float*>(g.pinned);
+    ::memset(beam_out, 0, n_f_per_detect * n_streams * sizeof(float));
+    {
+        std::vector<int8_t> fourier_coefficients((size_t)cfg.n_freq * cfg.n_ant * cfg.n_beams * 2);
+        generate_fourier_coefficients(cfg.n_beams, cfg.n_ant, cfg.n_freq, 0, opt.gpu, pos, dir, fourier_coefficients.data());
+        if ((rc = bf_set_weights(h, fourier_coefficients.data())) != BF_OK) return rc;
+    }
+    std::vector<int> timeSlice((size_t)n_streams);
+    for (int i = 0; i < n_streams; i++) timeSlice[i] = i;  // :319
+    std::vector<long long> last_gemm((size_t)n_streams, -1);
+
+    hip_backend backend(h);
+    observation_loop_state obs_state(kMaxTransferSep, kMaxTotalSep, cfg, &backend, /*debug_mode=*/false);  // :322
+    source.read_headers();  // :334
+    if (opt.burn_in > 0) {  // :348-355
+        log << "Burning IN" << std::endl;
+        for (int i = 0; i < opt.burn_in; i++) {
+            source.read();
+            source.close();
+        }
+        log << "Done Burn in" << std::endl;
+    }
+    const size_t block_bytes = bf_bytes_per_block(&cfg);
+    if (source.get_block_size() != block_bytes)
+        log << "ERROR: block size " << source.get_block_size() << ", Should also be " << block_bytes << std::endl;
+
+    bf_timer_start(h);  // :358
+    while (!obs_state.check_observations_complete()) {  // :364
+        if (opt.verbose) {
+            log << "##########################################" << std::endl;
+            log << obs_state << std::endl;
+        }
+        if (obs_state.check_ready_for_transfer()) {  // :378
+            char* block = source.read();             // :384
+            if (!source.check_transfers_complete()) {  // :386
+                rc = bf_submit_block(h, (int)obs_state.get_next_gpu_transfer_block(), block, block_bytes, nullptr);  // :389-393
+                if (rc != BF_OK) {
+                    log << "GPUassert: " << bf_last_error() << std::endl;
+                    return rc;
+                }
+                obs_state.generate_transfer_event();  // :396
+            } else {
+                obs_state.set_transfers_complete(true);  // :398
+            }
+            source.close();  // :401
+        }
+        obs_state.check_transfer_events();  // :446
+        if (obs_state.check_ready_for_analysis()) {  // :452
+            const long long block_index = (long long)obs_state.get_blocks_analysis_queue();
+            for (int part = 0; part < cfg.n_gemms_per_block / n_streams; part++) {
+                for (int st = 0; st < n_streams; st++) {
+                    rc = bf_enqueue_gemm_unit(h, st, (int)obs_state.get_next_gpu_analysis_block(), timeSlice[st],
+                                              &beam_out[(size_t)st * n_f_per_detect]);  // :464-488
+                    if (rc != BF_OK) {
+                        log << "GPUassert: " << bf_last_error() << std::endl;
+                        return rc;
+                    }
+                    last_gemm[st] = block_index * cfg.n_gemms_per_block + timeSlice[st];
+                    timeSlice[st] += n_streams;  // :515-519
+                    if (timeSlice[st] >= cfg.n_gemms_per_block) timeSlice[st] -= cfg.n_gemms_per_block;
+                }
+            }
+            obs_state.generate_analysis_event();  // :525
+        }
+        obs_state.check_analysis_events();  // :532
+    }
+    float ms = 0;
+    bf_timer_stop(h, &ms);
+    bf_stream_sync(h, -1);  // :560-562
+    const uint64_t blocks = obs_state.get_blocks_analyzed();
+    const uint64_t chunks = obs_state.get_current_transfer_gemm() * cfg.n_out_per_gemm;  // :552
+    const double rate = (double)source.get_block_size() * obs_state.get_blocks_transfer_queue() / ms / 1e6;  // :554
+    log << "Observation ran in " << ms << "milliseconds.\n";
+    log << "Code produced outputs for " << chunks << " data chunks.\n";
+    log << "Time per data chunk: " << ms / (chunks ? chunks : 1) << " milliseconds.\n";
+    log << "Approximate datarate: " << rate << "GB/s" << std::endl;
+    log << "Synchronized" << std::endl;
+    if (res) {
+        res->observation_time_ms = ms;
+        res->blocks = blocks;
+        res->data_chunks = chunks;
+        res->gbytes_per_s = rate;
+        res->beam_out.assign(beam_out, beam_out + n_f_per_detect * n_streams);
+        res->last_gemm = last_gemm;
+    }
+    return BF_OK;
+}
+
 }  // namespace dsabf
 
 // ======================================== C wrappers (include/dsabf_host.h) =========================================
@@ -919,6 +1082,36 @@ int bfh_run_debug_observation(const bf_config* cfg, int gpu, const char* positio
         if (ded.size() > ded_capacity) return BF_ERR_INVALID;
         std::memcpy(ded_out, ded.data(), ded.size() * sizeof(float));
     }
+    return BF_OK;
+}
+
+int bfh_run_observation_junk(const bf_config* cfg, uint64_t n_blocks, int ring_blocks, uint64_t seed, int gpu, int device,
+                             int burn_in, int verbose, float* observation_ms, float* beam_out, long long* last_gemm,
+                             void* ring_copy)
+{
+    if (!cfg) return BF_ERR_INVALID;
+    junk_block_source src(*cfg, n_blocks, ring_blocks, seed);
+    if (!src.ok()) return BF_ERR_DEVICE;
+    std::vector<antenna> pos((size_t)cfg->n_ant);
+    std::vector<beam_direction> dir((size_t)cfg->n_beams);
+    default_positions(cfg->n_ant, pos.data());
+    default_directions(cfg->n_beams, dir.data());
+    observation_options opt;
+    opt.gpu = gpu;
+    opt.device = device;
+    opt.burn_in = burn_in;
+    opt.verbose = verbose != 0;
+    observation_result res;
+    std::ostringstream quiet;
+    std::streambuf* keep = std::cout.rdbuf();
+    if (!verbose) std::cout.rdbuf(quiet.rdbuf());  // "obs Complete" etc.
+    int rc = run_observation(*cfg, opt, src, pos.data(), dir.data(), &res, verbose ? static_cast<std::ostream&>(std::cout) : quiet);
+    std::cout.rdbuf(keep);
+    if (rc != BF_OK) return rc;
+    if (observation_ms) *observation_ms = res.observation_time_ms;
+    if (beam_out) std::memcpy(beam_out, res.beam_out.data(), res.beam_out.size() * sizeof(float));
+    if (last_gemm) std::memcpy(last_gemm, res.last_gemm.data(), res.last_gemm.size() * sizeof(long long));
+    if (ring_copy) std::memcpy(ring_copy, src.ring_data(), (size_t)src.get_block_size() * src.get_ring_blocks());
     return BF_OK;
 }
 

@@ -205,3 +205,19 @@ def run_debug_observation(cfg: BfConfig, gpu: int = 0, positions: str | None = N
     check(load().bfh_run_debug_observation(C.byref(cfg), gpu, enc(positions), enc(directions), enc(sources), enc(output),
                                            device, 1 if verbose else 0, _p(ded), ded.size, C.byref(n), C.byref(ms)))
     return ded[:n.value].copy(), ms.value
+
+
+def run_observation_junk(cfg: BfConfig, n_blocks: int, ring_blocks: int = 4, seed: int = 0xD5A, gpu: int = 0,
+                         device: int = 0, burn_in: int = 0, verbose: bool = False):
+    """The reference's production observation loop fed by the in-memory dada_junkdb stand-in.
+    Returns dict(ms, beam_out [n_streams][n_out][n_freq][n_beams], last_gemm [n_streams], ring uint8
+    [ring_blocks][n_gemms_per_block][n_freq][n_time][n_ant])."""
+    lib = load()
+    n_time = cfg.n_out_per_gemm * cfg.n_pol * cfg.n_avg
+    beam_out = np.zeros((cfg.n_streams, cfg.n_out_per_gemm, cfg.n_freq, cfg.n_beams), np.float32)
+    last = np.zeros(cfg.n_streams, np.int64)
+    ring = np.zeros((ring_blocks, cfg.n_gemms_per_block, cfg.n_freq, n_time, cfg.n_ant), np.uint8)
+    ms = C.c_float()
+    check(lib.bfh_run_observation_junk(C.byref(cfg), n_blocks, ring_blocks, seed, gpu, device, burn_in,
+                                       1 if verbose else 0, C.byref(ms), _p(beam_out), _p(last), _p(ring)))
+    return {"ms": ms.value, "beam_out": beam_out, "last_gemm": last, "ring": ring}

@@ -70,6 +70,15 @@ int bfh_run_debug_observation(const bf_config *cfg, int gpu, const char *positio
                               const char *sources, const char *output, int device, int verbose, float *ded_out,
                               size_t ded_capacity, int *n_pt_sources, float *observation_ms);
 
+/* Production observation loop (src/beamformer.cu:364-534 without -DDEBUG) fed by the in-memory dada_junkdb stand-in:
+ * n_blocks pseudo-random PSRDADA-sized blocks from a pinned ring of ring_blocks distinct blocks, default linear
+ * geometry (src/beamformer.cu:135-147).  Outputs: elapsed ms; beam_out [n_streams][N_F_PER_DETECT] floats (final
+ * contents of the reference's beam_out); last_gemm[n_streams] = global gemm-unit index behind each stream's slot;
+ * ring_copy (optional, ring_blocks * block bytes) receives the ring so a caller can recompute any block. */
+int bfh_run_observation_junk(const bf_config *cfg, uint64_t n_blocks, int ring_blocks, uint64_t seed, int gpu, int device,
+                             int burn_in, int verbose, float *observation_ms, float *beam_out, long long *last_gemm,
+                             void *ring_copy);
+
 #ifdef __cplusplus
 }
 #endif

@@ -195,4 +195,60 @@ struct debug_run_result {
 int run_debug_observation(const bf_config& cfg, const debug_run_options& opt, debug_run_result* res,
                           std::vector<float>* dedispersed_out, std::ostream& log);
 
+// ---- observation (production) mode: src/beamformer.cu:364-534 without -DDEBUG ------------------------------------
+// The surface of dada_handler that the observation loop uses (src/dada_handler.hh:15-23).  The real PSRDADA
+// implementation needs libpsrdada (not in this build); anything that hands out pinned blocks
+// can stand behind this interface.
+struct block_source {
+    virtual ~block_source() {}
+    virtual void read_headers() {}                 // src/dada_handler.hh:66-90
+    virtual char* read() = 0;                      // :92-94  next block (the reference blocks on the shm semaphore)
+    virtual void close() = 0;                      // :96-98
+    virtual bool check_transfers_complete() = 0;   // :100-116 short block => the observation ends
+    virtual uint64_t get_block_size() const = 0;
+    virtual uint64_t get_bytes_read() const = 0;
+};
+
+// In-memory stand-in for `dada_junkdb` (makefile:28-29, README.md:173): a pinned ring of distinct pseudo-random
+// blocks, served n_blocks times, then one short (empty) block.
+class junk_block_source : public block_source {
+    bf_config cfg;
+    uint64_t block_size, bytes_read = 0, served = 0, n_blocks;
+    int ring_blocks;
+    char* ring = nullptr;
+    bool pinned = false;
+
+public:
+    junk_block_source(const bf_config& cfg, uint64_t n_blocks, int ring_blocks = 4, uint64_t seed = 0xD5A);
+    ~junk_block_source() override;
+    junk_block_source(const junk_block_source&) = delete;
+    junk_block_source& operator=(const junk_block_source&) = delete;
+    char* read() override;
+    void close() override {}
+    bool check_transfers_complete() override;
+    uint64_t get_block_size() const override { return block_size; }
+    uint64_t get_bytes_read() const override { return bytes_read; }
+    const char* ring_data() const { return ring; }           // tests: the bytes block i was served from are
+    int get_ring_blocks() const { return ring_blocks; }      // ring_data() + (i % ring_blocks) * block_size
+    bool ok() const { return ring != nullptr; }
+};
+
+struct observation_options {
+    int gpu = 0;          // -g
+    int device = 0;
+    int burn_in = 0;      // BURNIN read/close cycles before the loop (src/beamformer.cu:348-355)
+    bool verbose = false;
+};
+struct observation_result {
+    float observation_time_ms = 0;
+    uint64_t blocks = 0;            // blocks analysed
+    uint64_t data_chunks = 0;       // blocks * N_GEMMS_PER_BLOCK * N_OUTPUTS_PER_GEMM
+    double gbytes_per_s = 0;        // "Approximate datarate", src/beamformer.cu:554
+    std::vector<float> beam_out;    // final contents of beam_out: [stream][N_F_PER_DETECT] (src/beamformer.cu:249,485-488)
+    std::vector<long long> last_gemm;  // global gemm-unit index (block * N_GEMMS_PER_BLOCK + time_slice) behind each stream
+};
+// The reference's production main() loop on top of the C-ABI.  pos/dir: antenna positions and beam directions.
+int run_observation(const bf_config& cfg, const observation_options& opt, block_source& source, const antenna* pos,
+                    const beam_direction* dir, observation_result* res, std::ostream& log);
+
 }  // namespace dsabf

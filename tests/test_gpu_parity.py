@@ -358,3 +358,25 @@ def test_edge_geometries_and_arguments(torch, bfmod, orc):
         assert e.value.code == -1
         with pytest.raises(DsabfError):
             bf.beamform(d[1:], 1, o)  # misaligned input pointer
+
+
+def test_production_observation_loop_with_junk_source(bfmod, orc):
+    """Observation (non-DEBUG) mode, src/beamformer.cu:364-534: production geometry (N_AVERAGING 16, 128 MiB blocks),
+    blocks from the in-memory dada_junkdb stand-in, 8 compute queues.  After the run each queue's beam_out slot holds
+    the detected powers of the last gemm-unit it processed: must equal the oracle on that gemm-unit's bytes."""
+    from dsabeamformer_amd import host
+
+    cfg = bfmod.production_config()
+    n_blocks, ring_blocks = 6, 3
+    r = host.run_observation_junk(cfg, n_blocks, ring_blocks=ring_blocks, seed=7)
+    assert r["ms"] > 0
+    g = orc.PROD_GEOM
+    w = orc.make_weights(g, orc.default_positions(64), orc.default_directions(256), 0)
+    per_block = cfg.n_gemms_per_block
+    # every stream ends on the last block, time slices 24..31 (4 parts x 8 streams, src/beamformer.cu:454-519)
+    assert sorted(r["last_gemm"].tolist()) == [(n_blocks - 1) * per_block + 24 + i for i in range(8)]
+    for st in (0, 3, 7):
+        blk, ts = divmod(int(r["last_gemm"][st]), per_block)
+        unit = r["ring"][blk % ring_blocks, ts][None]
+        want = orc.beamform(g, w, unit)[0]
+        assert np.array_equal(r["beam_out"][st], want), st
