@@ -6,8 +6,9 @@ torch.distributed.run; RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the enviro
 
 Workload (BASELINE.json configs[2] geometry, "C3" in SURVEY.md section 8d): 64 antennas x 2 pol, 256 frequencies,
 256 beams, N_TIME = 512 voltage columns per gemm-unit (16 detected outputs x n_ipo 32), input = uniform random
-nibbles (all 16 codes) already resident in HBM.  One *step* = one launch over `--units` gemm-units (default 32 =
-one PSRDADA block of the reference, src/beamformer.hh:114) = units*16 beam-blocks.  The metric unit is the
+nibbles (all 16 codes) already resident in HBM.  One *step* = one launch over `--units` gemm-units (default 128 =
+the MAX_TOTAL_SEP = 4 PSRDADA blocks of 32 gemm-units that the reference's scheduler keeps in flight,
+src/beamformer.hh:85,114) = units*16 beam-blocks.  The metric unit is the
 beam-block: one detected [256 freq][256 beams] float32 output.
 
 N > 1 (strong scaling, BASELINE.json configs[3]): rank r owns frequencies [r*256/N, (r+1)*256/N) of every
@@ -35,8 +36,11 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=25)  # mirrors BURNIN 25, src/beamformer.hh:45
-    ap.add_argument("--units", type=int, default=32, help="gemm-units per step (one launch)")
-    ap.add_argument("--nbuf", type=int, default=3, help="distinct input step-buffers cycled (defeats L2/MALL reuse)")
+    ap.add_argument("--units", type=int, default=128,
+                    help="gemm-units per step = one launch; default 128 = MAX_TOTAL_SEP (4) PSRDADA blocks of "
+                         "N_GEMMS_PER_BLOCK (32) gemm-units, what the reference's scheduler keeps in flight "
+                         "(src/beamformer.hh:85,114)")
+    ap.add_argument("--nbuf", type=int, default=2, help="distinct input step-buffers cycled (defeats L2/MALL reuse)")
     ap.add_argument("--workload", default="c3", choices=["c3", "prod", "c2", "c5"],
                     help="c3: N_TIME 512 (16 outputs x n_ipo 32); prod: reference production N_TIME 256; "
                          "c2: DEBUG geometry N_TIME 16 (n_ipo 2, parity config; HBM-write bound); "
@@ -78,7 +82,7 @@ def pmc_traffic(args, world):
     and WRITE_SIZE collected in separate passes, KiB units; FETCH_SIZE doubled per MI355X_MICROARCH.md section HBM --
     gfx950 tallies 128-B read requests at 64 B).  Only valid for the exact launch it was measured on."""
     path = os.path.join(ROOT, "profiles", "r01_c3_pmc_summary.txt")
-    if not (args.workload == "c3" and args.units == 32 and world == 1 and os.path.exists(path)):
+    if not (args.workload == "c3" and args.units == 128 and world == 1 and os.path.exists(path)):
         return None
     vals = {}
     for line in open(path):

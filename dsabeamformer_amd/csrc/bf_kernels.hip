@@ -950,12 +950,18 @@ LaunchShape fused_launch_shape(const Geometry& g, int n_units, int n_cus)
     ls.chunks_total = (ls.chunks_total + cpg - 1) / cpg * cpg;
     const int base = g.n_freq * g.n_bgroups;
     const int waves_per_wg = use16(g) ? kWaves16 : kWavesPerWg;
-    // Workgroups per CU to aim for: 2x the resident count (measured best: finer time splits balance the tail;
-    // profiles/r01_variants_log.txt), but at least 2 chunks per workgroup so the weight-fragment load amortises.
+    // Time splits per frequency.  Measured (profiles/r01_variants_log.txt): the kernel is fastest with ~16-32 chunks
+    // per workgroup (long enough to amortise the weight-fragment load and the prologue, short enough that the tail
+    // of the launch is fine-grained); small launches still get ~2 workgroups per resident slot, but never fewer
+    // than 2 chunks each.
+    const int groups_avail = ls.chunks_total / cpg;
+    const int max_split = groups_avail >= 2 ? groups_avail / 2 : 1;
+    int want = (groups_avail + 10) / 20;                                       // ~20 chunk-groups per workgroup
     const int target_wgs_per_cu = 2 * (16 / waves_per_wg);
-    int want = (target_wgs_per_cu * n_cus + base - 1) / base;
-    const int max_split = ls.chunks_total / cpg >= 2 ? ls.chunks_total / cpg / 2 : 1;
-    if (want > max_split) want = max_split;
+    int want_fill = (target_wgs_per_cu * n_cus + base - 1) / base;            // enough workgroups to fill the chip
+    if (want_fill > max_split) want_fill = max_split;
+    if (want < want_fill) want = want_fill;
+    if (const char* e = getenv("DSABF_TSPLIT")) want = atoi(e);  // tuning override (time splits per frequency)
     if (want < 1) want = 1;
     if (want > ls.chunks_total / cpg) want = ls.chunks_total / cpg;
     ls.n_tsplit = want;
