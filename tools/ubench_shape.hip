@@ -74,6 +74,17 @@ int main(int argc, char** argv)
         }
     if (mode == 2)  // first 7*256 vectors feed a[]: make them 16*nibble bytes
         for (size_t j = 0; j < 7 * 256; j++) for (int i = 0; i < 4; i++) h[j][i] &= 0xF0F0F0F0;
+    if (mode == 3)  // a[]: sign-extended nibbles (-8..7) in every byte
+        for (size_t j = 0; j < 7 * 256; j++) for (int i = 0; i < 4; i++) {
+            unsigned w = (unsigned)h[j][i] & 0x0F0F0F0Fu;
+            h[j][i] = (int)((((w ^ 0x88888888u) - 0x08080808u) ^ 0x80808080u));
+        }
+    if (mode == 4)  // a[]: realistic small voltages: gaussian-like nibbles in [-3, 3], times 16
+        for (size_t j = 0; j < 7 * 256; j++) for (int i = 0; i < 4; i++) {
+            unsigned w = 0;
+            for (int b = 0; b < 4; b++) { int v = (rand() % 3) + (rand() % 3) + (rand() % 3) - 3; w |= ((unsigned)(v * 16) & 0xFFu) << (8 * b); }
+            h[j][i] = (int)w;
+        }
     v4i* d_src; int* d_out;
     (void)hipMalloc(&d_src, n * sizeof(v4i)); (void)hipMalloc(&d_out, 256 * 8 * 256 * sizeof(int));
     (void)hipMemcpy(d_src, h.data(), n * sizeof(v4i), hipMemcpyHostToDevice);
