@@ -46,6 +46,8 @@ def parse():
                          "c2: DEBUG geometry N_TIME 16 (n_ipo 2, parity config; HBM-write bound); "
                          "c5: DSA100 scale-up, 100 ant x 512 beams x 1024 freq, N_TIME 256 (use --units 4)")
     ap.add_argument("--gather", default="alltoall", choices=["alltoall", "root", "none"])
+    ap.add_argument("--detect", default="canonical", choices=["canonical", "fast"],
+                    help="canonical (default): bit-exact detect; fast: opt-in fma-contracted detect (tolerance mode)")
     ap.add_argument("--input", default="random", choices=["random", "zeros", "const"],
                     help="experiment only: voltage bit patterns (MFMA power depends on operand toggling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -146,6 +148,7 @@ def main():
     cfg = bfm.production_config(n_avg=n_avg, n_out_per_gemm=n_out, n_freq=n_freq)
     if args.workload == "c5":
         cfg.n_ant, cfg.n_beams = 100, 512
+    cfg.detect_mode = 1 if args.detect == "fast" else 0
     n_ipo, n_time = cfg.n_pol * cfg.n_avg, n_out * cfg.n_pol * cfg.n_avg
     bf = bfm.Beamformer(cfg, device=local)
     bf.set_weights(product_weights(torch, cfg, rank * n_freq))
@@ -253,6 +256,7 @@ def main():
                                           "unit is a 512-beam x 1024-freq block"}[args.workload],
                        "gemm_units_per_step": units, "beam_blocks_per_step": blocks_per_step,
                        "freq_per_gpu": n_freq, "gather": args.gather if world > 1 else "n/a",
+                       "detect_mode": args.detect,
                        "launch": info},
             "roofline": roof,
         }

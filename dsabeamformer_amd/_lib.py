@@ -15,7 +15,7 @@ class BfConfig(C.Structure):
     """Mirror of ``bf_config`` (include/dsabf.h)."""
 
     _fields_ = [(n, C.c_int) for n in ("n_beams", "n_ant", "n_freq", "n_pol", "n_avg", "n_out_per_gemm",
-                                       "n_gemms_per_block", "n_blocks_on_gpu", "n_streams", "verbose")]
+                                       "n_gemms_per_block", "n_blocks_on_gpu", "n_streams", "verbose", "detect_mode")]
 
 
 class DsabfError(RuntimeError):

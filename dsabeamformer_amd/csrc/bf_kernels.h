@@ -22,6 +22,7 @@ struct Geometry {
     int nks;                                            // k-steps of 16 antennas: ceil(n_ant / 16)
     int n_btiles;                                       // n_beams / 32
     int n_bgroups;                                      // ceil(n_btiles / 8)
+    bool fast_detect;                                   // BF_DETECT_FAST requested (honoured by fused16_kernel, n_ipo >= 16)
 };
 
 // Bytes of the MFMA-fragment weight image: [freq][btile][re|im][kstep][lane] x 16 B.

@@ -313,15 +313,17 @@ __global__ __launch_bounds__(kWgThreads, ((ANT + 15) / 16 <= 4 ? DSABF_OCC : 2))
     // cycles earlier (which stalled every wave for a store round trip per chunk: -11 % kernel time).
     constexpr int PEND = LONG ? (R <= kTilesPerChunk ? kTilesPerChunk / R : 1) : 1;
     v2f pend[PEND];
-    int pend_chunk = -1;  // chunk whose finished sums are in pend[]
+    int pend_chunk[PEND];  // chunk whose finished sums are in pend[g] (-1: none)
+#pragma unroll
+    for (int g = 0; g < PEND; g++) pend_chunk[g] = -1;
     const unsigned lane_out = (unsigned)(2 * hl) * (unsigned)FB + (unsigned)beam;  // lane part of the output index
     auto flush_pending = [&]() {
         if constexpr (LONG && !WRITE_C) {
-            if (pend_chunk >= 0 && wave_active) {
 #pragma unroll
-                for (int g = 0; g < PEND; g++) {
+            for (int g = 0; g < PEND; g++) {
+                if (pend_chunk[g] >= 0 && wave_active) {
                     // last tile of output group g of that chunk; ob = first of the group's 4 outputs (wave-uniform)
-                    const unsigned tile = (unsigned)pend_chunk * kTilesPerChunk + (R <= kTilesPerChunk ? (g + 1) * R - 1 : kTilesPerChunk - 1);
+                    const unsigned tile = (unsigned)pend_chunk[g] * kTilesPerChunk + (R <= kTilesPerChunk ? (g + 1) * R - 1 : kTilesPerChunk - 1);
                     const unsigned ob = 4u * (tile / R);
                     float* ub = a.out + (size_t)ob * FB + (size_t)f * a.n_beams;  // scalar (SALU) part of the address
                     const unsigned o = ob + 2u * hl;
@@ -330,8 +332,8 @@ __global__ __launch_bounds__(kWgThreads, ((ANT + 15) / 16 <= 4 ? DSABF_OCC : 2))
                         if ((o + 1) * (unsigned)L < a.S) ub[lane_out + (unsigned)FB] = pend[g][1];
                     }
                 }
+                pend_chunk[g] = -1;
             }
-            pend_chunk = -1;
         }
     };
 
@@ -460,7 +462,7 @@ __global__ __launch_bounds__(kWgThreads, ((ANT + 15) / 16 <= 4 ? DSABF_OCC : 2))
                         carry = v2f{s0, s1};
                         if (q == R - 1) {  // output pair complete: park it, flush_pending() stores it next chunk
                             pend[R <= kTilesPerChunk ? j / R : 0] = carry;
-                            pend_chunk = c;
+                            pend_chunk[R <= kTilesPerChunk ? j / R : 0] = c;
                         }
                     } else {
                         // 16/NIPO whole outputs per lane half; output u = 2m+e lives in registers 2*(m*NIPO+k)+e
@@ -606,9 +608,10 @@ constexpr int kWaves16 = 4;                  // waves per workgroup of fused16_k
 constexpr int kThreads16 = 64 * kWaves16;
 constexpr int kColTiles16 = 4;               // 16-beam column tiles per wave
 
-template <int NIPO, bool WRITE_C>
+template <int NIPO, bool WRITE_C, bool FAST = false>
 __global__ __launch_bounds__(kThreads16, DSABF_OCC16) void fused16_kernel(FusedArgs a)
 {
+    static_assert(!FAST || (NIPO >= 16 && !WRITE_C), "the fast detect exists for n_ipo >= 16 only");
     constexpr int A = 64, RB = 128, NB = kColTiles16;
     constexpr bool LONG = NIPO >= 16;
     constexpr int L = LONG ? NIPO : 16;                  // samples per stream
@@ -696,13 +699,15 @@ __global__ __launch_bounds__(kThreads16, DSABF_OCC16) void fused16_kernel(FusedA
     for (int ct = 0; ct < NB; ct++) sum[ct] = 0.0f;
     constexpr int PEND = LONG ? (L >= 32 ? 1 : 2) : 1;   // outputs completed per chunk per lane (LONG)
     float pend[PEND][NB];
-    int pend_chunk = -1;
+    int pend_chunk[PEND];                  // chunk whose finished sums sit in pend[gi] (-1: none); tracked per entry
+#pragma unroll                             // because entry 0 of chunk c can be parked before entry 1 of chunk c-1 left
+    for (int gi = 0; gi < PEND; gi++) pend_chunk[gi] = -1;
     auto flush_pending = [&]() {
         if constexpr (LONG && !WRITE_C) {
-            if (pend_chunk >= 0 && wave_active) {
 #pragma unroll
-                for (int gi = 0; gi < PEND; gi++) {
-                    const unsigned grp = (NIPO >= 32) ? (unsigned)(pend_chunk / CPG) : (2u * pend_chunk + gi);
+            for (int gi = 0; gi < PEND; gi++) {
+                if (pend_chunk[gi] >= 0 && wave_active) {
+                    const unsigned grp = (NIPO >= 32) ? (unsigned)(pend_chunk[gi] / CPG) : (2u * pend_chunk[gi] + gi);
                     float* ub = a.out + ((size_t)(4u * grp) * FB + (size_t)f * a.n_beams);  // wave-uniform part
                     const unsigned o = 4u * grp + (unsigned)g4;
                     if (o * (unsigned)L < a.S) {
@@ -711,8 +716,8 @@ __global__ __launch_bounds__(kThreads16, DSABF_OCC16) void fused16_kernel(FusedA
                             if (beam0 + 16 * ct < a.n_beams) ub[(size_t)g4 * FB + beam0 + 16 * ct] = pend[gi][ct];
                     }
                 }
+                pend_chunk[gi] = -1;
             }
-            pend_chunk = -1;
         }
     };
 
@@ -759,6 +764,22 @@ __global__ __launch_bounds__(kThreads16, DSABF_OCC16) void fused16_kernel(FusedA
                                 *reinterpret_cast<v2f*>(a.out + 2 * (((size_t)f * a.T + sidx) * a.n_beams + beam)) = cv;
                             }
                         }
+                    } else if constexpr (FAST) {
+                        // BF_DETECT_FAST: d = 16 n exactly (one subtract), acc = fma(d, d, acc): 4 ops per sample;
+                        // the (alpha/16)^2 scale is applied once per output when it is parked for the store.
+                        float sacc = (q4 == 0) ? 0.0f : sum[ct];
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            const float dr = fr[r] - kMagic, di = fi[r] - kMagic;
+                            sacc = __builtin_fmaf(dr, dr, sacc);
+                            sacc = __builtin_fmaf(di, di, sacc);
+                        }
+                        asm volatile("" : "+v"(sacc));
+                        sum[ct] = sacc;
+                        if (q4 + 4 == L) {
+                            pend[gi][ct] = sacc * (kAlpha16 * kAlpha16);
+                            pend_chunk[gi] = c;
+                        }
                     } else {
                         float p[4];
 #pragma unroll
@@ -778,7 +799,7 @@ __global__ __launch_bounds__(kThreads16, DSABF_OCC16) void fused16_kernel(FusedA
                             sum[ct] = sacc;
                             if (q4 + 4 == L) {
                                 pend[gi][ct] = sacc;
-                                pend_chunk = c;
+                                pend_chunk[gi] = c;
                             }
                         } else {
                             // 16-sample stream = 16/NIPO outputs; registers r hold positions q4 + r
@@ -866,10 +887,10 @@ hipError_t launch_fused_t(const FusedArgs& args, const LaunchShape& ls, hipStrea
     return hipGetLastError();
 }
 
-template <int NIPO, bool WRITE_C>
+template <int NIPO, bool WRITE_C, bool FAST = false>
 hipError_t launch_fused16_t(const FusedArgs& args, const LaunchShape& ls, hipStream_t s)
 {
-    hipLaunchKernelGGL((fused16_kernel<NIPO, WRITE_C>), dim3(ls.grid), dim3(ls.block), ls.lds_bytes, s, args);
+    hipLaunchKernelGGL((fused16_kernel<NIPO, WRITE_C, FAST>), dim3(ls.grid), dim3(ls.block), ls.lds_bytes, s, args);
     return hipGetLastError();
 }
 
@@ -896,6 +917,15 @@ template <bool WRITE_C>
 hipError_t dispatch_fused(const Geometry& g, const FusedArgs& args, const LaunchShape& ls, hipStream_t s)
 {
     if (use16(g)) {
+        if constexpr (!WRITE_C) {
+            if (g.fast_detect) {
+                switch (g.n_ipo) {
+                    case 16: return launch_fused16_t<16, false, true>(args, ls, s);
+                    case 32: return launch_fused16_t<32, false, true>(args, ls, s);
+                    case 64: return launch_fused16_t<64, false, true>(args, ls, s);
+                }
+            }
+        }
         switch (g.n_ipo) {
             case 2: return launch_fused16_t<2, WRITE_C>(args, ls, s);
             case 4: return launch_fused16_t<4, WRITE_C>(args, ls, s);
@@ -1045,7 +1075,8 @@ hipError_t launch_dedisperse(const Geometry& g, const float* d_out_unit, float* 
 const char* fused_kernel_name(const Geometry& g, char* buf, size_t n)
 {
     if (use16(g))
-        snprintf(buf, n, "dsabf::fused16_kernel<NIPO=%d> (v_mfma_i32_16x16x64_i8)", g.n_ipo);
+        snprintf(buf, n, "dsabf::fused16_kernel<NIPO=%d%s> (v_mfma_i32_16x16x64_i8)", g.n_ipo,
+                 (g.fast_detect && g.n_ipo >= 16) ? ",FAST" : "");
     else
         snprintf(buf, n, "dsabf::fused_kernel<ANT=%d,NIPO=%d> (v_mfma_i32_32x32x32_i8)", g.n_ant, g.n_ipo);
     return buf;

@@ -69,6 +69,8 @@ int check_cfg(const bf_config* c)
         return fail(BF_ERR_INVALID, "every geometry field must be positive");
     if (c->n_beams % 4) return fail(BF_ERR_INVALID, "N_BEAMS must be divisible by 4");       // src/beamformer.hh:155
     if (c->n_ant % 4) return fail(BF_ERR_INVALID, "N_ANTENNAS must be divisible by 4");      // src/beamformer.hh:156
+    if (c->detect_mode != BF_DETECT_CANONICAL && c->detect_mode != BF_DETECT_FAST)
+        return fail(BF_ERR_INVALID, "detect_mode must be BF_DETECT_CANONICAL or BF_DETECT_FAST");
     return BF_OK;
 }
 
@@ -84,6 +86,7 @@ dsabf::Geometry make_geom(const bf_config& c)
     g.nks = (c.n_ant + 15) / 16;
     g.n_btiles = c.n_beams / 32;
     g.n_bgroups = (g.n_btiles + dsabf::kWavesPerWg - 1) / dsabf::kWavesPerWg;
+    g.fast_detect = c.detect_mode == BF_DETECT_FAST;
     return g;
 }
 
@@ -109,6 +112,7 @@ int bf_config_default(bf_config* cfg, int debug)
     cfg->n_blocks_on_gpu = 8;
     cfg->n_streams = 8;
     cfg->verbose = 0;
+    cfg->detect_mode = BF_DETECT_CANONICAL;
     return BF_OK;
 }
 

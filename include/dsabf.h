@@ -53,7 +53,16 @@ typedef struct bf_config {
     int n_blocks_on_gpu;   /* N_BLOCKS_ON_GPU    src/beamformer.hh:124 */
     int n_streams;         /* N_STREAMS          src/beamformer.hh:83 */
     int verbose;           /* -DVERBOSE as a runtime flag */
+    int detect_mode;       /* BF_DETECT_CANONICAL (0, default) or BF_DETECT_FAST */
 } bf_config;
+
+/* detect_mode.  CANONICAL evaluates the reference's `acc += x*x + y*y` (src/beamformer.cuh:150-152) literally: two
+ * multiplies, one add, one accumulate add per sample, ascending time order -> bit-identical to the CPU restatement.
+ * FAST (64-antenna geometries with n_pol*n_avg >= 16; ignored elsewhere) accumulates the unscaled integer voltages with
+ * fused multiply-adds and applies (1/127)^2 once per output: 4 instead of 6 VALU ops per sample; the result is within
+ * 4*n_ipo*2^-24 relative of the canonical one (it is the more accurate of the two w.r.t. exact arithmetic). */
+#define BF_DETECT_CANONICAL 0
+#define BF_DETECT_FAST 1
 
 typedef struct bf_handle bf_handle; /* owns device memory, 1 transfer queue + n_streams compute queues */
 typedef struct bf_event bf_event;

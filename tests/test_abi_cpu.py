@@ -53,6 +53,7 @@ def test_default_configs_match_reference_constants(lib):
         assert lib.bf_bytes_per_gemm(C.byref(cfg)) == per_gemm
         assert lib.bf_bytes_per_block(C.byref(cfg)) == per_block
         assert lib.bf_floats_per_detect(C.byref(cfg)) == 524288
+        assert cfg.detect_mode == 0  # BF_DETECT_CANONICAL: bit-exact by default
 
 
 def test_error_convention_without_gpu(lib):

@@ -380,3 +380,49 @@ def test_production_observation_loop_with_junk_source(bfmod, orc):
         unit = r["ring"][blk % ring_blocks, ts][None]
         want = orc.beamform(g, w, unit)[0]
         assert np.array_equal(r["beam_out"][st], want), st
+
+
+@pytest.mark.parametrize("n_avg", [8, 16, 32])
+def test_fast_detect_mode_within_stated_tolerance(torch, bfmod, orc, n_avg):
+    """BF_DETECT_FAST (opt-in): fma-contracted detect, 4 VALU ops per sample instead of 6.  Stated tolerance vs the
+    canonical (bit-exact) result: 4 * n_ipo * 2^-24 relative (every term is non-negative, so the bound is on the sum)."""
+    n_ipo = 2 * n_avg
+    g = orc.Geom(n_beams=128, n_ant=64, n_freq=6, n_avg=n_avg, n_out_per_gemm=4)
+    rng = np.random.default_rng(77 + n_avg)
+    w = rng.integers(-127, 128, size=(g.n_freq, g.n_ant, g.n_beams, 2), dtype=np.int8)
+    packed = rng.integers(0, 256, size=(3, g.n_freq, g.n_time, g.n_ant), dtype=np.uint8)
+    want = orc.beamform(g, w, packed)
+    bf = bfmod.Beamformer(_cfg(bfmod, g, detect_mode=1))
+    assert "FAST" in bf.kernel_info()["kernel"]
+    bf.set_weights(w)
+    got = _run(torch, bf, packed, want.size).reshape(want.shape)
+    tol = 4 * n_ipo * 2.0 ** -24
+    rel = np.abs(got.astype(np.float64) - want) / np.maximum(want.astype(np.float64), 1e-30)
+    assert rel.max() <= tol, (rel.max(), tol)
+    assert not np.array_equal(got, want)  # it really is the other arithmetic
+    # the default mode on the same input stays bit-exact
+    bf0 = bfmod.Beamformer(_cfg(bfmod, g))
+    bf0.set_weights(w)
+    assert np.array_equal(_run(torch, bf0, packed, want.size).reshape(want.shape), want)
+
+
+@pytest.mark.parametrize("n_ant,n_avg", [(64, 1), (64, 2), (64, 4), (64, 8), (64, 16), (64, 32), (128, 1), (128, 16),
+                                         (100, 16), (32, 16), (16, 1)])
+@pytest.mark.parametrize("tsplit", ["1", "3"])
+def test_many_chunks_per_workgroup_bit_exact(torch, bfmod, orc, monkeypatch, n_ant, n_avg, tsplit):
+    """Long time ranges per workgroup (>= 5 LDS chunks, forced with the DSABF_TSPLIT tuning override): exercises the
+    double-buffered staging, the deferred stores across chunk boundaries and outputs that span chunks (n_ipo 64).
+    (Round 1 found a deferred-store bookkeeping bug for n_ipo = 16 that only shows with > 1 chunk per workgroup.)"""
+    monkeypatch.setenv("DSABF_TSPLIT", tsplit)
+    n_ipo = 2 * n_avg
+    n_out = max(2, 16 // n_ipo)
+    g = orc.Geom(n_beams=64, n_ant=n_ant, n_freq=3, n_avg=n_avg, n_out_per_gemm=n_out)
+    n_units = max(3, -(-(5 * 128 * (2 if n_ipo == 64 else 1) + 64) // g.n_time))  # > 5 chunks, ragged end
+    rng = np.random.default_rng(31 + n_ant + n_avg)
+    w = rng.integers(-127, 128, size=(g.n_freq, g.n_ant, g.n_beams, 2), dtype=np.int8)
+    packed = rng.integers(0, 256, size=(n_units, g.n_freq, g.n_time, g.n_ant), dtype=np.uint8)
+    bf = bfmod.Beamformer(_cfg(bfmod, g))
+    bf.set_weights(w)
+    want = orc.beamform(g, w, packed)
+    got = _run(torch, bf, packed, want.size).reshape(want.shape)
+    assert np.array_equal(got, want)
