@@ -426,3 +426,59 @@ def test_many_chunks_per_workgroup_bit_exact(torch, bfmod, orc, monkeypatch, n_a
     want = orc.beamform(g, w, packed)
     got = _run(torch, bf, packed, want.size).reshape(want.shape)
     assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("n_ant,n_avg,n_out", [(64, 16, 24), (64, 1, 40), (64, 8, 20), (128, 16, 12), (100, 16, 12)])
+def test_gemm_stage_many_chunks_bit_exact(torch, bfmod, orc, n_ant, n_avg, n_out):
+    """Stage parity of a2 (the reference's d_C) over several LDS chunks and both MFMA shapes."""
+    g = orc.Geom(n_beams=64, n_ant=n_ant, n_freq=2, n_avg=n_avg, n_out_per_gemm=n_out)
+    rng = np.random.default_rng(5 + n_ant + n_avg)
+    w = rng.integers(-127, 128, size=(g.n_freq, g.n_ant, g.n_beams, 2), dtype=np.int8)
+    packed = rng.integers(0, 256, size=(g.n_freq, g.n_time, g.n_ant), dtype=np.uint8)
+    bf = bfmod.Beamformer(_cfg(bfmod, g))
+    bf.set_weights(w)
+    d_in = torch.from_numpy(packed).cuda()
+    d_c = torch.full((g.n_freq * g.n_time * g.n_beams * 2,), float("nan"), dtype=torch.float32, device="cuda")
+    bf.gemm(d_in, d_c, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    want = orc.gemm(g, w, orc.expand(packed))
+    assert np.array_equal(d_c.cpu().numpy().reshape(want.shape), want)
+
+
+@pytest.mark.parametrize("n_freq,n_beams,n_avg", [(8, 512, 16), (16, 288, 1), (24, 512, 8), (8, 32, 32)])
+def test_xcd_block_map_and_beam_groups_bit_exact(torch, bfmod, orc, n_freq, n_beams, n_avg):
+    """n_freq % 8 == 0 takes the XCD-aware block decode; n_beams > 256 gives several beam groups per frequency,
+    n_beams = 288 a partially filled last group; several time splits and chunks per workgroup."""
+    n_ipo = 2 * n_avg
+    g = orc.Geom(n_beams=n_beams, n_ant=64, n_freq=n_freq, n_avg=n_avg, n_out_per_gemm=max(2, 16 // n_ipo))
+    n_units = -(-1100 // g.n_time)
+    rng = np.random.default_rng(n_freq * 1000 + n_beams)
+    w = rng.integers(-127, 128, size=(g.n_freq, g.n_ant, g.n_beams, 2), dtype=np.int8)
+    packed = rng.integers(0, 256, size=(n_units, g.n_freq, g.n_time, g.n_ant), dtype=np.uint8)
+    bf = bfmod.Beamformer(_cfg(bfmod, g))
+    bf.set_weights(w)
+    want = orc.beamform(g, w, packed)
+    got = _run(torch, bf, packed, want.size).reshape(want.shape)
+    assert np.array_equal(got, want)
+
+
+def test_seeded_geometry_fuzz_bit_exact(torch, bfmod, orc):
+    """Seeded fuzz over the supported geometry space (shape, units, ragged ends); every case bit-exact vs the oracle."""
+    rng = np.random.default_rng(20261002)
+    combos = [(64, a) for a in (1, 2, 4, 8, 16, 32)] + [(16, 1), (16, 16), (32, 1), (32, 16), (100, 1), (100, 16),
+                                                        (128, 1), (128, 16)]
+    for case in range(14):
+        n_ant, n_avg = combos[int(rng.integers(len(combos)))]
+        n_ipo = 2 * n_avg
+        n_out = int(rng.integers(1, 5)) * max(1, 16 // n_ipo)
+        g = orc.Geom(n_beams=32 * int(rng.integers(1, 11)), n_ant=n_ant, n_freq=int(rng.integers(1, 12)), n_avg=n_avg,
+                     n_out_per_gemm=n_out)
+        n_units = int(rng.integers(1, 1 + max(1, 700 // g.n_time)))
+        w = rng.integers(-127, 128, size=(g.n_freq, g.n_ant, g.n_beams, 2), dtype=np.int8)
+        packed = rng.integers(0, 256, size=(n_units, g.n_freq, g.n_time, g.n_ant), dtype=np.uint8)
+        bf = bfmod.Beamformer(_cfg(bfmod, g))
+        bf.set_weights(w)
+        want = orc.beamform(g, w, packed)
+        got = _run(torch, bf, packed, want.size).reshape(want.shape)
+        assert np.array_equal(got, want), (case, g, n_units)
+        bf.close()
