@@ -568,7 +568,15 @@ __global__ void dedisperse_kernel(const float* __restrict__ out_unit, float* __r
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= n_beams) return;
     float acc = 0.0f;
-    for (int f = 0; f < n_freq; f++) acc = acc + out_unit[(size_t)f * n_beams + b] * 1.0f;
+    int f = 0;
+    for (; f + 16 <= n_freq; f += 16) {  // 16 independent loads in flight, then the adds in ascending-f order
+        float v[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) v[i] = out_unit[(size_t)(f + i) * n_beams + b];
+#pragma unroll
+        for (int i = 0; i < 16; i++) acc = acc + v[i] * 1.0f;
+    }
+    for (; f < n_freq; f++) acc = acc + out_unit[(size_t)f * n_beams + b] * 1.0f;
     ded[b] = acc;
 }
 
@@ -1059,7 +1067,7 @@ hipError_t launch_expand(const void* d_in, size_t nbytes, void* d_out, hipStream
     const size_t n_vec = nbytes / 16;
     if (n_vec == 0) return hipSuccess;
     size_t grid = (n_vec + 255) / 256;
-    if (grid > 2048) grid = 2048;
+    if (grid > 65536) grid = 65536;  // measured best on MI355X (4.4 TB/s algorithmic vs 3.8 at 2048 blocks)
     hipLaunchKernelGGL(expand_kernel, dim3((unsigned)grid), dim3(256), 0, s, static_cast<const v4i*>(d_in),
                        static_cast<v4i*>(d_out), n_vec);
     return hipGetLastError();
