@@ -23,10 +23,16 @@ struct Geometry {
     int n_btiles;                                       // n_beams / 32
     int n_bgroups;                                      // ceil(n_btiles / 8)
     bool fast_detect;                                   // BF_DETECT_FAST requested (honoured by fused16_kernel, n_ipo >= 16)
+    bool paired = false;                                // weights verified conjugate-symmetric: beam B-1-b = conj(beam b)
 };
 
 // Bytes of the MFMA-fragment weight image: [freq][btile][re|im][kstep][lane] x 16 B.
 size_t weight_image_bytes(const Geometry& g);
+
+// Conjugate-pair image (fused16_kernel<..., PAIRED>): [freq][pair tile][Wr|Wi][lane] x 16 B; 0 bytes when the
+// geometry has no paired kernel.
+bool pairing_supported(const Geometry& g);
+size_t weight_pair_image_bytes(const Geometry& g);
 
 // True if the fused kernel has an instantiation for this geometry; `why` (optional) explains a refusal.
 bool fused_supported(const Geometry& g, const char** why);
@@ -37,12 +43,14 @@ struct LaunchShape {
 LaunchShape fused_launch_shape(const Geometry& g, int n_units, int n_cus);
 
 // Reference-layout weights [f][a][b]{re,im} (device) -> fragment image (device).  Sets *d_bad to non-zero if
-// any imaginary part is -128 (its negation does not fit int8).
-hipError_t launch_weight_relayout(const Geometry& g, const int8_t* d_w, void* d_image, int* d_bad, hipStream_t s);
+// any imaginary part is -128 (its negation does not fit int8).  With d_pair_image (pairing_supported geometries) also
+// builds the conjugate-pair image and sets d_bad[1] to non-zero unless W[f][a][B-1-b] == conj(W[f][a][b]) everywhere.
+hipError_t launch_weight_relayout(const Geometry& g, const int8_t* d_w, void* d_image, void* d_pair_image, int* d_bad,
+                                  hipStream_t s);
 
-// Fused expand -> int8 MFMA -> detect over n_units gemm-units.
-hipError_t launch_fused(const Geometry& g, const void* d_image, const void* d_packed, int n_units, float* d_out,
-                        int n_cus, hipStream_t s);
+// Fused expand -> int8 MFMA -> detect over n_units gemm-units (g.paired selects the conjugate-pair kernel + image).
+hipError_t launch_fused(const Geometry& g, const void* d_image, const void* d_pair_image, const void* d_packed,
+                        int n_units, float* d_out, int n_cus, hipStream_t s);
 
 // Same pipeline but stores the scaled complex GEMM result c[f][t][b]{re,im} for ONE gemm-unit (stage parity).
 hipError_t launch_gemm_only(const Geometry& g, const void* d_image, const void* d_packed, float* d_c, int n_cus,

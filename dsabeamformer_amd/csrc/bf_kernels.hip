@@ -41,6 +41,9 @@
 #ifndef DSABF_USE16
 #define DSABF_USE16 1     // 64-antenna geometries run fused16_kernel (v_mfma_i32_16x16x64_i8); 0 = 32x32x32 everywhere
 #endif
+#ifndef DSABF_PAIRED
+#define DSABF_PAIRED 1    // build the conjugate-pair variants of fused16_kernel (used when the weights allow it)
+#endif
 #ifndef DSABF_OCC16
 #define DSABF_OCC16 3     // 147 VGPRs, no spills; 4 would spill 15 registers for no gain (the kernel is energy-bound)
 #endif
@@ -616,11 +619,20 @@ constexpr int kWaves16 = 4;                  // waves per workgroup of fused16_k
 constexpr int kThreads16 = 64 * kWaves16;
 constexpr int kColTiles16 = 4;               // 16-beam column tiles per wave
 
-template <int NIPO, bool WRITE_C, bool FAST = false>
+// PAIRED: the steering weights of beam B-1-b are the complex conjugates of those of beam b for every (frequency,
+// antenna) -- true for any beam set that is symmetric about the boresight, e.g. the reference's linear fan and 16x16
+// grid (checked exactly by pair_check_kernel when the weights are set).  Then with the four REAL K=64 products
+//   P1 = sum Wr*Vr, P2 = sum Wi*Vi, P3 = sum Wr*Vi, P4 = sum Wi*Vr        (one 16x16x64 MFMA each)
+// C(b) = (P1 - P2) + j(P3 + P4) and C(B-1-b) = (P1 + P2) + j(P3 - P4): two beams for the MFMA work of one, exact in
+// int32 (the +-P2 / +-P4 are 4 integer VALU ops per sample pair; P1 and P3 carry the float seed, P2 and P4 start at 0).
+template <int NIPO, bool WRITE_C, bool FAST = false, bool PAIRED = false>
 __global__ __launch_bounds__(kThreads16, DSABF_OCC16) void fused16_kernel(FusedArgs a)
 {
     static_assert(!FAST || (NIPO >= 16 && !WRITE_C), "the fast detect exists for n_ipo >= 16 only");
-    constexpr int A = 64, RB = 128, NB = kColTiles16;
+    static_assert(!(PAIRED && WRITE_C), "the stage-parity path always runs the general kernel");
+    constexpr int A = 64, RB = 128;
+    constexpr int NS = kColTiles16;                      // 16-beam output slots per lane (beams per wave = 16 * NS)
+    constexpr int NT = PAIRED ? NS / 2 : NS;             // MFMA column tiles per wave (a paired tile feeds 2 slots)
     constexpr bool LONG = NIPO >= 16;
     constexpr int L = LONG ? NIPO : 16;                  // samples per stream
     constexpr int LR = NIPO >= 32 ? 32 : 16;             // stream rows held by one chunk
@@ -641,26 +653,41 @@ __global__ __launch_bounds__(kThreads16, DSABF_OCC16) void fused16_kernel(FusedA
     const int c_begin = (int)(((long long)units_total * ts) / a.n_tsplit) * CPG;
     const int c_end = (int)(((long long)units_total * (ts + 1)) / a.n_tsplit) * CPG;
 
-    const int ct0 = (bg * kWaves16 + wave) * NB;          // first 16-beam column tile of this wave
-    const int n_ctiles = a.n_btiles * 2;
-    const bool wave_active = ct0 < n_ctiles;
-    const int beam0 = ct0 * 16 + c16;                     // + 16*ct
-
-    // ---- weight fragments -> registers: [ct][rho][s] ---------------------------------------------------------
-    v4i bw[NB][2][2];
+    // ---- which beams this lane produces, and the weight fragments ------------------------------------------
+    int slot_beam[NS];                                    // beam index of output slot s (>= n_beams: none)
+    v4i bw[NT][PAIRED ? 2 : 4];                           // general: [ct][2*rho + s]; paired: [pct][0 = Wr, 1 = Wi]
+    bool wave_active;
+    if constexpr (PAIRED) {
+        const int n_pct = a.n_btiles;                     // pair tiles of 16 base beams = n_beams / 32
+        const int pct0 = (bg * kWaves16 + wave) * NT;
+        wave_active = pct0 < n_pct;
 #pragma unroll
-    for (int ct = 0; ct < NB; ct++)
+        for (int t = 0; t < NT; t++) {
+            const int bb = (pct0 + t) * 16 + c16;         // base beam (< n_beams / 2)
+            const bool ok = pct0 + t < n_pct;
+            slot_beam[2 * t] = ok ? bb : a.n_beams;
+            slot_beam[2 * t + 1] = ok ? a.n_beams - 1 - bb : a.n_beams;
 #pragma unroll
-        for (int rho = 0; rho < 2; rho++)
+            for (int comp = 0; comp < 2; comp++)
+                bw[t][comp] = ok ? a.wimg[(((size_t)f * n_pct + pct0 + t) * 2 + comp) * 64 + lane] : v4i{0, 0, 0, 0};
+        }
+    } else {
+        const int n_ctiles = a.n_btiles * 2;
+        const int ct0 = (bg * kWaves16 + wave) * NT;      // first 16-beam column tile of this wave
+        wave_active = ct0 < n_ctiles;
 #pragma unroll
-            for (int sk = 0; sk < 2; sk++) {
-                bw[ct][rho][sk] = v4i{0, 0, 0, 0};
-                if (ct0 + ct < n_ctiles)
-                    bw[ct][rho][sk] = a.wimg[((((size_t)f * n_ctiles + ct0 + ct) * 2 + rho) * 2 + sk) * 64 + lane];
-            }
+        for (int t = 0; t < NT; t++) {
+            const bool ok = ct0 + t < n_ctiles;
+            slot_beam[t] = ok ? (ct0 + t) * 16 + c16 : a.n_beams;
+#pragma unroll
+            for (int k = 0; k < 4; k++)                    // k = 2*rho + s
+                bw[t][k] = ok ? a.wimg[(((size_t)f * n_ctiles + ct0 + t) * 4 + k) * 64 + lane] : v4i{0, 0, 0, 0};
+        }
+    }
 
     v4i kc = {(int)kMagicBits, (int)kMagicBits, (int)kMagicBits, (int)kMagicBits};
     asm volatile("" : "+v"(kc));
+    const v4i kzero = {0, 0, 0, 0};
 
     // ---- staging (the chunk's 128 samples are contiguous in time for n_ipo <= 32) ------------------------------
     auto run_sample0 = [&](int c, int run) -> unsigned {   // first global sample of stream-run `run` of chunk c
@@ -702,11 +729,11 @@ __global__ __launch_bounds__(kThreads16, DSABF_OCC16) void fused16_kernel(FusedA
     };
 
     const size_t FB = (size_t)a.n_freq * a.n_beams;
-    float sum[NB];                         // running sum of this lane's current output, per column tile
+    float sum[NS];                         // running sum of this lane's current output, per slot
 #pragma unroll
-    for (int ct = 0; ct < NB; ct++) sum[ct] = 0.0f;
+    for (int sl = 0; sl < NS; sl++) sum[sl] = 0.0f;
     constexpr int PEND = LONG ? (L >= 32 ? 1 : 2) : 1;   // outputs completed per chunk per lane (LONG)
-    float pend[PEND][NB];
+    float pend[PEND][NS];
     int pend_chunk[PEND];                  // chunk whose finished sums sit in pend[gi] (-1: none); tracked per entry
 #pragma unroll                             // because entry 0 of chunk c can be parked before entry 1 of chunk c-1 left
     for (int gi = 0; gi < PEND; gi++) pend_chunk[gi] = -1;
@@ -720,8 +747,8 @@ __global__ __launch_bounds__(kThreads16, DSABF_OCC16) void fused16_kernel(FusedA
                     const unsigned o = 4u * grp + (unsigned)g4;
                     if (o * (unsigned)L < a.S) {
 #pragma unroll
-                        for (int ct = 0; ct < NB; ct++)
-                            if (beam0 + 16 * ct < a.n_beams) ub[(size_t)g4 * FB + beam0 + 16 * ct] = pend[gi][ct];
+                        for (int sl = 0; sl < NS; sl++)
+                            if (slot_beam[sl] < a.n_beams) ub[(size_t)g4 * FB + slot_beam[sl]] = pend[gi][sl];
                     }
                 }
                 pend_chunk[gi] = -1;
@@ -746,22 +773,17 @@ __global__ __launch_bounds__(kThreads16, DSABF_OCC16) void fused16_kernel(FusedA
 #pragma unroll
             for (int t8 = 0; t8 < 8; t8++) {
                 const int row = lds_row16<NIPO>(t8, c16);
-                const v4i a0 = *reinterpret_cast<const v4i*>(cur + row * RB + 16 * swz16<NIPO>(g4, row));
-                const v4i a1 = *reinterpret_cast<const v4i*>(cur + row * RB + 16 * swz16<NIPO>(4 + g4, row));
+                const v4i a0 = *reinterpret_cast<const v4i*>(cur + row * RB + 16 * swz16<NIPO>(g4, row));      // 16*re
+                const v4i a1 = *reinterpret_cast<const v4i*>(cur + row * RB + 16 * swz16<NIPO>(4 + g4, row));  // 16*im
                 // stream position of this tile's rows and whether it starts / ends an output
                 const int gi = (NIPO >= 32) ? 0 : (t8 >> 2);          // group inside the chunk (L = 16)
                 const int q4 = (NIPO >= 32) ? (32 * (c % CPG) + 4 * t8) : 4 * (t8 & 3);  // position of register 0
                 const unsigned grp = (NIPO >= 32) ? (unsigned)(c / CPG) : (2u * (unsigned)c + gi);
                 const unsigned o = 4u * grp + (unsigned)g4;           // this lane's stream (output index if LONG)
-#pragma unroll
-                for (int ct = 0; ct < NB; ct++) {
-                    v4i cr = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, bw[ct][0][0], kc, 0, 0, 0);
-                    v4i ci = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, bw[ct][1][0], kc, 0, 0, 0);
-                    cr = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, bw[ct][0][1], cr, 0, 0, 0);
-                    ci = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, bw[ct][1][1], ci, 0, 0, 0);
-                    const v4f fr = __builtin_bit_cast(v4f, cr);
-                    const v4f fi = __builtin_bit_cast(v4f, ci);
-                    const int beam = beam0 + 16 * ct;
+
+                // detect + accumulate the 4 samples (fr, fi: accumulator bit patterns K + 16 n) of output slot sl
+                auto detect = [&](const v4f fr, const v4f fi, const int sl) {
+                    const int beam = slot_beam[sl];
                     if constexpr (WRITE_C) {
 #pragma unroll
                         for (int r = 0; r < 4; r++) {
@@ -775,7 +797,7 @@ __global__ __launch_bounds__(kThreads16, DSABF_OCC16) void fused16_kernel(FusedA
                     } else if constexpr (FAST) {
                         // BF_DETECT_FAST: d = 16 n exactly (one subtract), acc = fma(d, d, acc): 4 ops per sample;
                         // the (alpha/16)^2 scale is applied once per output when it is parked for the store.
-                        float sacc = (q4 == 0) ? 0.0f : sum[ct];
+                        float sacc = (q4 == 0) ? 0.0f : sum[sl];
 #pragma unroll
                         for (int r = 0; r < 4; r++) {
                             const float dr = fr[r] - kMagic, di = fi[r] - kMagic;
@@ -783,9 +805,9 @@ __global__ __launch_bounds__(kThreads16, DSABF_OCC16) void fused16_kernel(FusedA
                             sacc = __builtin_fmaf(di, di, sacc);
                         }
                         asm volatile("" : "+v"(sacc));
-                        sum[ct] = sacc;
+                        sum[sl] = sacc;
                         if (q4 + 4 == L) {
-                            pend[gi][ct] = sacc * (kAlpha16 * kAlpha16);
+                            pend[gi][sl] = sacc * (kAlpha16 * kAlpha16);
                             pend_chunk[gi] = c;
                         }
                     } else {
@@ -799,14 +821,14 @@ __global__ __launch_bounds__(kThreads16, DSABF_OCC16) void fused16_kernel(FusedA
                             p[r] = xx + yy;
                         }
                         if constexpr (LONG) {
-                            float sacc = (q4 == 0) ? p[0] : (sum[ct] + p[0]);
+                            float sacc = (q4 == 0) ? p[0] : (sum[sl] + p[0]);
                             sacc = sacc + p[1];
                             sacc = sacc + p[2];
                             sacc = sacc + p[3];
                             asm volatile("" : "+v"(sacc));
-                            sum[ct] = sacc;
+                            sum[sl] = sacc;
                             if (q4 + 4 == L) {
-                                pend[gi][ct] = sacc;
+                                pend[gi][sl] = sacc;
                                 pend_chunk[gi] = c;
                             }
                         } else {
@@ -825,15 +847,33 @@ __global__ __launch_bounds__(kThreads16, DSABF_OCC16) void fused16_kernel(FusedA
                                 sacc = sacc + p[3];
                                 if (valid) op[(size_t)(q4 / 4) * FB] = sacc;
                             } else {  // NIPO == 8
-                                float sacc = (q4 % 8 == 0) ? p[0] : (sum[ct] + p[0]);
+                                float sacc = (q4 % 8 == 0) ? p[0] : (sum[sl] + p[0]);
                                 sacc = sacc + p[1];
                                 sacc = sacc + p[2];
                                 sacc = sacc + p[3];
                                 asm volatile("" : "+v"(sacc));
-                                sum[ct] = sacc;
+                                sum[sl] = sacc;
                                 if (q4 % 8 == 4 && valid) op[(size_t)(q4 / 8) * FB] = sacc;
                             }
                         }
+                    }
+                };
+
+#pragma unroll
+                for (int t = 0; t < NT; t++) {
+                    if constexpr (PAIRED) {
+                        const v4i p1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, bw[t][0], kc, 0, 0, 0);     // Wr*Vr + K
+                        const v4i p2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, bw[t][1], kzero, 0, 0, 0);  // Wi*Vi
+                        const v4i p3 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, bw[t][0], kc, 0, 0, 0);     // Wr*Vi + K
+                        const v4i p4 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, bw[t][1], kzero, 0, 0, 0);  // Wi*Vr
+                        detect(__builtin_bit_cast(v4f, p1 - p2), __builtin_bit_cast(v4f, p3 + p4), 2 * t);      // beam b
+                        detect(__builtin_bit_cast(v4f, p1 + p2), __builtin_bit_cast(v4f, p3 - p4), 2 * t + 1);  // B-1-b
+                    } else {
+                        v4i cr = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, bw[t][0], kc, 0, 0, 0);
+                        v4i ci = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, bw[t][2], kc, 0, 0, 0);
+                        cr = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, bw[t][1], cr, 0, 0, 0);
+                        ci = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, bw[t][3], ci, 0, 0, 0);
+                        detect(__builtin_bit_cast(v4f, cr), __builtin_bit_cast(v4f, ci), t);
                     }
                 }
                 // staging work in the shadow of the MFMA stream (see fused_kernel)
@@ -847,6 +887,47 @@ __global__ __launch_bounds__(kThreads16, DSABF_OCC16) void fused16_kernel(FusedA
         __syncthreads();
     }
     flush_pending();
+}
+
+// Conjugate-pair test: *flag stays 0 iff W[f][a][B-1-b] == conj(W[f][a][b]) for every f, a and b < B/2.
+__global__ void pair_check_kernel(const int8_t* __restrict__ w, size_t n_fa, int n_beams, int* __restrict__ flag)
+{
+    const size_t total = n_fa * (size_t)(n_beams / 2);
+    bool bad = false;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const size_t fa = idx / (n_beams / 2);
+        const int b = (int)(idx % (n_beams / 2));
+        const int8_t* e0 = w + 2 * (fa * n_beams + b);
+        const int8_t* e1 = w + 2 * (fa * n_beams + (n_beams - 1 - b));
+        bad |= (e0[0] != e1[0]) || (e0[1] != -e1[1]);
+    }
+    if (bad) *flag = 1;
+}
+
+// Paired weight image: image[f][pct][comp][lane] (16 bytes): lane = 16*kb + c; byte i = Wr (comp 0) or Wi (comp 1) of
+// antenna 16*kb + i for base beam 16*pct + c (< n_beams / 2).
+__global__ void weight_relayout16p_kernel(const int8_t* __restrict__ w, v4i* __restrict__ image, int n_freq, int n_ant,
+                                          int n_beams)
+{
+    const int n_pct = n_beams / 32;
+    const size_t total = (size_t)n_freq * n_pct * 2 * 64;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int lane = (int)(idx & 63);
+        size_t r = idx >> 6;
+        const int comp = (int)(r & 1);
+        r >>= 1;
+        const int pct = (int)(r % n_pct);
+        const int f = (int)(r / n_pct);
+        const int kb = lane >> 4, b = pct * 16 + (lane & 15);
+        unsigned d[4] = {0, 0, 0, 0};
+        for (int i = 0; i < 16; i++) {
+            const int ant = kb * 16 + i;
+            int v = 0;
+            if (ant < n_ant) v = w[2 * (((size_t)f * n_ant + ant) * n_beams + b) + comp];
+            d[i >> 2] |= ((unsigned)v & 0xFFu) << (8 * (i & 3));
+        }
+        image[idx] = v4i{(int)d[0], (int)d[1], (int)d[2], (int)d[3]};
+    }
 }
 
 // 16x16x64 weight image: image[f][ct16][rho][s][lane] (16 bytes): lane = 16*kb + c; byte i multiplies LDS chunk
@@ -895,10 +976,11 @@ hipError_t launch_fused_t(const FusedArgs& args, const LaunchShape& ls, hipStrea
     return hipGetLastError();
 }
 
-template <int NIPO, bool WRITE_C, bool FAST = false>
+template <int NIPO, bool WRITE_C, bool FAST = false, bool PAIRED = false>
 hipError_t launch_fused16_t(const FusedArgs& args, const LaunchShape& ls, hipStream_t s)
 {
-    hipLaunchKernelGGL((fused16_kernel<NIPO, WRITE_C, FAST>), dim3(ls.grid), dim3(ls.block), ls.lds_bytes, s, args);
+    hipLaunchKernelGGL((fused16_kernel<NIPO, WRITE_C, FAST, PAIRED>), dim3(ls.grid), dim3(ls.block), ls.lds_bytes, s,
+                       args);
     return hipGetLastError();
 }
 
@@ -926,6 +1008,23 @@ hipError_t dispatch_fused(const Geometry& g, const FusedArgs& args, const Launch
 {
     if (use16(g)) {
         if constexpr (!WRITE_C) {
+            if (g.paired) {
+                if (g.fast_detect) {
+                    switch (g.n_ipo) {
+                        case 16: return launch_fused16_t<16, false, true, true>(args, ls, s);
+                        case 32: return launch_fused16_t<32, false, true, true>(args, ls, s);
+                        case 64: return launch_fused16_t<64, false, true, true>(args, ls, s);
+                    }
+                }
+                switch (g.n_ipo) {
+                    case 2: return launch_fused16_t<2, false, false, true>(args, ls, s);
+                    case 4: return launch_fused16_t<4, false, false, true>(args, ls, s);
+                    case 8: return launch_fused16_t<8, false, false, true>(args, ls, s);
+                    case 16: return launch_fused16_t<16, false, false, true>(args, ls, s);
+                    case 32: return launch_fused16_t<32, false, false, true>(args, ls, s);
+                    case 64: return launch_fused16_t<64, false, false, true>(args, ls, s);
+                }
+            }
             if (g.fast_detect) {
                 switch (g.n_ipo) {
                     case 16: return launch_fused16_t<16, false, true>(args, ls, s);
@@ -953,6 +1052,12 @@ hipError_t dispatch_fused(const Geometry& g, const FusedArgs& args, const Launch
 }  // namespace
 
 size_t weight_image_bytes(const Geometry& g) { return (size_t)g.n_freq * g.n_btiles * 2 * g.nks * 64 * 16; }
+
+bool pairing_supported(const Geometry& g) { return DSABF_PAIRED && use16(g); }
+size_t weight_pair_image_bytes(const Geometry& g)
+{
+    return pairing_supported(g) ? (size_t)g.n_freq * g.n_btiles * 2 * 64 * 16 : 0;
+}
 
 bool fused_supported(const Geometry& g, const char** why)
 {
@@ -1029,29 +1134,43 @@ static FusedArgs make_args(const Geometry& g, const void* d_image, const void* d
     return a;
 }
 
-hipError_t launch_fused(const Geometry& g, const void* d_image, const void* d_packed, int n_units, float* d_out,
-                        int n_cus, hipStream_t s)
+hipError_t launch_fused(const Geometry& g, const void* d_image, const void* d_pair_image, const void* d_packed,
+                        int n_units, float* d_out, int n_cus, hipStream_t s)
 {
     if (n_units <= 0) return hipSuccess;
     if ((long long)n_units * g.n_time > 0x7fffffffLL / 2) return hipErrorInvalidValue;
+    if (g.paired && !(pairing_supported(g) && d_pair_image)) return hipErrorInvalidValue;
     const LaunchShape ls = fused_launch_shape(g, n_units, n_cus);
-    const FusedArgs a = make_args(g, d_image, d_packed, n_units, d_out, ls);
+    const FusedArgs a = make_args(g, g.paired ? d_pair_image : d_image, d_packed, n_units, d_out, ls);
     return dispatch_fused<false>(g, a, ls, s);
 }
 
 hipError_t launch_gemm_only(const Geometry& g, const void* d_image, const void* d_packed, float* d_c, int n_cus,
                             hipStream_t s)
 {
-    const LaunchShape ls = fused_launch_shape(g, 1, n_cus);
-    const FusedArgs a = make_args(g, d_image, d_packed, 1, d_c, ls);
-    return dispatch_fused<true>(g, a, ls, s);
+    Geometry gg = g;
+    gg.paired = false;  // the stage-parity path always runs the general kernel on the general image
+    const LaunchShape ls = fused_launch_shape(gg, 1, n_cus);
+    const FusedArgs a = make_args(gg, d_image, d_packed, 1, d_c, ls);
+    return dispatch_fused<true>(gg, a, ls, s);
 }
 
-hipError_t launch_weight_relayout(const Geometry& g, const int8_t* d_w, void* d_image, int* d_bad, hipStream_t s)
+hipError_t launch_weight_relayout(const Geometry& g, const int8_t* d_w, void* d_image, void* d_pair_image, int* d_bad,
+                                  hipStream_t s)
 {
     const size_t total = weight_image_bytes(g) / 16;
     int grid = (int)((total + 255) / 256);
     if (grid > 4096) grid = 4096;
+    if (pairing_supported(g) && d_pair_image) {
+        const size_t n_fa = (size_t)g.n_freq * g.n_ant;
+        int pgrid = (int)((n_fa * (g.n_beams / 2) + 255) / 256);
+        if (pgrid > 4096) pgrid = 4096;
+        hipLaunchKernelGGL(pair_check_kernel, dim3(pgrid), dim3(256), 0, s, d_w, n_fa, g.n_beams, d_bad + 1);
+        int rgrid = (int)((weight_pair_image_bytes(g) / 16 + 255) / 256);
+        if (rgrid > 4096) rgrid = 4096;
+        hipLaunchKernelGGL(weight_relayout16p_kernel, dim3(rgrid), dim3(256), 0, s, d_w, static_cast<v4i*>(d_pair_image),
+                           g.n_freq, g.n_ant, g.n_beams);
+    }
     if (use16(g)) {
         hipLaunchKernelGGL(weight_relayout16_kernel, dim3(grid), dim3(256), 0, s, d_w, static_cast<v4i*>(d_image), g.n_freq,
                            g.n_ant, g.n_beams, d_bad);
@@ -1083,8 +1202,8 @@ hipError_t launch_dedisperse(const Geometry& g, const float* d_out_unit, float* 
 const char* fused_kernel_name(const Geometry& g, char* buf, size_t n)
 {
     if (use16(g))
-        snprintf(buf, n, "dsabf::fused16_kernel<NIPO=%d%s> (v_mfma_i32_16x16x64_i8)", g.n_ipo,
-                 (g.fast_detect && g.n_ipo >= 16) ? ",FAST" : "");
+        snprintf(buf, n, "dsabf::fused16_kernel<NIPO=%d%s%s> (v_mfma_i32_16x16x64_i8)", g.n_ipo,
+                 (g.fast_detect && g.n_ipo >= 16) ? ",FAST" : "", g.paired ? ",PAIRED" : "");
     else
         snprintf(buf, n, "dsabf::fused_kernel<ANT=%d,NIPO=%d> (v_mfma_i32_32x32x32_i8)", g.n_ant, g.n_ipo);
     return buf;
@@ -1094,6 +1213,28 @@ int fused_vgprs(const Geometry& g)
 {
     hipFuncAttributes attr{};
     const void* fn = nullptr;
+    if (use16(g) && g.paired) {
+        const bool fast = g.fast_detect && g.n_ipo >= 16;
+        switch (g.n_ipo) {
+            case 2: fn = reinterpret_cast<const void*>(fused16_kernel<2, false, false, true>); break;
+            case 4: fn = reinterpret_cast<const void*>(fused16_kernel<4, false, false, true>); break;
+            case 8: fn = reinterpret_cast<const void*>(fused16_kernel<8, false, false, true>); break;
+            case 16:
+                fn = fast ? reinterpret_cast<const void*>(fused16_kernel<16, false, true, true>)
+                          : reinterpret_cast<const void*>(fused16_kernel<16, false, false, true>);
+                break;
+            case 32:
+                fn = fast ? reinterpret_cast<const void*>(fused16_kernel<32, false, true, true>)
+                          : reinterpret_cast<const void*>(fused16_kernel<32, false, false, true>);
+                break;
+            case 64:
+                fn = fast ? reinterpret_cast<const void*>(fused16_kernel<64, false, true, true>)
+                          : reinterpret_cast<const void*>(fused16_kernel<64, false, false, true>);
+                break;
+        }
+        if (!fn || hipFuncGetAttributes(&attr, fn) != hipSuccess) return -1;
+        return attr.numRegs;
+    }
     if (use16(g)) {
         switch (g.n_ipo) {
             case 2: fn = reinterpret_cast<const void*>(fused16_kernel<2, false>); break;

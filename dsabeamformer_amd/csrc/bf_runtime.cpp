@@ -6,6 +6,7 @@
 // entry point fails with BF_ERR_NO_DEVICE / BF_ERR_DEVICE.
 #include "../../include/dsabf.h"
 
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 
 #include <cstdarg>
@@ -29,7 +30,8 @@ struct bf_handle {
     int n_cus = 256;
     bool weights_set = false;
     void* d_wimage = nullptr;     // MFMA fragment image of the weights
-    int* d_flag = nullptr;        // relayout validity flag
+    void* d_wimage_p = nullptr;   // conjugate-pair image (geometries with a paired kernel)
+    int* d_flag = nullptr;        // relayout flags: [0] weight out of range, [1] weights are not conjugate-paired
     uint8_t* d_data = nullptr;    // ring: n_blocks_on_gpu x bytes_per_block
     float* d_out = nullptr;       // n_streams x floats_per_detect
     float* d_ded = nullptr;       // n_streams x n_beams
@@ -191,7 +193,8 @@ int bf_create(const bf_config* cfg, int device, bf_handle** out)
     } while (0)
 
     CREATE_TRY(hipMalloc(&h->d_wimage, dsabf::weight_image_bytes(g)));
-    CREATE_TRY(hipMalloc((void**)&h->d_flag, sizeof(int)));
+    if (dsabf::weight_pair_image_bytes(g)) CREATE_TRY(hipMalloc(&h->d_wimage_p, dsabf::weight_pair_image_bytes(g)));
+    CREATE_TRY(hipMalloc((void**)&h->d_flag, 2 * sizeof(int)));
     CREATE_TRY(hipMalloc((void**)&h->d_data, bf_bytes_per_block(cfg) * (size_t)cfg->n_blocks_on_gpu));
     CREATE_TRY(hipMalloc((void**)&h->d_out, bf_floats_per_detect(cfg) * sizeof(float) * (size_t)cfg->n_streams));
     CREATE_TRY(hipMalloc((void**)&h->d_ded, (size_t)cfg->n_beams * sizeof(float) * (size_t)cfg->n_streams));
@@ -225,6 +228,7 @@ int bf_destroy(bf_handle* h)
     if (h->t0) (void)hipEventDestroy(h->t0);
     if (h->t1) (void)hipEventDestroy(h->t1);
     (void)hipFree(h->d_wimage);
+    (void)hipFree(h->d_wimage_p);
     (void)hipFree(h->d_flag);
     (void)hipFree(h->d_data);
     (void)hipFree(h->d_out);
@@ -242,15 +246,20 @@ int bf_get_config(const bf_handle* h, bf_config* cfg)
 
 static int finish_weights(bf_handle* h, const int8_t* d_w, hipStream_t s)
 {
-    HIP_TRY(hipMemsetAsync(h->d_flag, 0, sizeof(int), s));
-    HIP_TRY(dsabf::launch_weight_relayout(h->geom, d_w, h->d_wimage, h->d_flag, s));
-    int bad = 0;
-    HIP_TRY(hipMemcpyAsync(&bad, h->d_flag, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemsetAsync(h->d_flag, 0, 2 * sizeof(int), s));
+    HIP_TRY(dsabf::launch_weight_relayout(h->geom, d_w, h->d_wimage, h->d_wimage_p, h->d_flag, s));
+    int bad[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(bad, h->d_flag, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
-    if (bad) {
+    h->geom.paired = false;
+    if (bad[0]) {
         h->weights_set = false;
         return fail(BF_ERR_INVALID, "weights contain an imaginary part of -128 (must be >= -127)");
     }
+    // Beam sets symmetric about the boresight (the reference's linear fan and grid) have W[B-1-b] = conj(W[b]) exactly;
+    // the device check above decides per weight set, DSABF_PAIRED=0 in the environment forces the general kernel.
+    const char* env = getenv("DSABF_PAIRED");
+    h->geom.paired = h->d_wimage_p != nullptr && bad[1] == 0 && !(env && env[0] == '0');
     h->weights_set = true;
     return BF_OK;
 }
@@ -373,7 +382,7 @@ int bf_enqueue_gemm_unit(bf_handle* h, int stream_idx, int slot, int time_slice,
     const uint8_t* in = h->d_data + per_gemm * ((size_t)h->cfg.n_gemms_per_block * slot + time_slice);
     float* out = h->d_out + per_det * (size_t)stream_idx;
     hipStream_t s = h->streams[stream_idx];
-    HIP_TRY(dsabf::launch_fused(h->geom, h->d_wimage, in, 1, out, h->n_cus, s));
+    HIP_TRY(dsabf::launch_fused(h->geom, h->d_wimage, h->d_wimage_p, in, 1, out, h->n_cus, s));
     if (host_out) HIP_TRY(hipMemcpyAsync(host_out, out, per_det * sizeof(float), hipMemcpyDeviceToHost, s));
     return BF_OK;
 }
@@ -447,7 +456,7 @@ int bf_beamform_device(bf_handle* h, const void* d_packed, int n_units, float* d
     if (!h->weights_set) return fail(BF_ERR_STATE, "bf_set_weights has not been called");
     if (((uintptr_t)d_packed & 15) || ((uintptr_t)d_out & 3)) return fail(BF_ERR_INVALID, "misaligned device pointer");
     HIP_TRY(hipSetDevice(h->device));
-    HIP_TRY(dsabf::launch_fused(h->geom, h->d_wimage, d_packed, n_units, d_out, h->n_cus, as_stream(hip_stream)));
+    HIP_TRY(dsabf::launch_fused(h->geom, h->d_wimage, h->d_wimage_p, d_packed, n_units, d_out, h->n_cus, as_stream(hip_stream)));
     return BF_OK;
 }
 

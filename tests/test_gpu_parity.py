@@ -482,3 +482,99 @@ def test_seeded_geometry_fuzz_bit_exact(torch, bfmod, orc):
         got = _run(torch, bf, packed, want.size).reshape(want.shape)
         assert np.array_equal(got, want), (case, g, n_units)
         bf.close()
+
+
+def _conj_symmetric(w):
+    """Make beam B-1-b the complex conjugate of beam b (what a beam set symmetric about the boresight produces)."""
+    w = w.copy()
+    B = w.shape[2]
+    w[:, :, B // 2:, 0] = w[:, :, :B // 2, 0][:, :, ::-1]
+    w[:, :, B // 2:, 1] = -w[:, :, :B // 2, 1][:, :, ::-1]
+    return w
+
+
+@pytest.mark.parametrize("n_avg", [1, 2, 4, 8, 16, 32])
+@pytest.mark.parametrize("tsplit", ["1", "3"])
+def test_conjugate_paired_kernel_bit_exact(torch, bfmod, orc, monkeypatch, n_avg, tsplit):
+    """Conjugate-symmetric weights select fused16_kernel<..., PAIRED> (half the MFMA work); its results must be the
+    same bits as the oracle's and as the general kernel's (DSABF_PAIRED=0), over several chunks per workgroup."""
+    monkeypatch.setenv("DSABF_TSPLIT", tsplit)
+    n_ipo = 2 * n_avg
+    g = orc.Geom(n_beams=96, n_ant=64, n_freq=3, n_avg=n_avg, n_out_per_gemm=max(2, 16 // n_ipo))
+    n_units = max(3, -(-(5 * 128 * (2 if n_ipo == 64 else 1) + 64) // g.n_time))
+    rng = np.random.default_rng(77 + n_avg)
+    w = _conj_symmetric(rng.integers(-127, 128, size=(g.n_freq, g.n_ant, g.n_beams, 2), dtype=np.int8))
+    packed = rng.integers(0, 256, size=(n_units, g.n_freq, g.n_time, g.n_ant), dtype=np.uint8)
+    want = orc.beamform(g, w, packed)
+    bf = bfmod.Beamformer(_cfg(bfmod, g))
+    bf.set_weights(w)
+    assert "PAIRED" in bf.kernel_info(n_units)["kernel"]
+    assert np.array_equal(_run(torch, bf, packed, want.size).reshape(want.shape), want)
+    monkeypatch.setenv("DSABF_PAIRED", "0")
+    bf.set_weights(w)
+    assert "PAIRED" not in bf.kernel_info(n_units)["kernel"]
+    assert np.array_equal(_run(torch, bf, packed, want.size).reshape(want.shape), want)
+
+
+def test_pairing_is_decided_per_weight_set(torch, bfmod, orc):
+    """One element off the symmetry -> the general kernel; symmetric again -> the paired one; both bit-exact.  The
+    reference's own default geometry (linear fan about the boresight) is symmetric, so the product path pairs."""
+    g = orc.Geom(n_beams=64, n_ant=64, n_freq=4, n_avg=16, n_out_per_gemm=2)
+    rng = np.random.default_rng(5150)
+    ws = _conj_symmetric(rng.integers(-127, 128, size=(g.n_freq, g.n_ant, g.n_beams, 2), dtype=np.int8))
+    packed = rng.integers(0, 256, size=(3, g.n_freq, g.n_time, g.n_ant), dtype=np.uint8)
+    bf = bfmod.Beamformer(_cfg(bfmod, g))
+    for f, a, b, c in [(3, 63, 63, 1), (0, 0, 0, 0), (2, 17, 31, 1)]:
+        wb = ws.copy()
+        wb[f, a, b, c] = np.int8(wb[f, a, b, c] + 1 if wb[f, a, b, c] < 127 else 126)  # its partner stays
+        bf.set_weights(wb)
+        assert "PAIRED" not in bf.kernel_info(3)["kernel"], (f, a, b, c)
+        want = orc.beamform(g, wb, packed)
+        assert np.array_equal(_run(torch, bf, packed, want.size).reshape(want.shape), want)
+    bf.set_weights(ws)
+    assert "PAIRED" in bf.kernel_info(3)["kernel"]
+    want = orc.beamform(g, ws, packed)
+    assert np.array_equal(_run(torch, bf, packed, want.size).reshape(want.shape), want)
+    from dsabeamformer_amd import host
+    gd = orc.DEBUG_GEOM
+    bfd = bfmod.Beamformer(_cfg(bfmod, gd))
+    bfd.set_weights(host.make_weights_default(gd.n_beams, gd.n_ant, gd.n_freq))
+    assert "PAIRED" in bfd.kernel_info(1)["kernel"]
+
+
+@pytest.mark.parametrize("n_freq,n_beams,n_avg", [(8, 512, 16), (16, 288, 1), (24, 512, 8), (8, 32, 32), (5, 544, 16)])
+def test_conjugate_paired_beam_groups_bit_exact(torch, bfmod, orc, n_freq, n_beams, n_avg):
+    """Paired kernel across several beam groups (base beams of one workgroup pair with the far end of the beam axis),
+    a partially filled last group, and the XCD-aware block decode."""
+    n_ipo = 2 * n_avg
+    g = orc.Geom(n_beams=n_beams, n_ant=64, n_freq=n_freq, n_avg=n_avg, n_out_per_gemm=max(2, 16 // n_ipo))
+    n_units = -(-1100 // g.n_time)
+    rng = np.random.default_rng(n_freq * 1000 + n_beams + 1)
+    w = _conj_symmetric(rng.integers(-127, 128, size=(g.n_freq, g.n_ant, g.n_beams, 2), dtype=np.int8))
+    packed = rng.integers(0, 256, size=(n_units, g.n_freq, g.n_time, g.n_ant), dtype=np.uint8)
+    bf = bfmod.Beamformer(_cfg(bfmod, g))
+    bf.set_weights(w)
+    assert "PAIRED" in bf.kernel_info(n_units)["kernel"]
+    want = orc.beamform(g, w, packed)
+    assert np.array_equal(_run(torch, bf, packed, want.size).reshape(want.shape), want)
+
+
+@pytest.mark.parametrize("n_avg", [8, 16, 32])
+def test_fast_detect_paired_equals_fast_general(torch, bfmod, orc, monkeypatch, n_avg):
+    """BF_DETECT_FAST on the paired kernel: the integer part is exact, so it gives the same bits as FAST on the general
+    kernel (and both stay within the stated tolerance of the canonical result)."""
+    g = orc.Geom(n_beams=64, n_ant=64, n_freq=3, n_avg=n_avg, n_out_per_gemm=2)
+    rng = np.random.default_rng(909 + n_avg)
+    w = _conj_symmetric(rng.integers(-127, 128, size=(g.n_freq, g.n_ant, g.n_beams, 2), dtype=np.int8))
+    packed = rng.integers(0, 256, size=(5, g.n_freq, g.n_time, g.n_ant), dtype=np.uint8)
+    want = orc.beamform(g, w, packed)
+    bf = bfmod.Beamformer(_cfg(bfmod, g, detect_mode=1))
+    bf.set_weights(w)
+    assert "FAST,PAIRED" in bf.kernel_info(5)["kernel"]
+    got_p = _run(torch, bf, packed, want.size).reshape(want.shape)
+    monkeypatch.setenv("DSABF_PAIRED", "0")
+    bf.set_weights(w)
+    got_g = _run(torch, bf, packed, want.size).reshape(want.shape)
+    assert np.array_equal(got_p, got_g)
+    rel = np.abs(got_p.astype(np.float64) - want) / np.maximum(want.astype(np.float64), 1e-30)
+    assert rel.max() <= 4 * g.n_ipo * 2.0 ** -24
