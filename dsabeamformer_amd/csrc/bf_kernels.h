@@ -29,7 +29,7 @@ struct Geometry {
 // Bytes of the MFMA-fragment weight image: [freq][btile][re|im][kstep][lane] x 16 B.
 size_t weight_image_bytes(const Geometry& g);
 
-// Conjugate-pair image (fused16_kernel<..., PAIRED>): [freq][pair tile][Wr|Wi][lane] x 16 B; 0 bytes when the
+// Conjugate-pair image (fused16_kernel<..., PAIRED>): [freq][pair tile][Wr|Wi|-Wi][lane] x 16 B; 0 bytes when the
 // geometry has no paired kernel.
 bool pairing_supported(const Geometry& g);
 size_t weight_pair_image_bytes(const Geometry& g);

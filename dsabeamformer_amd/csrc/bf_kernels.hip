@@ -44,6 +44,9 @@
 #ifndef DSABF_PAIRED
 #define DSABF_PAIRED 1    // build the conjugate-pair variants of fused16_kernel (used when the weights allow it)
 #endif
+#ifndef DSABF_PAIR_MFMA
+#define DSABF_PAIR_MFMA 4 // MFMAs per conjugate pair tile: 4 (+-P2, +-P4 on the VALU), 5 (real part chained on the MFMA), 6
+#endif
 #ifndef DSABF_OCC16
 #define DSABF_OCC16 3     // 147 VGPRs, no spills; 4 would spill 15 registers for no gain (the kernel is energy-bound)
 #endif
@@ -655,7 +658,8 @@ __global__ __launch_bounds__(kThreads16, DSABF_OCC16) void fused16_kernel(FusedA
 
     // ---- which beams this lane produces, and the weight fragments ------------------------------------------
     int slot_beam[NS];                                    // beam index of output slot s (>= n_beams: none)
-    v4i bw[NT][PAIRED ? 2 : 4];                           // general: [ct][2*rho + s]; paired: [pct][0 = Wr, 1 = Wi]
+    constexpr int NPC = DSABF_PAIR_MFMA >= 5 ? 3 : 2;     // paired fragments per tile: Wr, Wi (, -Wi)
+    v4i bw[NT][PAIRED ? NPC : 4];                         // general: [ct][2*rho + s]; paired: [pct][Wr, Wi, -Wi]
     bool wave_active;
     if constexpr (PAIRED) {
         const int n_pct = a.n_btiles;                     // pair tiles of 16 base beams = n_beams / 32
@@ -668,8 +672,8 @@ __global__ __launch_bounds__(kThreads16, DSABF_OCC16) void fused16_kernel(FusedA
             slot_beam[2 * t] = ok ? bb : a.n_beams;
             slot_beam[2 * t + 1] = ok ? a.n_beams - 1 - bb : a.n_beams;
 #pragma unroll
-            for (int comp = 0; comp < 2; comp++)
-                bw[t][comp] = ok ? a.wimg[(((size_t)f * n_pct + pct0 + t) * 2 + comp) * 64 + lane] : v4i{0, 0, 0, 0};
+            for (int comp = 0; comp < NPC; comp++)
+                bw[t][comp] = ok ? a.wimg[(((size_t)f * n_pct + pct0 + t) * 3 + comp) * 64 + lane] : v4i{0, 0, 0, 0};
         }
     } else {
         const int n_ctiles = a.n_btiles * 2;
@@ -770,118 +774,149 @@ __global__ __launch_bounds__(kThreads16, DSABF_OCC16) void fused16_kernel(FusedA
             if (c + 1 < c_end) write_chunk(nxt);
             if (c + 2 < c_end) load_chunk(c + 2);
         } else {
-#pragma unroll
-            for (int t8 = 0; t8 < 8; t8++) {
-                const int row = lds_row16<NIPO>(t8, c16);
-                const v4i a0 = *reinterpret_cast<const v4i*>(cur + row * RB + 16 * swz16<NIPO>(g4, row));      // 16*re
-                const v4i a1 = *reinterpret_cast<const v4i*>(cur + row * RB + 16 * swz16<NIPO>(4 + g4, row));  // 16*im
+            // detect + accumulate the 4 samples (fr, fi: accumulator bit patterns K + 16 n) of output slot sl
+            auto detect = [&](const int t8, const v4f fr, const v4f fi, const int sl) {
                 // stream position of this tile's rows and whether it starts / ends an output
                 const int gi = (NIPO >= 32) ? 0 : (t8 >> 2);          // group inside the chunk (L = 16)
                 const int q4 = (NIPO >= 32) ? (32 * (c % CPG) + 4 * t8) : 4 * (t8 & 3);  // position of register 0
                 const unsigned grp = (NIPO >= 32) ? (unsigned)(c / CPG) : (2u * (unsigned)c + gi);
                 const unsigned o = 4u * grp + (unsigned)g4;           // this lane's stream (output index if LONG)
-
-                // detect + accumulate the 4 samples (fr, fi: accumulator bit patterns K + 16 n) of output slot sl
-                auto detect = [&](const v4f fr, const v4f fi, const int sl) {
-                    const int beam = slot_beam[sl];
-                    if constexpr (WRITE_C) {
+                const int beam = slot_beam[sl];
+                if constexpr (WRITE_C) {
 #pragma unroll
-                        for (int r = 0; r < 4; r++) {
-                            const unsigned sidx = o * (unsigned)L + (unsigned)(q4 + r);
-                            if (o * (unsigned)L < a.S && beam < a.n_beams) {
-                                v2f cv = {__builtin_fmaf(fr[r], kAlpha16, kNegMagicAlpha16),
-                                          __builtin_fmaf(fi[r], kAlpha16, kNegMagicAlpha16)};
-                                *reinterpret_cast<v2f*>(a.out + 2 * (((size_t)f * a.T + sidx) * a.n_beams + beam)) = cv;
-                            }
+                    for (int r = 0; r < 4; r++) {
+                        const unsigned sidx = o * (unsigned)L + (unsigned)(q4 + r);
+                        if (o * (unsigned)L < a.S && beam < a.n_beams) {
+                            v2f cv = {__builtin_fmaf(fr[r], kAlpha16, kNegMagicAlpha16),
+                                      __builtin_fmaf(fi[r], kAlpha16, kNegMagicAlpha16)};
+                            *reinterpret_cast<v2f*>(a.out + 2 * (((size_t)f * a.T + sidx) * a.n_beams + beam)) = cv;
                         }
-                    } else if constexpr (FAST) {
-                        // BF_DETECT_FAST: d = 16 n exactly (one subtract), acc = fma(d, d, acc): 4 ops per sample;
-                        // the (alpha/16)^2 scale is applied once per output when it is parked for the store.
-                        float sacc = (q4 == 0) ? 0.0f : sum[sl];
+                    }
+                } else if constexpr (FAST) {
+                    // BF_DETECT_FAST: d = 16 n exactly (one subtract), acc = fma(d, d, acc): 4 ops per sample;
+                    // the (alpha/16)^2 scale is applied once per output when it is parked for the store.
+                    float sacc = (q4 == 0) ? 0.0f : sum[sl];
 #pragma unroll
-                        for (int r = 0; r < 4; r++) {
-                            const float dr = fr[r] - kMagic, di = fi[r] - kMagic;
-                            sacc = __builtin_fmaf(dr, dr, sacc);
-                            sacc = __builtin_fmaf(di, di, sacc);
-                        }
+                    for (int r = 0; r < 4; r++) {
+                        const float dr = fr[r] - kMagic, di = fi[r] - kMagic;
+                        sacc = __builtin_fmaf(dr, dr, sacc);
+                        sacc = __builtin_fmaf(di, di, sacc);
+                    }
+                    asm volatile("" : "+v"(sacc));
+                    sum[sl] = sacc;
+                    if (q4 + 4 == L) {
+                        pend[gi][sl] = sacc * (kAlpha16 * kAlpha16);
+                        pend_chunk[gi] = c;
+                    }
+                } else {
+                    float p[4];
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const float x = __builtin_fmaf(fr[r], kAlpha16, kNegMagicAlpha16);
+                        const float y = __builtin_fmaf(fi[r], kAlpha16, kNegMagicAlpha16);
+                        const float xx = x * x;
+                        const float yy = y * y;
+                        p[r] = xx + yy;
+                    }
+                    if constexpr (LONG) {
+                        float sacc = (q4 == 0) ? p[0] : (sum[sl] + p[0]);
+                        sacc = sacc + p[1];
+                        sacc = sacc + p[2];
+                        sacc = sacc + p[3];
                         asm volatile("" : "+v"(sacc));
                         sum[sl] = sacc;
                         if (q4 + 4 == L) {
-                            pend[gi][sl] = sacc * (kAlpha16 * kAlpha16);
+                            pend[gi][sl] = sacc;
                             pend_chunk[gi] = c;
                         }
                     } else {
-                        float p[4];
-#pragma unroll
-                        for (int r = 0; r < 4; r++) {
-                            const float x = __builtin_fmaf(fr[r], kAlpha16, kNegMagicAlpha16);
-                            const float y = __builtin_fmaf(fi[r], kAlpha16, kNegMagicAlpha16);
-                            const float xx = x * x;
-                            const float yy = y * y;
-                            p[r] = xx + yy;
-                        }
-                        if constexpr (LONG) {
-                            float sacc = (q4 == 0) ? p[0] : (sum[sl] + p[0]);
+                        // 16-sample stream = 16/NIPO outputs; registers r hold positions q4 + r
+                        const bool valid = (o * 16u < a.S) && (beam < a.n_beams);
+                        float* op = a.out + ((size_t)o * (16 / NIPO)) * FB + (size_t)f * a.n_beams + beam;
+                        if constexpr (NIPO == 2) {
+                            const float o0 = p[0] + p[1], o1 = p[2] + p[3];
+                            if (valid) {
+                                op[(size_t)(q4 / 2) * FB] = o0;
+                                op[(size_t)(q4 / 2 + 1) * FB] = o1;
+                            }
+                        } else if constexpr (NIPO == 4) {
+                            float sacc = p[0] + p[1];
+                            sacc = sacc + p[2];
+                            sacc = sacc + p[3];
+                            if (valid) op[(size_t)(q4 / 4) * FB] = sacc;
+                        } else {  // NIPO == 8
+                            float sacc = (q4 % 8 == 0) ? p[0] : (sum[sl] + p[0]);
                             sacc = sacc + p[1];
                             sacc = sacc + p[2];
                             sacc = sacc + p[3];
                             asm volatile("" : "+v"(sacc));
                             sum[sl] = sacc;
-                            if (q4 + 4 == L) {
-                                pend[gi][sl] = sacc;
-                                pend_chunk[gi] = c;
-                            }
-                        } else {
-                            // 16-sample stream = 16/NIPO outputs; registers r hold positions q4 + r
-                            const bool valid = (o * 16u < a.S) && (beam < a.n_beams);
-                            float* op = a.out + ((size_t)o * (16 / NIPO)) * FB + (size_t)f * a.n_beams + beam;
-                            if constexpr (NIPO == 2) {
-                                const float o0 = p[0] + p[1], o1 = p[2] + p[3];
-                                if (valid) {
-                                    op[(size_t)(q4 / 2) * FB] = o0;
-                                    op[(size_t)(q4 / 2 + 1) * FB] = o1;
-                                }
-                            } else if constexpr (NIPO == 4) {
-                                float sacc = p[0] + p[1];
-                                sacc = sacc + p[2];
-                                sacc = sacc + p[3];
-                                if (valid) op[(size_t)(q4 / 4) * FB] = sacc;
-                            } else {  // NIPO == 8
-                                float sacc = (q4 % 8 == 0) ? p[0] : (sum[sl] + p[0]);
-                                sacc = sacc + p[1];
-                                sacc = sacc + p[2];
-                                sacc = sacc + p[3];
-                                asm volatile("" : "+v"(sacc));
-                                sum[sl] = sacc;
-                                if (q4 % 8 == 4 && valid) op[(size_t)(q4 / 8) * FB] = sacc;
-                            }
+                            if (q4 % 8 == 4 && valid) op[(size_t)(q4 / 8) * FB] = sacc;
                         }
                     }
-                };
-
-#pragma unroll
-                for (int t = 0; t < NT; t++) {
-                    if constexpr (PAIRED) {
-                        const v4i p1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, bw[t][0], kc, 0, 0, 0);     // Wr*Vr + K
-                        const v4i p2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, bw[t][1], kzero, 0, 0, 0);  // Wi*Vi
-                        const v4i p3 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, bw[t][0], kc, 0, 0, 0);     // Wr*Vi + K
-                        const v4i p4 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, bw[t][1], kzero, 0, 0, 0);  // Wi*Vr
-                        detect(__builtin_bit_cast(v4f, p1 - p2), __builtin_bit_cast(v4f, p3 + p4), 2 * t);      // beam b
-                        detect(__builtin_bit_cast(v4f, p1 + p2), __builtin_bit_cast(v4f, p3 - p4), 2 * t + 1);  // B-1-b
-                    } else {
-                        v4i cr = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, bw[t][0], kc, 0, 0, 0);
-                        v4i ci = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, bw[t][2], kc, 0, 0, 0);
-                        cr = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, bw[t][1], cr, 0, 0, 0);
-                        ci = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, bw[t][3], ci, 0, 0, 0);
-                        detect(__builtin_bit_cast(v4f, cr), __builtin_bit_cast(v4f, ci), t);
-                    }
                 }
-                // staging work in the shadow of the MFMA stream (see fused_kernel)
+            };
+
+            // LDS fragments of row-tile t8: a0 = 16*re, a1 = 16*im of 16 antennas x 16 samples per lane group
+            auto read_frag = [&](const int t8, v4i& a0, v4i& a1) {
+                const int row = lds_row16<NIPO>(t8, c16);
+                a0 = *reinterpret_cast<const v4i*>(cur + row * RB + 16 * swz16<NIPO>(g4, row));
+                a1 = *reinterpret_cast<const v4i*>(cur + row * RB + 16 * swz16<NIPO>(4 + g4, row));
+            };
+            // One step = the MFMAs of column tile t on row-tile fragments (a0, a1); its SPS output slots land in
+            // re[] / im[] as accumulator bit patterns K + 16 n.
+            constexpr int SPS = PAIRED ? 2 : 1;                 // output slots per step
+            auto issue = [&](const v4i a0, const v4i a1, const int t, v4i (&re)[SPS], v4i (&im)[SPS]) {
+                if constexpr (PAIRED) {
+                    const v4i p1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, bw[t][0], kc, 0, 0, 0);     // Wr*Vr + K
+                    const v4i p3 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, bw[t][0], kc, 0, 0, 0);     // Wr*Vi + K
+                    if constexpr (DSABF_PAIR_MFMA >= 5) {   // +-P2 chained on the MFMA pipe (bw[t][2] = -Wi)
+                        re[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, bw[t][2], p1, 0, 0, 0);
+                        re[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, bw[t][1], p1, 0, 0, 0);
+                    } else {
+                        const v4i p2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, bw[t][1], kzero, 0, 0, 0);  // Wi*Vi
+                        re[0] = p1 - p2;
+                        re[1] = p1 + p2;
+                    }
+                    if constexpr (DSABF_PAIR_MFMA >= 6) {
+                        im[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, bw[t][1], p3, 0, 0, 0);
+                        im[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, bw[t][2], p3, 0, 0, 0);
+                    } else {
+                        const v4i p4 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, bw[t][1], kzero, 0, 0, 0);  // Wi*Vr
+                        im[0] = p3 + p4;
+                        im[1] = p3 - p4;
+                    }
+                } else {
+                    v4i cr = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, bw[t][0], kc, 0, 0, 0);
+                    v4i ci = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, bw[t][2], kc, 0, 0, 0);
+                    re[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, bw[t][1], cr, 0, 0, 0);
+                    im[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, bw[t][3], ci, 0, 0, 0);
+                }
+            };
+            auto consume = [&](const int t8, const int t, const v4i (&re)[SPS], const v4i (&im)[SPS]) {
+#pragma unroll
+                for (int e = 0; e < SPS; e++)   // paired: slot 2t = beam b, slot 2t+1 = beam B-1-b
+                    detect(t8, __builtin_bit_cast(v4f, re[e]), __builtin_bit_cast(v4f, im[e]), SPS * t + e);
+            };
+            // staging work in the shadow of the MFMA stream (see fused_kernel)
+            auto staging = [&](const int t8) {
                 if (t8 == 1 && c + 1 < c_end) write_chunk(nxt);
                 if (t8 == 3) {
                     flush_pending();
                     if (c + 2 < c_end) load_chunk(c + 2);
                 }
+            };
+#pragma unroll
+            for (int t8 = 0; t8 < 8; t8++) {
+                v4i a0, a1;
+                read_frag(t8, a0, a1);
+#pragma unroll
+                for (int t = 0; t < NT; t++) {
+                    v4i re[SPS], im[SPS];
+                    issue(a0, a1, t, re, im);
+                    consume(t8, t, re, im);
+                }
+                staging(t8);
             }
         }
         __syncthreads();
@@ -904,18 +939,18 @@ __global__ void pair_check_kernel(const int8_t* __restrict__ w, size_t n_fa, int
     if (bad) *flag = 1;
 }
 
-// Paired weight image: image[f][pct][comp][lane] (16 bytes): lane = 16*kb + c; byte i = Wr (comp 0) or Wi (comp 1) of
-// antenna 16*kb + i for base beam 16*pct + c (< n_beams / 2).
+// Paired weight image: image[f][pct][comp][lane] (16 bytes): lane = 16*kb + c; byte i = Wr (comp 0), Wi (comp 1) or
+// -Wi (comp 2) of antenna 16*kb + i for base beam 16*pct + c (< n_beams / 2).
 __global__ void weight_relayout16p_kernel(const int8_t* __restrict__ w, v4i* __restrict__ image, int n_freq, int n_ant,
                                           int n_beams)
 {
     const int n_pct = n_beams / 32;
-    const size_t total = (size_t)n_freq * n_pct * 2 * 64;
+    const size_t total = (size_t)n_freq * n_pct * 3 * 64;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
         const int lane = (int)(idx & 63);
         size_t r = idx >> 6;
-        const int comp = (int)(r & 1);
-        r >>= 1;
+        const int comp = (int)(r % 3);
+        r /= 3;
         const int pct = (int)(r % n_pct);
         const int f = (int)(r / n_pct);
         const int kb = lane >> 4, b = pct * 16 + (lane & 15);
@@ -923,7 +958,8 @@ __global__ void weight_relayout16p_kernel(const int8_t* __restrict__ w, v4i* __r
         for (int i = 0; i < 16; i++) {
             const int ant = kb * 16 + i;
             int v = 0;
-            if (ant < n_ant) v = w[2 * (((size_t)f * n_ant + ant) * n_beams + b) + comp];
+            if (ant < n_ant) v = w[2 * (((size_t)f * n_ant + ant) * n_beams + b) + (comp ? 1 : 0)];
+            if (comp == 2) v = -v;
             d[i >> 2] |= ((unsigned)v & 0xFFu) << (8 * (i & 3));
         }
         image[idx] = v4i{(int)d[0], (int)d[1], (int)d[2], (int)d[3]};
@@ -1056,7 +1092,7 @@ size_t weight_image_bytes(const Geometry& g) { return (size_t)g.n_freq * g.n_bti
 bool pairing_supported(const Geometry& g) { return DSABF_PAIRED && use16(g); }
 size_t weight_pair_image_bytes(const Geometry& g)
 {
-    return pairing_supported(g) ? (size_t)g.n_freq * g.n_btiles * 2 * 64 * 16 : 0;
+    return pairing_supported(g) ? (size_t)g.n_freq * g.n_btiles * 3 * 64 * 16 : 0;
 }
 
 bool fused_supported(const Geometry& g, const char** why)

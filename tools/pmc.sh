@@ -3,7 +3,7 @@
 # Runs separate rocprofv3 --pmc passes (never combined with trace domains) and leaves CSVs under gpurun_out/<outdir>/.
 R=$PWD; OUT=$R/gpurun_out/$1; shift
 mkdir -p $OUT; export TMPDIR=/tmp; cd /tmp
-ARGS="--steps 6 --warmup 2 --no-cpu-baseline $@"
+ARGS="--steps 6 --warmup 2 --no-cpu-baseline --no-extras $@"
 i=0
 for C in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_VALU_MFMA_I8 SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY" \
          "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_VALU_MFMA_COEXEC_CYCLES SQ_INSTS_LDS SQ_INSTS_SALU" \
