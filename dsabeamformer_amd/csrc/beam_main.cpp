@@ -15,6 +15,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -26,12 +27,12 @@ int main(int argc, char* argv[])
     bf_config cfg;
     bf_config_default(&cfg, /*debug=*/1);
     debug_run_options opt;
-    std::string positions, directions, sources, output = "bin/data.py";
+    std::string positions, directions, sources, output = "bin/data.py", detected_path;
     bool dada_requested = false;
     long junk_blocks = -1;
 
     int arg = 0;
-    while ((arg = getopt(argc, argv, "s:g:p:d:o:D:a:c:k:j:vh")) != -1) {  // src/beamformer.cu:41-43 (+ -o -D -a -v)
+    while ((arg = getopt(argc, argv, "s:g:p:d:o:D:a:c:k:j:w:vh")) != -1) {  // src/beamformer.cu:41-43 (+ -o -D -a -v)
         switch (arg) {
             case 's': sources = optarg; break;                 // :77-89
             case 'g': opt.gpu = atoi(optarg); break;           // :92-100
@@ -41,6 +42,7 @@ int main(int argc, char* argv[])
             case 'D': opt.device = atoi(optarg); break;
             case 'a': cfg.n_avg = atoi(optarg); break;
             case 'j': junk_blocks = atol(optarg); break;
+            case 'w': detected_path = optarg; break;
             case 'v': opt.verbose = true; cfg.verbose = 1; break;
             case 'c':
             case 'k': dada_requested = true; break;            // :59-75
@@ -85,8 +87,18 @@ int main(int argc, char* argv[])
         oopt.device = opt.device;
         oopt.verbose = opt.verbose;
         oopt.burn_in = kBurnIn;
+        std::unique_ptr<file_sink> sink;
+        if (!detected_path.empty()) {  // -w: keep the detected stream (the reference drops it, README.md:149)
+            sink.reset(new file_sink(pcfg, detected_path.c_str(), opt.gpu));
+            if (!sink->ok() || !sink->is_open()) {
+                fprintf(stderr, "beam: could not open %s\n", detected_path.c_str());
+                return EXIT_FAILURE;
+            }
+            oopt.sink = sink.get();
+        }
         observation_result ores;
         int orc = run_observation(pcfg, oopt, src, pos.data(), dir.data(), &ores, std::cout);
+        if (sink) std::cout << "Wrote " << sink->get_delivered() << " gemm-units of detected powers to " << detected_path << std::endl;
         if (orc != BF_OK) {
             fprintf(stderr, "GPUassert: %s (%d)\n", bf_last_error(), orc);
             return EXIT_FAILURE;

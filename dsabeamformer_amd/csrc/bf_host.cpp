@@ -668,7 +668,7 @@ int run_debug_observation(const bf_config& cfg, const debug_run_options& opt, de
 
 // ---- junk_block_source -------------------------------------------------------------------------------------------
 junk_block_source::junk_block_source(const bf_config& c, uint64_t nb, int rb, uint64_t seed)
-    : cfg(c), block_size(bf_bytes_per_block(&c)), n_blocks(nb), ring_blocks(rb < 1 ? 1 : rb)
+    : block_size(bf_bytes_per_block(&c)), n_blocks(nb), ring_blocks(rb < 1 ? 1 : rb)
 {
     const size_t total = (size_t)block_size * ring_blocks;
     void* p = nullptr;
@@ -715,6 +715,74 @@ char* junk_block_source::read()
 }
 
 bool junk_block_source::check_transfers_complete() { return bytes_read < block_size; }  // src/dada_handler.hh:105-113
+
+// ---- detected-stream sinks ------------------------------------------------------------------------------------------
+detected_sink::detected_sink(const bf_config& cfg, uint64_t slots)
+    : floats_per_gemm(bf_floats_per_detect(&cfg)), n_slots(slots ? slots : slots_for(cfg))
+{
+    const size_t bytes = floats_per_gemm * n_slots * sizeof(float);
+    void* p = nullptr;
+    if (bf_alloc_pinned(&p, bytes) == BF_OK)
+        pinned = true;
+    else
+        p = ::malloc(bytes);  // no device (CPU tests of the ring logic)
+    ring = static_cast<float*>(p);
+}
+
+detected_sink::~detected_sink()
+{
+    if (!ring) return;
+    if (pinned)
+        bf_free_pinned(ring);
+    else
+        ::free(ring);
+}
+
+float* detected_sink::acquire(uint64_t gemm_index)
+{
+    if (!ring || gemm_index < next_commit || gemm_index >= next_commit + n_slots) return nullptr;
+    return ring + (size_t)(gemm_index % n_slots) * floats_per_gemm;
+}
+
+bool detected_sink::commit(uint64_t gemm_index)
+{
+    if (!ring || gemm_index != next_commit) return false;
+    if (!deliver(gemm_index, ring + (size_t)(gemm_index % n_slots) * floats_per_gemm, floats_per_gemm)) failed = true;
+    next_commit++;
+    delivered++;
+    return !failed;
+}
+
+file_sink::file_sink(const bf_config& cfg, const char* path, int gpu, uint64_t slots) : detected_sink(cfg, slots)
+{
+    fp = ::fopen(path, "wb");
+    if (!fp) return;
+    char header[kHeaderBytes];
+    ::memset(header, 0, sizeof(header));
+    ::snprintf(header, sizeof(header),
+               "HDR_VERSION 1.0\nHDR_SIZE %zu\nINSTRUMENT DSA\nCONTENT detected_power\nDTYPE float32\nENDIAN little\n"
+               "ORDER gemm,output,frequency,beam\nN_BEAMS %d\nN_FREQUENCIES %d\nN_OUTPUTS_PER_GEMM %d\nN_ANTENNAS %d\n"
+               "N_POL %d\nN_AVERAGING %d\nN_GEMMS_PER_BLOCK %d\nGPU %d\nFLOATS_PER_GEMM %zu\n",
+               kHeaderBytes, cfg.n_beams, cfg.n_freq, cfg.n_out_per_gemm, cfg.n_ant, cfg.n_pol, cfg.n_avg,
+               cfg.n_gemms_per_block, gpu, get_floats_per_gemm());
+    if (::fwrite(header, 1, sizeof(header), fp) != sizeof(header)) {
+        ::fclose(fp);
+        fp = nullptr;
+    }
+}
+
+file_sink::~file_sink() { finish(); }
+
+bool file_sink::deliver(uint64_t, const float* data, size_t n_floats)
+{
+    return fp && ::fwrite(data, sizeof(float), n_floats, fp) == n_floats;
+}
+
+void file_sink::finish()
+{
+    if (fp) ::fclose(fp);
+    fp = nullptr;
+}
 
 // ---- production observation loop (src/beamformer.cu:364-534, #ifndef DEBUG branches) -------------------------------------
 int run_observation(const bf_config& cfg, const observation_options& opt, block_source& source, const antenna* pos,
@@ -767,6 +835,7 @@ int run_observation(const bf_config& cfg, const observation_options& opt, block_
     if (source.get_block_size() != block_bytes)
         log << "ERROR: block size " << source.get_block_size() << ", Should also be " << block_bytes << std::endl;
 
+    uint64_t sink_committed = 0;
     bf_timer_start(h);  // :358
     while (!obs_state.check_observations_complete()) {  // :364
         if (opt.verbose) {
@@ -792,8 +861,15 @@ int run_observation(const bf_config& cfg, const observation_options& opt, block_
             const long long block_index = (long long)obs_state.get_blocks_analysis_queue();
             for (int part = 0; part < cfg.n_gemms_per_block / n_streams; part++) {
                 for (int st = 0; st < n_streams; st++) {
-                    rc = bf_enqueue_gemm_unit(h, st, (int)obs_state.get_next_gpu_analysis_block(), timeSlice[st],
-                                              &beam_out[(size_t)st * n_f_per_detect]);  // :464-488
+                    float* dst = &beam_out[(size_t)st * n_f_per_detect];  // the reference's destination, :485-488
+                    if (opt.sink) {
+                        dst = opt.sink->acquire((uint64_t)block_index * cfg.n_gemms_per_block + timeSlice[st]);
+                        if (!dst) {
+                            log << "ERROR: detected sink has no free slot" << std::endl;
+                            return BF_ERR_STATE;
+                        }
+                    }
+                    rc = bf_enqueue_gemm_unit(h, st, (int)obs_state.get_next_gpu_analysis_block(), timeSlice[st], dst);  // :464-488
                     if (rc != BF_OK) {
                         log << "GPUassert: " << bf_last_error() << std::endl;
                         return rc;
@@ -806,10 +882,18 @@ int run_observation(const bf_config& cfg, const observation_options& opt, block_
             obs_state.generate_analysis_event();  // :525
         }
         obs_state.check_analysis_events();  // :532
+        if (opt.sink) {  // every D2H copy of an analysed block has landed: hand its gemm-units over, in order
+            for (; sink_committed < obs_state.get_blocks_analyzed() * (uint64_t)cfg.n_gemms_per_block; sink_committed++)
+                if (!opt.sink->commit(sink_committed)) {
+                    log << "ERROR: detected sink failed at gemm-unit " << sink_committed << std::endl;
+                    return BF_ERR_STATE;
+                }
+        }
     }
     float ms = 0;
     bf_timer_stop(h, &ms);
     bf_stream_sync(h, -1);  // :560-562
+    if (opt.sink) opt.sink->close();
     const uint64_t blocks = obs_state.get_blocks_analyzed();
     const uint64_t chunks = obs_state.get_current_transfer_gemm() * cfg.n_out_per_gemm;  // :552
     const double rate = (double)source.get_block_size() * obs_state.get_blocks_transfer_queue() / ms / 1e6;  // :554
@@ -1085,11 +1169,9 @@ int bfh_run_debug_observation(const bf_config* cfg, int gpu, const char* positio
     return BF_OK;
 }
 
-int bfh_run_observation_junk(const bf_config* cfg, uint64_t n_blocks, int ring_blocks, uint64_t seed, int gpu, int device,
-                             int burn_in, int verbose, float* observation_ms, float* beam_out, long long* last_gemm,
-                             void* ring_copy)
+static int run_junk(const bf_config* cfg, uint64_t n_blocks, int ring_blocks, uint64_t seed, int gpu, int device,
+                    int burn_in, int verbose, detected_sink* sink, observation_result* res, void* ring_copy)
 {
-    if (!cfg) return BF_ERR_INVALID;
     junk_block_source src(*cfg, n_blocks, ring_blocks, seed);
     if (!src.ok()) return BF_ERR_DEVICE;
     std::vector<antenna> pos((size_t)cfg->n_ant);
@@ -1101,17 +1183,82 @@ int bfh_run_observation_junk(const bf_config* cfg, uint64_t n_blocks, int ring_b
     opt.device = device;
     opt.burn_in = burn_in;
     opt.verbose = verbose != 0;
-    observation_result res;
+    opt.sink = sink;
     std::ostringstream quiet;
     std::streambuf* keep = std::cout.rdbuf();
     if (!verbose) std::cout.rdbuf(quiet.rdbuf());  // "obs Complete" etc.
-    int rc = run_observation(*cfg, opt, src, pos.data(), dir.data(), &res, verbose ? static_cast<std::ostream&>(std::cout) : quiet);
+    int rc = run_observation(*cfg, opt, src, pos.data(), dir.data(), res, verbose ? static_cast<std::ostream&>(std::cout) : quiet);
     std::cout.rdbuf(keep);
+    if (rc == BF_OK && ring_copy) std::memcpy(ring_copy, src.ring_data(), (size_t)src.get_block_size() * src.get_ring_blocks());
+    return rc;
+}
+
+int bfh_run_observation_junk(const bf_config* cfg, uint64_t n_blocks, int ring_blocks, uint64_t seed, int gpu, int device,
+                             int burn_in, int verbose, float* observation_ms, float* beam_out, long long* last_gemm,
+                             void* ring_copy)
+{
+    if (!cfg) return BF_ERR_INVALID;
+    observation_result res;
+    int rc = run_junk(cfg, n_blocks, ring_blocks, seed, gpu, device, burn_in, verbose, nullptr, &res, ring_copy);
     if (rc != BF_OK) return rc;
     if (observation_ms) *observation_ms = res.observation_time_ms;
     if (beam_out) std::memcpy(beam_out, res.beam_out.data(), res.beam_out.size() * sizeof(float));
     if (last_gemm) std::memcpy(last_gemm, res.last_gemm.data(), res.last_gemm.size() * sizeof(long long));
-    if (ring_copy) std::memcpy(ring_copy, src.ring_data(), (size_t)src.get_block_size() * src.get_ring_blocks());
+    return BF_OK;
+}
+
+int bfh_run_observation_junk_to_file(const bf_config* cfg, uint64_t n_blocks, int ring_blocks, uint64_t seed, int gpu,
+                                     int device, int burn_in, int verbose, const char* path, float* observation_ms,
+                                     uint64_t* gemms_written, void* ring_copy)
+{
+    if (!cfg || !path) return BF_ERR_INVALID;
+    file_sink sink(*cfg, path, gpu);
+    if (!sink.ok() || !sink.is_open()) return BF_ERR_INVALID;
+    observation_result res;
+    int rc = run_junk(cfg, n_blocks, ring_blocks, seed, gpu, device, burn_in, verbose, &sink, &res, ring_copy);
+    if (rc != BF_OK) return rc;
+    if (observation_ms) *observation_ms = res.observation_time_ms;
+    if (gemms_written) *gemms_written = sink.get_delivered();
+    return BF_OK;
+}
+
+struct bfh_sink {
+    file_sink* s;
+};
+
+int bfh_file_sink_create(const bf_config* cfg, const char* path, int gpu, uint64_t slots, bfh_sink** out)
+{
+    if (!cfg || !path || !out) return BF_ERR_INVALID;
+    file_sink* s = new (std::nothrow) file_sink(*cfg, path, gpu, slots);
+    if (!s || !s->ok() || !s->is_open()) {
+        delete s;
+        return BF_ERR_INVALID;
+    }
+    *out = new bfh_sink{s};
+    return BF_OK;
+}
+int bfh_sink_acquire(bfh_sink* s, uint64_t gemm_index, float** slot)
+{
+    if (!s || !slot) return BF_ERR_INVALID;
+    *slot = s->s->acquire(gemm_index);
+    return *slot ? BF_OK : BF_ERR_STATE;
+}
+int bfh_sink_commit(bfh_sink* s, uint64_t gemm_index)
+{
+    if (!s) return BF_ERR_INVALID;
+    return s->s->commit(gemm_index) ? BF_OK : BF_ERR_STATE;
+}
+int bfh_sink_close(bfh_sink* s)
+{
+    if (!s) return BF_ERR_INVALID;
+    s->s->close();
+    return BF_OK;
+}
+int bfh_sink_destroy(bfh_sink* s)
+{
+    if (!s) return BF_OK;
+    delete s->s;
+    delete s;
     return BF_OK;
 }
 

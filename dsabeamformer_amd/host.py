@@ -221,3 +221,59 @@ def run_observation_junk(cfg: BfConfig, n_blocks: int, ring_blocks: int = 4, see
     check(lib.bfh_run_observation_junk(C.byref(cfg), n_blocks, ring_blocks, seed, gpu, device, burn_in,
                                        1 if verbose else 0, C.byref(ms), _p(beam_out), _p(last), _p(ring)))
     return {"ms": ms.value, "beam_out": beam_out, "last_gemm": last, "ring": ring}
+
+
+DETECTED_HEADER_BYTES = 4096
+
+
+def read_detected_file(path: str):
+    """Parse a dsabf::file_sink file: returns (header dict, float32 array [n_gemms][n_out][n_freq][n_beams])."""
+    raw = open(path, "rb").read()
+    text = raw[:DETECTED_HEADER_BYTES].split(b"\0", 1)[0].decode()
+    hdr = dict(line.split(None, 1) for line in text.splitlines() if line.strip())
+    shape = (int(hdr["N_OUTPUTS_PER_GEMM"]), int(hdr["N_FREQUENCIES"]), int(hdr["N_BEAMS"]))
+    data = np.frombuffer(raw, dtype="<f4", offset=int(hdr["HDR_SIZE"]))
+    per = shape[0] * shape[1] * shape[2]
+    assert per == int(hdr["FLOATS_PER_GEMM"]) and data.size % per == 0
+    return hdr, data.reshape((-1,) + shape)
+
+
+def run_observation_junk_to_file(cfg: BfConfig, n_blocks: int, path: str, ring_blocks: int = 4, seed: int = 0xD5A,
+                                 gpu: int = 0, device: int = 0, burn_in: int = 0, verbose: bool = False):
+    """Production observation loop with every gemm-unit's detected powers written to `path` (dsabf::file_sink).
+    Returns dict(ms, gemms_written, ring)."""
+    lib = load()
+    n_time = cfg.n_out_per_gemm * cfg.n_pol * cfg.n_avg
+    ring = np.zeros((ring_blocks, cfg.n_gemms_per_block, cfg.n_freq, n_time, cfg.n_ant), np.uint8)
+    ms = C.c_float()
+    n = C.c_uint64()
+    check(lib.bfh_run_observation_junk_to_file(C.byref(cfg), n_blocks, ring_blocks, seed, gpu, device, burn_in,
+                                               1 if verbose else 0, path.encode(), C.byref(ms), C.byref(n), _p(ring)))
+    return {"ms": ms.value, "gemms_written": n.value, "ring": ring}
+
+
+class FileSink:
+    """The sink's pinned ring + file writer on its own (dsabf::file_sink)."""
+
+    def __init__(self, cfg: BfConfig, path: str, gpu: int = 0, slots: int = 0):
+        self._lib = load()
+        self._h = C.c_void_p()
+        self.floats_per_gemm = cfg.n_out_per_gemm * cfg.n_freq * cfg.n_beams
+        check(self._lib.bfh_file_sink_create(C.byref(cfg), path.encode(), gpu, slots, C.byref(self._h)))
+
+    def acquire(self, gemm_index: int):
+        """numpy view of the slot, or None if the ring has no free slot for this index."""
+        p = C.POINTER(C.c_float)()
+        rc = self._lib.bfh_sink_acquire(self._h, gemm_index, C.byref(p))
+        if rc != 0:
+            return None
+        return np.ctypeslib.as_array(p, shape=(self.floats_per_gemm,))
+
+    def commit(self, gemm_index: int) -> bool:
+        return self._lib.bfh_sink_commit(self._h, gemm_index) == 0
+
+    def close(self):
+        if self._h:
+            self._lib.bfh_sink_close(self._h)
+            self._lib.bfh_sink_destroy(self._h)
+            self._h = C.c_void_p()

@@ -79,6 +79,20 @@ int bfh_run_observation_junk(const bf_config *cfg, uint64_t n_blocks, int ring_b
                              int burn_in, int verbose, float *observation_ms, float *beam_out, long long *last_gemm,
                              void *ring_copy);
 
+/* Same loop with every gemm-unit's detected powers written to `path` (dsabf::file_sink: 4096-byte ASCII header, then
+ * [gemm][o][f][b] float32).  gemms_written (optional) receives the number of gemm-units delivered. */
+int bfh_run_observation_junk_to_file(const bf_config *cfg, uint64_t n_blocks, int ring_blocks, uint64_t seed, int gpu,
+                                     int device, int burn_in, int verbose, const char *path, float *observation_ms,
+                                     uint64_t *gemms_written, void *ring_copy);
+
+/* The sink's ring on its own (tests; works without a device, the ring is then plain memory). */
+typedef struct bfh_sink bfh_sink;
+int bfh_file_sink_create(const bf_config *cfg, const char *path, int gpu, uint64_t slots, bfh_sink **out);
+int bfh_sink_acquire(bfh_sink *s, uint64_t gemm_index, float **slot); /* BF_ERR_STATE if the slot is still occupied */
+int bfh_sink_commit(bfh_sink *s, uint64_t gemm_index);                 /* in order, each once */
+int bfh_sink_close(bfh_sink *s);
+int bfh_sink_destroy(bfh_sink *s);
+
 #ifdef __cplusplus
 }
 #endif

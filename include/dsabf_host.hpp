@@ -212,7 +212,6 @@ struct block_source {
 // In-memory stand-in for `dada_junkdb` (makefile:28-29, README.md:173): a pinned ring of distinct pseudo-random
 // blocks, served n_blocks times, then one short (empty) block.
 class junk_block_source : public block_source {
-    bf_config cfg;
     uint64_t block_size, bytes_read = 0, served = 0, n_blocks;
     int ring_blocks;
     char* ring = nullptr;
@@ -233,11 +232,76 @@ public:
     bool ok() const { return ring != nullptr; }
 };
 
+// ---- detected-stream sink ---------------------------------------------------------------
+// The reference copies each gemm-unit's detected powers into beam_out[stream] and the next gemm-unit of that stream
+// overwrites them (src/beamformer.cu:485-488); "writing out ... has not yet been implemented" (README.md:149).  A sink
+// gives the stream a consumer without changing the loop: the D2H copy of gemm-unit g lands in acquire(g) -- a pinned
+// slot of a ring -- and once the analysis event of g's block has been observed (src/observation_loop.hh:100-117) the
+// loop commits the block's gemm-units in index order; commit hands the slot to deliver() and frees it.
+class detected_sink {
+    size_t floats_per_gemm;
+    uint64_t n_slots;
+    float* ring = nullptr;
+    bool pinned = false;
+    uint64_t next_commit = 0, delivered = 0;
+    bool failed = false;
+
+protected:
+    virtual bool deliver(uint64_t gemm_index, const float* data, size_t n_floats) = 0;  // in gemm order
+    virtual void finish() {}
+
+public:
+    // slots: gemm-units that can be in flight; the loop needs (MAX_TOTAL_SEP + 1) * N_GEMMS_PER_BLOCK
+    detected_sink(const bf_config& cfg, uint64_t slots);
+    virtual ~detected_sink();
+    detected_sink(const detected_sink&) = delete;
+    detected_sink& operator=(const detected_sink&) = delete;
+    static uint64_t slots_for(const bf_config& cfg) { return (uint64_t)(kMaxTotalSep + 1) * cfg.n_gemms_per_block; }
+    bool ok() const { return ring != nullptr && !failed; }
+    float* acquire(uint64_t gemm_index);   // nullptr if the slot still holds an uncommitted gemm-unit
+    bool commit(uint64_t gemm_index);      // gemm units must be committed in increasing order, each exactly once
+    void close() { finish(); }
+    uint64_t get_delivered() const { return delivered; }
+    size_t get_floats_per_gemm() const { return floats_per_gemm; }
+};
+
+// Raw file: a 4096-byte ASCII header (PSRDADA style `KEY value` lines, NUL padded) followed by the gemm-units in
+// order, each [N_OUTPUTS_PER_GEMM][N_FREQUENCIES][N_BEAMS] little-endian float32 -- i.e. one long [o][f][b] series.
+class file_sink : public detected_sink {
+    FILE* fp = nullptr;
+
+protected:
+    bool deliver(uint64_t gemm_index, const float* data, size_t n_floats) override;
+    void finish() override;
+
+public:
+    static constexpr size_t kHeaderBytes = 4096;
+    file_sink(const bf_config& cfg, const char* path, int gpu, uint64_t slots = 0);
+    ~file_sink() override;
+    bool is_open() const { return fp != nullptr; }
+};
+
+// Keeps everything in host memory (tests, small runs).
+class memory_sink : public detected_sink {
+protected:
+    bool deliver(uint64_t, const float* data, size_t n_floats) override
+    {
+        data_.insert(data_.end(), data, data + n_floats);
+        return true;
+    }
+
+public:
+    std::vector<float> data_;
+    memory_sink(const bf_config& cfg, uint64_t slots = 0) : detected_sink(cfg, slots ? slots : slots_for(cfg)) {}
+};
+
 struct observation_options {
     int gpu = 0;          // -g
     int device = 0;
     int burn_in = 0;      // BURNIN read/close cycles before the loop (src/beamformer.cu:348-355)
     bool verbose = false;
+    detected_sink* sink = nullptr;  // optional consumer of every gemm-unit's detected powers; replaces beam_out as
+                                    // the D2H destination (beam_out then stays zero)
 };
 struct observation_result {
     float observation_time_ms = 0;

@@ -578,3 +578,63 @@ def test_fast_detect_paired_equals_fast_general(torch, bfmod, orc, monkeypatch, 
     assert np.array_equal(got_p, got_g)
     rel = np.abs(got_p.astype(np.float64) - want) / np.maximum(want.astype(np.float64), 1e-30)
     assert rel.max() <= 4 * g.n_ipo * 2.0 ** -24
+
+
+def test_observation_detected_stream_to_file_bit_exact(bfmod, orc, tmp_path):
+    """the production loop with a file sink keeps EVERY gemm-unit's detected powers (the reference
+    overwrites beam_out and drops them).  Small geometry so the oracle can check the whole stream bit for bit; the
+    gemm-units reach the file in index order although the 4 queues finish them in time-slice order."""
+    from dsabeamformer_amd import host
+
+    cfg = bfmod.production_config(n_freq=8)
+    cfg.n_beams, cfg.n_gemms_per_block, cfg.n_streams = 64, 8, 4
+    n_blocks, ring_blocks = 7, 3
+    path = str(tmp_path / "detected.bin")
+    r = host.run_observation_junk_to_file(cfg, n_blocks, path, ring_blocks=ring_blocks, seed=99, gpu=2)
+    assert r["gemms_written"] == n_blocks * cfg.n_gemms_per_block
+    hdr, data = host.read_detected_file(path)
+    assert hdr["GPU"] == "2" and data.shape == (n_blocks * 8, cfg.n_out_per_gemm, 8, 64)
+    g = orc.Geom(n_beams=64, n_ant=64, n_freq=8, n_avg=16, n_out_per_gemm=cfg.n_out_per_gemm)
+    pos, dirs = orc.default_positions(64), orc.default_directions(64)
+    w = orc.make_weights(g, pos, dirs, 2)
+    for blk in range(n_blocks):
+        want = orc.beamform(g, w, r["ring"][blk % ring_blocks])       # [8 units * n_out][f][b]
+        got = data[blk * 8:(blk + 1) * 8].reshape(want.shape)
+        assert np.array_equal(got, want), blk
+
+
+def test_observation_production_size_to_file_sampled(bfmod, orc, tmp_path):
+    """Same at the reference's production geometry (128 MiB blocks, 32 gemm-units of 2 MiB detected each, 8 queues):
+    file size, and sampled gemm-units against the oracle."""
+    from dsabeamformer_amd import host
+
+    cfg = bfmod.production_config()
+    n_blocks, ring_blocks = 3, 2
+    path = str(tmp_path / "detected_prod.bin")
+    r = host.run_observation_junk_to_file(cfg, n_blocks, path, ring_blocks=ring_blocks, seed=5)
+    per = cfg.n_gemms_per_block
+    assert r["gemms_written"] == n_blocks * per
+    hdr, data = host.read_detected_file(path)
+    assert data.shape == (n_blocks * per, cfg.n_out_per_gemm, 256, 256)
+    g = orc.PROD_GEOM
+    w = orc.make_weights(g, orc.default_positions(64), orc.default_directions(256), 0)
+    for gi in (0, 31, 32, 50, n_blocks * per - 1):
+        blk, ts = divmod(gi, per)
+        want = orc.beamform(g, w, r["ring"][blk % ring_blocks, ts][None])
+        assert np.array_equal(data[gi], want.reshape(data[gi].shape)), gi
+
+
+def test_beam_cli_junk_mode_writes_detected_file(tmp_path):
+    import subprocess
+
+    from conftest import ROOT
+    from dsabeamformer_amd import host
+
+    exe = os.path.join(ROOT, "dsabeamformer_amd", "beam")
+    path = str(tmp_path / "d.bin")
+    # 25 of the 27 blocks go to the burn-in reads (BURNIN, src/beamformer.hh:45), 2 are analysed
+    p = subprocess.run([exe, "-j", "27", "-w", path], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr
+    assert "Wrote 64 gemm-units of detected powers" in p.stdout
+    hdr, data = host.read_detected_file(path)
+    assert data.shape[0] == 64 and np.isfinite(data).all() and data.max() > 0

@@ -218,3 +218,37 @@ def test_observation_loop_backpressure_rules(host, bfm):
     assert obs.check_observations_complete()
     assert obs.get_current_transfer_gemm() == 4 * 32
     obs.close()
+
+
+def test_detected_sink_ring_and_file_format(host, bfm, tmp_path):
+    """dsabf::file_sink without a device: ring slots, in-order commit, back-pressure, header + payload layout."""
+    cfg = bfm.debug_config()
+    cfg.n_beams, cfg.n_freq, cfg.n_out_per_gemm, cfg.n_gemms_per_block = 32, 4, 2, 3
+    per = cfg.n_out_per_gemm * cfg.n_freq * cfg.n_beams
+    path = str(tmp_path / "detected.bin")
+    sink = host.FileSink(cfg, path, gpu=3, slots=4)
+    rng = np.random.default_rng(11)
+    want = rng.standard_normal((9, per)).astype(np.float32)
+    # fill the 4-slot ring out of order (streams finish gemm-units in time-slice order, not index order)
+    for g in (2, 0, 3, 1):
+        sink.acquire(g)[:] = want[g]
+    assert sink.acquire(4) is None          # ring full: slot of gemm 0 not yet committed
+    assert not sink.commit(1)               # commits are in order
+    assert sink.commit(0) and sink.commit(1)
+    assert not sink.commit(1)               # ... and happen once
+    for g in (4, 5):
+        sink.acquire(g)[:] = want[g]
+    assert sink.acquire(6) is None
+    for g in (2, 3, 4, 5):
+        assert sink.commit(g)
+    for g in (8, 7, 6):
+        sink.acquire(g)[:] = want[g]
+    for g in (6, 7, 8):
+        assert sink.commit(g)
+    assert sink.acquire(8) is None          # already delivered
+    sink.close()
+    hdr, data = host.read_detected_file(path)
+    assert hdr["CONTENT"] == "detected_power" and hdr["DTYPE"] == "float32" and hdr["GPU"] == "3"
+    assert (int(hdr["N_BEAMS"]), int(hdr["N_FREQUENCIES"]), int(hdr["N_OUTPUTS_PER_GEMM"])) == (32, 4, 2)
+    assert os.path.getsize(path) == host.DETECTED_HEADER_BYTES + want.nbytes
+    assert np.array_equal(data.reshape(9, per), want)
