@@ -47,6 +47,9 @@
 #ifndef DSABF_PAIR_MFMA
 #define DSABF_PAIR_MFMA 4 // MFMAs per conjugate pair tile: 4 (+-P2, +-P4 on the VALU), 5 (real part chained on the MFMA), 6
 #endif
+#ifndef DSABF_FASTADDR
+#define DSABF_FASTADDR 1  // scalar chunk addressing in fused16_kernel when gemm-units are a multiple of the chunk span
+#endif
 #ifndef DSABF_OCC16
 #define DSABF_OCC16 3     // 147 VGPRs, no spills; 4 would spill 15 registers for no gain (the kernel is energy-bound)
 #endif
@@ -701,7 +704,49 @@ __global__ __launch_bounds__(kThreads16, DSABF_OCC16) void fused16_kernel(FusedA
             return (unsigned)c * 128u + 16u * (unsigned)run;
     };
     v4i stage[PPT];
+    // Fast addressing: when a chunk's sample span (128 samples, 256 for n_ipo = 64) never straddles a gemm-unit, the
+    // unit / time split of the chunk is wave-uniform -- a scalar base that advances by one span per chunk -- and the
+    // per-lane part (row and 16-byte piece) is a constant 32-bit offset: no vector integer arithmetic (the generic
+    // path costs ~17 VALU ops, 6 of them quarter-rate 32-bit multiplies, per 16-byte load).
+    constexpr unsigned SPAN = (NIPO == 64) ? 256u : 128u;
+    const bool fast_addr = DSABF_FASTADDR && ((unsigned)a.T % SPAN) == 0;
+    unsigned lane_off[PPT];
+#pragma unroll
+    for (int k = 0; k < PPT; k++) {
+        const int pc = tid + k * kThreads16;
+        const int row = pc >> 2, ks = pc & 3;
+        const unsigned ls = (NIPO == 64) ? (unsigned)((row / LR) * L + (row % LR)) : (unsigned)row;  // sample in the span
+        lane_off[k] = ls * A + ks * 16;
+    }
+    int ld_span = -1;                 // span the scalar state below describes
+    unsigned ld_u = 0, ld_t0 = 0;     // its gemm-unit and first sample inside the unit
     auto load_chunk = [&](int c) {
+        if (fast_addr) {
+            const int span = (NIPO == 64) ? c / 2 : c;
+            if (ld_span < 0) {
+                const unsigned s_c = (unsigned)span * SPAN;
+                ld_u = a.t_shift >= 0 ? (s_c >> a.t_shift) : (s_c / (unsigned)a.T);
+                ld_t0 = s_c - ld_u * (unsigned)a.T;
+                ld_span = span;
+            }
+            while (ld_span < span) {  // at most one step: chunks are loaded in order
+                ld_t0 += SPAN;
+                if (ld_t0 >= (unsigned)a.T) {
+                    ld_t0 = 0;
+                    ld_u++;
+                }
+                ld_span++;
+            }
+            const bool valid = (unsigned)span * SPAN < a.S;
+            const unsigned half = (NIPO == 64) ? 32u * (unsigned)(c & 1) : 0u;
+            const uint8_t* base = a.in + ((size_t)((size_t)ld_u * a.n_freq + f) * a.T + ld_t0 + half) * A;
+#pragma unroll
+            for (int k = 0; k < PPT; k++) {
+                stage[k] = v4i{0, 0, 0, 0};
+                if (valid) stage[k] = *reinterpret_cast<const v4i*>(base + lane_off[k]);
+            }
+            return;
+        }
 #pragma unroll
         for (int k = 0; k < PPT; k++) {
             const int pc = tid + k * kThreads16;

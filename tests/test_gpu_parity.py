@@ -638,3 +638,25 @@ def test_beam_cli_junk_mode_writes_detected_file(tmp_path):
     assert "Wrote 64 gemm-units of detected powers" in p.stdout
     hdr, data = host.read_detected_file(path)
     assert data.shape[0] == 64 and np.isfinite(data).all() and data.max() > 0
+
+
+@pytest.mark.parametrize("n_avg,n_out", [(32, 4), (32, 6), (32, 8), (16, 4), (16, 5), (16, 12), (8, 8), (8, 24), (4, 16),
+                                         (1, 64), (1, 192), (2, 36)])
+@pytest.mark.parametrize("paired", [False, True])
+def test_scalar_and_generic_chunk_addressing_bit_exact(torch, bfmod, orc, monkeypatch, n_avg, n_out, paired):
+    """fused16_kernel addresses a chunk through a scalar base when gemm-units are a multiple of the chunk span
+    (128 samples; 256 for n_ipo = 64) and through the generic per-row path otherwise; power-of-two and other unit
+    lengths, several units per workgroup range, ragged ends, both kernels."""
+    monkeypatch.setenv("DSABF_TSPLIT", "2")
+    g = orc.Geom(n_beams=64, n_ant=64, n_freq=2, n_avg=n_avg, n_out_per_gemm=n_out)
+    n_units = -(-1700 // g.n_time)
+    rng = np.random.default_rng(1000 * n_avg + n_out)
+    w = rng.integers(-127, 128, size=(g.n_freq, g.n_ant, g.n_beams, 2), dtype=np.int8)
+    if paired:
+        w = _conj_symmetric(w)
+    packed = rng.integers(0, 256, size=(n_units, g.n_freq, g.n_time, g.n_ant), dtype=np.uint8)
+    bf = bfmod.Beamformer(_cfg(bfmod, g))
+    bf.set_weights(w)
+    assert ("PAIRED" in bf.kernel_info(n_units)["kernel"]) == paired
+    want = orc.beamform(g, w, packed)
+    assert np.array_equal(_run(torch, bf, packed, want.size).reshape(want.shape), want)
