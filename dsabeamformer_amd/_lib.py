@@ -45,6 +45,8 @@ SIGNATURES = {
     "bf_set_weights_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "bf_alloc_pinned": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t]),
     "bf_free_pinned": (C.c_int, [C.c_void_p]),
+    "bf_host_register": (C.c_int, [C.c_void_p, C.c_size_t]),
+    "bf_host_unregister": (C.c_int, [C.c_void_p]),
     "bf_event_create": (C.c_int, [C.POINTER(C.c_void_p)]),
     "bf_event_destroy": (C.c_int, [C.c_void_p]),
     "bf_event_query": (C.c_int, [C.c_void_p]),
@@ -113,6 +115,16 @@ SIGNATURES = {
     "bfh_sink_commit": (C.c_int, [C.c_void_p, C.c_uint64]),
     "bfh_sink_close": (C.c_int, [C.c_void_p]),
     "bfh_sink_destroy": (C.c_int, [C.c_void_p]),
+    "bfh_junk_fill": (C.c_int, [C.POINTER(BfConfig), C.c_int, C.c_uint64, C.c_void_p]),
+    "bfh_shm_ring_create": (C.c_int, [C.c_char_p, C.c_uint64, C.c_uint64, C.c_char_p, C.POINTER(C.c_void_p)]),
+    "bfh_shm_ring_attach": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]),
+    "bfh_shm_ring_detach": (C.c_int, [C.c_void_p]),
+    "bfh_shm_ring_unlink": (C.c_int, [C.c_char_p]),
+    "bfh_shm_ring_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_char_p, C.c_size_t]),
+    "bfh_shm_ring_write": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64]),
+    "bfh_shm_ring_read": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "bfh_run_observation_shm": (C.c_int, [C.POINTER(BfConfig), C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p,
+                                          C.POINTER(C.c_float), C.POINTER(C.c_uint64), C.POINTER(C.c_int)]),
     "bfh_run_debug_observation": (C.c_int, [C.POINTER(BfConfig), C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p,
                                             C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_int),
                                             C.POINTER(C.c_float)]),

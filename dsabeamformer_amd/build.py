@@ -24,21 +24,24 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 
 BEAM = os.path.join(PKG, "beam")                      # the `beam` CLI driver (reference: bin/beam)
 BEAM_SRC = os.path.join(CSRC, "beam_main.cpp")
+JUNKDB = os.path.join(PKG, "junkdb")                  # writer side of the shared-memory input ring (dada_db + dada_junkdb)
+JUNKDB_SRC = os.path.join(CSRC, "junkdb_main.cpp")
+MAINS = {BEAM: BEAM_SRC, JUNKDB: JUNKDB_SRC}
 
 
 def sources() -> list[str]:
     """Sources of libdsabf.so (everything under csrc/ except the CLI driver)."""
     return sorted(p for p in glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.cpp"))
-                  if os.path.abspath(p) != os.path.abspath(BEAM_SRC))
+                  if os.path.abspath(p) not in [os.path.abspath(m) for m in MAINS.values()])
 
 
 def _stale() -> bool:
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    if not os.path.exists(BEAM):
+    if not all(os.path.exists(b) for b in MAINS):
         return True
-    deps = [BEAM_SRC] + sources() + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.hpp")) + \
+    deps = list(MAINS.values()) + sources() + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.hpp")) + \
         glob.glob(os.path.join(ROOT, "include", "*.h")) + [os.path.abspath(__file__)]
     return any(os.path.getmtime(p) > t for p in deps)
 
@@ -76,16 +79,17 @@ def build(force: bool = False, verbose: bool = False) -> str:
     cxx = os.path.join(os.path.dirname(os.path.realpath(HIPCC)), "..", "lib", "llvm", "bin", "clang++")
     if not os.path.exists(cxx):
         cxx = shutil.which("g++") or "g++"
-    cmd = [cxx, "-shared", "-fPIC", "-o", LIB] + objs + ["-lpthread"]
+    cmd = [cxx, "-shared", "-fPIC", "-o", LIB] + objs + ["-lpthread", "-lrt"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
-    # the CLI driver is an ordinary HIP application: it links libdsabf.so AND the HIP runtime
-    cmd = [HIPCC, "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "include"), BEAM_SRC, "-o", BEAM, "-L" + PKG, "-ldsabf",
-           "-Wl,-rpath,$ORIGIN"]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    # the CLI programs are ordinary HIP applications: they link libdsabf.so AND the HIP runtime
+    for exe, src in MAINS.items():
+        cmd = [HIPCC, "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "include"), src, "-o", exe, "-L" + PKG, "-ldsabf",
+               "-Wl,-rpath,$ORIGIN"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
     return LIB
 
 

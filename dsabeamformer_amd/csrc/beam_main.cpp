@@ -28,7 +28,8 @@ int main(int argc, char* argv[])
     bf_config_default(&cfg, /*debug=*/1);
     debug_run_options opt;
     std::string positions, directions, sources, output = "bin/data.py", detected_path;
-    bool dada_requested = false;
+    std::string ring_key;
+    int core = -1;
     long junk_blocks = -1;
 
     int arg = 0;
@@ -44,15 +45,11 @@ int main(int argc, char* argv[])
             case 'j': junk_blocks = atol(optarg); break;
             case 'w': detected_path = optarg; break;
             case 'v': opt.verbose = true; cfg.verbose = 1; break;
-            case 'c':
-            case 'k': dada_requested = true; break;            // :59-75
+            case 'c': core = atoi(optarg); break;              // :59-65
+            case 'k': ring_key = optarg; break;                // :66-75 (a shared-memory ring name instead of a hex key)
             case 'h': usage(true, std::cout); return EXIT_SUCCESS;  // :123-125
             default: usage(true, std::cerr); return EXIT_FAILURE;
         }
-    }
-    if (dada_requested) {
-        std::cerr << "beam: PSRDADA observation mode (-c/-k) is not available in this build (no libpsrdada); "
-                     "running the synthetic-source mode instead" << std::endl;
     }
     opt.positions = positions.empty() ? nullptr : positions.c_str();
     opt.directions = directions.empty() ? nullptr : directions.c_str();
@@ -67,7 +64,7 @@ int main(int argc, char* argv[])
     char name[256];
     if (bf_device_name(opt.device, name, sizeof name) == BF_OK) std::cout << "Selected: " << name << std::endl;
 
-    if (junk_blocks >= 0) {  // observation (production) mode: N_AVERAGING 16, blocks from the junk source
+    if (junk_blocks >= 0 || !ring_key.empty()) {  // observation (production) mode: N_AVERAGING 16
         bf_config pcfg;
         bf_config_default(&pcfg, /*debug=*/0);
         pcfg.verbose = cfg.verbose;
@@ -77,16 +74,25 @@ int main(int argc, char* argv[])
             default_positions(pcfg.n_ant, pos.data());
         if (!opt.directions || read_in_beam_directions(opt.directions, pcfg.n_beams, dir.data()) != 0)
             default_directions(pcfg.n_beams, dir.data());
-        junk_block_source src(pcfg, (uint64_t)junk_blocks);
-        if (!src.ok()) {
-            fprintf(stderr, "beam: could not allocate the junk ring\n");
-            return EXIT_FAILURE;
-        }
+        std::unique_ptr<block_source> src;
         observation_options oopt;
+        if (!ring_key.empty()) {  // -k: blocks from the shared-memory ring (the PSRDADA stand-in), no burn-in reads
+            shm_block_source* s = new shm_block_source(ring_key.c_str(), core, /*pin=*/true, std::cout);
+            src.reset(s);
+            if (!s->ok()) return EXIT_FAILURE;  // "Error: could not connect to dada buffer", src/dada_handler.hh:35-38
+            s->expect_block_bytes(bf_bytes_per_block(&pcfg));
+        } else {                  // -j: the in-memory dada_junkdb source
+            junk_block_source* s = new junk_block_source(pcfg, (uint64_t)junk_blocks);
+            src.reset(s);
+            if (!s->ok()) {
+                fprintf(stderr, "beam: could not allocate the junk ring\n");
+                return EXIT_FAILURE;
+            }
+            oopt.burn_in = kBurnIn;
+        }
         oopt.gpu = opt.gpu;
         oopt.device = opt.device;
         oopt.verbose = opt.verbose;
-        oopt.burn_in = kBurnIn;
         std::unique_ptr<file_sink> sink;
         if (!detected_path.empty()) {  // -w: keep the detected stream (the reference drops it, README.md:149)
             sink.reset(new file_sink(pcfg, detected_path.c_str(), opt.gpu));
@@ -97,7 +103,7 @@ int main(int argc, char* argv[])
             oopt.sink = sink.get();
         }
         observation_result ores;
-        int orc = run_observation(pcfg, oopt, src, pos.data(), dir.data(), &ores, std::cout);
+        int orc = run_observation(pcfg, oopt, *src, pos.data(), dir.data(), &ores, std::cout);
         if (sink) std::cout << "Wrote " << sink->get_delivered() << " gemm-units of detected powers to " << detected_path << std::endl;
         if (orc != BF_OK) {
             fprintf(stderr, "GPUassert: %s (%d)\n", bf_last_error(), orc);

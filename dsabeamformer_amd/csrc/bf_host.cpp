@@ -14,6 +14,7 @@
 #include <fstream>
 #include <functional>
 #include <iostream>
+#include <memory>
 #include <sstream>
 #include <thread>
 
@@ -679,7 +680,13 @@ junk_block_source::junk_block_source(const bf_config& c, uint64_t nb, int rb, ui
     }
     ring = static_cast<char*>(p);
     if (!ring) return;
+    junk_fill(c, ring_blocks, seed, ring);
+}
+
+void junk_fill(const bf_config& c, int ring_blocks, uint64_t seed, char* ring)
+{
     // every byte value (all 16 nibble codes in both halves), distinct blocks: 64-bit xorshift* per 8 bytes
+    const size_t total = (size_t)bf_bytes_per_block(&c) * ring_blocks;
     parallel_for((long)ring_blocks * 64, [&](long lo, long hi) {
         for (long part = lo; part < hi; part++) {
             const size_t n8 = total / 8 / ((size_t)ring_blocks * 64);
@@ -1219,6 +1226,110 @@ int bfh_run_observation_junk_to_file(const bf_config* cfg, uint64_t n_blocks, in
     if (rc != BF_OK) return rc;
     if (observation_ms) *observation_ms = res.observation_time_ms;
     if (gemms_written) *gemms_written = sink.get_delivered();
+    return BF_OK;
+}
+
+int bfh_junk_fill(const bf_config* cfg, int ring_blocks, uint64_t seed, void* out)
+{
+    if (!cfg || !out || ring_blocks < 1) return BF_ERR_INVALID;
+    junk_fill(*cfg, ring_blocks, seed, static_cast<char*>(out));
+    return BF_OK;
+}
+
+struct bfh_shm_ring {
+    shm_ring* r;
+};
+
+int bfh_shm_ring_create(const char* name, uint64_t n_blocks, uint64_t block_size, const char* header_text,
+                        bfh_shm_ring** out)
+{
+    if (!name || !out) return BF_ERR_INVALID;
+    shm_ring* r = shm_ring::create(name, n_blocks, block_size, header_text);
+    if (!r) return BF_ERR_INVALID;
+    *out = new bfh_shm_ring{r};
+    return BF_OK;
+}
+int bfh_shm_ring_attach(const char* name, int timeout_ms, bfh_shm_ring** out)
+{
+    if (!name || !out) return BF_ERR_INVALID;
+    shm_ring* r = shm_ring::attach(name, timeout_ms);
+    if (!r) return BF_ERR_STATE;
+    *out = new bfh_shm_ring{r};
+    return BF_OK;
+}
+int bfh_shm_ring_detach(bfh_shm_ring* r)
+{
+    if (!r) return BF_OK;
+    delete r->r;
+    delete r;
+    return BF_OK;
+}
+int bfh_shm_ring_unlink(const char* name) { return name && shm_ring::unlink(name) == 0 ? BF_OK : BF_ERR_INVALID; }
+int bfh_shm_ring_info(bfh_shm_ring* r, uint64_t* n_blocks, uint64_t* block_size, char* header, size_t header_cap)
+{
+    if (!r) return BF_ERR_INVALID;
+    if (n_blocks) *n_blocks = r->r->get_n_blocks();
+    if (block_size) *block_size = r->r->get_block_size();
+    if (header && header_cap) {
+        std::strncpy(header, r->r->get_header(), header_cap - 1);
+        header[header_cap - 1] = 0;
+    }
+    return BF_OK;
+}
+int bfh_shm_ring_write(bfh_shm_ring* r, const void* data, uint64_t bytes)
+{
+    if (!r || bytes > r->r->get_block_size() || (bytes && !data)) return BF_ERR_INVALID;
+    char* b = r->r->open_block_write();
+    if (!b) return BF_ERR_STATE;
+    if (bytes) std::memcpy(b, data, bytes);
+    r->r->close_block_write(bytes);
+    return BF_OK;
+}
+int bfh_shm_ring_read(bfh_shm_ring* r, void* out, uint64_t cap, uint64_t* bytes, uint64_t* block_id)
+{
+    if (!r) return BF_ERR_INVALID;
+    uint64_t n = 0, id = 0;
+    char* b = r->r->open_block_read(&n, &id);
+    if (!b) return BF_ERR_STATE;
+    if (out) std::memcpy(out, b, n < cap ? n : cap);
+    r->r->close_block_read();
+    if (bytes) *bytes = n;
+    if (block_id) *block_id = id;
+    return BF_OK;
+}
+
+int bfh_run_observation_shm(const bf_config* cfg, const char* name, int core, int gpu, int device, int verbose,
+                            const char* path, float* observation_ms, uint64_t* gemms_written, int* pinned)
+{
+    if (!cfg || !name) return BF_ERR_INVALID;
+    std::ostringstream quiet;
+    std::ostream& log = verbose ? static_cast<std::ostream&>(std::cout) : quiet;
+    shm_block_source src(name, core, /*pin=*/true, log);
+    if (!src.ok()) return BF_ERR_STATE;
+    src.expect_block_bytes(bf_bytes_per_block(cfg));
+    if (pinned) *pinned = src.is_pinned() ? 1 : 0;
+    std::unique_ptr<file_sink> sink;
+    if (path) {
+        sink.reset(new file_sink(*cfg, path, gpu));
+        if (!sink->ok() || !sink->is_open()) return BF_ERR_INVALID;
+    }
+    std::vector<antenna> pos((size_t)cfg->n_ant);
+    std::vector<beam_direction> dir((size_t)cfg->n_beams);
+    default_positions(cfg->n_ant, pos.data());
+    default_directions(cfg->n_beams, dir.data());
+    observation_options opt;
+    opt.gpu = gpu;
+    opt.device = device;
+    opt.verbose = verbose != 0;
+    opt.sink = sink.get();
+    observation_result res;
+    std::streambuf* keep = std::cout.rdbuf();
+    if (!verbose) std::cout.rdbuf(quiet.rdbuf());
+    int rc = run_observation(*cfg, opt, src, pos.data(), dir.data(), &res, log);
+    std::cout.rdbuf(keep);
+    if (rc != BF_OK) return rc;
+    if (observation_ms) *observation_ms = res.observation_time_ms;
+    if (gemms_written) *gemms_written = sink ? sink->get_delivered() : res.blocks * cfg->n_gemms_per_block;
     return BF_OK;
 }
 

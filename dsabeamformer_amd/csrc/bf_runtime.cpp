@@ -303,6 +303,20 @@ int bf_free_pinned(void* ptr)
     return BF_OK;
 }
 
+int bf_host_register(void* ptr, size_t nbytes)
+{
+    if (!ptr || !nbytes) return fail(BF_ERR_INVALID, "NULL argument");
+    HIP_TRY(hipHostRegister(ptr, nbytes, hipHostRegisterDefault));
+    return BF_OK;
+}
+
+int bf_host_unregister(void* ptr)
+{
+    if (!ptr) return BF_OK;
+    HIP_TRY(hipHostUnregister(ptr));
+    return BF_OK;
+}
+
 int bf_event_create(bf_event** ev)
 {
     if (!ev) return fail(BF_ERR_INVALID, "ev is NULL");

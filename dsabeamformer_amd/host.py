@@ -277,3 +277,68 @@ class FileSink:
             self._lib.bfh_sink_close(self._h)
             self._lib.bfh_sink_destroy(self._h)
             self._h = C.c_void_p()
+
+
+def junk_bytes(block_bytes: int, distinct: int, seed: int, cfg: BfConfig | None = None) -> np.ndarray:
+    """The bytes `junkdb` / junk_block_source serve: uint8 [distinct][block_bytes]; block i of a run is row i % distinct."""
+    from .api import production_config
+
+    if cfg is None:
+        cfg = production_config()
+        if block_bytes != cfg.n_gemms_per_block * cfg.n_freq * cfg.n_out_per_gemm * cfg.n_pol * cfg.n_avg * cfg.n_ant:
+            cfg.n_gemms_per_block = cfg.n_freq = cfg.n_ant = cfg.n_pol = cfg.n_avg = 1
+            cfg.n_out_per_gemm = block_bytes
+    out = np.zeros((distinct, block_bytes), np.uint8)
+    check(load().bfh_junk_fill(C.byref(cfg), distinct, seed, _p(out)))
+    return out
+
+
+class ShmRing:
+    """dsabf::shm_ring (the PSRDADA stand-in) from Python: create or attach, blocking write / read of whole blocks."""
+
+    def __init__(self, name: str, n_blocks: int = 0, block_size: int = 0, header: str = "", timeout_ms: int = 10000):
+        self._lib = load()
+        self._h = C.c_void_p()
+        self.name = name
+        if n_blocks:
+            check(self._lib.bfh_shm_ring_create(name.encode(), n_blocks, block_size, header.encode(), C.byref(self._h)))
+        else:
+            check(self._lib.bfh_shm_ring_attach(name.encode(), timeout_ms, C.byref(self._h)))
+        nb, bs = C.c_uint64(), C.c_uint64()
+        hdr = C.create_string_buffer(4096)
+        check(self._lib.bfh_shm_ring_info(self._h, C.byref(nb), C.byref(bs), hdr, 4096))
+        self.n_blocks, self.block_size, self.header = nb.value, bs.value, hdr.value.decode()
+
+    def write(self, data) -> None:
+        """data: bytes-like / uint8 array of at most block_size bytes (fewer = end of data)."""
+        a = np.ascontiguousarray(np.frombuffer(data, np.uint8) if not isinstance(data, np.ndarray) else data)
+        check(self._lib.bfh_shm_ring_write(self._h, _p(a) if a.size else None, a.size))
+
+    def read(self):
+        """-> (uint8 array of the valid bytes, block id)."""
+        out = np.empty(self.block_size, np.uint8)
+        n, bid = C.c_uint64(), C.c_uint64()
+        check(self._lib.bfh_shm_ring_read(self._h, _p(out), out.size, C.byref(n), C.byref(bid)))
+        return out[:n.value], bid.value
+
+    def detach(self) -> None:
+        if self._h:
+            self._lib.bfh_shm_ring_detach(self._h)
+            self._h = C.c_void_p()
+
+    def unlink(self) -> None:
+        shm_ring_unlink(self.name)
+
+
+def shm_ring_unlink(name: str) -> None:
+    """`dada_db -k name -d`: remove the ring's shared-memory object (no error if it is gone)."""
+    load().bfh_shm_ring_unlink(name.encode())
+
+
+def run_observation_shm(cfg: BfConfig, name: str, path: str | None = None, core: int = -1, gpu: int = 0, device: int = 0,
+                        verbose: bool = False):
+    """Production observation loop fed from the shared-memory ring `name`.  Returns dict(ms, gemms, pinned)."""
+    ms, n, pinned = C.c_float(), C.c_uint64(), C.c_int()
+    check(load().bfh_run_observation_shm(C.byref(cfg), name.encode(), core, gpu, device, 1 if verbose else 0,
+                                         path.encode() if path else None, C.byref(ms), C.byref(n), C.byref(pinned)))
+    return {"ms": ms.value, "gemms": n.value, "pinned": bool(pinned.value)}

@@ -100,6 +100,10 @@ int bf_set_weights_device(bf_handle *h, const int8_t *d_w, void *hip_stream);
  * 605,613 (pinned input batch, beam_out, dedispersed_out). */
 int bf_alloc_pinned(void **ptr, size_t nbytes);
 int bf_free_pinned(void *ptr);
+/* Replace cudaHostRegister / cudaHostUnregister on the PSRDADA data blocks (dada_cuda_dbregister /
+ * dada_cuda_dbunregister, src/dada_handler.hh:127-177): page-lock caller-owned host memory for DMA. */
+int bf_host_register(void *ptr, size_t nbytes);
+int bf_host_unregister(void *ptr);
 
 /* Events.  Replace the cudaEvent ring of observation_loop_state (src/observation_loop.hh:58-61,65-68,73,
  * 79,86,95-96,105,112-113).  bf_event_query returns BF_OK (done), BF_NOT_READY, or a negative error. */

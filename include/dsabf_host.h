@@ -93,6 +93,27 @@ int bfh_sink_commit(bfh_sink *s, uint64_t gemm_index);                 /* in ord
 int bfh_sink_close(bfh_sink *s);
 int bfh_sink_destroy(bfh_sink *s);
 
+/* The junk source's bytes: ring_blocks blocks of cfg's block size into `out` (dsabf::junk_fill). */
+int bfh_junk_fill(const bf_config *cfg, int ring_blocks, uint64_t seed, void *out);
+
+/* Shared-memory input ring (dsabf::shm_ring, the PSRDADA stand-in: csrc/bf_shmring.cpp). */
+typedef struct bfh_shm_ring bfh_shm_ring;
+int bfh_shm_ring_create(const char *name, uint64_t n_blocks, uint64_t block_size, const char *header_text,
+                        bfh_shm_ring **out);
+int bfh_shm_ring_attach(const char *name, int timeout_ms, bfh_shm_ring **out);
+int bfh_shm_ring_detach(bfh_shm_ring *r);
+int bfh_shm_ring_unlink(const char *name);
+int bfh_shm_ring_info(bfh_shm_ring *r, uint64_t *n_blocks, uint64_t *block_size, char *header, size_t header_cap);
+/* copy `bytes` (<= block size; fewer = end of data) into the next free block; blocks while the ring is full */
+int bfh_shm_ring_write(bfh_shm_ring *r, const void *data, uint64_t bytes);
+/* copy the next filled block out (at most cap bytes); blocks while the ring is empty */
+int bfh_shm_ring_read(bfh_shm_ring *r, void *out, uint64_t cap, uint64_t *bytes, uint64_t *block_id);
+
+/* Production observation loop fed from the shared-memory ring `name` (what `beam -k name` runs): detected stream to
+ * `path` if not NULL.  pinned (optional) receives whether the ring blocks could be page-locked. */
+int bfh_run_observation_shm(const bf_config *cfg, const char *name, int core, int gpu, int device, int verbose,
+                            const char *path, float *observation_ms, uint64_t *gemms_written, int *pinned);
+
 #ifdef __cplusplus
 }
 #endif

@@ -232,6 +232,65 @@ public:
     bool ok() const { return ring != nullptr; }
 };
 
+// Fills `ring_blocks` consecutive blocks of cfg's block size at `ring` with the junk source's bytes (64-bit xorshift*,
+// every nibble code in both halves; depends only on seed, ring_blocks and the block size).
+void junk_fill(const bf_config& cfg, int ring_blocks, uint64_t seed, char* ring);
+
+// ---- shared-memory input ring: the PSRDADA stand-in, csrc/bf_shmring.cpp -------------------
+constexpr int kMaxRingBlocks = 64;
+constexpr size_t kRingHeaderBytes = 4096;   // HDR_SIZE of config/correlator_header_dsaX.txt
+
+class shm_ring {
+    struct control;
+    control* ctl = nullptr;
+    size_t map_bytes = 0;
+    shm_ring();
+
+public:
+    ~shm_ring();
+    shm_ring(const shm_ring&) = delete;
+    shm_ring& operator=(const shm_ring&) = delete;
+    // `dada_db -k name -n n_blocks -b block_size` (README.md:151-160); header_text: the ASCII header block
+    static shm_ring* create(const char* name, uint64_t n_blocks, uint64_t block_size, const char* header_text);
+    static shm_ring* attach(const char* name, int timeout_ms = 10000);
+    static int unlink(const char* name);    // `dada_db -k name -d`
+    char* open_block_write();               // blocks while the ring is full
+    void close_block_write(uint64_t bytes); // bytes < block_size: end of data
+    char* open_block_read(uint64_t* bytes, uint64_t* block_id);  // blocks while the ring is empty
+    void close_block_read();
+    uint64_t get_n_blocks() const;
+    uint64_t get_block_size() const;
+    uint64_t get_header_size() const;
+    const char* get_header() const;
+    uint64_t get_blocks_written() const;
+    uint64_t get_blocks_read() const;
+    char* block(uint64_t slot) const;
+};
+
+// dada_handler (src/dada_handler.hh:1-177) on the shared-memory ring: same constructor arguments and messages.
+class shm_block_source : public block_source {
+    shm_ring* ring = nullptr;
+    std::ostream& log;
+    uint64_t header_size = 0, block_size = 0, bytes_read = 0, block_id = 0, expected_bytes = 0;
+    bool registered = false;
+
+public:
+    shm_block_source(const char* name, int core, bool pin, std::ostream& log);
+    ~shm_block_source() override;
+    shm_block_source(const shm_block_source&) = delete;
+    shm_block_source& operator=(const shm_block_source&) = delete;
+    bool ok() const { return ring != nullptr; }
+    bool is_pinned() const { return registered; }
+    void expect_block_bytes(uint64_t n) { expected_bytes = n; }  // N_BYTES_PRE_EXPANSION_PER_BLOCK check, :101-103
+    void read_headers() override;
+    char* read() override;
+    void close() override;
+    bool check_transfers_complete() override;
+    uint64_t get_block_size() const override { return block_size; }
+    uint64_t get_bytes_read() const override { return bytes_read; }
+    const char* get_header() const { return ring ? ring->get_header() : ""; }
+};
+
 // ---- detected-stream sink ---------------------------------------------------------------
 // The reference copies each gemm-unit's detected powers into beam_out[stream] and the next gemm-unit of that stream
 // overwrites them (src/beamformer.cu:485-488); "writing out ... has not yet been implemented" (README.md:149).  A sink

@@ -660,3 +660,80 @@ def test_scalar_and_generic_chunk_addressing_bit_exact(torch, bfmod, orc, monkey
     assert ("PAIRED" in bf.kernel_info(n_units)["kernel"]) == paired
     want = orc.beamform(g, w, packed)
     assert np.array_equal(_run(torch, bf, packed, want.size).reshape(want.shape), want)
+
+
+def test_observation_from_shared_memory_ring_bit_exact(bfmod, orc, tmp_path):
+    """SURVEY 8f-3 end to end: `junkdb` (writer process) feeds production-size blocks (128 MiB) through a 3-slot
+    shared-memory ring, `beam -k <ring> -w <file>` attaches, page-locks the blocks (hipHostRegister, the reference's
+    dada_cuda_dbregister), runs the production observation loop until the short block and keeps the detected stream;
+    sampled gemm-units must equal the oracle on the junk bytes."""
+    import subprocess
+
+    from conftest import ROOT
+    from dsabeamformer_amd import host
+
+    cfg = bfmod.production_config()
+    name, n_blocks, distinct, seed = "dsabf_gpu_%d" % os.getpid(), 5, 2, 31
+    path = str(tmp_path / "detected_shm.bin")
+    w = subprocess.Popen([os.path.join(ROOT, "dsabeamformer_amd", "junkdb"), "-k", name, "-n", str(n_blocks), "-r", "3",
+                          "-d", str(distinct), "-s", str(seed)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    try:
+        r = subprocess.run([os.path.join(ROOT, "dsabeamformer_amd", "beam"), "-k", name, "-w", path],
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert "block size is: 134217728" in r.stdout
+        assert "Wrote %d gemm-units" % (n_blocks * cfg.n_gemms_per_block) in r.stdout
+        wout, werr = w.communicate(timeout=60)
+        assert w.returncode == 0, werr
+    finally:
+        if w.poll() is None:
+            w.kill()
+        host.shm_ring_unlink(name)
+    hdr, data = host.read_detected_file(path)
+    per = cfg.n_gemms_per_block
+    assert data.shape == (n_blocks * per, cfg.n_out_per_gemm, 256, 256)
+    junk = host.junk_bytes(134217728, distinct, seed).reshape(distinct, per, 256, -1, 64)
+    g = orc.PROD_GEOM
+    wts = orc.make_weights(g, orc.default_positions(64), orc.default_directions(256), 0)
+    for gi in (0, 33, 95, n_blocks * per - 1):
+        blk, ts = divmod(gi, per)
+        want = orc.beamform(g, wts, junk[blk % distinct, ts][None])
+        assert np.array_equal(data[gi], want.reshape(data[gi].shape)), gi
+
+
+def test_observation_shm_python_api_small_blocks(bfmod, orc, tmp_path):
+    """Same path through the C wrapper with a small geometry: writer thread in this process, whole stream checked."""
+    import threading
+
+    from dsabeamformer_amd import host
+
+    cfg = bfmod.production_config(n_freq=4)
+    cfg.n_beams, cfg.n_gemms_per_block, cfg.n_streams = 64, 4, 2
+    n_time = cfg.n_out_per_gemm * cfg.n_pol * cfg.n_avg
+    block_bytes = cfg.n_gemms_per_block * cfg.n_freq * n_time * cfg.n_ant
+    name, n_blocks = "dsabf_gpu_small_%d" % os.getpid(), 9
+    rng = np.random.default_rng(3)
+    blocks = rng.integers(0, 256, size=(n_blocks, cfg.n_gemms_per_block, cfg.n_freq, n_time, cfg.n_ant), dtype=np.uint8)
+    ring = host.ShmRing(name, n_blocks=3, block_size=block_bytes, header="HDR_SIZE 4096\n")
+
+    def writer():
+        for b in blocks:
+            ring.write(b.reshape(-1))
+        ring.write(np.zeros(0, np.uint8))
+
+    t = threading.Thread(target=writer)
+    t.start()
+    path = str(tmp_path / "d.bin")
+    try:
+        r = host.run_observation_shm(cfg, name, path=path, gpu=1)
+        t.join(timeout=30)
+        assert r["gemms"] == n_blocks * cfg.n_gemms_per_block
+    finally:
+        ring.detach()
+        ring.unlink()
+    hdr, data = host.read_detected_file(path)
+    g = orc.Geom(n_beams=64, n_ant=64, n_freq=4, n_avg=16, n_out_per_gemm=cfg.n_out_per_gemm)
+    wts = orc.make_weights(g, orc.default_positions(64), orc.default_directions(64), 1)
+    for b in range(n_blocks):
+        want = orc.beamform(g, wts, blocks[b])
+        assert np.array_equal(data[b * 4:(b + 1) * 4].reshape(want.shape), want), b

@@ -252,3 +252,84 @@ def test_detected_sink_ring_and_file_format(host, bfm, tmp_path):
     assert (int(hdr["N_BEAMS"]), int(hdr["N_FREQUENCIES"]), int(hdr["N_OUTPUTS_PER_GEMM"])) == (32, 4, 2)
     assert os.path.getsize(path) == host.DETECTED_HEADER_BYTES + want.nbytes
     assert np.array_equal(data.reshape(9, per), want)
+
+
+def _ring_name(tag):
+    return "dsabf_test_%s_%d" % (tag, os.getpid())
+
+
+def test_shm_ring_writer_process_to_reader(host, tmp_path):
+    """the PSRDADA stand-in.  `junkdb` (separate process) creates the ring and writes 11 blocks through 3
+    slots; the reader sees them in order with the junk source's bytes, then the short end-of-data block; the writer
+    deletes the ring once it is drained.  Blocking in both directions is exercised by the ring being shorter than the
+    stream and by a slow reader."""
+    import subprocess
+    import time
+
+    from conftest import ROOT
+
+    name, bs, n, distinct, seed = _ring_name("w"), 64 * 1024, 11, 4, 77
+    hdr_file = os.path.join(CFG, "correlator_header_dsaX.txt")
+    args = [os.path.join(ROOT, "dsabeamformer_amd", "junkdb"), "-k", name, "-n", str(n), "-r", "3", "-b", str(bs),
+            "-d", str(distinct), "-s", str(seed)]
+    if os.path.exists(hdr_file):
+        args += ["-H", hdr_file]
+    p = subprocess.Popen(args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    try:
+        ring = host.ShmRing(name)
+        assert (ring.n_blocks, ring.block_size) == (3, bs)
+        assert "HDR_SIZE" in ring.header
+        want = host.junk_bytes(bs, distinct, seed)
+        assert len(np.unique(want)) == 256
+        for i in range(n):
+            if i == 4:
+                time.sleep(0.3)  # the writer runs into a full ring
+            data, bid = ring.read()
+            assert bid == i and data.size == bs and np.array_equal(data, want[i % distinct]), i
+        data, bid = ring.read()
+        assert bid == n and data.size == 0   # short block = end of data (src/dada_handler.hh:105-113)
+        ring.detach()
+        out, err = p.communicate(timeout=30)
+        assert p.returncode == 0, err
+        assert "wrote 11 blocks" in out
+    finally:
+        if p.poll() is None:
+            p.kill()
+        host.shm_ring_unlink(name)
+    assert not os.path.exists("/dev/shm/" + name)
+
+
+def test_shm_ring_in_process_backpressure(host):
+    """Writer and reader threads on a 2-slot ring: order, sizes, and that a full ring blocks the writer."""
+    import threading
+
+    name = _ring_name("t")
+    ring = host.ShmRing(name, n_blocks=2, block_size=4096, header="HDR_SIZE 4096\nSOURCE TEST\n")
+    try:
+        reader = host.ShmRing(name)
+        assert reader.header.startswith("HDR_SIZE 4096")
+        wrote = []
+
+        def writer():
+            for i in range(6):
+                ring.write(np.full(4096, i, np.uint8))
+                wrote.append(i)
+            ring.write(np.zeros(100, np.uint8))  # short block
+
+        t = threading.Thread(target=writer)
+        t.start()
+        import time
+
+        time.sleep(0.3)
+        assert wrote == [0, 1]  # two slots: the third write is blocked until a block is read
+        for i in range(6):
+            data, bid = reader.read()
+            assert bid == i and data.size == 4096 and (data == i).all()
+        data, bid = reader.read()
+        assert data.size == 100
+        t.join(timeout=10)
+        assert not t.is_alive()
+        reader.detach()
+    finally:
+        ring.detach()
+        ring.unlink()
