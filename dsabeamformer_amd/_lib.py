@@ -63,6 +63,8 @@ SIGNATURES = {
     "bf_expand_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "bf_gemm_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bf_dedisperse_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "bf_dedisperse_dm_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
+                                          C.c_void_p]),
     "bf_kernel_info": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
                                  C.POINTER(C.c_int)]),
     "bf_kernel_name": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t]),
@@ -115,6 +117,10 @@ SIGNATURES = {
     "bfh_sink_commit": (C.c_int, [C.c_void_p, C.c_uint64]),
     "bfh_sink_close": (C.c_int, [C.c_void_p]),
     "bfh_sink_destroy": (C.c_int, [C.c_void_p]),
+    "bfh_dm_trials": (C.c_int, [C.c_double, C.c_double, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,
+                                C.c_double, C.POINTER(C.c_double), C.c_int]),
+    "bfh_dm_delays": (C.c_int, [C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_float), C.c_int, C.c_double, C.c_double,
+                                C.POINTER(C.c_int32)]),
     "bfh_junk_fill": (C.c_int, [C.POINTER(BfConfig), C.c_int, C.c_uint64, C.c_void_p]),
     "bfh_shm_ring_create": (C.c_int, [C.c_char_p, C.c_uint64, C.c_uint64, C.c_char_p, C.POINTER(C.c_void_p)]),
     "bfh_shm_ring_attach": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]),

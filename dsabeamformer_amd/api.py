@@ -93,6 +93,11 @@ class Beamformer:
     def dedisperse(self, d_out_unit, d_ded, stream: int = 0) -> None:
         check(self._lib.bf_dedisperse_device(self._h, _ptr(d_out_unit), _ptr(d_ded), C.c_void_p(stream)))
 
+    def dedisperse_dm(self, d_series, n_t: int, d_delays, n_dm: int, n_t_out: int, d_out, stream: int = 0) -> None:
+        """d_series float32 [n_t][freq][beam], d_delays int32 [n_dm][freq] -> d_out float32 [n_dm][n_t_out][beam]."""
+        check(self._lib.bf_dedisperse_dm_device(self._h, _ptr(d_series), int(n_t), _ptr(d_delays), int(n_dm),
+                                                int(n_t_out), _ptr(d_out), C.c_void_p(stream)))
+
     # -- streaming entry points (the reference's observation loop) ---------------------------------------------
     def submit_block(self, slot: int, host, nbytes: int, event=None) -> None:
         check(self._lib.bf_submit_block(self._h, slot, _ptr(host), nbytes, _ptr(event)))

@@ -723,6 +723,35 @@ char* junk_block_source::read()
 
 bool junk_block_source::check_transfers_complete() { return bytes_read < block_size; }  // src/dada_handler.hh:105-113
 
+// ---- dedispersion trial ladder and delays (sandbox/Dispersion Theory.ipynb) ------------------------------------------
+std::vector<double> dm_trials(double dm0, double dm_max, int nchan, double epsilon, double nu_ghz, double chan_bw_mhz,
+                              double ti_us, double tscat_us, double tsamp_us)
+{
+    const double n2 = (double)nchan * (double)nchan;                               // cell 1
+    const double alpha = 1.0 / (16 + n2);
+    const double beta = ti_us * ti_us + tscat_us * tscat_us + tsamp_us * tsamp_us;
+    const double k = (nu_ghz * nu_ghz * nu_ghz) / (8.3 * chan_bw_mhz);
+    std::vector<double> dms{dm0};
+    double dm_prev = dm0;
+    while (dm_prev < dm_max) {                                                      // cell 2
+        dm_prev = n2 * alpha * dm_prev + 4 * std::sqrt(alpha * (epsilon * epsilon - n2 * alpha) * dm_prev * dm_prev +
+                                                       alpha * beta * (epsilon * epsilon - 1) * (k * k));
+        dms.push_back(dm_prev);
+    }
+    return dms;
+}
+
+void dm_delays(const double* dms, int n_dm, const float* freq_ghz, int n_freq, double f_ref_ghz, double tsamp_ms,
+               int32_t* out)
+{
+    for (int d = 0; d < n_dm; d++)
+        for (int f = 0; f < n_freq; f++) {
+            const double fr = (double)freq_ghz[f];                                  // cell 5
+            out[(size_t)d * n_freq + f] =
+                (int32_t)(4.15 * dms[d] * (-1.0 / (f_ref_ghz * f_ref_ghz) + 1.0 / (fr * fr)) / tsamp_ms);
+        }
+}
+
 // ---- detected-stream sinks ------------------------------------------------------------------------------------------
 detected_sink::detected_sink(const bf_config& cfg, uint64_t slots)
     : floats_per_gemm(bf_floats_per_detect(&cfg)), n_slots(slots ? slots : slots_for(cfg))
@@ -1226,6 +1255,24 @@ int bfh_run_observation_junk_to_file(const bf_config* cfg, uint64_t n_blocks, in
     if (rc != BF_OK) return rc;
     if (observation_ms) *observation_ms = res.observation_time_ms;
     if (gemms_written) *gemms_written = sink.get_delivered();
+    return BF_OK;
+}
+
+int bfh_dm_trials(double dm0, double dm_max, int nchan, double epsilon, double nu_ghz, double chan_bw_mhz, double ti_us,
+                  double tscat_us, double tsamp_us, double* out, int cap)
+{
+    if (!out || cap < 1) return BF_ERR_INVALID;
+    const std::vector<double> v = dm_trials(dm0, dm_max, nchan, epsilon, nu_ghz, chan_bw_mhz, ti_us, tscat_us, tsamp_us);
+    const int n = (int)v.size() < cap ? (int)v.size() : cap;
+    std::memcpy(out, v.data(), (size_t)n * sizeof(double));
+    return n;
+}
+
+int bfh_dm_delays(const double* dms, int n_dm, const float* freq_ghz, int n_freq, double f_ref_ghz, double tsamp_ms,
+                  int32_t* out)
+{
+    if (!dms || !freq_ghz || !out || n_dm < 0 || n_freq < 0) return BF_ERR_INVALID;
+    dm_delays(dms, n_dm, freq_ghz, n_freq, f_ref_ghz, tsamp_ms, out);
     return BF_OK;
 }
 

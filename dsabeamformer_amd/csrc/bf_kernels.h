@@ -58,6 +58,9 @@ hipError_t launch_gemm_only(const Geometry& g, const void* d_image, const void* 
 
 hipError_t launch_expand(const void* d_in, size_t nbytes, void* d_out, hipStream_t s);
 hipError_t launch_dedisperse(const Geometry& g, const float* d_out_unit, float* d_ded, hipStream_t s);
+// out[dm][t][b] = sum_f series[t + delays[dm][f]][f][b]  (series: n_t beam-blocks [f][b]; t < n_t_out)
+hipError_t launch_dedisperse_dm(const Geometry& g, const float* d_series, int n_t, const int* d_delays, int n_dm,
+                                int n_t_out, float* d_out, hipStream_t s);
 
 int fused_vgprs(const Geometry& g);  // from hipFuncGetAttributes, for reports
 const char* fused_kernel_name(const Geometry& g, char* buf, size_t n);

@@ -589,6 +589,43 @@ __global__ void dedisperse_kernel(const float* __restrict__ out_unit, float* __r
     ded[b] = acc;
 }
 
+// 8f-4: incoherent dedispersion of a detected series: out[dm][t][b] = sum over f (ascending, fp32) of
+// series[t + delay[dm][f]][f][b].  One thread per beam and kDmTb consecutive output times; the delay is wave-uniform
+// (scalar load), every load is a coalesced row of beams; rows past the end of the series contribute nothing.
+// blockIdx.x runs over DM trials (fastest): neighbouring trials read nearly the same rows, so the series is served
+// from L2 / Infinity Cache after the first trial touches it.
+constexpr int kDmTb = 8;
+__global__ __launch_bounds__(256) void dedisperse_dm_kernel(const float* __restrict__ series, const int* __restrict__ delays,
+                                                            float* __restrict__ out, int n_t, int n_freq, int n_beams,
+                                                            int n_t_out)
+{
+    const int dm = blockIdx.x;
+    const int t0 = blockIdx.y * kDmTb;
+    const int b = blockIdx.z * 256 + threadIdx.x;
+    if (b >= n_beams) return;
+    float acc[kDmTb];
+#pragma unroll
+    for (int i = 0; i < kDmTb; i++) acc[i] = 0.0f;
+    const size_t row_stride = (size_t)n_freq * n_beams;
+    const int* dl = delays + (size_t)dm * n_freq;
+    for (int f = 0; f < n_freq; f++) {
+        const int row = t0 + __builtin_amdgcn_readfirstlane(dl[f]);
+        const float* p = series + (size_t)f * n_beams + b;
+        float v[kDmTb];
+#pragma unroll
+        for (int i = 0; i < kDmTb; i++) {
+            const int r = row + i;
+            v[i] = (r >= 0 && r < n_t) ? p[(size_t)r * row_stride] : 0.0f;
+        }
+#pragma unroll
+        for (int i = 0; i < kDmTb; i++)
+            if (row + i >= 0 && row + i < n_t) acc[i] = acc[i] + v[i];  // a skipped row must not even add +0 (-0 sums)
+    }
+#pragma unroll
+    for (int i = 0; i < kDmTb; i++)
+        if (t0 + i < n_t_out) out[((size_t)dm * n_t_out + t0 + i) * n_beams + b] = acc[i];
+}
+
 // =========================================================================================================
 // fused16_kernel -- the same fused stage built on v_mfma_i32_16x16x64_i8 (64-antenna geometries).
 //
@@ -1277,6 +1314,17 @@ hipError_t launch_dedisperse(const Geometry& g, const float* d_out_unit, float* 
 {
     hipLaunchKernelGGL(dedisperse_kernel, dim3((g.n_beams + 63) / 64), dim3(64), 0, s, d_out_unit, d_ded, g.n_freq,
                        g.n_beams);
+    return hipGetLastError();
+}
+
+hipError_t launch_dedisperse_dm(const Geometry& g, const float* d_series, int n_t, const int* d_delays, int n_dm,
+                                int n_t_out, float* d_out, hipStream_t s)
+{
+    if (n_dm <= 0 || n_t_out <= 0) return hipSuccess;
+    const dim3 grid((unsigned)n_dm, (unsigned)((n_t_out + kDmTb - 1) / kDmTb), (unsigned)((g.n_beams + 255) / 256));
+    if (grid.y > 65535u || grid.z > 65535u) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(dedisperse_dm_kernel, grid, dim3(256), 0, s, d_series, d_delays, d_out, n_t, g.n_freq, g.n_beams,
+                       n_t_out);
     return hipGetLastError();
 }
 

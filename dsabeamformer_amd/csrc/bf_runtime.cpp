@@ -501,6 +501,16 @@ int bf_dedisperse_device(bf_handle* h, const float* d_out_unit, float* d_ded, vo
     return BF_OK;
 }
 
+int bf_dedisperse_dm_device(bf_handle* h, const float* d_series, int n_t, const int32_t* d_delays, int n_dm, int n_t_out,
+                            float* d_out, void* hip_stream)
+{
+    if (!h || !d_series || !d_delays || !d_out) return fail(BF_ERR_INVALID, "NULL argument");
+    if (n_t <= 0 || n_dm < 0 || n_t_out < 0 || n_t_out > n_t) return fail(BF_ERR_INVALID, "need 0 <= n_t_out <= n_t, n_dm >= 0");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(dsabf::launch_dedisperse_dm(h->geom, d_series, n_t, d_delays, n_dm, n_t_out, d_out, as_stream(hip_stream)));
+    return BF_OK;
+}
+
 int bf_kernel_info(const bf_handle* h, int n_units, int* grid, int* block, int* lds_bytes, int* vgprs)
 {
     if (!h) return fail(BF_ERR_INVALID, "handle is NULL");

@@ -342,3 +342,26 @@ def run_observation_shm(cfg: BfConfig, name: str, path: str | None = None, core:
     check(load().bfh_run_observation_shm(C.byref(cfg), name.encode(), core, gpu, device, 1 if verbose else 0,
                                          path.encode() if path else None, C.byref(ms), C.byref(n), C.byref(pinned)))
     return {"ms": ms.value, "gemms": n.value, "pinned": bool(pinned.value)}
+
+
+def dm_trials(dm0: float = 0.0, dm_max: float = 2000.0, nchan: int = 2048, epsilon: float = 1.25,
+              nu_ghz: float = (1.28 + 1.53) / 2, chan_bw_mhz: float = (1.53 - 1.28) / 2048 * 1000, ti_us: float = 40.0,
+              tscat_us: float = 0.0, tsamp_us: float = 131.0) -> np.ndarray:
+    """DM trial ladder (sandbox/Dispersion Theory.ipynb cells 1-2; defaults are the notebook's values)."""
+    out = np.zeros(1 << 16, np.float64)
+    n = load().bfh_dm_trials(dm0, dm_max, nchan, epsilon, nu_ghz, chan_bw_mhz, ti_us, tscat_us, tsamp_us,
+                             out.ctypes.data_as(C.POINTER(C.c_double)), out.size)
+    if n < 0:
+        check(n)
+    return out[:n].copy()
+
+
+def dm_delays(dms, freq_ghz, f_ref_ghz: float, tsamp_ms: float) -> np.ndarray:
+    """int32 [n_dm][n_freq] sample delays (notebook cell 5)."""
+    dms = np.ascontiguousarray(dms, np.float64)
+    fr = np.ascontiguousarray(freq_ghz, np.float32)
+    out = np.zeros((dms.size, fr.size), np.int32)
+    check(load().bfh_dm_delays(dms.ctypes.data_as(C.POINTER(C.c_double)), dms.size,
+                               fr.ctypes.data_as(C.POINTER(C.c_float)), fr.size, f_ref_ghz, tsamp_ms,
+                               out.ctypes.data_as(C.POINTER(C.c_int32))))
+    return out

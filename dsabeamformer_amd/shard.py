@@ -95,3 +95,25 @@ class DetectedGather:
             for r in range(R):
                 dst[:, r].copy_(self.recv[slot][r].view(self.no, self.fl, self.nb))
         return self.full[slot]
+
+
+def reduce_dedispersed(torch, dist, partial, group=None):
+    """Sub-band dedispersion across frequency shards (SURVEY.md section 8f-4 on the section 8e partition).
+
+    Each rank dedisperses ITS channels (bf_dedisperse_dm_device on its local detected series, delays computed for its
+    channels against the band-wide reference frequency): ``partial`` [n_dm][n_t][n_beams] float32.  The band-wide
+    result is the sum of the partials; to keep it bit-reproducible (fp32 addition is not associative and a ring
+    all-reduce fixes no order a caller can name) the partials are all-gathered and added in rank order -- ascending
+    frequency, the same order the single-device kernel uses within a band.  Every rank returns the full result.
+    """
+    world = dist.get_world_size(group)
+    if world == 1:
+        return partial.clone()
+    flat = partial.contiguous().reshape(-1)
+    gathered = torch.empty(world * flat.numel(), dtype=partial.dtype, device=partial.device)
+    dist.all_gather_into_tensor(gathered, flat, group=group)
+    parts = gathered.reshape((world,) + tuple(partial.shape))
+    out = parts[0].clone()
+    for r in range(1, world):
+        out += parts[r]
+    return out

@@ -164,6 +164,14 @@ int bf_gemm_device(bf_handle *h, const void *d_packed_unit, float *d_c, void *hi
 /* a8 alone: d_out_unit [output][freq][beam] -> d_ded [beam] = sum over freq of output 0. */
 int bf_dedisperse_device(bf_handle *h, const float *d_out_unit, float *d_ded, void *hip_stream);
 
+/* Incoherent dedispersion beyond DM 0 (the reference stops at the DM-0 sum above and sketches
+ * the delay law in sandbox/Dispersion Theory.ipynb).  d_series: n_t consecutive beam-blocks [t][freq][beam] (the
+ * detected stream is exactly that); d_delays: int32 [n_dm][freq] sample delays (dsabf::dm_delays / bfh_dm_delays);
+ * d_out [n_dm][n_t_out][beam] = sum over freq, ascending, fp32, of d_series[t + delay][freq][beam]; rows >= n_t
+ * contribute nothing, so size n_t_out = n_t - (largest delay) for complete sums. */
+int bf_dedisperse_dm_device(bf_handle *h, const float *d_series, int n_t, const int32_t *d_delays, int n_dm, int n_t_out,
+                            float *d_out, void *hip_stream);
+
 /* Introspection for benchmarks/roofline reports. */
 int bf_kernel_info(const bf_handle *h, int n_units, int *grid, int *block, int *lds_bytes, int *vgprs);
 int bf_kernel_name(const bf_handle *h, char *buf, size_t buflen); /* which fused kernel this geometry runs */

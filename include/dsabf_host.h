@@ -93,6 +93,13 @@ int bfh_sink_commit(bfh_sink *s, uint64_t gemm_index);                 /* in ord
 int bfh_sink_close(bfh_sink *s);
 int bfh_sink_destroy(bfh_sink *s);
 
+/* DM trial ladder and per-channel sample delays (sandbox/Dispersion Theory.ipynb cells 1-2 and 5; dsabf::dm_trials,
+ * dsabf::dm_delays).  bfh_dm_trials returns the number of trials written (<= cap). */
+int bfh_dm_trials(double dm0, double dm_max, int nchan, double epsilon, double nu_ghz, double chan_bw_mhz, double ti_us,
+                  double tscat_us, double tsamp_us, double *out, int cap);
+int bfh_dm_delays(const double *dms, int n_dm, const float *freq_ghz, int n_freq, double f_ref_ghz, double tsamp_ms,
+                  int32_t *out);
+
 /* The junk source's bytes: ring_blocks blocks of cfg's block size into `out` (dsabf::junk_fill). */
 int bfh_junk_fill(const bf_config *cfg, int ring_blocks, uint64_t seed, void *out);
 

@@ -232,6 +232,15 @@ public:
     bool ok() const { return ring != nullptr; }
 };
 
+// ---- dedispersion beyond DM 0: the formulas of sandbox/Dispersion Theory.ipynb ------------
+// Trial ladder of cells 1-2 (double arithmetic, as numpy): appends trials until the first one >= dm_max.
+std::vector<double> dm_trials(double dm0 = 0.0, double dm_max = 2000.0, int nchan = 2048, double epsilon = 1.25,
+                              double nu_ghz = (1.28 + 1.53) / 2, double chan_bw_mhz = (1.53 - 1.28) / 2048 * 1000,
+                              double ti_us = 40.0, double tscat_us = 0.0, double tsamp_us = 131.0);
+// Cell 5: delay[dm][f] = (int)(4.15 * dm * (freq_f^-2 - f_ref^-2) / tsamp_ms); freq in GHz (channel_frequency()).
+void dm_delays(const double* dms, int n_dm, const float* freq_ghz, int n_freq, double f_ref_ghz, double tsamp_ms,
+               int32_t* out);
+
 // Fills `ring_blocks` consecutive blocks of cfg's block size at `ring` with the junk source's bytes (64-bit xorshift*,
 // every nibble code in both halves; depends only on seed, ring_blocks and the block size).
 void junk_fill(const bf_config& cfg, int ring_blocks, uint64_t seed, char* ring);

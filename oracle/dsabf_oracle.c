@@ -289,6 +289,62 @@ void orc_dedisperse(const orc_geom *g, const float *out_unit, float *ded)
     }
 }
 
+/* 8f-4 -- sandbox/Dispersion Theory.ipynb cells 1-2 (parity unpinned: no reference implementation, see the header). */
+int orc_dm_trials(double dm0, double dm_max, int nchan, double epsilon, double nu_ghz, double chan_bw_mhz, double ti_us,
+                  double tscat_us, double tsamp_us, double *out, int cap)
+{
+    const double n2 = (double)nchan * (double)nchan;
+    const double alpha = 1.0 / (16 + n2);
+    const double beta = ti_us * ti_us + tscat_us * tscat_us + tsamp_us * tsamp_us;
+    const double k = (nu_ghz * nu_ghz * nu_ghz) / (8.3 * chan_bw_mhz);
+    double dm_prev = dm0;
+    int n = 0;
+    if (n < cap)
+        out[n] = dm0;
+    n++;
+    while (dm_prev < dm_max) {
+        dm_prev = n2 * alpha * dm_prev +
+                  4 * sqrt(alpha * (epsilon * epsilon - n2 * alpha) * dm_prev * dm_prev +
+                           alpha * beta * (epsilon * epsilon - 1) * (k * k));
+        if (n < cap)
+            out[n] = dm_prev;
+        n++;
+    }
+    return n < cap ? n : cap;
+}
+
+/* cell 5: int(d * (-f1**(-2) + f**(-2)) / tsamp_ms), d = 4.15 * DM */
+void orc_dm_delays(const double *dms, int n_dm, const float *freq_ghz, int n_freq, double f_ref_ghz, double tsamp_ms,
+                   int32_t *out)
+{
+    for (int d = 0; d < n_dm; d++)
+        for (int f = 0; f < n_freq; f++) {
+            const double fr = (double)freq_ghz[f];
+            const double v = 4.15 * dms[d] * (-1.0 / (f_ref_ghz * f_ref_ghz) + 1.0 / (fr * fr)) / tsamp_ms;
+            out[(size_t)d * n_freq + f] = (int32_t)v;
+        }
+}
+
+void orc_dedisperse_dm(const float *series, int n_t, int n_freq, int n_beams, const int32_t *delays, int n_dm,
+                       int n_t_out, float *out)
+{
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int d = 0; d < n_dm; d++)
+        for (int t = 0; t < n_t_out; t++) {
+            float *o = out + ((size_t)d * n_t_out + t) * n_beams;
+            for (int b = 0; b < n_beams; b++)
+                o[b] = 0.0f;
+            for (int f = 0; f < n_freq; f++) {
+                const long row = (long)t + delays[(size_t)d * n_freq + f];
+                if (row < 0 || row >= n_t)
+                    continue;
+                const float *p = series + ((size_t)row * n_freq + f) * n_beams;
+                for (int b = 0; b < n_beams; b++)
+                    o[b] = o[b] + p[b];
+            }
+        }
+}
+
 /* src/beamformer.hh:250-284: `in >> count; for (i < expected) in >> entry;` -- whitespace-separated floats;
  * once extraction fails (EOF or a non-numeric token such as the U+200B at the end of
  * config/linear_directions.txt) every later entry keeps its zero default. */

@@ -90,6 +90,23 @@ void orc_beamform(const orc_geom *g, const int8_t *w, const uint8_t *packed, int
  * only), fp32, accumulated in ascending f (cuBLAS's order is unspecified; this is the canonical one). */
 void orc_dedisperse(const orc_geom *g, const float *out_unit, float *ded);
 
+/* ---- incoherent dedispersion beyond DM 0 -------------------------------------------------
+ * PARITY UNPINNED: the reference has no implementation of this stage (only the DM-0 column sum above, a8); these
+ * restate the formulas of its design notebook, sandbox/Dispersion Theory.ipynb, in the a8 summation order.
+ * orc_dm_trials: the trial ladder of cells 1-2 (all double, as numpy): dm_{k+1} = N^2 a dm_k +
+ *   4 sqrt(a (eps^2 - N^2 a) dm_k^2 + a beta (eps^2 - 1) (nu^3 / (8.3 B))^2), a = 1/(16 + N^2), beta = ti^2+tscat^2+tsamp^2;
+ *   stops after the first trial >= dm_max; returns the count (<= cap).
+ * orc_dm_delays: cell 5: delay[dm][f] = (int)(4.15 * dm * (freq_f^-2 - f_ref^-2) / tsamp_ms), truncated toward zero,
+ *   freq in GHz (the channel table of a5), evaluated in double.
+ * orc_dedisperse_dm: out[dm][t][b] = sum_f series[t + delay[dm][f]][f][b], fp32, ascending f (a8's order); t < n_t_out;
+ *   rows beyond n_t contribute nothing (the caller sizes n_t_out = n_t - max delay to avoid that). */
+int orc_dm_trials(double dm0, double dm_max, int nchan, double epsilon, double nu_ghz, double chan_bw_mhz, double ti_us,
+                  double tscat_us, double tsamp_us, double *out, int cap);
+void orc_dm_delays(const double *dms, int n_dm, const float *freq_ghz, int n_freq, double f_ref_ghz, double tsamp_ms,
+                   int32_t *out);
+void orc_dedisperse_dm(const float *series, int n_t, int n_freq, int n_beams, const int32_t *delays, int n_dm,
+                       int n_t_out, float *out);
+
 /* Config readers, src/beamformer.hh:250-284 and src/test_data_generator.hh:43-60.  Return the count the
  * file announces (first token), or -1 if the file cannot be opened.  Entries beyond `expected` are ignored,
  * missing ones stay 0 (caller zero-fills), exactly as the reference's stream extraction behaves. */

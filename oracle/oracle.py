@@ -230,6 +230,44 @@ def dedisperse(g: Geom, out_unit: np.ndarray) -> np.ndarray:
     return ded
 
 
+def dm_trials(dm0: float = 0.0, dm_max: float = 2000.0, nchan: int = 2048, epsilon: float = 1.25,
+              nu_ghz: float = (1.28 + 1.53) / 2, chan_bw_mhz: float = (1.53 - 1.28) / 2048 * 1000, ti_us: float = 40.0,
+              tscat_us: float = 0.0, tsamp_us: float = 131.0) -> np.ndarray:
+    """8f-4: the DM trial ladder of sandbox/Dispersion Theory.ipynb cells 1-2 (defaults = the notebook's values)."""
+    out = np.zeros(65536, np.float64)
+    f = lib().orc_dm_trials
+    f.restype = C.c_int
+    f.argtypes = [C.c_double, C.c_double, C.c_int] + [C.c_double] * 6 + [C.c_void_p, C.c_int]
+    n = f(dm0, dm_max, nchan, epsilon, nu_ghz, chan_bw_mhz, ti_us, tscat_us, tsamp_us, _p(out), out.size)
+    return out[:n].copy()
+
+
+def dm_delays(dms: np.ndarray, freq_ghz: np.ndarray, f_ref_ghz: float, tsamp_ms: float) -> np.ndarray:
+    """8f-4: int32 [n_dm][n_freq] sample delays (notebook cell 5)."""
+    dms = np.ascontiguousarray(dms, np.float64)
+    fr = np.ascontiguousarray(freq_ghz, np.float32)
+    out = np.zeros((dms.size, fr.size), np.int32)
+    f = lib().orc_dm_delays
+    f.restype = None
+    f.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_void_p]
+    f(_p(dms), dms.size, _p(fr), fr.size, f_ref_ghz, tsamp_ms, _p(out))
+    return out
+
+
+def dedisperse_dm(series: np.ndarray, delays: np.ndarray, n_t_out: int) -> np.ndarray:
+    """8f-4: series float32 [t][f][b], delays int32 [dm][f] -> float32 [dm][n_t_out][b] (ascending-f fp32 sums)."""
+    series = np.ascontiguousarray(series, np.float32)
+    delays = np.ascontiguousarray(delays, np.int32)
+    n_t, n_f, n_b = series.shape
+    assert delays.shape[1] == n_f
+    out = np.empty((delays.shape[0], n_t_out, n_b), np.float32)
+    f = lib().orc_dedisperse_dm
+    f.restype = None
+    f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    f(_p(series), n_t, n_f, n_b, _p(delays), delays.shape[0], n_t_out, _p(out))
+    return out
+
+
 def write_python_file(data: np.ndarray, path: str) -> None:
     data = np.ascontiguousarray(data, np.float32)
     if lib().orc_write_python_file(_p(data), data.shape[0], data.shape[1], path.encode()) != 0:

@@ -737,3 +737,70 @@ def test_observation_shm_python_api_small_blocks(bfmod, orc, tmp_path):
     for b in range(n_blocks):
         want = orc.beamform(g, wts, blocks[b])
         assert np.array_equal(data[b * 4:(b + 1) * 4].reshape(want.shape), want), b
+
+
+@pytest.mark.parametrize("n_t,n_f,n_b,n_dm,tsamp", [(64, 16, 32, 5, 8.0), (300, 256, 256, 12, 0.131), (37, 5, 96, 3, 4.0),
+                                                    (129, 32, 544, 7, 2.0)])
+def test_dedisperse_dm_bit_exact(torch, bfmod, orc, n_t, n_f, n_b, n_dm, tsamp):
+    """8f-4: out[dm][t][b] = sum_f series[t + delay[dm][f]][f][b], ascending-f fp32: bit-exact vs the oracle, for
+    complete sums (n_t_out = n_t - max delay) and for the ragged tail (n_t_out = n_t: rows past the end are skipped)."""
+    from dsabeamformer_amd import host
+
+    g = orc.Geom(n_beams=n_b, n_ant=64, n_freq=n_f, n_avg=1, n_out_per_gemm=8)
+    bf = bfmod.Beamformer(_cfg(bfmod, g))
+    rng = np.random.default_rng(n_t * n_f)
+    series = (rng.random((n_t, n_f, n_b), dtype=np.float32) * 1e5).astype(np.float32)
+    freq = np.array([host.channel_frequency(0, c * (256 // n_f) if n_f <= 256 else c) for c in range(n_f)], np.float32)
+    dms = np.linspace(0.0, 180.0, n_dm)
+    delays = host.dm_delays(dms, freq, float(freq[0]), tsamp)
+    assert delays.min() == 0 and 0 < delays.max() < n_t
+    d_series = torch.from_numpy(series).cuda()
+    d_delays = torch.from_numpy(delays).cuda()
+    for n_t_out in (n_t - int(delays.max()), n_t):
+        d_out = torch.full((n_dm, n_t_out, n_b), float("nan"), dtype=torch.float32, device="cuda")
+        bf.dedisperse_dm(d_series, n_t, d_delays, n_dm, n_t_out, d_out, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        want = orc.dedisperse_dm(series, delays, n_t_out)
+        assert np.array_equal(d_out.cpu().numpy(), want), n_t_out
+
+
+def test_dedisperse_dm_recovers_dispersed_pulse_from_detected_stream(torch, bfmod, orc):
+    """End to end on the product path: a source whose voltage burst arrives later at lower frequencies (the sample
+    delays of DM 120) goes through the fused kernel; the DM ladder's matched trial collects the whole burst in one
+    sample of the right beam, DM 0 does not.  Every trial equals the oracle on the same detected series."""
+    from dsabeamformer_amd import host
+
+    g = orc.Geom(n_beams=64, n_ant=64, n_freq=32, n_avg=16, n_out_per_gemm=8)
+    n_units, n_t = 12, 96
+    pos, dirs = orc.default_positions(64), orc.default_directions(64)
+    w = orc.make_weights(g, pos, dirs, 0)
+    freq = np.array([host.channel_frequency(0, c) for c in range(g.n_freq)], np.float32)
+    tsamp_ms = 0.131                                                       # the production output sample time
+    dms = np.array([0.0, 60.0, 120.0, 180.0])
+    delays = host.dm_delays(dms, freq, float(freq[0]), tsamp_ms)
+    assert delays[2].max() >= 5
+    src = np.array([[dirs[40][0], 0.0]], np.float32)   # a source in the direction of beam 40
+    tone = orc.generate_test_data(g, pos, src, 0, n_units=1)[0]           # [f][t][a], the same column at every t
+    packed = np.zeros((n_units, g.n_freq, g.n_time, g.n_ant), np.uint8)
+    t_burst = 20
+    for f in range(g.n_freq):
+        o = t_burst + int(delays[2, f])                                    # output sample in which channel f is lit
+        u, oo = divmod(o, g.n_out_per_gemm)
+        packed[u, f, oo * g.n_ipo:(oo + 1) * g.n_ipo] = tone[f, 0]
+    bf = bfmod.Beamformer(_cfg(bfmod, g))
+    bf.set_weights(w)
+    want_series = orc.beamform(g, w, packed)                               # [n_t][f][b]
+    d_in = torch.from_numpy(packed).cuda()
+    d_series = torch.empty(n_t * g.n_freq * g.n_beams, dtype=torch.float32, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    bf.beamform(d_in, n_units, d_series, s)
+    n_t_out = n_t - int(delays.max())
+    d_out = torch.empty((len(dms), n_t_out, g.n_beams), dtype=torch.float32, device="cuda")
+    bf.dedisperse_dm(d_series, n_t, torch.from_numpy(delays).cuda(), len(dms), n_t_out, d_out, s)
+    torch.cuda.synchronize()
+    got = d_out.cpu().numpy()
+    assert np.array_equal(d_series.cpu().numpy().reshape(want_series.shape), want_series)
+    assert np.array_equal(got, orc.dedisperse_dm(want_series.reshape(n_t, g.n_freq, g.n_beams), delays, n_t_out))
+    dm_best, t_best, b_best = np.unravel_index(np.argmax(got), got.shape)
+    assert (dm_best, t_best) == (2, t_burst) and abs(int(b_best) - 40) <= 1
+    assert got[2, t_burst, b_best] > 3 * got[0].max()

@@ -333,3 +333,40 @@ def test_shm_ring_in_process_backpressure(host):
     finally:
         ring.detach()
         ring.unlink()
+
+
+def test_dm_trials_and_delays_match_oracle_and_notebook_values(host, orc):
+    """8f-4: host mirror == oracle, and both == the values the notebook's own formulas give (fixture generated by
+    tests/golden/make_golden.py restating sandbox/Dispersion Theory.ipynb cells 1, 2, 5 in numpy)."""
+    gold = json.load(open(os.path.join(GOLDEN, "golden.json")))["dispersion"]
+    dms = host.dm_trials()
+    assert np.array_equal(dms, orc.dm_trials())
+    assert len(dms) == gold["n_trials"] and dms[1] == gold["dm1"] and dms[-1] == gold["dm_last"]
+    freq = np.array([1.28 + (1.53 - 1.28) / 2048 * i for i in range(2048)], np.float32)
+    d = host.dm_delays([2000.0, 56.5], freq, 1.53, 0.131 * 16)
+    assert np.array_equal(d, orc.dm_delays(np.array([2000.0, 56.5]), freq, 1.53, 0.131 * 16))
+    assert d[0, 0] == gold["delay_dm2000_chan0"] and int(d[0].sum()) == gold["delay_dm2000_sum"]
+    assert d[:, -1].tolist() == [0, 0] and (np.diff(d[0]) <= 0).all()
+    # a different ladder (coarser channels, shorter span)
+    assert np.array_equal(host.dm_trials(5.0, 300.0, 256, 1.5, 1.4, 0.9765625, 20.0, 5.0, 65.5),
+                          orc.dm_trials(5.0, 300.0, 256, 1.5, 1.4, 0.9765625, 20.0, 5.0, 65.5))
+
+
+def test_oracle_dedisperse_dm_properties(orc):
+    """DM 0 (all delays 0) is the a8 column sum per time sample; a dispersed impulse is recovered at its DM."""
+    rng = np.random.default_rng(8)
+    n_t, n_f, n_b = 40, 16, 8
+    series = rng.random((n_t, n_f, n_b), dtype=np.float32)
+    zero = np.zeros((1, n_f), np.int32)
+    out = orc.dedisperse_dm(series, zero, n_t)
+    g = orc.Geom(n_beams=n_b, n_ant=64, n_freq=n_f, n_avg=1, n_out_per_gemm=1)
+    for t in (0, 17, 39):
+        assert np.array_equal(out[0, t], orc.dedisperse(g, series[t][None]))
+    freq = np.linspace(1.4, 1.5, n_f).astype(np.float32)
+    delays = orc.dm_delays(np.array([0.0, 300.0, 600.0]), freq, 1.5, 0.131 * 64)   # up to 19 samples
+    assert 0 < delays[1].max() < delays[2].max() < n_t - 6
+    pulse = np.zeros((n_t, n_f, n_b), np.float32)
+    for f in range(n_f):
+        pulse[5 + delays[1, f], f, :] = 1.0
+    out = orc.dedisperse_dm(pulse, delays, n_t - int(delays.max()))
+    assert out[1, 5, 0] == n_f and out[1].max() == n_f and out[0].max() < n_f and out[2].max() < n_f

@@ -48,6 +48,23 @@ for mode in ("alltoall", "root"):
             assert np.array_equal(res.numpy(), full * np.float32(it + 1)), (mode, rank)
         else:
             assert res is None
+# sub-band dedispersion: each rank sums its own channels (delays against the band-wide reference frequency), the
+# partials are added in rank order -> identical on every rank and equal to the banded oracle sum
+series = full                                                       # [t][F][B] detected series, t = og outputs
+freq = np.array([orc.freq_weights(0, 8 * c) for c in range(g.n_freq)], np.float32)
+delays = orc.dm_delays(np.array([0.0, 20.0, 40.0]), freq, float(freq[0]), 0.131)
+assert 0 < delays.max() < og
+n_t_out = og - int(delays.max())
+mine = torch.from_numpy(orc.dedisperse_dm(np.ascontiguousarray(series[:, f0:f1]), delays[:, f0:f1], n_t_out))
+tot = shard.reduce_dedispersed(torch, dist, mine)
+want = None
+for r in range(world):
+    a, b = shard.freq_range(r, world, g.n_freq)
+    part = orc.dedisperse_dm(np.ascontiguousarray(series[:, a:b]), delays[:, a:b], n_t_out)
+    want = part if want is None else want + part
+assert np.array_equal(tot.numpy(), want), rank
+single = orc.dedisperse_dm(series, delays, n_t_out)                  # one device, whole band: same up to fp32 grouping
+assert np.allclose(tot.numpy(), single, rtol=1e-6, atol=0)
 dist.barrier()
 dist.destroy_process_group()
 print("rank %d ok" % rank)

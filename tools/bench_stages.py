@@ -36,4 +36,30 @@ for a, b in ev:
 torch.cuda.synchronize()
 ms = sorted(a.elapsed_time(b) for a, b in ev)
 res["dedisperse"] = {"us_median": ms[len(ms) // 2] * 1e3}
+# 8f-4 bf_dedisperse_dm_device: 1024 beam-blocks (0.134 s of sky at 131 us) x 64 DM trials of the notebook ladder spread
+# to DM ~ 250; algorithmic bytes = series once + output once; the kernel re-reads the series once per trial from L2/MALL
+from dsabeamformer_amd import host  # noqa: E402
+
+n_t, n_dm = 1024, 64
+freq = [host.channel_frequency(0, c) for c in range(256)]
+ladder = host.dm_trials(dm_max=250.0)
+dms = ladder[:: max(1, len(ladder) // n_dm)][:n_dm]
+delays = host.dm_delays(dms, freq, freq[0], 0.131)
+n_t_out = n_t - int(delays.max())
+d_series = torch.rand(n_t * 256 * 256, device="cuda")
+d_delays = torch.from_numpy(delays).cuda()
+d_dd = torch.empty(len(dms) * n_t_out * 256, device="cuda")
+for _ in range(3):
+    bf.dedisperse_dm(d_series, n_t, d_delays, len(dms), n_t_out, d_dd, s)
+ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(10)]
+for a, b in ev:
+    a.record(); bf.dedisperse_dm(d_series, n_t, d_delays, len(dms), n_t_out, d_dd, s); b.record()
+torch.cuda.synchronize()
+ms = sorted(a.elapsed_time(b) for a, b in ev)
+alg = 4 * (n_t * 256 * 256 + len(dms) * n_t_out * 256)
+loads = 4 * len(dms) * n_t_out * 256 * 256
+res["dedisperse_dm"] = {"n_t": n_t, "n_dm": len(dms), "max_delay": int(delays.max()), "n_t_out": n_t_out,
+                        "ms_median": ms[len(ms) // 2], "algorithmic_bytes": alg,
+                        "algorithmic_GBps": alg / (ms[len(ms) // 2] * 1e-3) / 1e9,
+                        "load_bytes_issued": loads, "load_GBps": loads / (ms[len(ms) // 2] * 1e-3) / 1e9}
 print(json.dumps(res))
