@@ -50,6 +50,9 @@ def parse():
                     help="canonical (default): bit-exact detect; fast: opt-in fma-contracted detect (tolerance mode)")
     ap.add_argument("--input", default="random", choices=["random", "zeros", "const"],
                     help="experiment only: voltage bit patterns (MFMA power depends on operand toggling)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="single process: still create the RCCL process group (world size 1) and run the gather path "
+                         "(plumbing check on a 1-GPU box; the driver's multi-GPU runs use torch.distributed.run)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the supplementary runs (fast detect, general kernel): profiling passes see one kernel")
@@ -136,9 +139,14 @@ def main():
         args.gpus = world
     torch.cuda.set_device(local)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
 
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29541")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     import dsabeamformer_amd as bfm
@@ -172,7 +180,7 @@ def main():
     # ---- gather plumbing (N > 1): dsabeamformer_amd/shard.py, covered by tests/test_shard_gloo.py ------------
     og = units * n_out
     gather = None
-    if world > 1 and args.gather != "none":
+    if dist is not None and args.gather != "none":
         from dsabeamformer_amd.shard import DetectedGather
 
         gather = DetectedGather(torch, dist, args.gather, og, n_freq, cfg.n_beams, torch.device("cuda", local))
@@ -257,7 +265,7 @@ def main():
                                     "c5": "C5 DSA100 scale-up: 100 ant x 2 pol, 1024 freq, 512 beams, N_TIME=256; the "
                                           "unit is a 512-beam x 1024-freq block"}[args.workload],
                        "gemm_units_per_step": units, "beam_blocks_per_step": blocks_per_step,
-                       "freq_per_gpu": n_freq, "gather": args.gather if world > 1 else "n/a",
+                       "freq_per_gpu": n_freq, "gather": args.gather if dist is not None else "n/a",
                        "detect_mode": args.detect,
                        "launch": info},
             "roofline": roof,
