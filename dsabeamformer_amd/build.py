@@ -42,7 +42,7 @@ def _stale() -> bool:
     if not all(os.path.exists(b) for b in MAINS):
         return True
     deps = list(MAINS.values()) + sources() + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.hpp")) + \
-        glob.glob(os.path.join(ROOT, "include", "*.h")) + [os.path.abspath(__file__)]
+        glob.glob(os.path.join(ROOT, "include", "*.h*")) + [os.path.abspath(__file__)]
     return any(os.path.getmtime(p) > t for p in deps)
 
 
@@ -59,7 +59,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         objs.append(obj)
         if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(
                 [os.path.getmtime(src)] + [os.path.getmtime(p) for p in glob.glob(os.path.join(CSRC, "*.h*"))] +
-                [os.path.getmtime(p) for p in glob.glob(os.path.join(ROOT, "include", "*.h"))]):
+                [os.path.getmtime(p) for p in glob.glob(os.path.join(ROOT, "include", "*.h*"))]):
             continue
         # .hip: device + host; .cpp: plain host C++ (HIP host API only), also through hipcc for the include paths
         cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]

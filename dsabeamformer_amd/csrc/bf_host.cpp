@@ -887,6 +887,9 @@ int run_observation(const bf_config& cfg, const observation_options& opt, block_
                     return rc;
                 }
                 obs_state.generate_transfer_event();  // :396
+                if (source.close_releases_block())      // not in the reference: see block_source::close_releases_block
+                    while (obs_state.get_blocks_transferred() < obs_state.get_blocks_transfer_queue())
+                        obs_state.check_transfer_events();
             } else {
                 obs_state.set_transfers_complete(true);  // :398
             }

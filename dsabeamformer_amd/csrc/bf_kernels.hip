@@ -41,6 +41,9 @@
 #ifndef DSABF_USE16
 #define DSABF_USE16 1     // 64-antenna geometries run fused16_kernel (v_mfma_i32_16x16x64_i8); 0 = 32x32x32 everywhere
 #endif
+#ifndef DSABF_USE16_WIDE
+#define DSABF_USE16_WIDE 1 // 100- and 128-antenna geometries also run fused16_kernel (two k-steps); 0 = the 32x32x32 kernel
+#endif
 #ifndef DSABF_PAIRED
 #define DSABF_PAIRED 1    // build the conjugate-pair variants of fused16_kernel (used when the weights allow it)
 #endif
@@ -668,21 +671,35 @@ constexpr int kColTiles16 = 4;               // 16-beam column tiles per wave
 //   P1 = sum Wr*Vr, P2 = sum Wi*Vi, P3 = sum Wr*Vi, P4 = sum Wi*Vr        (one 16x16x64 MFMA each)
 // C(b) = (P1 - P2) + j(P3 + P4) and C(B-1-b) = (P1 + P2) + j(P3 - P4): two beams for the MFMA work of one, exact in
 // int32 (the +-P2 / +-P4 are 4 integer VALU ops per sample pair; P1 and P3 carry the float seed, P2 and P4 start at 0).
-template <int NIPO, bool WRITE_C, bool FAST = false, bool PAIRED = false>
-__global__ __launch_bounds__(kThreads16, DSABF_OCC16) void fused16_kernel(FusedArgs a)
+//
+// AIN = antennas per time sample (64, 100 or 128).  More than 64 antennas are two k-steps of 64: the LDS chunk image
+// becomes two 128-row planes (antennas 0-63 | 64-127), every product is a chain of two MFMAs, and the detect -- whose
+// cost does not depend on the antenna count -- is amortised over twice the MACs.  100 antennas run as 128 with zero
+// weights behind antenna 99; their packed rows (100 B) are only dword-aligned, so they are staged in 4-byte pieces.
+template <int AIN, int NIPO, bool WRITE_C, bool FAST = false, bool PAIRED = false>
+__global__ __launch_bounds__(kThreads16, AIN > 64 ? 2 : DSABF_OCC16) void fused16_kernel(FusedArgs a)
 {
     static_assert(!FAST || (NIPO >= 16 && !WRITE_C), "the fast detect exists for n_ipo >= 16 only");
     static_assert(!(PAIRED && WRITE_C), "the stage-parity path always runs the general kernel");
-    constexpr int A = 64, RB = 128;
+    static_assert(AIN % 4 == 0 && AIN <= 128, "antenna count");
+    constexpr int A = AIN, RB = 128;
+    constexpr int KS = AIN > 64 ? 2 : 1;                 // k-steps of 64 antennas
+    constexpr int PLANE = kRowsPerChunk * RB;            // LDS bytes of one k-step's chunk image
+    constexpr int BUF = KS * PLANE;
+    constexpr bool DW = (AIN % 16) != 0;                 // rows only dword-aligned: 4-byte staging pieces
+    constexpr int PB = DW ? 4 : 16;                      // bytes per staging piece
+    constexpr int PPR = AIN / PB;                        // pieces per time sample
+    constexpr int TOTALP = kRowsPerChunk * PPR;          // pieces per chunk
     constexpr int NS = kColTiles16;                      // 16-beam output slots per lane (beams per wave = 16 * NS)
     constexpr int NT = PAIRED ? NS / 2 : NS;             // MFMA column tiles per wave (a paired tile feeds 2 slots)
     constexpr bool LONG = NIPO >= 16;
     constexpr int L = LONG ? NIPO : 16;                  // samples per stream
     constexpr int LR = NIPO >= 32 ? 32 : 16;             // stream rows held by one chunk
     constexpr int CPG = L > 32 ? L / 32 : 1;             // chunks per group of 4 streams
-    constexpr int PPT = (kRowsPerChunk * 4) / kThreads16; // 16-byte pieces per thread per chunk (= 2)
+    constexpr int PPT = (TOTALP + kThreads16 - 1) / kThreads16;  // pieces per thread per chunk (2; 4; 13 for 100 antennas)
+    using stage_t = std::conditional_t<DW, int, v4i>;
 
-    extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 x 128 rows x 128 B
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 buffers x KS planes x 128 rows x 128 B
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -699,7 +716,7 @@ __global__ __launch_bounds__(kThreads16, DSABF_OCC16) void fused16_kernel(FusedA
     // ---- which beams this lane produces, and the weight fragments ------------------------------------------
     int slot_beam[NS];                                    // beam index of output slot s (>= n_beams: none)
     constexpr int NPC = DSABF_PAIR_MFMA >= 5 ? 3 : 2;     // paired fragments per tile: Wr, Wi (, -Wi)
-    v4i bw[NT][PAIRED ? NPC : 4];                         // general: [ct][2*rho + s]; paired: [pct][Wr, Wi, -Wi]
+    v4i bw[NT][PAIRED ? NPC : 4][KS];                     // general: [ct][2*rho + s][k-step]; paired: [pct][Wr, Wi, -Wi][k-step]
     bool wave_active;
     if constexpr (PAIRED) {
         const int n_pct = a.n_btiles;                     // pair tiles of 16 base beams = n_beams / 32
@@ -713,7 +730,10 @@ __global__ __launch_bounds__(kThreads16, DSABF_OCC16) void fused16_kernel(FusedA
             slot_beam[2 * t + 1] = ok ? a.n_beams - 1 - bb : a.n_beams;
 #pragma unroll
             for (int comp = 0; comp < NPC; comp++)
-                bw[t][comp] = ok ? a.wimg[(((size_t)f * n_pct + pct0 + t) * 3 + comp) * 64 + lane] : v4i{0, 0, 0, 0};
+#pragma unroll
+                for (int h = 0; h < KS; h++)
+                    bw[t][comp][h] =
+                        ok ? a.wimg[((((size_t)f * n_pct + pct0 + t) * 3 + comp) * KS + h) * 64 + lane] : v4i{0, 0, 0, 0};
         }
     } else {
         const int n_ctiles = a.n_btiles * 2;
@@ -725,7 +745,10 @@ __global__ __launch_bounds__(kThreads16, DSABF_OCC16) void fused16_kernel(FusedA
             slot_beam[t] = ok ? (ct0 + t) * 16 + c16 : a.n_beams;
 #pragma unroll
             for (int k = 0; k < 4; k++)                    // k = 2*rho + s
-                bw[t][k] = ok ? a.wimg[(((size_t)f * n_ctiles + ct0 + t) * 4 + k) * 64 + lane] : v4i{0, 0, 0, 0};
+#pragma unroll
+                for (int h = 0; h < KS; h++)
+                    bw[t][k][h] =
+                        ok ? a.wimg[((((size_t)f * n_ctiles + ct0 + t) * 4 + k) * KS + h) * 64 + lane] : v4i{0, 0, 0, 0};
         }
     }
 
@@ -740,21 +763,35 @@ __global__ __launch_bounds__(kThreads16, DSABF_OCC16) void fused16_kernel(FusedA
         else
             return (unsigned)c * 128u + 16u * (unsigned)run;
     };
-    v4i stage[PPT];
+    stage_t stage[PPT];
     // Fast addressing: when a chunk's sample span (128 samples, 256 for n_ipo = 64) never straddles a gemm-unit, the
     // unit / time split of the chunk is wave-uniform -- a scalar base that advances by one span per chunk -- and the
-    // per-lane part (row and 16-byte piece) is a constant 32-bit offset: no vector integer arithmetic (the generic
-    // path costs ~17 VALU ops, 6 of them quarter-rate 32-bit multiplies, per 16-byte load).
+    // per-lane part (row and piece) is a constant 32-bit offset: no vector integer arithmetic (the generic
+    // path costs ~17 VALU ops, 6 of them quarter-rate 32-bit multiplies, per load).
     constexpr unsigned SPAN = (NIPO == 64) ? 256u : 128u;
     const bool fast_addr = DSABF_FASTADDR && ((unsigned)a.T % SPAN) == 0;
-    unsigned lane_off[PPT];
+    // Piece k of this thread is piece pc = tid + 256 k of the chunk: row pc / PPR, position pc % PPR.  Its byte offset
+    // from the chunk's first sample is PB * pc (rows are PPR * PB bytes and consecutive) -- except for n_ipo = 64, whose
+    // chunk rows are four runs of 32 samples, 64 apart.  The 16*im image sits 4 pieces after the 16*re image, and the
+    // swizzle only XORs the low 3 piece bits with a value < 8, so its LDS offset is the re offset ^ 64.
+    [[maybe_unused]] unsigned lane_off64[NIPO == 64 ? PPT : 1];
+    int lds_re[PPT];                      // LDS byte offset (inside one buffer) of the piece's 16*re image
 #pragma unroll
     for (int k = 0; k < PPT; k++) {
         const int pc = tid + k * kThreads16;
-        const int row = pc >> 2, ks = pc & 3;
-        const unsigned ls = (NIPO == 64) ? (unsigned)((row / LR) * L + (row % LR)) : (unsigned)row;  // sample in the span
-        lane_off[k] = ls * A + ks * 16;
+        const int row = (pc / PPR) % kRowsPerChunk, pi = pc % PPR;   // (% keeps the unused tail pieces in range)
+        if constexpr (NIPO == 64) lane_off64[k] = (unsigned)((row / LR) * L + (row % LR)) * A + pi * PB;
+        const int blk = DW ? pi / 4 : pi;                            // 16-antenna block of the piece
+        const int h = blk / 4, kp = blk % 4, sub = DW ? 4 * (pi % 4) : 0;
+        lds_re[k] = h * PLANE + row * RB + 16 * swz16<NIPO>(kp, row) + sub;
     }
+    auto lane_off = [&](int k) -> unsigned {
+        if constexpr (NIPO == 64)
+            return lane_off64[k];
+        else
+            return (unsigned)PB * (unsigned)(tid + k * kThreads16);
+    };
+    auto piece_live = [&](int k) { return (TOTALP % kThreads16 == 0) || (tid + k * kThreads16 < TOTALP); };
     int ld_span = -1;                 // span the scalar state below describes
     unsigned ld_u = 0, ld_t0 = 0;     // its gemm-unit and first sample inside the unit
     auto load_chunk = [&](int c) {
@@ -779,38 +816,43 @@ __global__ __launch_bounds__(kThreads16, DSABF_OCC16) void fused16_kernel(FusedA
             const uint8_t* base = a.in + ((size_t)((size_t)ld_u * a.n_freq + f) * a.T + ld_t0 + half) * A;
 #pragma unroll
             for (int k = 0; k < PPT; k++) {
-                stage[k] = v4i{0, 0, 0, 0};
-                if (valid) stage[k] = *reinterpret_cast<const v4i*>(base + lane_off[k]);
+                stage[k] = stage_t{};
+                if (valid && piece_live(k)) stage[k] = *reinterpret_cast<const stage_t*>(base + lane_off(k));
             }
             return;
         }
 #pragma unroll
         for (int k = 0; k < PPT; k++) {
             const int pc = tid + k * kThreads16;
-            const int row = pc >> 2, ks = pc & 3;
+            const int row = (pc / PPR) % kRowsPerChunk, pi = pc % PPR;
             const unsigned s0 = run_sample0(c, row / LR) + (unsigned)(row % LR);
-            stage[k] = v4i{0, 0, 0, 0};
-            if (s0 < a.S) {
+            stage[k] = stage_t{};
+            if (s0 < a.S && piece_live(k)) {
                 const unsigned u = a.t_shift >= 0 ? (s0 >> a.t_shift) : (s0 / (unsigned)a.T);
                 const unsigned t = s0 - u * (unsigned)a.T;
-                stage[k] = *reinterpret_cast<const v4i*>(a.in + ((size_t)((size_t)u * a.n_freq + f) * a.T + t) * A + ks * 16);
+                stage[k] = *reinterpret_cast<const stage_t*>(a.in + ((size_t)((size_t)u * a.n_freq + f) * a.T + t) * A + pi * PB);
             }
         }
     };
     auto write_chunk = [&](char* buf) {
 #pragma unroll
         for (int k = 0; k < PPT; k++) {
-            const int pc = tid + k * kThreads16;
-            const int row = pc >> 2, ks = pc & 3;
-            v4i re, im;
+            if (!piece_live(k)) continue;
+            if constexpr (DW) {
+                const unsigned w = (unsigned)stage[k];
+                *reinterpret_cast<int*>(buf + lds_re[k]) = (int)(w & 0xF0F0F0F0u);
+                *reinterpret_cast<int*>(buf + (lds_re[k] ^ 64)) = (int)((w << 4) & 0xF0F0F0F0u);
+            } else {
+                v4i re, im;
 #pragma unroll
-            for (int d = 0; d < 4; d++) {
-                const unsigned w = (unsigned)stage[k][d];
-                re[d] = (int)(w & 0xF0F0F0F0u);
-                im[d] = (int)((w << 4) & 0xF0F0F0F0u);
+                for (int d = 0; d < 4; d++) {
+                    const unsigned w = (unsigned)stage[k][d];
+                    re[d] = (int)(w & 0xF0F0F0F0u);
+                    im[d] = (int)((w << 4) & 0xF0F0F0F0u);
+                }
+                *reinterpret_cast<v4i*>(buf + lds_re[k]) = re;
+                *reinterpret_cast<v4i*>(buf + (lds_re[k] ^ 64)) = im;
             }
-            *reinterpret_cast<v4i*>(buf + row * RB + 16 * swz16<NIPO>(ks, row)) = re;
-            *reinterpret_cast<v4i*>(buf + row * RB + 16 * swz16<NIPO>(4 + ks, row)) = im;
         }
     };
 
@@ -850,8 +892,8 @@ __global__ __launch_bounds__(kThreads16, DSABF_OCC16) void fused16_kernel(FusedA
     __syncthreads();
 
     for (int c = c_begin; c < c_end; c++) {
-        char* cur = smem + ((c - c_begin) & 1) * (kRowsPerChunk * RB);
-        char* nxt = smem + ((c - c_begin + 1) & 1) * (kRowsPerChunk * RB);
+        char* cur = smem + ((c - c_begin) & 1) * BUF;
+        char* nxt = smem + ((c - c_begin + 1) & 1) * BUF;
         if (!wave_active) {
             if (c + 1 < c_end) write_chunk(nxt);
             if (c + 2 < c_end) load_chunk(c + 2);
@@ -939,40 +981,47 @@ __global__ __launch_bounds__(kThreads16, DSABF_OCC16) void fused16_kernel(FusedA
                 }
             };
 
-            // LDS fragments of row-tile t8: a0 = 16*re, a1 = 16*im of 16 antennas x 16 samples per lane group
-            auto read_frag = [&](const int t8, v4i& a0, v4i& a1) {
+            // LDS fragments of row-tile t8: a0[h] = 16*re, a1[h] = 16*im of 16 antennas x 16 samples per lane group, k-step h
+            auto read_frag = [&](const int t8, v4i (&a0)[KS], v4i (&a1)[KS]) {
                 const int row = lds_row16<NIPO>(t8, c16);
-                a0 = *reinterpret_cast<const v4i*>(cur + row * RB + 16 * swz16<NIPO>(g4, row));
-                a1 = *reinterpret_cast<const v4i*>(cur + row * RB + 16 * swz16<NIPO>(4 + g4, row));
+#pragma unroll
+                for (int h = 0; h < KS; h++) {
+                    a0[h] = *reinterpret_cast<const v4i*>(cur + h * PLANE + row * RB + 16 * swz16<NIPO>(g4, row));
+                    a1[h] = *reinterpret_cast<const v4i*>(cur + h * PLANE + row * RB + 16 * swz16<NIPO>(4 + g4, row));
+                }
+            };
+            // acc = seed + sum over the k-steps of x[h] * w[h]  (one MFMA per k-step, chained through srcC)
+            auto dot = [&](const v4i (&x)[KS], const v4i (&w)[KS], v4i acc) {
+#pragma unroll
+                for (int h = 0; h < KS; h++) acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(x[h], w[h], acc, 0, 0, 0);
+                return acc;
             };
             // One step = the MFMAs of column tile t on row-tile fragments (a0, a1); its SPS output slots land in
             // re[] / im[] as accumulator bit patterns K + 16 n.
             constexpr int SPS = PAIRED ? 2 : 1;                 // output slots per step
-            auto issue = [&](const v4i a0, const v4i a1, const int t, v4i (&re)[SPS], v4i (&im)[SPS]) {
+            auto issue = [&](const v4i (&a0)[KS], const v4i (&a1)[KS], const int t, v4i (&re)[SPS], v4i (&im)[SPS]) {
                 if constexpr (PAIRED) {
-                    const v4i p1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, bw[t][0], kc, 0, 0, 0);     // Wr*Vr + K
-                    const v4i p3 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, bw[t][0], kc, 0, 0, 0);     // Wr*Vi + K
+                    const v4i p1 = dot(a0, bw[t][0], kc);     // Wr*Vr + K
+                    const v4i p3 = dot(a1, bw[t][0], kc);     // Wr*Vi + K
                     if constexpr (DSABF_PAIR_MFMA >= 5) {   // +-P2 chained on the MFMA pipe (bw[t][2] = -Wi)
-                        re[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, bw[t][2], p1, 0, 0, 0);
-                        re[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, bw[t][1], p1, 0, 0, 0);
+                        re[0] = dot(a1, bw[t][2], p1);
+                        re[1] = dot(a1, bw[t][1], p1);
                     } else {
-                        const v4i p2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, bw[t][1], kzero, 0, 0, 0);  // Wi*Vi
+                        const v4i p2 = dot(a1, bw[t][1], kzero);  // Wi*Vi
                         re[0] = p1 - p2;
                         re[1] = p1 + p2;
                     }
                     if constexpr (DSABF_PAIR_MFMA >= 6) {
-                        im[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, bw[t][1], p3, 0, 0, 0);
-                        im[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, bw[t][2], p3, 0, 0, 0);
+                        im[0] = dot(a0, bw[t][1], p3);
+                        im[1] = dot(a0, bw[t][2], p3);
                     } else {
-                        const v4i p4 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, bw[t][1], kzero, 0, 0, 0);  // Wi*Vr
+                        const v4i p4 = dot(a0, bw[t][1], kzero);  // Wi*Vr
                         im[0] = p3 + p4;
                         im[1] = p3 - p4;
                     }
                 } else {
-                    v4i cr = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, bw[t][0], kc, 0, 0, 0);
-                    v4i ci = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, bw[t][2], kc, 0, 0, 0);
-                    re[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, bw[t][1], cr, 0, 0, 0);
-                    im[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, bw[t][3], ci, 0, 0, 0);
+                    re[0] = dot(a1, bw[t][1], dot(a0, bw[t][0], kc));
+                    im[0] = dot(a1, bw[t][3], dot(a0, bw[t][2], kc));
                 }
             };
             auto consume = [&](const int t8, const int t, const v4i (&re)[SPS], const v4i (&im)[SPS]) {
@@ -990,7 +1039,7 @@ __global__ __launch_bounds__(kThreads16, DSABF_OCC16) void fused16_kernel(FusedA
             };
 #pragma unroll
             for (int t8 = 0; t8 < 8; t8++) {
-                v4i a0, a1;
+                v4i a0[KS], a1[KS];
                 read_frag(t8, a0, a1);
 #pragma unroll
                 for (int t = 0; t < NT; t++) {
@@ -1021,16 +1070,18 @@ __global__ void pair_check_kernel(const int8_t* __restrict__ w, size_t n_fa, int
     if (bad) *flag = 1;
 }
 
-// Paired weight image: image[f][pct][comp][lane] (16 bytes): lane = 16*kb + c; byte i = Wr (comp 0), Wi (comp 1) or
-// -Wi (comp 2) of antenna 16*kb + i for base beam 16*pct + c (< n_beams / 2).
+// Paired weight image: image[f][pct][comp][h][lane] (16 bytes): lane = 16*kb + c; byte i = Wr (comp 0), Wi (comp 1) or
+// -Wi (comp 2) of antenna 64*h + 16*kb + i (zero behind the last antenna) for base beam 16*pct + c (< n_beams / 2).
 __global__ void weight_relayout16p_kernel(const int8_t* __restrict__ w, v4i* __restrict__ image, int n_freq, int n_ant,
-                                          int n_beams)
+                                          int n_beams, int ks)
 {
     const int n_pct = n_beams / 32;
-    const size_t total = (size_t)n_freq * n_pct * 3 * 64;
+    const size_t total = (size_t)n_freq * n_pct * 3 * ks * 64;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
         const int lane = (int)(idx & 63);
         size_t r = idx >> 6;
+        const int h = (int)(r % ks);
+        r /= ks;
         const int comp = (int)(r % 3);
         r /= 3;
         const int pct = (int)(r % n_pct);
@@ -1038,7 +1089,7 @@ __global__ void weight_relayout16p_kernel(const int8_t* __restrict__ w, v4i* __r
         const int kb = lane >> 4, b = pct * 16 + (lane & 15);
         unsigned d[4] = {0, 0, 0, 0};
         for (int i = 0; i < 16; i++) {
-            const int ant = kb * 16 + i;
+            const int ant = 64 * h + kb * 16 + i;
             int v = 0;
             if (ant < n_ant) v = w[2 * (((size_t)f * n_ant + ant) * n_beams + b) + (comp ? 1 : 0)];
             if (comp == 2) v = -v;
@@ -1048,16 +1099,19 @@ __global__ void weight_relayout16p_kernel(const int8_t* __restrict__ w, v4i* __r
     }
 }
 
-// 16x16x64 weight image: image[f][ct16][rho][s][lane] (16 bytes): lane = 16*kb + c; byte i multiplies LDS chunk
-// 4*s + kb of the A row = component s (0 = re, 1 = im) of antenna 16*kb + i, for output row rho of beam 16*ct16 + c.
+// 16x16x64 weight image: image[f][ct16][rho][s][h][lane] (16 bytes): lane = 16*kb + c; byte i multiplies LDS chunk
+// 4*s + kb of the A row of k-step h = component s (0 = re, 1 = im) of antenna 64*h + 16*kb + i (zero behind the last
+// antenna), for output row rho of beam 16*ct16 + c.
 __global__ void weight_relayout16_kernel(const int8_t* __restrict__ w, v4i* __restrict__ image, int n_freq, int n_ant,
-                                         int n_beams, int* __restrict__ bad)
+                                         int n_beams, int ks, int* __restrict__ bad)
 {
     const int n_ct = n_beams / 16;
-    const size_t total = (size_t)n_freq * n_ct * 2 * 2 * 64;
+    const size_t total = (size_t)n_freq * n_ct * 2 * 2 * ks * 64;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
         const int lane = (int)(idx & 63);
         size_t r = idx >> 6;
+        const int h = (int)(r % ks);
+        r /= ks;
         const int sk = (int)(r & 1);
         r >>= 1;
         const int rho = (int)(r & 1);
@@ -1067,7 +1121,7 @@ __global__ void weight_relayout16_kernel(const int8_t* __restrict__ w, v4i* __re
         const int kb = lane >> 4, b = ct * 16 + (lane & 15);
         unsigned d[4] = {0, 0, 0, 0};
         for (int i = 0; i < 16; i++) {
-            const int ant = kb * 16 + i;
+            const int ant = 64 * h + kb * 16 + i;
             int v = 0;
             if (ant < n_ant && b < n_beams) {
                 const int8_t* e = w + 2 * (((size_t)f * n_ant + ant) * n_beams + b);
@@ -1094,19 +1148,81 @@ hipError_t launch_fused_t(const FusedArgs& args, const LaunchShape& ls, hipStrea
     return hipGetLastError();
 }
 
-template <int NIPO, bool WRITE_C, bool FAST = false, bool PAIRED = false>
+template <int AIN, int NIPO, bool WRITE_C, bool FAST = false, bool PAIRED = false>
 hipError_t launch_fused16_t(const FusedArgs& args, const LaunchShape& ls, hipStream_t s)
 {
-    hipLaunchKernelGGL((fused16_kernel<NIPO, WRITE_C, FAST, PAIRED>), dim3(ls.grid), dim3(ls.block), ls.lds_bytes, s,
-                       args);
+    auto kern = fused16_kernel<AIN, NIPO, WRITE_C, FAST, PAIRED>;
+    if (ls.lds_bytes > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           ls.lds_bytes);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3(ls.grid), dim3(ls.block), ls.lds_bytes, s, args);
     return hipGetLastError();
+}
+
+// the fused16_kernel instantiation for (n_ant, n_ipo, mode); nullptr if there is none
+template <int AIN, bool WRITE_C, bool FAST, bool PAIRED>
+const void* fused16_fn_ant(int n_ipo, hipError_t (**launch)(const FusedArgs&, const LaunchShape&, hipStream_t))
+{
+#define DSABF_CASE16(nipo_)                                                              \
+    case nipo_:                                                                          \
+        if constexpr (!FAST || nipo_ >= 16) {                                            \
+            *launch = launch_fused16_t<AIN, nipo_, WRITE_C, FAST, PAIRED>;               \
+            return reinterpret_cast<const void*>(fused16_kernel<AIN, nipo_, WRITE_C, FAST, PAIRED>); \
+        }                                                                                \
+        return nullptr;
+    switch (n_ipo) {
+        DSABF_CASE16(2)
+        DSABF_CASE16(32)
+        default: break;
+    }
+    if constexpr (AIN == 64) {
+        switch (n_ipo) {
+            DSABF_CASE16(4)
+            DSABF_CASE16(8)
+            DSABF_CASE16(16)
+            DSABF_CASE16(64)
+            default: break;
+        }
+    }
+#undef DSABF_CASE16
+    return nullptr;
+}
+
+template <bool WRITE_C, bool FAST, bool PAIRED>
+const void* fused16_fn(int n_ant, int n_ipo, hipError_t (**launch)(const FusedArgs&, const LaunchShape&, hipStream_t))
+{
+    switch (n_ant) {
+        case 64: return fused16_fn_ant<64, WRITE_C, FAST, PAIRED>(n_ipo, launch);
+#if DSABF_USE16_WIDE
+        case 100: return fused16_fn_ant<100, WRITE_C, FAST, PAIRED>(n_ipo, launch);
+        case 128: return fused16_fn_ant<128, WRITE_C, FAST, PAIRED>(n_ipo, launch);
+#endif
+        default: return nullptr;
+    }
+}
+
+// picks the variant the geometry runs (fast detect and pairing only where they exist)
+template <bool WRITE_C>
+const void* fused16_select(const Geometry& g, hipError_t (**launch)(const FusedArgs&, const LaunchShape&, hipStream_t))
+{
+    if constexpr (!WRITE_C) {
+        const bool fast = g.fast_detect && g.n_ipo >= 16;
+        if (g.paired && fast) return fused16_fn<false, true, true>(g.n_ant, g.n_ipo, launch);
+        if (g.paired) return fused16_fn<false, false, true>(g.n_ant, g.n_ipo, launch);
+        if (fast) return fused16_fn<false, true, false>(g.n_ant, g.n_ipo, launch);
+    }
+    return fused16_fn<WRITE_C, false, false>(g.n_ant, g.n_ipo, launch);
 }
 
 bool use16(const Geometry& g)
 {
-    return DSABF_USE16 && g.n_ant == 64 &&
-           (g.n_ipo == 2 || g.n_ipo == 4 || g.n_ipo == 8 || g.n_ipo == 16 || g.n_ipo == 32 || g.n_ipo == 64);
+    if (!DSABF_USE16) return false;
+    if (g.n_ant == 64) return g.n_ipo == 2 || g.n_ipo == 4 || g.n_ipo == 8 || g.n_ipo == 16 || g.n_ipo == 32 || g.n_ipo == 64;
+    return DSABF_USE16_WIDE && (g.n_ant == 100 || g.n_ant == 128) && (g.n_ipo == 2 || g.n_ipo == 32);
 }
+int ksteps16(const Geometry& g) { return g.n_ant > 64 ? 2 : 1; }
 
 int ilog2_exact(int v)
 {
@@ -1125,40 +1241,9 @@ template <bool WRITE_C>
 hipError_t dispatch_fused(const Geometry& g, const FusedArgs& args, const LaunchShape& ls, hipStream_t s)
 {
     if (use16(g)) {
-        if constexpr (!WRITE_C) {
-            if (g.paired) {
-                if (g.fast_detect) {
-                    switch (g.n_ipo) {
-                        case 16: return launch_fused16_t<16, false, true, true>(args, ls, s);
-                        case 32: return launch_fused16_t<32, false, true, true>(args, ls, s);
-                        case 64: return launch_fused16_t<64, false, true, true>(args, ls, s);
-                    }
-                }
-                switch (g.n_ipo) {
-                    case 2: return launch_fused16_t<2, false, false, true>(args, ls, s);
-                    case 4: return launch_fused16_t<4, false, false, true>(args, ls, s);
-                    case 8: return launch_fused16_t<8, false, false, true>(args, ls, s);
-                    case 16: return launch_fused16_t<16, false, false, true>(args, ls, s);
-                    case 32: return launch_fused16_t<32, false, false, true>(args, ls, s);
-                    case 64: return launch_fused16_t<64, false, false, true>(args, ls, s);
-                }
-            }
-            if (g.fast_detect) {
-                switch (g.n_ipo) {
-                    case 16: return launch_fused16_t<16, false, true>(args, ls, s);
-                    case 32: return launch_fused16_t<32, false, true>(args, ls, s);
-                    case 64: return launch_fused16_t<64, false, true>(args, ls, s);
-                }
-            }
-        }
-        switch (g.n_ipo) {
-            case 2: return launch_fused16_t<2, WRITE_C>(args, ls, s);
-            case 4: return launch_fused16_t<4, WRITE_C>(args, ls, s);
-            case 8: return launch_fused16_t<8, WRITE_C>(args, ls, s);
-            case 16: return launch_fused16_t<16, WRITE_C>(args, ls, s);
-            case 32: return launch_fused16_t<32, WRITE_C>(args, ls, s);
-            case 64: return launch_fused16_t<64, WRITE_C>(args, ls, s);
-        }
+        hipError_t (*launch)(const FusedArgs&, const LaunchShape&, hipStream_t) = nullptr;
+        if (!fused16_select<WRITE_C>(g, &launch) || !launch) return hipErrorInvalidValue;
+        return launch(args, ls, s);
     }
 #define X(ant_, nipo_) \
     if (g.n_ant == ant_ && g.n_ipo == nipo_) return launch_fused_t<ant_, nipo_, WRITE_C>(args, ls, s);
@@ -1169,12 +1254,16 @@ hipError_t dispatch_fused(const Geometry& g, const FusedArgs& args, const Launch
 
 }  // namespace
 
-size_t weight_image_bytes(const Geometry& g) { return (size_t)g.n_freq * g.n_btiles * 2 * g.nks * 64 * 16; }
+size_t weight_image_bytes(const Geometry& g)
+{
+    if (use16(g)) return (size_t)g.n_freq * g.n_btiles * 2 * 4 * ksteps16(g) * 64 * 16;  // [f][ct16][rho][s][k-step][lane]
+    return (size_t)g.n_freq * g.n_btiles * 2 * g.nks * 64 * 16;
+}
 
 bool pairing_supported(const Geometry& g) { return DSABF_PAIRED && use16(g); }
 size_t weight_pair_image_bytes(const Geometry& g)
 {
-    return pairing_supported(g) ? (size_t)g.n_freq * g.n_btiles * 3 * 64 * 16 : 0;
+    return pairing_supported(g) ? (size_t)g.n_freq * g.n_btiles * 3 * ksteps16(g) * 64 * 16 : 0;
 }
 
 bool fused_supported(const Geometry& g, const char** why)
@@ -1229,7 +1318,7 @@ LaunchShape fused_launch_shape(const Geometry& g, int n_units, int n_cus)
     ls.grid = base * ls.n_tsplit;
     ls.block = use16(g) ? kThreads16 : kWgThreads;
     const int rbc = g.nks <= 4 ? 8 : 16;
-    ls.lds_bytes = 2 * kRowsPerChunk * rbc * 16;
+    ls.lds_bytes = use16(g) ? 2 * ksteps16(g) * kRowsPerChunk * 128 : 2 * kRowsPerChunk * rbc * 16;
     return ls;
 }
 
@@ -1287,11 +1376,11 @@ hipError_t launch_weight_relayout(const Geometry& g, const int8_t* d_w, void* d_
         int rgrid = (int)((weight_pair_image_bytes(g) / 16 + 255) / 256);
         if (rgrid > 4096) rgrid = 4096;
         hipLaunchKernelGGL(weight_relayout16p_kernel, dim3(rgrid), dim3(256), 0, s, d_w, static_cast<v4i*>(d_pair_image),
-                           g.n_freq, g.n_ant, g.n_beams);
+                           g.n_freq, g.n_ant, g.n_beams, ksteps16(g));
     }
     if (use16(g)) {
         hipLaunchKernelGGL(weight_relayout16_kernel, dim3(grid), dim3(256), 0, s, d_w, static_cast<v4i*>(d_image), g.n_freq,
-                           g.n_ant, g.n_beams, d_bad);
+                           g.n_ant, g.n_beams, ksteps16(g), d_bad);
         return hipGetLastError();
     }
     hipLaunchKernelGGL(weight_relayout_kernel, dim3(grid), dim3(256), 0, s, d_w, static_cast<v4i*>(d_image), g.n_freq,
@@ -1331,7 +1420,7 @@ hipError_t launch_dedisperse_dm(const Geometry& g, const float* d_series, int n_
 const char* fused_kernel_name(const Geometry& g, char* buf, size_t n)
 {
     if (use16(g))
-        snprintf(buf, n, "dsabf::fused16_kernel<NIPO=%d%s%s> (v_mfma_i32_16x16x64_i8)", g.n_ipo,
+        snprintf(buf, n, "dsabf::fused16_kernel<ANT=%d,NIPO=%d%s%s> (v_mfma_i32_16x16x64_i8)", g.n_ant, g.n_ipo,
                  (g.fast_detect && g.n_ipo >= 16) ? ",FAST" : "", g.paired ? ",PAIRED" : "");
     else
         snprintf(buf, n, "dsabf::fused_kernel<ANT=%d,NIPO=%d> (v_mfma_i32_32x32x32_i8)", g.n_ant, g.n_ipo);
@@ -1342,37 +1431,9 @@ int fused_vgprs(const Geometry& g)
 {
     hipFuncAttributes attr{};
     const void* fn = nullptr;
-    if (use16(g) && g.paired) {
-        const bool fast = g.fast_detect && g.n_ipo >= 16;
-        switch (g.n_ipo) {
-            case 2: fn = reinterpret_cast<const void*>(fused16_kernel<2, false, false, true>); break;
-            case 4: fn = reinterpret_cast<const void*>(fused16_kernel<4, false, false, true>); break;
-            case 8: fn = reinterpret_cast<const void*>(fused16_kernel<8, false, false, true>); break;
-            case 16:
-                fn = fast ? reinterpret_cast<const void*>(fused16_kernel<16, false, true, true>)
-                          : reinterpret_cast<const void*>(fused16_kernel<16, false, false, true>);
-                break;
-            case 32:
-                fn = fast ? reinterpret_cast<const void*>(fused16_kernel<32, false, true, true>)
-                          : reinterpret_cast<const void*>(fused16_kernel<32, false, false, true>);
-                break;
-            case 64:
-                fn = fast ? reinterpret_cast<const void*>(fused16_kernel<64, false, true, true>)
-                          : reinterpret_cast<const void*>(fused16_kernel<64, false, false, true>);
-                break;
-        }
-        if (!fn || hipFuncGetAttributes(&attr, fn) != hipSuccess) return -1;
-        return attr.numRegs;
-    }
     if (use16(g)) {
-        switch (g.n_ipo) {
-            case 2: fn = reinterpret_cast<const void*>(fused16_kernel<2, false>); break;
-            case 4: fn = reinterpret_cast<const void*>(fused16_kernel<4, false>); break;
-            case 8: fn = reinterpret_cast<const void*>(fused16_kernel<8, false>); break;
-            case 16: fn = reinterpret_cast<const void*>(fused16_kernel<16, false>); break;
-            case 32: fn = reinterpret_cast<const void*>(fused16_kernel<32, false>); break;
-            case 64: fn = reinterpret_cast<const void*>(fused16_kernel<64, false>); break;
-        }
+        hipError_t (*launch)(const FusedArgs&, const LaunchShape&, hipStream_t) = nullptr;
+        fn = fused16_select<false>(g, &launch);
         if (!fn || hipFuncGetAttributes(&attr, fn) != hipSuccess) return -1;
         return attr.numRegs;
     }

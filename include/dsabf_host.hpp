@@ -207,6 +207,11 @@ struct block_source {
     virtual bool check_transfers_complete() = 0;   // :100-116 short block => the observation ends
     virtual uint64_t get_block_size() const = 0;
     virtual uint64_t get_bytes_read() const = 0;
+    // true if close() lets a producer overwrite the block.  The reference closes the PSRDADA block right after
+    // ENQUEUEING the asynchronous H2D copy (src/beamformer.cu:389-401), i.e. while the DMA may still be reading it -- a
+    // latent race that a fast writer turns into corrupted voltages.  For such sources the loop waits for the block's
+    // transfer event before close() (PSRDADA allows one open block, so the wait cannot be deferred past the next read).
+    virtual bool close_releases_block() const { return false; }
 };
 
 // In-memory stand-in for `dada_junkdb` (makefile:28-29, README.md:173): a pinned ring of distinct pseudo-random
@@ -291,6 +296,7 @@ public:
     bool ok() const { return ring != nullptr; }
     bool is_pinned() const { return registered; }
     void expect_block_bytes(uint64_t n) { expected_bytes = n; }  // N_BYTES_PRE_EXPANSION_PER_BLOCK check, :101-103
+    bool close_releases_block() const override { return true; }  // the writer reuses the slot as soon as it is closed
     void read_headers() override;
     char* read() override;
     void close() override;

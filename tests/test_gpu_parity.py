@@ -804,3 +804,43 @@ def test_dedisperse_dm_recovers_dispersed_pulse_from_detected_stream(torch, bfmo
     dm_best, t_best, b_best = np.unravel_index(np.argmax(got), got.shape)
     assert (dm_best, t_best) == (2, t_burst) and abs(int(b_best) - 40) <= 1
     assert got[2, t_burst, b_best] > 3 * got[0].max()
+
+
+@pytest.mark.parametrize("n_ant,n_avg", [(128, 16), (128, 1), (100, 16), (100, 1)])
+@pytest.mark.parametrize("paired", [False, True])
+@pytest.mark.parametrize("tsplit", ["1", "3"])
+def test_wide_antenna_16x16_kernel_bit_exact(torch, bfmod, orc, monkeypatch, n_ant, n_avg, paired, tsplit):
+    """100 and 128 antennas on fused16_kernel: two k-steps of 64 (two LDS planes, chained MFMAs), 100-byte rows staged
+    in dwords with zero weights behind antenna 99; general and conjugate-pair variants, several chunks per workgroup,
+    several beam groups, ragged end.  Extreme weights and voltages exercise the +-2^22 accumulator range."""
+    monkeypatch.setenv("DSABF_TSPLIT", tsplit)
+    n_ipo = 2 * n_avg
+    g = orc.Geom(n_beams=288, n_ant=n_ant, n_freq=3, n_avg=n_avg, n_out_per_gemm=max(2, 16 // n_ipo) * (3 if n_avg > 1 else 1))
+    n_units = max(2, -(-700 // g.n_time))
+    rng = np.random.default_rng(n_ant + n_avg + 17 * paired)
+    w = rng.integers(-127, 128, size=(g.n_freq, g.n_ant, g.n_beams, 2), dtype=np.int8)
+    w[0, :, 5] = 127                      # all-max weights on one beam ...
+    if paired:
+        w = _conj_symmetric(w)
+    packed = rng.integers(0, 256, size=(n_units, g.n_freq, g.n_time, g.n_ant), dtype=np.uint8)
+    packed[0, 0, :4] = 0x88               # ... against all (-8, -8) voltages: the largest |sum| the path can see
+    bf = bfmod.Beamformer(_cfg(bfmod, g))
+    bf.set_weights(w)
+    name = bf.kernel_info(n_units)["kernel"]
+    assert "fused16_kernel<ANT=%d" % n_ant in name and ("PAIRED" in name) == paired
+    want = orc.beamform(g, w, packed)
+    assert np.array_equal(_run(torch, bf, packed, want.size).reshape(want.shape), want)
+
+
+def test_wide_antenna_fast_detect_tolerance(torch, bfmod, orc):
+    g = orc.Geom(n_beams=64, n_ant=128, n_freq=2, n_avg=16, n_out_per_gemm=4)
+    rng = np.random.default_rng(4)
+    w = _conj_symmetric(rng.integers(-127, 128, size=(g.n_freq, g.n_ant, g.n_beams, 2), dtype=np.int8))
+    packed = rng.integers(0, 256, size=(3, g.n_freq, g.n_time, g.n_ant), dtype=np.uint8)
+    bf = bfmod.Beamformer(_cfg(bfmod, g, detect_mode=1))
+    bf.set_weights(w)
+    assert "FAST,PAIRED" in bf.kernel_info(3)["kernel"]
+    want = orc.beamform(g, w, packed)
+    got = _run(torch, bf, packed, want.size).reshape(want.shape)
+    rel = np.abs(got.astype(np.float64) - want) / np.maximum(want.astype(np.float64), 1e-30)
+    assert rel.max() <= 4 * g.n_ipo * 2.0 ** -24
