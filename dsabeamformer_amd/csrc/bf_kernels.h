@@ -8,25 +8,18 @@
 
 namespace dsabf {
 
-#ifndef DSABF_WAVES
-#define DSABF_WAVES 8
-#endif
-constexpr int kWavesPerWg = DSABF_WAVES;      // one 32-beam tile per wave -> 32*waves beams per workgroup
-constexpr int kWgThreads = 64 * kWavesPerWg;
-constexpr int kTilesPerChunk = 4;    // MFMA row-tiles (32 time samples each) staged per LDS buffer
 constexpr int kRowsPerChunk = 128;   // time samples per LDS buffer
-constexpr int kRunsPerChunk = 8;     // contiguous 16-sample runs per LDS buffer
+constexpr int kBeamsPerWg = 256;     // 4 waves x 4 column tiles x 16 beams
 
 struct Geometry {
     int n_beams, n_ant, n_freq, n_ipo, n_out, n_time;  // n_time = n_out * n_ipo (per gemm-unit)
-    int nks;                                            // k-steps of 16 antennas: ceil(n_ant / 16)
     int n_btiles;                                       // n_beams / 32
-    int n_bgroups;                                      // ceil(n_btiles / 8)
+    int n_bgroups;                                      // workgroups along the beam axis: ceil(n_beams / 256)
     bool fast_detect;                                   // BF_DETECT_FAST requested (honoured by fused16_kernel, n_ipo >= 16)
     bool paired = false;                                // weights verified conjugate-symmetric: beam B-1-b = conj(beam b)
 };
 
-// Bytes of the MFMA-fragment weight image: [freq][btile][re|im][kstep][lane] x 16 B.
+// Bytes of the MFMA-fragment weight image: [freq][16-beam tile][re|im row][re|im operand][k-step][lane] x 16 B.
 size_t weight_image_bytes(const Geometry& g);
 
 // Conjugate-pair image (fused16_kernel<..., PAIRED>): [freq][pair tile][Wr|Wi|-Wi][lane] x 16 B; 0 bytes when the

@@ -1,24 +1,24 @@
 // bf_kernels.hip -- hand-written gfx950 (CDNA4, MI355X) kernels for the DSA beamformer hot path.
 //
-// Replaces the reference's three device stages with ONE kernel:
+// Replaces the reference's three device stages with ONE kernel, fused16_kernel:
 //   expand_input (src/beamformer.cuh:66-109)  -> nibble expand in registers while staging into LDS
-//   cublasGemmStridedBatchedEx (src/beamformer.cu:470-477) -> v_mfma_i32_32x32x32_i8 on a real-embedded K
+//   cublasGemmStridedBatchedEx (src/beamformer.cu:470-477) -> v_mfma_i32_16x16x64_i8 on a real-embedded K
 //   detect_sum (src/beamformer.cuh:115-155)   -> power detect + time/pol accumulate in the accumulator VGPRs
 // so the reference's d_B (expanded voltages) and d_C (complex fp32 beams, 16 MiB per beam-block in production)
 // never touch HBM.  This is not a translation of those kernels; the design notes are in DESIGN.md section 3.
 //
 // Work decomposition
-//   workgroup = 512 threads = 8 wave64, owns (frequency f, group of 256 beams, contiguous range of time chunks)
-//   wave w    = one 32-beam tile: its weight fragments (re-row and im-row images, K' = 32*NKS int8) live in
-//               VGPRs for the whole kernel; it streams every time tile of the workgroup's range through MFMA.
-//   time      = the MFMA row (M) axis, beams = the column (N) axis: each lane owns ONE beam and holds 16 time
-//               samples of it in its accumulator registers, so the detect/accumulate is a sequential in-register
+//   workgroup = 256 threads = 4 wave64, owns (frequency f, group of 256 beams, contiguous range of time chunks)
+//   wave w    = 64 beams: its weight fragments live in VGPRs for the whole kernel; it streams every time tile of
+//               the workgroup's range through MFMA.
+//   time      = the MFMA row (M) axis, beams = the column (N) axis: each lane owns ONE beam per column tile and holds
+//               4 consecutive time samples of it per accumulator, so the detect/accumulate is a sequential in-register
 //               fp32 add chain in exactly the reference's order (bit-exact for every n_ipo, not only n_ipo = 2).
 //
 // Exact-arithmetic tricks (all proven in tests/test_numerics_tricks.py on the CPU):
 //   * a packed byte b = (re << 4 | im & 15) is expanded to the int8 pair (b & 0xF0, (b << 4) & 0xF0) = (16*re,
 //     16*im): two's complement places the signed nibble in the top of the byte, no sign-extension ops needed.
-//     The MFMA therefore accumulates 16 * n (|16 n| <= 2,080,768).
+//     The MFMA therefore accumulates 16 * n (|16 n| <= 4,161,536 with 128 antennas).
 //   * the accumulator is seeded with the int32 0x4B400000, the bit pattern of the float 1.5 * 2^23; adding the
 //     integer 16 n to it yields the bit pattern of the float K + 16 n (K = 12582912) exactly, so no
 //     v_cvt_f32_i32 is needed.
@@ -35,15 +35,6 @@
 #include <cstdlib>
 #include <type_traits>
 
-#ifndef DSABF_OCC
-#define DSABF_OCC 4   // waves per SIMD requested for NKS <= 4
-#endif
-#ifndef DSABF_USE16
-#define DSABF_USE16 1     // 64-antenna geometries run fused16_kernel (v_mfma_i32_16x16x64_i8); 0 = 32x32x32 everywhere
-#endif
-#ifndef DSABF_USE16_WIDE
-#define DSABF_USE16_WIDE 1 // 100- and 128-antenna geometries also run fused16_kernel (two k-steps); 0 = the 32x32x32 kernel
-#endif
 #ifndef DSABF_PAIRED
 #define DSABF_PAIRED 1    // build the conjugate-pair variants of fused16_kernel (used when the weights allow it)
 #endif
@@ -56,9 +47,6 @@
 #ifndef DSABF_OCC16
 #define DSABF_OCC16 3     // 147 VGPRs, no spills; 4 would spill 15 registers for no gain (the kernel is energy-bound)
 #endif
-#ifndef DSABF_ABLATE
-#define DSABF_ABLATE 0  // perf experiments only (tools/ablate.sh): 1 no loop barrier, 2 no LDS fragment reads,
-#endif                  // 3 no stores, 4 no staging in the loop, 5 no detect VALU.  0 = product.
 
 namespace dsabf {
 
@@ -111,432 +99,6 @@ __device__ __forceinline__ void decode_block(const FusedArgs& a, int& f, int& bg
         bid /= a.n_freq;
         bg = bid % a.n_bgroups;
         ts = bid / a.n_bgroups;
-    }
-}
-
-// ---- time-sample <-> MFMA-row mapping ------------------------------------------------------------------------
-// v_mfma_*_32x32: lane (column c = lane&31, half h = lane>>5) holds D rows (reg&3) + 8*(reg>>2) + 4*h in
-// accumulator registers reg = 0..15.  The A-operand row <-> time-sample mapping is free, so it is chosen such that
-// the registers of one lane hold, in increasing register order, consecutive samples of the accumulation windows of
-// TWO different outputs (even registers: one output, odd registers: the next): each output's fp32 sum runs in the
-// reference's sequential order (src/beamformer.cuh:150-152) entirely inside one lane -- no cross-lane reduction --
-// and the two interleaved chains give the in-order wave two independent dependency chains to overlap.
-// (The pairing also makes every step expressible as v_pk_*_f32 on register pairs; measured, packed fp32 does not
-// co-execute with MFMA on gfx950 and is 5 % slower here, so the product uses plain ops.)
-//
-//   NIPO >= 16 (L = NIPO samples per output): a lane half carries TWO output streams; a tile advances each stream
-//     by 8 samples (pair i = sample 8q+i of output 4*grp + 2h + e); an output needs R = L/8 tiles.
-//     Staging unit ("run") = 8 contiguous samples; LDS row of (tile j, stream sidx = 2h+e, i) = 32j + 8*sidx + i.
-//   NIPO < 16: a lane half carries one run of 16 contiguous samples = 16/NIPO whole outputs; pair i, element e is
-//     sample k = i % NIPO of output u = 2*(i / NIPO) + e of that run.  Run = 16 samples; LDS row = 32j + 16h + sigma.
-template <int NIPO>
-__device__ __forceinline__ int sample_in_half(int i, int e)  // NIPO < 16: position of (pair i, elem e) in the run
-{
-    return (2 * (i / NIPO) + e) * NIPO + (i % NIPO);
-}
-
-template <int NIPO>
-__device__ __forceinline__ int lds_row_of_mfma_row(int r)  // r = D row = lane&31 of the A operand
-{
-    const int reg = (r & 3) + 4 * (r >> 3), h = (r >> 2) & 1, i = reg >> 1, e = reg & 1;
-    if constexpr (NIPO >= 16)
-        return (2 * h + e) * 8 + i;
-    else
-        return 16 * h + sample_in_half<NIPO>(i, e);
-}
-
-// XOR swizzle of the 16-byte chunk index inside an LDS row so that both the ds_write_b128 of the staging pass
-// and the ds_read_b128 of the fragment pass are bank-conflict free (modelled exhaustively
-// in tests/test_numerics_tricks.py).
-template <int RBC>
-__device__ __forceinline__ int swz(int chunk, int row)
-{
-    return RBC == 8 ? (chunk ^ (((row >> 1) & 7) ^ ((row & 1) << 2))) : (chunk ^ (row & 15));
-}
-
-template <int ANT, int NIPO, bool WRITE_C>
-__global__ __launch_bounds__(kWgThreads, ((ANT + 15) / 16 <= 4 ? DSABF_OCC : 2)) void fused_kernel(FusedArgs a)
-{
-    constexpr int NKS = (ANT + 15) / 16;                 // k-steps of 16 antennas (K' = 32 per step: re | im)
-    constexpr int RBC = (NKS <= 4) ? 8 : 16;            // 16-byte chunks per LDS row
-    constexpr int RB = RBC * 16;                         // LDS row bytes: [16*re of ant 0.. | 16*im of ant 0..]
-    constexpr bool LONG = NIPO >= 16;                    // an output spans several tiles
-    constexpr int L = LONG ? NIPO : 16;                  // samples per output stream (LONG) / per run (short)
-    constexpr int R = LONG ? L / 8 : 1;                  // tiles per output group
-    constexpr int RUN = LONG ? 8 : 16;                   // contiguous samples per staging run
-    constexpr int RUNS_PER_TILE = 32 / RUN;
-    constexpr int A = ANT;                               // packed bytes per time sample (= n_ant)
-    constexpr bool DW = (ANT % 16) != 0;                 // rows are only dword-aligned (e.g. 100 antennas)
-    constexpr int PW = DW ? 4 : 16;                      // staging piece width in bytes
-    constexpr int PPS = A / PW;                          // pieces per time sample
-    constexpr int PIECES = kRowsPerChunk * PPS;          // packed pieces per chunk
-    constexpr int PPT = (PIECES + kWgThreads - 1) / kWgThreads;
-    static_assert(ANT % 4 == 0, "N_ANTENNAS must be divisible by 4 (src/beamformer.hh:156)");
-    static_assert(R <= kTilesPerChunk ? (kTilesPerChunk % R == 0) : (R % kTilesPerChunk == 0), "bad NIPO");
-
-    extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 x 128 rows x RB
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int hl = lane >> 5;   // lane half
-    const int lc = lane & 31;   // MFMA column (beam within tile) / MFMA row for the A operand
-
-    int f, bg, ts;
-    decode_block(a, f, bg, ts);
-    // split in units of whole output groups (R tiles; a chunk is 4 tiles)
-    constexpr int CPG = R > kTilesPerChunk ? R / kTilesPerChunk : 1;  // chunks per group
-    const int units_total = a.chunks_total / CPG;
-    const int c_begin = (int)(((long long)units_total * ts) / a.n_tsplit) * CPG;
-    const int c_end = (int)(((long long)units_total * (ts + 1)) / a.n_tsplit) * CPG;
-
-    const int bt = bg * kWavesPerWg + wave;  // this wave's 32-beam tile
-    const bool wave_active = bt < a.n_btiles;
-    const int beam = bt * 32 + lc;
-
-    // ---- weight fragments -> registers (once) ------------------------------------------------------------
-    v4i bre[NKS], bim[NKS];
-    if (wave_active) {
-        const v4i* wp = a.wimg + ((size_t)(f * a.n_btiles + bt) * 2 * NKS) * 64 + lane;
-#pragma unroll
-        for (int ks = 0; ks < NKS; ks++) {
-            bre[ks] = wp[(size_t)ks * 64];
-            bim[ks] = wp[(size_t)(NKS + ks) * 64];
-        }
-    } else {
-#pragma unroll
-        for (int ks = 0; ks < NKS; ks++) {
-            bre[ks] = v4i{0, 0, 0, 0};
-            bim[ks] = v4i{0, 0, 0, 0};
-        }
-    }
-
-    v16i kc;
-#pragma unroll
-    for (int i = 0; i < 16; i++) kc[i] = (int)kMagicBits;
-    asm volatile("" : "+v"(kc));  // keep the seed in registers; do not rematerialise 16 v_mov per tile
-
-    // ---- staging: global -> registers ------------------------------------------------------------------------
-    // First sample of run rr of chunk c is  chunk_base(c) + toff(rr)  with a chunk-uniform base and a per-thread
-    // constant offset (all six NIPO modes; derivation in DESIGN.md 3.1).  When a chunk never straddles two gemm-units
-    // (n_time % span == 0) the source address is  scalar base (SALU)  +  per-thread constant byte offset, so the
-    // steady-state loop spends no VALU on addressing.
-    constexpr int SPAN = (LONG && R > kTilesPerChunk) ? 32 * R : kRowsPerChunk;  // samples touched by one chunk
-    auto chunk_base = [&](int c) -> unsigned {
-        if constexpr (LONG && R > kTilesPerChunk)
-            return (unsigned)(c / CPG) * (4u * L) + (unsigned)(c % CPG) * 32u;
-        else
-            return (unsigned)c * kRowsPerChunk;
-    };
-    unsigned toff[PPT];       // per-thread sample offset of its run inside the chunk
-    unsigned tbyte[PPT];      // per-thread byte offset inside the chunk's unit (fast path)
-#pragma unroll
-    for (int k = 0; k < PPT; k++) {
-        const int pc = tid + k * kWgThreads;
-        const int rr = pc / (RUN * PPS), pi = pc % (RUN * PPS);
-        const int jt = rr / RUNS_PER_TILE, sidx = rr % RUNS_PER_TILE;
-        if constexpr (LONG) {
-            if constexpr (R > kTilesPerChunk)
-                toff[k] = (unsigned)(sidx * L + 8 * jt);
-            else
-                toff[k] = (unsigned)(((jt / R) * 4 + sidx) * L + 8 * (jt % R));
-        } else {
-            toff[k] = (unsigned)(32 * jt + 16 * sidx);
-        }
-        tbyte[k] = toff[k] * A + (unsigned)pi * PW;
-    }
-    const bool fast_addr = (a.T % SPAN) == 0;
-
-    typedef typename std::conditional<DW, int, v4i>::type piece_t;
-    piece_t stage[PPT];
-    auto load_chunk = [&](int c) {
-        const unsigned base = chunk_base(c);
-        if (fast_addr) {
-            const unsigned u = a.t_shift >= 0 ? (base >> a.t_shift) : (base / (unsigned)a.T);
-            const unsigned tb = base - u * (unsigned)a.T;
-            const uint8_t* cb = a.in + ((size_t)((size_t)u * a.n_freq + f) * a.T + tb) * A;  // wave-uniform
-#pragma unroll
-            for (int k = 0; k < PPT; k++) {
-                stage[k] = piece_t{};
-                if (tid + k * kWgThreads < PIECES && base + toff[k] < a.S)
-                    stage[k] = *reinterpret_cast<const piece_t*>(cb + tbyte[k]);
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < PPT; k++) {
-                const unsigned s0 = base + toff[k];
-                stage[k] = piece_t{};
-                if (tid + k * kWgThreads < PIECES && s0 < a.S) {
-                    const unsigned u = a.t_shift >= 0 ? (s0 >> a.t_shift) : (s0 / (unsigned)a.T);
-                    const unsigned t = s0 - u * (unsigned)a.T;
-                    const int pi = (tid + k * kWgThreads) % (RUN * PPS);
-                    const uint8_t* src = a.in + ((size_t)((size_t)u * a.n_freq + f) * a.T + t) * A + (size_t)pi * PW;
-                    stage[k] = *reinterpret_cast<const piece_t*>(src);
-                }
-            }
-        }
-    };
-    auto write_chunk = [&](char* buf) {
-#pragma unroll
-        for (int k = 0; k < PPT; k++) {
-            const int pc = tid + k * kWgThreads;
-            if (pc < PIECES) {
-                const int rr = pc / (RUN * PPS);
-                const int pi = pc % (RUN * PPS);
-                const int row = rr * RUN + pi / PPS;
-                const int pp = pi % PPS;  // piece within the sample
-                if constexpr (DW) {
-                    // 4 antennas per piece: ks = antenna / 16, byte position inside that 16-byte chunk = antenna % 16.
-                    // Bytes of antennas >= ANT inside the last chunk are never written; they multiply zero weights.
-                    const int ks = (pp * 4) / 16, sub = (pp * 4) % 16;
-                    const unsigned w = (unsigned)stage[k];
-                    *reinterpret_cast<int*>(buf + row * RB + 16 * swz<RBC>(ks, row) + sub) = (int)(w & 0xF0F0F0F0u);
-                    *reinterpret_cast<int*>(buf + row * RB + 16 * swz<RBC>(RBC / 2 + ks, row) + sub) =
-                        (int)((w << 4) & 0xF0F0F0F0u);
-                } else {
-                    const int ks = pp;
-                    v4i re, im;
-#pragma unroll
-                    for (int d = 0; d < 4; d++) {
-                        const unsigned w = (unsigned)stage[k][d];
-                        re[d] = (int)(w & 0xF0F0F0F0u);          // 16 * real nibble, as int8 x4
-                        im[d] = (int)((w << 4) & 0xF0F0F0F0u);   // 16 * imag nibble
-                    }
-                    *reinterpret_cast<v4i*>(buf + row * RB + 16 * swz<RBC>(ks, row)) = re;
-                    *reinterpret_cast<v4i*>(buf + row * RB + 16 * swz<RBC>(RBC / 2 + ks, row)) = im;
-                }
-            }
-        }
-    };
-
-    // ---- per-lane constants for the fragment reads and the epilogue --------------------------------------
-    const int arow = lds_row_of_mfma_row<NIPO>(lc);
-    int aoff[NKS];
-#pragma unroll
-    for (int ks = 0; ks < NKS; ks++) aoff[ks] = arow * RB + 16 * swz<RBC>(hl * (RBC / 2) + ks, arow);
-
-    const size_t FB = (size_t)a.n_freq * a.n_beams;
-    float* const out_lane = a.out + (size_t)f * a.n_beams + beam;  // + output_index * FB
-    v2f carry = {0.0f, 0.0f};  // running sums of this lane's two output streams (LONG)
-
-    // Deferred output stores (LONG): the sums finished in chunk c are stored at the top of chunk c+1, BEFORE the
-    // prefetch load of chunk c+2 is issued.  The compiler guards the prefetched registers with s_waitcnt vmcnt(0);
-    // with in-order vmcnt that wait then only covers operations a whole chunk old instead of stores issued a few
-    // cycles earlier (which stalled every wave for a store round trip per chunk: -11 % kernel time).
-    constexpr int PEND = LONG ? (R <= kTilesPerChunk ? kTilesPerChunk / R : 1) : 1;
-    v2f pend[PEND];
-    int pend_chunk[PEND];  // chunk whose finished sums are in pend[g] (-1: none)
-#pragma unroll
-    for (int g = 0; g < PEND; g++) pend_chunk[g] = -1;
-    const unsigned lane_out = (unsigned)(2 * hl) * (unsigned)FB + (unsigned)beam;  // lane part of the output index
-    auto flush_pending = [&]() {
-        if constexpr (LONG && !WRITE_C) {
-#pragma unroll
-            for (int g = 0; g < PEND; g++) {
-                if (pend_chunk[g] >= 0 && wave_active) {
-                    // last tile of output group g of that chunk; ob = first of the group's 4 outputs (wave-uniform)
-                    const unsigned tile = (unsigned)pend_chunk[g] * kTilesPerChunk + (R <= kTilesPerChunk ? (g + 1) * R - 1 : kTilesPerChunk - 1);
-                    const unsigned ob = 4u * (tile / R);
-                    float* ub = a.out + (size_t)ob * FB + (size_t)f * a.n_beams;  // scalar (SALU) part of the address
-                    const unsigned o = ob + 2u * hl;
-                    if (o * (unsigned)L < a.S && beam < a.n_beams && DSABF_ABLATE != 3) {
-                        ub[lane_out] = pend[g][0];
-                        if ((o + 1) * (unsigned)L < a.S) ub[lane_out + (unsigned)FB] = pend[g][1];
-                    }
-                }
-                pend_chunk[g] = -1;
-            }
-        }
-    };
-
-    if (c_begin >= c_end) return;
-
-    // ---- prologue ------------------------------------------------------------------------------------------
-    load_chunk(c_begin);
-    write_chunk(smem);
-    if (c_begin + 1 < c_end) load_chunk(c_begin + 1);
-    __syncthreads();
-
-    for (int c = c_begin; c < c_end; c++) {
-        char* cur = smem + ((c - c_begin) & 1) * (kRowsPerChunk * RB);
-        char* nxt = smem + ((c - c_begin + 1) & 1) * (kRowsPerChunk * RB);
-
-        // stage chunk c+1 (its global loads were issued one iteration ago) and issue the loads of chunk c+2
-        // Staging of chunk c+1 (its global loads were issued one chunk ago), the deferred stores of chunk c-1 and the
-        // prefetch of chunk c+2 are all independent of this chunk's MFMA results: they are issued right AFTER the
-        // MFMA clusters of tiles 0 and 1, i.e. in the shadow of this wave's own 256-cycle MFMA burst, instead of in
-        // a separate phase at the top of the chunk where the matrix pipe would idle.
-        auto stage_part0 = [&]() {
-#if DSABF_ABLATE != 4
-            if (c + 1 < c_end) write_chunk(nxt);
-#endif
-        };
-        auto stage_part1 = [&]() {
-            flush_pending();
-#if DSABF_ABLATE != 4
-            if (c + 2 < c_end) load_chunk(c + 2);
-#endif
-        };
-        if (!wave_active) {
-            stage_part0();
-            stage_part1();
-        }
-
-        if (wave_active) {
-#pragma unroll
-            for (int j = 0; j < kTilesPerChunk; j++) {
-                // -- A fragments: 32 time rows x (16*NKS re | 16*NKS im) int8 --
-                v4i af[NKS];
-#pragma unroll
-                for (int ks = 0; ks < NKS; ks++) {
-#if DSABF_ABLATE == 2
-                    af[ks] = v4i{aoff[ks], j, (int)c, ks};
-#else
-                    af[ks] = *reinterpret_cast<const v4i*>(cur + j * 32 * RB + aoff[ks]);
-#endif
-                }
-
-                v16i are = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[0], bre[0], kc, 0, 0, 0);
-                v16i aim = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[0], bim[0], kc, 0, 0, 0);
-#pragma unroll
-                for (int ks = 1; ks < NKS; ks++) {
-                    are = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[ks], bre[ks], are, 0, 0, 0);
-                    aim = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[ks], bim[ks], aim, 0, 0, 0);
-                }
-
-                if (j == 0 || j == 1) {
-                    __builtin_amdgcn_sched_barrier(0);  // MFMAs first, then the independent staging work
-                    if (j == 0) stage_part0(); else stage_part1();
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                // -- epilogue ------------------------------------------------------------------------------
-                // Plain (unpacked) fp32 VALU on purpose: v_pk_* f32 ops do not co-execute with the MFMAs of the
-                // other waves on this SIMD (SQ_VALU_MFMA_COEXEC_CYCLES drops 7x, kernel +5 %); the build uses
-                // -fno-slp-vectorize so that the compiler does not re-pack these.
-                // NOTE: bit-cast the WHOLE vector; __builtin_bit_cast(float, vec[i]) is miscompiled by ROCm 7.2
-                // clang (it reads element 0 for every i).
-                const v16f fre = __builtin_bit_cast(v16f, are);
-                const v16f fim = __builtin_bit_cast(v16f, aim);
-                const unsigned tile = (unsigned)c * kTilesPerChunk + j;
-
-                if constexpr (WRITE_C) {
-                    // stage-parity path: store the scaled complex beam voltages c[f][t][b]{re,im} (one gemm-unit)
-#pragma unroll
-                    for (int r = 0; r < 16; r++) {
-                        const int i = r >> 1, e = r & 1;
-                        unsigned s;
-                        bool ok;
-                        if constexpr (LONG) {
-                            const unsigned o = 4u * (tile / R) + 2u * hl + e;
-                            s = o * (unsigned)L + 8u * (tile % R) + i;
-                            ok = o * (unsigned)L < a.S;
-                        } else {
-                            s = (2u * tile + hl) * 16u + sample_in_half<NIPO>(i, e);
-                            ok = (2u * tile + hl) * 16u < a.S;
-                        }
-                        if (ok && beam < a.n_beams) {
-                            v2f cv = {__builtin_fmaf(fre[r], kAlpha16, kNegMagicAlpha16),
-                                      __builtin_fmaf(fim[r], kAlpha16, kNegMagicAlpha16)};
-                            *reinterpret_cast<v2f*>(a.out + 2 * (((size_t)f * a.T + s) * a.n_beams + beam)) = cv;
-                        }
-                    }
-                } else {
-                    // detected power of accumulator register r: x = fl(n * alpha) by ONE fma (exact, see header),
-                    // then x*x + y*y as two multiplies and one add (no contraction)
-                    float p[16];
-#pragma unroll
-                    for (int r = 0; r < 16; r++) {
-#if DSABF_ABLATE == 5
-                        p[r] = fre[r] + fim[r];
-#else
-                        const float x = __builtin_fmaf(fre[r], kAlpha16, kNegMagicAlpha16);
-                        const float y = __builtin_fmaf(fim[r], kAlpha16, kNegMagicAlpha16);
-                        const float xx = x * x;
-                        const float yy = y * y;
-                        p[r] = xx + yy;
-#endif
-                    }
-                    if constexpr (LONG) {
-                        // two output streams per lane (registers 2i+e, e = 0, 1), 8 more samples each, summed in
-                        // the reference's sequential order (src/beamformer.cuh:150-152)
-                        const unsigned q = (R <= kTilesPerChunk) ? (unsigned)(j % R) : (tile % R);
-                        float s0 = (q == 0) ? p[0] : (carry[0] + p[0]);
-                        float s1 = (q == 0) ? p[1] : (carry[1] + p[1]);
-#pragma unroll
-                        for (int i = 1; i < 8; i++) {
-                            s0 = s0 + p[2 * i];
-                            s1 = s1 + p[2 * i + 1];
-                        }
-                        // Pin the values here: otherwise the compiler sinks the whole detect under the store
-                        // predicate, hoists the MFMAs of the next tile above that branch and doubles the live
-                        // accumulators.
-                        asm volatile("" : "+v"(s0), "+v"(s1));
-                        carry = v2f{s0, s1};
-                        if (q == R - 1) {  // output pair complete: park it, flush_pending() stores it next chunk
-                            pend[R <= kTilesPerChunk ? j / R : 0] = carry;
-                            pend_chunk[R <= kTilesPerChunk ? j / R : 0] = c;
-                        }
-                    } else {
-                        // 16/NIPO whole outputs per lane half; output u = 2m+e lives in registers 2*(m*NIPO+k)+e
-                        constexpr int OPR = 16 / NIPO;  // outputs per run (even)
-                        const unsigned hs = 2u * tile + hl;
-                        const bool valid = (hs * 16u < a.S) && (beam < a.n_beams) && DSABF_ABLATE != 3;
-                        float* op = out_lane + ((size_t)hs * OPR) * FB;
-#pragma unroll
-                        for (int u = 0; u < OPR; u++) {
-                            const int m = u >> 1, e = u & 1;
-                            float sacc = p[2 * (m * NIPO) + e];
-#pragma unroll
-                            for (int k = 1; k < NIPO; k++) sacc = sacc + p[2 * (m * NIPO + k) + e];
-                            asm volatile("" : "+v"(sacc));
-                            if (valid) op[(size_t)u * FB] = sacc;
-                        }
-                    }
-                }
-                // One tile at a time per wave: 4 waves/SIMD overlap each other's MFMA and VALU phases; letting the
-                // scheduler interleave two tiles doubles the live accumulators and spills at the 128-VGPR budget.
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-#if DSABF_ABLATE != 1
-        __syncthreads();
-#endif
-    }
-    flush_pending();
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// Weight re-layout: reference [f][a][b]{re,im} -> MFMA B-operand fragment image
-//   image[f][bt][rho][ks][lane] (16 bytes): lane = 32*h + c; byte i multiplies component h (0 = re, 1 = im) of
-//   antenna 16*ks + i in the A operand, for output row rho of beam 32*bt + c:
-//     rho = 0 (Re C): h=0 -> Wr, h=1 -> -Wi         rho = 1 (Im C): h=0 -> Wi, h=1 -> Wr
-__global__ void weight_relayout_kernel(const int8_t* __restrict__ w, v4i* __restrict__ image, int n_freq, int n_ant,
-                                       int n_beams, int n_btiles, int nks, int* __restrict__ bad)
-{
-    const size_t total = (size_t)n_freq * n_btiles * 2 * nks * 64;
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-        const int lane = (int)(idx & 63);
-        size_t r = idx >> 6;
-        const int ks = (int)(r % nks);
-        r /= nks;
-        const int rho = (int)(r & 1);
-        r >>= 1;
-        const int bt = (int)(r % n_btiles);
-        const int f = (int)(r / n_btiles);
-        const int h = lane >> 5, b = bt * 32 + (lane & 31);
-        unsigned d[4] = {0, 0, 0, 0};
-        for (int i = 0; i < 16; i++) {
-            const int ant = ks * 16 + i;
-            int v = 0;
-            if (ant < n_ant && b < n_beams) {
-                const int8_t* e = w + 2 * (((size_t)f * n_ant + ant) * n_beams + b);
-                const int wr = e[0], wi = e[1];
-                if (wi == -128) *bad = 1;
-                v = (rho == 0) ? (h == 0 ? wr : -wi) : (h == 0 ? wi : wr);
-            }
-            d[i >> 2] |= ((unsigned)v & 0xFFu) << (8 * (i & 3));
-        }
-        image[idx] = v4i{(int)d[0], (int)d[1], (int)d[2], (int)d[3]};
     }
 }
 
@@ -630,13 +192,14 @@ __global__ __launch_bounds__(256) void dedisperse_dm_kernel(const float* __restr
 }
 
 // =========================================================================================================
-// fused16_kernel -- the same fused stage built on v_mfma_i32_16x16x64_i8 (64-antenna geometries).
+// fused16_kernel -- expand + complex int8 GEMM + detect in one kernel, built on v_mfma_i32_16x16x64_i8.
 //
-// Why a second shape: on random int8 operands the chip holds a higher clock on the 16x16x64 instruction than on
+// Why this shape: on random int8 operands the chip holds a higher clock on the 16x16x64 instruction than on
 // 32x32x32 (tools/ubench_shape.hip: 129-142 ns vs 149-157 ns per 262,144 MACs per SIMD) and the composite tile
-// (MFMA + LDS fragment reads + canonical detect) is 7 % faster (tools/ubench_tile16.hip).  The small 4-register
-// accumulator tile also lets one wave cover 64 beams with half the accumulator/seed registers, which halves the
-// LDS fragment traffic per MFMA, and the detect of one 16x16 tile interleaves with the MFMAs of the next in the
+// (MFMA + LDS fragment reads + canonical detect) is 7 % faster (tools/ubench_tile16.hip); a 32x32x32 implementation
+// of the same design was measured 4 % (64 antennas) to 5 % (100 antennas) slower on the whole kernel and removed
+// (git history, profiles/r01_variants_log.txt).  The 4-register accumulator tile lets one wave cover 64 beams, which
+// halves the LDS fragment traffic per MFMA, and the detect of one tile interleaves with the MFMAs of the next in the
 // wave's own in-order stream.
 //
 // Mapping (K' = 128 = 64 re | 64 im, two k-steps of 64):
@@ -772,8 +335,8 @@ __global__ __launch_bounds__(kThreads16, AIN > 64 ? 2 : DSABF_OCC16) void fused1
     const bool fast_addr = DSABF_FASTADDR && ((unsigned)a.T % SPAN) == 0;
     // Piece k of this thread is piece pc = tid + 256 k of the chunk: row pc / PPR, position pc % PPR.  Its byte offset
     // from the chunk's first sample is PB * pc (rows are PPR * PB bytes and consecutive) -- except for n_ipo = 64, whose
-    // chunk rows are four runs of 32 samples, 64 apart.  The 16*im image sits 4 pieces after the 16*re image, and the
-    // swizzle only XORs the low 3 piece bits with a value < 8, so its LDS offset is the re offset ^ 64.
+    // chunk rows are four runs of 32 samples, 64 apart.  The 16*im image sits 4 pieces away from the 16*re image (after it
+    // in plane 0, before it in plane 1), and the swizzle only XORs the 3 piece bits, so its LDS offset is the re offset ^ 64.
     [[maybe_unused]] unsigned lane_off64[NIPO == 64 ? PPT : 1];
     int lds_re[PPT];                      // LDS byte offset (inside one buffer) of the piece's 16*re image
 #pragma unroll
@@ -783,7 +346,7 @@ __global__ __launch_bounds__(kThreads16, AIN > 64 ? 2 : DSABF_OCC16) void fused1
         if constexpr (NIPO == 64) lane_off64[k] = (unsigned)((row / LR) * L + (row % LR)) * A + pi * PB;
         const int blk = DW ? pi / 4 : pi;                            // 16-antenna block of the piece
         const int h = blk / 4, kp = blk % 4, sub = DW ? 4 * (pi % 4) : 0;
-        lds_re[k] = h * PLANE + row * RB + 16 * swz16<NIPO>(kp, row) + sub;
+        lds_re[k] = h * PLANE + row * RB + 16 * swz16<NIPO>(kp + 4 * (h & 1), row) + sub;  // plane 1: halves swapped
     }
     auto lane_off = [&](int k) -> unsigned {
         if constexpr (NIPO == 64)
@@ -985,9 +548,9 @@ __global__ __launch_bounds__(kThreads16, AIN > 64 ? 2 : DSABF_OCC16) void fused1
             auto read_frag = [&](const int t8, v4i (&a0)[KS], v4i (&a1)[KS]) {
                 const int row = lds_row16<NIPO>(t8, c16);
 #pragma unroll
-                for (int h = 0; h < KS; h++) {
-                    a0[h] = *reinterpret_cast<const v4i*>(cur + h * PLANE + row * RB + 16 * swz16<NIPO>(g4, row));
-                    a1[h] = *reinterpret_cast<const v4i*>(cur + h * PLANE + row * RB + 16 * swz16<NIPO>(4 + g4, row));
+                for (int h = 0; h < KS; h++) {  // plane 1 keeps (im | re): the two planes' staging writes then never collide
+                    a0[h] = *reinterpret_cast<const v4i*>(cur + h * PLANE + row * RB + 16 * swz16<NIPO>(g4 + 4 * (h & 1), row));
+                    a1[h] = *reinterpret_cast<const v4i*>(cur + h * PLANE + row * RB + 16 * swz16<NIPO>(g4 + 4 * ((h & 1) ^ 1), row));
                 }
             };
             // acc = seed + sum over the k-steps of x[h] * w[h]  (one MFMA per k-step, chained through srcC)
@@ -1029,7 +592,8 @@ __global__ __launch_bounds__(kThreads16, AIN > 64 ? 2 : DSABF_OCC16) void fused1
                 for (int e = 0; e < SPS; e++)   // paired: slot 2t = beam b, slot 2t+1 = beam B-1-b
                     detect(t8, __builtin_bit_cast(v4f, re[e]), __builtin_bit_cast(v4f, im[e]), SPS * t + e);
             };
-            // staging work in the shadow of the MFMA stream (see fused_kernel)
+            // staging work in the shadow of the MFMA stream: the next chunk's LDS image after tile 1, the parked stores
+            // of the previous chunk and the prefetch of chunk c+2 after tile 3
             auto staging = [&](const int t8) {
                 if (t8 == 1 && c + 1 < c_end) write_chunk(nxt);
                 if (t8 == 3) {
@@ -1135,19 +699,6 @@ __global__ void weight_relayout16_kernel(const int8_t* __restrict__ w, v4i* __re
     }
 }
 
-template <int ANT, int NIPO, bool WRITE_C>
-hipError_t launch_fused_t(const FusedArgs& args, const LaunchShape& ls, hipStream_t s)
-{
-    auto kern = fused_kernel<ANT, NIPO, WRITE_C>;
-    if (ls.lds_bytes > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           ls.lds_bytes);
-        if (e != hipSuccess) return e;
-    }
-    hipLaunchKernelGGL(kern, dim3(ls.grid), dim3(ls.block), ls.lds_bytes, s, args);
-    return hipGetLastError();
-}
-
 template <int AIN, int NIPO, bool WRITE_C, bool FAST = false, bool PAIRED = false>
 hipError_t launch_fused16_t(const FusedArgs& args, const LaunchShape& ls, hipStream_t s)
 {
@@ -1195,10 +746,10 @@ const void* fused16_fn(int n_ant, int n_ipo, hipError_t (**launch)(const FusedAr
 {
     switch (n_ant) {
         case 64: return fused16_fn_ant<64, WRITE_C, FAST, PAIRED>(n_ipo, launch);
-#if DSABF_USE16_WIDE
+        case 16: return fused16_fn_ant<16, WRITE_C, FAST, PAIRED>(n_ipo, launch);
+        case 32: return fused16_fn_ant<32, WRITE_C, FAST, PAIRED>(n_ipo, launch);
         case 100: return fused16_fn_ant<100, WRITE_C, FAST, PAIRED>(n_ipo, launch);
         case 128: return fused16_fn_ant<128, WRITE_C, FAST, PAIRED>(n_ipo, launch);
-#endif
         default: return nullptr;
     }
 }
@@ -1216,11 +767,11 @@ const void* fused16_select(const Geometry& g, hipError_t (**launch)(const FusedA
     return fused16_fn<WRITE_C, false, false>(g.n_ant, g.n_ipo, launch);
 }
 
+// geometries with an instantiation: 64 antennas with n_ipo 2..64, 16 / 32 / 100 / 128 antennas with n_ipo 2 and 32
 bool use16(const Geometry& g)
 {
-    if (!DSABF_USE16) return false;
     if (g.n_ant == 64) return g.n_ipo == 2 || g.n_ipo == 4 || g.n_ipo == 8 || g.n_ipo == 16 || g.n_ipo == 32 || g.n_ipo == 64;
-    return DSABF_USE16_WIDE && (g.n_ant == 100 || g.n_ant == 128) && (g.n_ipo == 2 || g.n_ipo == 32);
+    return (g.n_ant == 16 || g.n_ant == 32 || g.n_ant == 100 || g.n_ant == 128) && (g.n_ipo == 2 || g.n_ipo == 32);
 }
 int ksteps16(const Geometry& g) { return g.n_ant > 64 ? 2 : 1; }
 
@@ -1232,32 +783,19 @@ int ilog2_exact(int v)
     return s;
 }
 
-// (n_ant, n_ipo) instantiation table.
-#define DSABF_FOR_EACH_VARIANT(X) \
-    X(16, 2) X(16, 32) X(32, 2) X(32, 32) X(64, 2) X(64, 4) X(64, 8) X(64, 16) X(64, 32) X(64, 64) X(100, 2) \
-    X(100, 32) X(128, 2) X(128, 32)
-
 template <bool WRITE_C>
 hipError_t dispatch_fused(const Geometry& g, const FusedArgs& args, const LaunchShape& ls, hipStream_t s)
 {
-    if (use16(g)) {
-        hipError_t (*launch)(const FusedArgs&, const LaunchShape&, hipStream_t) = nullptr;
-        if (!fused16_select<WRITE_C>(g, &launch) || !launch) return hipErrorInvalidValue;
-        return launch(args, ls, s);
-    }
-#define X(ant_, nipo_) \
-    if (g.n_ant == ant_ && g.n_ipo == nipo_) return launch_fused_t<ant_, nipo_, WRITE_C>(args, ls, s);
-    DSABF_FOR_EACH_VARIANT(X)
-#undef X
-    return hipErrorInvalidValue;
+    hipError_t (*launch)(const FusedArgs&, const LaunchShape&, hipStream_t) = nullptr;
+    if (!use16(g) || !fused16_select<WRITE_C>(g, &launch) || !launch) return hipErrorInvalidValue;
+    return launch(args, ls, s);
 }
 
 }  // namespace
 
 size_t weight_image_bytes(const Geometry& g)
 {
-    if (use16(g)) return (size_t)g.n_freq * g.n_btiles * 2 * 4 * ksteps16(g) * 64 * 16;  // [f][ct16][rho][s][k-step][lane]
-    return (size_t)g.n_freq * g.n_btiles * 2 * g.nks * 64 * 16;
+    return (size_t)g.n_freq * g.n_btiles * 2 * 4 * ksteps16(g) * 64 * 16;  // [f][ct16][rho][s][k-step][lane] x 16 B
 }
 
 bool pairing_supported(const Geometry& g) { return DSABF_PAIRED && use16(g); }
@@ -1273,10 +811,7 @@ bool fused_supported(const Geometry& g, const char** why)
     if (g.n_beams <= 0 || g.n_beams % 32) { *why = "n_beams must be a positive multiple of 32"; return false; }
     if (g.n_ant % 4) { *why = "N_ANTENNAS must be divisible by 4"; return false; }
     if (g.n_ipo < 16 && g.n_time % 16) { *why = "n_out_per_gemm * n_pol * n_avg must be a multiple of 16"; return false; }
-#define X(ant_, nipo_) \
-    if (g.n_ant == ant_ && g.n_ipo == nipo_) return true;
-    DSABF_FOR_EACH_VARIANT(X)
-#undef X
+    if (use16(g)) return true;
     *why = "no kernel instantiation for this (n_ant, n_pol*n_avg); supported: n_ant 16/32/100/128 with n_ipo 2/32, "
            "n_ant 64 with n_ipo 2/4/8/16/32/64";
     return false;
@@ -1286,20 +821,18 @@ LaunchShape fused_launch_shape(const Geometry& g, int n_units, int n_cus)
 {
     LaunchShape ls{};
     const long long S = (long long)n_units * g.n_time;
-    long long tiles;
+    long long rows;
     int cpg = 1;  // chunks per output group: a workgroup's chunk range must cover whole groups
     if (g.n_ipo >= 16) {
-        const int R = g.n_ipo / 8;                       // tiles per group of 4 outputs
-        const long long groups = (S / g.n_ipo + 3) / 4;
-        tiles = groups * R;
-        if (R > kTilesPerChunk) cpg = R / kTilesPerChunk;
+        const long long groups = (S / g.n_ipo + 3) / 4;  // a lane group carries one output: 4 outputs advance together
+        rows = groups * 4 * g.n_ipo;
+        if (4 * g.n_ipo > kRowsPerChunk) cpg = 4 * g.n_ipo / kRowsPerChunk;
     } else {
-        tiles = (S / 16 + 1) / 2;                        // two 16-sample runs per tile
+        rows = (S + 15) / 16 * 16;                       // 16-sample runs
     }
-    ls.chunks_total = (int)((tiles + kTilesPerChunk - 1) / kTilesPerChunk);
+    ls.chunks_total = (int)((rows + kRowsPerChunk - 1) / kRowsPerChunk);
     ls.chunks_total = (ls.chunks_total + cpg - 1) / cpg * cpg;
     const int base = g.n_freq * g.n_bgroups;
-    const int waves_per_wg = use16(g) ? kWaves16 : kWavesPerWg;
     // Time splits per frequency.  Measured (profiles/r01_variants_log.txt): the kernel is fastest with ~16-32 chunks
     // per workgroup (long enough to amortise the weight-fragment load and the prologue, short enough that the tail
     // of the launch is fine-grained); small launches still get ~2 workgroups per resident slot, but never fewer
@@ -1307,7 +840,7 @@ LaunchShape fused_launch_shape(const Geometry& g, int n_units, int n_cus)
     const int groups_avail = ls.chunks_total / cpg;
     const int max_split = groups_avail >= 2 ? groups_avail / 2 : 1;
     int want = (groups_avail + 10) / 20;                                       // ~20 chunk-groups per workgroup
-    const int target_wgs_per_cu = 2 * (16 / waves_per_wg);
+    const int target_wgs_per_cu = 2 * (16 / kWaves16);
     int want_fill = (target_wgs_per_cu * n_cus + base - 1) / base;            // enough workgroups to fill the chip
     if (want_fill > max_split) want_fill = max_split;
     if (want < want_fill) want = want_fill;
@@ -1316,9 +849,8 @@ LaunchShape fused_launch_shape(const Geometry& g, int n_units, int n_cus)
     if (want > ls.chunks_total / cpg) want = ls.chunks_total / cpg;
     ls.n_tsplit = want;
     ls.grid = base * ls.n_tsplit;
-    ls.block = use16(g) ? kThreads16 : kWgThreads;
-    const int rbc = g.nks <= 4 ? 8 : 16;
-    ls.lds_bytes = use16(g) ? 2 * ksteps16(g) * kRowsPerChunk * 128 : 2 * kRowsPerChunk * rbc * 16;
+    ls.block = kThreads16;
+    ls.lds_bytes = 2 * ksteps16(g) * kRowsPerChunk * 128;  // double buffer x k-step planes x 128 rows x (64 re | 64 im)
     return ls;
 }
 
@@ -1378,13 +910,8 @@ hipError_t launch_weight_relayout(const Geometry& g, const int8_t* d_w, void* d_
         hipLaunchKernelGGL(weight_relayout16p_kernel, dim3(rgrid), dim3(256), 0, s, d_w, static_cast<v4i*>(d_pair_image),
                            g.n_freq, g.n_ant, g.n_beams, ksteps16(g));
     }
-    if (use16(g)) {
-        hipLaunchKernelGGL(weight_relayout16_kernel, dim3(grid), dim3(256), 0, s, d_w, static_cast<v4i*>(d_image), g.n_freq,
-                           g.n_ant, g.n_beams, ksteps16(g), d_bad);
-        return hipGetLastError();
-    }
-    hipLaunchKernelGGL(weight_relayout_kernel, dim3(grid), dim3(256), 0, s, d_w, static_cast<v4i*>(d_image), g.n_freq,
-                       g.n_ant, g.n_beams, g.n_btiles, g.nks, d_bad);
+    hipLaunchKernelGGL(weight_relayout16_kernel, dim3(grid), dim3(256), 0, s, d_w, static_cast<v4i*>(d_image), g.n_freq,
+                       g.n_ant, g.n_beams, ksteps16(g), d_bad);
     return hipGetLastError();
 }
 
@@ -1419,11 +946,8 @@ hipError_t launch_dedisperse_dm(const Geometry& g, const float* d_series, int n_
 
 const char* fused_kernel_name(const Geometry& g, char* buf, size_t n)
 {
-    if (use16(g))
-        snprintf(buf, n, "dsabf::fused16_kernel<ANT=%d,NIPO=%d%s%s> (v_mfma_i32_16x16x64_i8)", g.n_ant, g.n_ipo,
-                 (g.fast_detect && g.n_ipo >= 16) ? ",FAST" : "", g.paired ? ",PAIRED" : "");
-    else
-        snprintf(buf, n, "dsabf::fused_kernel<ANT=%d,NIPO=%d> (v_mfma_i32_32x32x32_i8)", g.n_ant, g.n_ipo);
+    snprintf(buf, n, "dsabf::fused16_kernel<ANT=%d,NIPO=%d%s%s> (v_mfma_i32_16x16x64_i8)", g.n_ant, g.n_ipo,
+             (g.fast_detect && g.n_ipo >= 16) ? ",FAST" : "", g.paired ? ",PAIRED" : "");
     return buf;
 }
 
@@ -1431,16 +955,8 @@ int fused_vgprs(const Geometry& g)
 {
     hipFuncAttributes attr{};
     const void* fn = nullptr;
-    if (use16(g)) {
-        hipError_t (*launch)(const FusedArgs&, const LaunchShape&, hipStream_t) = nullptr;
-        fn = fused16_select<false>(g, &launch);
-        if (!fn || hipFuncGetAttributes(&attr, fn) != hipSuccess) return -1;
-        return attr.numRegs;
-    }
-#define X(ant_, nipo_) \
-    if (g.n_ant == ant_ && g.n_ipo == nipo_) fn = reinterpret_cast<const void*>(fused_kernel<ant_, nipo_, false>);
-    DSABF_FOR_EACH_VARIANT(X)
-#undef X
+    hipError_t (*launch)(const FusedArgs&, const LaunchShape&, hipStream_t) = nullptr;
+    if (use16(g)) fn = fused16_select<false>(g, &launch);
     if (!fn || hipFuncGetAttributes(&attr, fn) != hipSuccess) return -1;
     return attr.numRegs;
 }

@@ -85,9 +85,8 @@ dsabf::Geometry make_geom(const bf_config& c)
     g.n_ipo = c.n_pol * c.n_avg;
     g.n_out = c.n_out_per_gemm;
     g.n_time = g.n_out * g.n_ipo;
-    g.nks = (c.n_ant + 15) / 16;
     g.n_btiles = c.n_beams / 32;
-    g.n_bgroups = (g.n_btiles + dsabf::kWavesPerWg - 1) / dsabf::kWavesPerWg;
+    g.n_bgroups = (c.n_beams + dsabf::kBeamsPerWg - 1) / dsabf::kBeamsPerWg;
     g.fast_detect = c.detect_mode == BF_DETECT_FAST;
     return g;
 }

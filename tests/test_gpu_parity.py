@@ -806,13 +806,14 @@ def test_dedisperse_dm_recovers_dispersed_pulse_from_detected_stream(torch, bfmo
     assert got[2, t_burst, b_best] > 3 * got[0].max()
 
 
-@pytest.mark.parametrize("n_ant,n_avg", [(128, 16), (128, 1), (100, 16), (100, 1)])
+@pytest.mark.parametrize("n_ant,n_avg", [(128, 16), (128, 1), (100, 16), (100, 1), (32, 16), (32, 1), (16, 16), (16, 1)])
 @pytest.mark.parametrize("paired", [False, True])
 @pytest.mark.parametrize("tsplit", ["1", "3"])
 def test_wide_antenna_16x16_kernel_bit_exact(torch, bfmod, orc, monkeypatch, n_ant, n_avg, paired, tsplit):
-    """100 and 128 antennas on fused16_kernel: two k-steps of 64 (two LDS planes, chained MFMAs), 100-byte rows staged
-    in dwords with zero weights behind antenna 99; general and conjugate-pair variants, several chunks per workgroup,
-    several beam groups, ragged end.  Extreme weights and voltages exercise the +-2^22 accumulator range."""
+    """Antenna counts other than 64 on fused16_kernel: 100 and 128 antennas are two k-steps of 64 (two LDS planes,
+    chained MFMAs), 100-byte rows are staged in dwords, 16 / 32 / 100 antennas have zero weights behind the last
+    antenna; general and conjugate-pair variants, several chunks per workgroup, several beam groups, ragged end.
+    Extreme weights and voltages exercise the +-2^22 accumulator range."""
     monkeypatch.setenv("DSABF_TSPLIT", tsplit)
     n_ipo = 2 * n_avg
     g = orc.Geom(n_beams=288, n_ant=n_ant, n_freq=3, n_avg=n_avg, n_out_per_gemm=max(2, 16 // n_ipo) * (3 if n_avg > 1 else 1))

@@ -66,75 +66,84 @@ def test_standalone_expand_bit_tricks():
     assert np.array_equal(got, want)
 
 
-def _sample_in_half(i, e, nipo):
-    return (2 * (i // nipo) + e) * nipo + (i % nipo)
+def _lds_row16(t8, rho, nipo):
+    """Mirror of lds_row16<NIPO> in bf_kernels.hip: A row rho of 16-row tile t8 -> row of the 128-row chunk image."""
+    if nipo >= 32:
+        return (rho >> 2) * 32 + 4 * t8 + (rho & 3)
+    return (t8 >> 2) * 64 + (rho >> 2) * 16 + 4 * (t8 & 3) + (rho & 3)
 
 
-def _lds_row_of_mfma_row(r, nipo):
-    """Mirror of lds_row_of_mfma_row<NIPO> in bf_kernels.hip: D row r -> row of the tile's LDS image."""
-    reg, h = (r & 3) + 4 * (r >> 3), (r >> 2) & 1
-    i, e = reg >> 1, reg & 1
-    if nipo >= 16:
-        return (2 * h + e) * 8 + i
-    return 16 * h + _sample_in_half(i, e, nipo)
+def _swz16(piece, row, nipo):
+    """Mirror of swz16<NIPO>: XOR swizzle of the 16-byte piece index (0..7) inside a 128-byte row."""
+    lr = 32 if nipo >= 32 else 16
+    return piece ^ ((((row >> 1) & 1) | (((row // lr) & 3) << 1)) ^ ((row & 1) << 2))
 
 
-def test_mfma_row_mapping_pairs_two_outputs_per_register_pair():
-    """D row of (half h, reg) is (reg&3) + 8*(reg>>2) + 4*h (cdna guide section 3).  The mapping must (a) be a
-    bijection on the 32 rows of a tile, (b) put the SAME window position of two different outputs in the two
-    elements of every register pair, (c) walk each output's window in increasing time order over the pairs."""
+def test_mfma_row_mapping_keeps_each_output_in_one_lane_in_time_order():
+    """v_mfma_i32_16x16x64_i8: lane (column c = lane & 15, group g = lane >> 4) holds D rows 4g + r in registers
+    r = 0..3 (cdna guide section 3).  The chunk image is the chunk's 128 samples in time order (n_ipo <= 32), so the
+    mapping must (a) be a bijection of (tile, D row) onto the 128 rows, (b) give every lane group ONE stream per tile
+    whose samples are consecutive over the registers and over the tiles, so the fp32 sum runs in the reference's order
+    inside a lane, (c) make streams = whole outputs (n_ipo >= 16) or 16-sample runs of whole outputs (n_ipo < 16)."""
     for nipo in (2, 4, 8, 16, 32, 64):
-        rows = {}
-        for h in range(2):
-            for reg in range(16):
-                d_row = (reg & 3) + 8 * (reg >> 2) + 4 * h
-                rows[(h, reg >> 1, reg & 1)] = _lds_row_of_mfma_row(d_row, nipo)
-        assert sorted(rows.values()) == list(range(32))
-        for h in range(2):
-            if nipo >= 16:
-                # stream (h, e) = 8 contiguous samples, pair i = sample i
-                for e in range(2):
-                    assert [rows[(h, i, e)] for i in range(8)] == list(range((2 * h + e) * 8, (2 * h + e) * 8 + 8))
-            else:
-                for i in range(8):
-                    s0, s1 = rows[(h, i, 0)] - 16 * h, rows[(h, i, 1)] - 16 * h
-                    assert s0 // nipo != s1 // nipo and s0 % nipo == s1 % nipo == i % nipo   # (b)
-                    assert s1 // nipo == s0 // nipo + 1 and (s0 // nipo) % 2 == 0
-                for u in range(16 // nipo):                                                    # (c)
-                    pos = [(i, e) for i in range(8) for e in range(2) if (rows[(h, i, e)] - 16 * h) // nipo == u]
-                    assert [rows[(h, i, e)] - 16 * h - u * nipo for i, e in pos] == list(range(nipo))
+        rows = {(t8, rho): _lds_row16(t8, rho, nipo) for t8 in range(8) for rho in range(16)}
+        assert sorted(rows.values()) == list(range(128))                                    # (a)
+        stream_len = 32 if nipo >= 32 else 16
+        for g in range(4):
+            for t8 in range(8):
+                r4 = [rows[(t8, 4 * g + r)] for r in range(4)]
+                assert r4 == list(range(r4[0], r4[0] + 4))                                  # registers = consecutive samples
+                assert r4[0] % 4 == 0 and r4[0] // stream_len == r4[3] // stream_len        # inside one stream
+            if nipo >= 32:   # stream g = rows [32g, 32g+32): tiles t8 = 0..7 walk it in order
+                assert [rows[(t8, 4 * g)] for t8 in range(8)] == [32 * g + 4 * t8 for t8 in range(8)]
+            else:            # streams (t8 >> 2, g) = 16 rows each: tiles 0-3 and 4-7 walk one stream each
+                for hi in range(2):
+                    assert [rows[(4 * hi + q, 4 * g)] for q in range(4)] == [64 * hi + 16 * g + 4 * q for q in range(4)]
+        assert stream_len % min(nipo, stream_len) == 0                                       # (c)
 
 
 def test_lds_swizzle_is_bank_conflict_free():
     """ds_read_b128: 4 groups of 16 lanes, bank = (addr/4) % 64; ds_write_b128: 8 groups of 8 contiguous lanes,
-    bank = (addr/4) % 32 (MI355X_MICROARCH.md LDS table).  Conflict-free <=> the 16-byte slots are distinct."""
+    bank = (addr/4) % 32 (MI355X_MICROARCH.md LDS table).  Conflict-free <=> the 16-byte slots are distinct.
+    Mirrors fused16_kernel: fragment reads (lane -> row lds_row16(t8, lane & 15), piece swz16(lane >> 4 [+4])) and the
+    staging writes of the 64- and 128-antenna layouts (plane 1 keeps its re / im halves swapped for that reason)."""
     groups_r = [list(range(0, 4)) + list(range(12, 16)) + list(range(20, 28)),
                 list(range(4, 12)) + list(range(16, 20)) + list(range(28, 32))]
     groups_r += [[l + 32 for l in g] for g in groups_r]
+    plane = 128 * 128
     for nipo in (2, 4, 8, 16, 32, 64):
-        run = 8 if nipo >= 16 else 16
-        for rbc, nks in ((8, 4), (8, 2), (16, 8)):
-            rb = rbc * 16
-            swz = (lambda c, row: c ^ (((row >> 1) & 7) ^ ((row & 1) << 2))) if rbc == 8 else (lambda c, row: c ^ (row & 15))
-            for tile in range(4):
-                for ks in range(nks):
+        for t8 in range(8):
+            for h in range(2):
+                for comp in range(2):
                     for g in groups_r:
                         slots = set()
                         for lane in g:
-                            hl, lc = lane >> 5, lane & 31
-                            row = tile * 32 + _lds_row_of_mfma_row(lc, nipo)
-                            addr = row * rb + 16 * swz(hl * (rbc // 2) + ks, row)
-                            slots.add((addr // 16) % 16)
-                        assert len(slots) == 16, (nipo, rbc, tile, ks)
-            # staging writes: thread tid writes piece pc: row = rr*run + (pi // nks), ks = pi % nks
-            if nks == 2:
-                continue  # half-empty rows: 8 consecutive pieces span 4 rows (2-way at most, irrelevant sizes)
-            for pc0 in range(0, 128 * nks, 8):
+                            row = _lds_row16(t8, lane & 15, nipo)
+                            piece = (lane >> 4) + 4 * ((h & 1) ^ comp)
+                            slots.add(((h * plane + row * 128 + 16 * _swz16(piece, row, nipo)) // 16) % 16)
+                        assert len(slots) == 16, (nipo, t8, h, comp)
+        for ppr in (4, 8):                      # 16-byte pieces per time sample: 64 and 128 antennas
+            for k in range(128 * ppr // 256):
+                for l0 in range(0, 256, 8):
+                    for comp in range(2):
+                        slots = set()
+                        for tid in range(l0, l0 + 8):
+                            row, pi = divmod(tid + 256 * k, ppr)
+                            h, kp = divmod(pi, 4)
+                            addr = h * plane + row * 128 + 16 * _swz16(kp + 4 * (h & 1), row, nipo)
+                            slots.add(((addr ^ (64 * comp)) // 16) % 8)
+                        assert len(slots) == 8, (nipo, ppr, k, l0, comp)
+        # 100 antennas: 4-byte pieces (ds_write_b32, 64 lanes, bank = (addr/4) % 64): at most 2 lanes per bank
+        for k in range(13):
+            for w in range(4):
                 for comp in range(2):
-                    slots = set()
-                    for pc in range(pc0, pc0 + 8):
-                        rr, pi = divmod(pc, run * nks)
-                        row, ks = rr * run + pi // nks, pi % nks
-                        addr = row * rb + 16 * swz(comp * (rbc // 2) + ks, row)
-                        slots.add((addr // 16) % 8)
-                    assert len(slots) == 8, (nipo, rbc, pc0, comp)
+                    banks = {}
+                    for lane in range(64):
+                        pc = w * 64 + lane + 256 * k
+                        if pc >= 3200:
+                            continue
+                        row, pi = divmod(pc, 25)
+                        h, kp = divmod(pi // 4, 4)
+                        addr = (h * plane + row * 128 + 16 * _swz16(kp + 4 * (h & 1), row, nipo) + 4 * (pi % 4)) ^ (64 * comp)
+                        banks.setdefault((addr // 4) % 64, set()).add(addr)
+                    assert max(len(v) for v in banks.values()) <= 2 if banks else True
