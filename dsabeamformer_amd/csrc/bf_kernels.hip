@@ -41,6 +41,9 @@
 #ifndef DSABF_PAIR_MFMA
 #define DSABF_PAIR_MFMA 4 // MFMAs per conjugate pair tile: 4 (+-P2, +-P4 on the VALU), 5 (real part chained on the MFMA), 6
 #endif
+#ifndef DSABF_INTERLEAVE
+#define DSABF_INTERLEAVE 1 // deal beams to a wave's column tiles 4 (pairs: 2) at a time -> 16- / 8-byte stores (beam_of_tile)
+#endif
 #ifndef DSABF_FASTADDR
 #define DSABF_FASTADDR 1  // scalar chunk addressing in fused16_kernel when gemm-units are a multiple of the chunk span
 #endif
@@ -76,7 +79,19 @@ struct FusedArgs {
     unsigned S;                      // total time samples per frequency in this launch (n_units * T)
     int chunks_total;                // ceil(tiles / 4)
     int n_tsplit;                    // workgroups along time
+    int interleave;                  // beams are dealt to the column tiles of a wave 4 (pairs: 2) at a time: see beam_of_tile
 };
+
+// Which beam MFMA column c of a wave's column tile t computes.  A wave owns 64 consecutive beams (paired: 32 base
+// beams and their mirror images).  Interleaved (n_beams % 64 == 0): beam = first + 4c + t (paired: 2c + t), so a lane's
+// four results of one output are 4 (2 + 2) consecutive floats -> one 16-byte (two 8-byte) stores per lane, 256 (128)
+// contiguous bytes per lane group, instead of four scattered 64-byte rows.  Otherwise: tile t = beams first + 16t + c.
+__host__ __device__ inline int beam_of_tile(int interleave, int paired, int tile, int c)
+{
+    const int per = paired ? 2 : 4;                    // column tiles per wave
+    if (!interleave) return tile * 16 + c;
+    return (tile / per) * (16 * per) + per * c + tile % per;
+}
 
 // blockIdx -> (frequency f, beam group bg, time split ts).  Workgroups are dealt round-robin over the 8 XCDs, each
 // with its own L2, so blocks b and b+8 share an L2: the low 3 bits of the block index select f % 8 (a frequency
@@ -287,7 +302,7 @@ __global__ __launch_bounds__(kThreads16, AIN > 64 ? 2 : DSABF_OCC16) void fused1
         wave_active = pct0 < n_pct;
 #pragma unroll
         for (int t = 0; t < NT; t++) {
-            const int bb = (pct0 + t) * 16 + c16;         // base beam (< n_beams / 2)
+            const int bb = beam_of_tile(a.interleave, 1, pct0 + t, c16);  // base beam (< n_beams / 2)
             const bool ok = pct0 + t < n_pct;
             slot_beam[2 * t] = ok ? bb : a.n_beams;
             slot_beam[2 * t + 1] = ok ? a.n_beams - 1 - bb : a.n_beams;
@@ -305,7 +320,7 @@ __global__ __launch_bounds__(kThreads16, AIN > 64 ? 2 : DSABF_OCC16) void fused1
 #pragma unroll
         for (int t = 0; t < NT; t++) {
             const bool ok = ct0 + t < n_ctiles;
-            slot_beam[t] = ok ? (ct0 + t) * 16 + c16 : a.n_beams;
+            slot_beam[t] = ok ? beam_of_tile(a.interleave, 0, ct0 + t, c16) : a.n_beams;
 #pragma unroll
             for (int k = 0; k < 4; k++)                    // k = 2*rho + s
 #pragma unroll
@@ -428,6 +443,22 @@ __global__ __launch_bounds__(kThreads16, AIN > 64 ? 2 : DSABF_OCC16) void fused1
     int pend_chunk[PEND];                  // chunk whose finished sums sit in pend[gi] (-1: none); tracked per entry
 #pragma unroll                             // because entry 0 of chunk c can be parked before entry 1 of chunk c-1 left
     for (int gi = 0; gi < PEND; gi++) pend_chunk[gi] = -1;
+    // x[sl] -> row[beam of slot sl]; `row` points at beam 0 of one output's frequency row.  Interleaved tiles give every
+    // lane consecutive beams: vector stores.
+    auto store_slots = [&](float* row, const float (&x)[NS]) {
+        if (a.interleave) {
+            if constexpr (PAIRED) {   // slots 0, 2 = base beams bb, bb + 1; slots 1, 3 = their mirrors B-1-bb, B-2-bb
+                *reinterpret_cast<v2f*>(row + slot_beam[0]) = v2f{x[0], x[2]};
+                *reinterpret_cast<v2f*>(row + slot_beam[3]) = v2f{x[3], x[1]};
+            } else {
+                *reinterpret_cast<v4f*>(row + slot_beam[0]) = v4f{x[0], x[1], x[2], x[3]};
+            }
+        } else {
+#pragma unroll
+            for (int sl = 0; sl < NS; sl++)
+                if (slot_beam[sl] < a.n_beams) row[slot_beam[sl]] = x[sl];
+        }
+    };
     auto flush_pending = [&]() {
         if constexpr (LONG && !WRITE_C) {
 #pragma unroll
@@ -436,11 +467,7 @@ __global__ __launch_bounds__(kThreads16, AIN > 64 ? 2 : DSABF_OCC16) void fused1
                     const unsigned grp = (NIPO >= 32) ? (unsigned)(pend_chunk[gi] / CPG) : (2u * pend_chunk[gi] + gi);
                     float* ub = a.out + ((size_t)(4u * grp) * FB + (size_t)f * a.n_beams);  // wave-uniform part
                     const unsigned o = 4u * grp + (unsigned)g4;
-                    if (o * (unsigned)L < a.S) {
-#pragma unroll
-                        for (int sl = 0; sl < NS; sl++)
-                            if (slot_beam[sl] < a.n_beams) ub[(size_t)g4 * FB + slot_beam[sl]] = pend[gi][sl];
-                    }
+                    if (o * (unsigned)L < a.S) store_slots(ub + (size_t)g4 * FB, pend[gi]);
                 }
                 pend_chunk[gi] = -1;
             }
@@ -461,6 +488,7 @@ __global__ __launch_bounds__(kThreads16, AIN > 64 ? 2 : DSABF_OCC16) void fused1
             if (c + 1 < c_end) write_chunk(nxt);
             if (c + 2 < c_end) load_chunk(c + 2);
         } else {
+            [[maybe_unused]] float ov[2][NS];   // n_ipo < 16: the outputs the current tile completed, per slot
             // detect + accumulate the 4 samples (fr, fi: accumulator bit patterns K + 16 n) of output slot sl
             auto detect = [&](const int t8, const v4f fr, const v4f fi, const int sl) {
                 // stream position of this tile's rows and whether it starts / ends an output
@@ -517,20 +545,15 @@ __global__ __launch_bounds__(kThreads16, AIN > 64 ? 2 : DSABF_OCC16) void fused1
                             pend_chunk[gi] = c;
                         }
                     } else {
-                        // 16-sample stream = 16/NIPO outputs; registers r hold positions q4 + r
-                        const bool valid = (o * 16u < a.S) && (beam < a.n_beams);
-                        float* op = a.out + ((size_t)o * (16 / NIPO)) * FB + (size_t)f * a.n_beams + beam;
+                        // 16-sample stream = 16/NIPO outputs; registers r hold positions q4 + r.  Finished outputs are
+                        // collected per slot (ov) and stored together after the tile's last column tile.
                         if constexpr (NIPO == 2) {
-                            const float o0 = p[0] + p[1], o1 = p[2] + p[3];
-                            if (valid) {
-                                op[(size_t)(q4 / 2) * FB] = o0;
-                                op[(size_t)(q4 / 2 + 1) * FB] = o1;
-                            }
+                            ov[0][sl] = p[0] + p[1];
+                            ov[1][sl] = p[2] + p[3];
                         } else if constexpr (NIPO == 4) {
                             float sacc = p[0] + p[1];
                             sacc = sacc + p[2];
-                            sacc = sacc + p[3];
-                            if (valid) op[(size_t)(q4 / 4) * FB] = sacc;
+                            ov[0][sl] = sacc + p[3];
                         } else {  // NIPO == 8
                             float sacc = (q4 % 8 == 0) ? p[0] : (sum[sl] + p[0]);
                             sacc = sacc + p[1];
@@ -538,7 +561,25 @@ __global__ __launch_bounds__(kThreads16, AIN > 64 ? 2 : DSABF_OCC16) void fused1
                             sacc = sacc + p[3];
                             asm volatile("" : "+v"(sacc));
                             sum[sl] = sacc;
-                            if (q4 % 8 == 4 && valid) op[(size_t)(q4 / 8) * FB] = sacc;
+                            ov[0][sl] = sacc;
+                        }
+                    }
+                }
+            };
+            // stores of the outputs a short-window (n_ipo < 16) tile completed
+            auto store_short = [&](const int t8) {
+                if constexpr (!LONG && !WRITE_C) {
+                    const int gi = t8 >> 2, q4 = 4 * (t8 & 3);
+                    const unsigned o = 4u * (2u * (unsigned)c + gi) + (unsigned)g4;   // this lane's 16-sample stream
+                    if (o * 16u < a.S) {
+                        float* base = a.out + ((size_t)o * (16 / NIPO)) * FB + (size_t)f * a.n_beams;
+                        if constexpr (NIPO == 2) {
+                            store_slots(base + (size_t)(q4 / 2) * FB, ov[0]);
+                            store_slots(base + (size_t)(q4 / 2 + 1) * FB, ov[1]);
+                        } else if constexpr (NIPO == 4) {
+                            store_slots(base + (size_t)(q4 / 4) * FB, ov[0]);
+                        } else {
+                            if (q4 % 8 == 4) store_slots(base + (size_t)(q4 / 8) * FB, ov[0]);
                         }
                     }
                 }
@@ -611,6 +652,7 @@ __global__ __launch_bounds__(kThreads16, AIN > 64 ? 2 : DSABF_OCC16) void fused1
                     issue(a0, a1, t, re, im);
                     consume(t8, t, re, im);
                 }
+                store_short(t8);
                 staging(t8);
             }
         }
@@ -635,9 +677,9 @@ __global__ void pair_check_kernel(const int8_t* __restrict__ w, size_t n_fa, int
 }
 
 // Paired weight image: image[f][pct][comp][h][lane] (16 bytes): lane = 16*kb + c; byte i = Wr (comp 0), Wi (comp 1) or
-// -Wi (comp 2) of antenna 64*h + 16*kb + i (zero behind the last antenna) for base beam 16*pct + c (< n_beams / 2).
+// -Wi (comp 2) of antenna 64*h + 16*kb + i (zero behind the last antenna) for base beam beam_of_tile(pct, c) (< n_beams / 2).
 __global__ void weight_relayout16p_kernel(const int8_t* __restrict__ w, v4i* __restrict__ image, int n_freq, int n_ant,
-                                          int n_beams, int ks)
+                                          int n_beams, int ks, int interleave)
 {
     const int n_pct = n_beams / 32;
     const size_t total = (size_t)n_freq * n_pct * 3 * ks * 64;
@@ -650,7 +692,7 @@ __global__ void weight_relayout16p_kernel(const int8_t* __restrict__ w, v4i* __r
         r /= 3;
         const int pct = (int)(r % n_pct);
         const int f = (int)(r / n_pct);
-        const int kb = lane >> 4, b = pct * 16 + (lane & 15);
+        const int kb = lane >> 4, b = beam_of_tile(interleave, 1, pct, lane & 15);
         unsigned d[4] = {0, 0, 0, 0};
         for (int i = 0; i < 16; i++) {
             const int ant = 64 * h + kb * 16 + i;
@@ -665,9 +707,9 @@ __global__ void weight_relayout16p_kernel(const int8_t* __restrict__ w, v4i* __r
 
 // 16x16x64 weight image: image[f][ct16][rho][s][h][lane] (16 bytes): lane = 16*kb + c; byte i multiplies LDS chunk
 // 4*s + kb of the A row of k-step h = component s (0 = re, 1 = im) of antenna 64*h + 16*kb + i (zero behind the last
-// antenna), for output row rho of beam 16*ct16 + c.
+// antenna), for output row rho of beam beam_of_tile(ct16, c).
 __global__ void weight_relayout16_kernel(const int8_t* __restrict__ w, v4i* __restrict__ image, int n_freq, int n_ant,
-                                         int n_beams, int ks, int* __restrict__ bad)
+                                         int n_beams, int ks, int interleave, int* __restrict__ bad)
 {
     const int n_ct = n_beams / 16;
     const size_t total = (size_t)n_freq * n_ct * 2 * 2 * ks * 64;
@@ -682,7 +724,7 @@ __global__ void weight_relayout16_kernel(const int8_t* __restrict__ w, v4i* __re
         r >>= 1;
         const int ct = (int)(r % n_ct);
         const int f = (int)(r / n_ct);
-        const int kb = lane >> 4, b = ct * 16 + (lane & 15);
+        const int kb = lane >> 4, b = beam_of_tile(interleave, 0, ct, lane & 15);
         unsigned d[4] = {0, 0, 0, 0};
         for (int i = 0; i < 16; i++) {
             const int ant = 64 * h + kb * 16 + i;
@@ -774,6 +816,7 @@ bool use16(const Geometry& g)
     return (g.n_ant == 16 || g.n_ant == 32 || g.n_ant == 100 || g.n_ant == 128) && (g.n_ipo == 2 || g.n_ipo == 32);
 }
 int ksteps16(const Geometry& g) { return g.n_ant > 64 ? 2 : 1; }
+int interleaved(const Geometry& g) { return DSABF_INTERLEAVE && g.n_beams % 64 == 0; }  // every wave owns 64 whole beams
 
 int ilog2_exact(int v)
 {
@@ -870,6 +913,7 @@ static FusedArgs make_args(const Geometry& g, const void* d_image, const void* d
     a.S = (unsigned)((long long)n_units * g.n_time);
     a.chunks_total = ls.chunks_total;
     a.n_tsplit = ls.n_tsplit;
+    a.interleave = interleaved(g);
     return a;
 }
 
@@ -908,10 +952,10 @@ hipError_t launch_weight_relayout(const Geometry& g, const int8_t* d_w, void* d_
         int rgrid = (int)((weight_pair_image_bytes(g) / 16 + 255) / 256);
         if (rgrid > 4096) rgrid = 4096;
         hipLaunchKernelGGL(weight_relayout16p_kernel, dim3(rgrid), dim3(256), 0, s, d_w, static_cast<v4i*>(d_pair_image),
-                           g.n_freq, g.n_ant, g.n_beams, ksteps16(g));
+                           g.n_freq, g.n_ant, g.n_beams, ksteps16(g), interleaved(g));
     }
     hipLaunchKernelGGL(weight_relayout16_kernel, dim3(grid), dim3(256), 0, s, d_w, static_cast<v4i*>(d_image), g.n_freq,
-                       g.n_ant, g.n_beams, ksteps16(g), d_bad);
+                       g.n_ant, g.n_beams, ksteps16(g), interleaved(g), d_bad);
     return hipGetLastError();
 }
 
