@@ -315,6 +315,31 @@ def main():
                 out["general_kernel"] = supplementary(0, env="0")
                 out["general_kernel"]["note"] = ("DSABF_PAIRED=0: every int8 op of the algorithmic count executes on "
                                                  "the MFMA pipe; not the headline")
+        if world == 1 and args.workload == "c3" and not args.no_extras:
+            # supplementary: BASELINE configs[1], the reference's DEBUG geometry (N_TIME 16, n_ipo 2) -- the parity
+            # configuration; HBM-write-bound (4 B out per 0.125 B in per beam), so its roofline is the HBM one
+            cfg3 = bfm.production_config(n_avg=1, n_out_per_gemm=8, n_freq=n_freq)
+            bf3 = bfm.Beamformer(cfg3, device=local)
+            bf3.set_weights(product_weights(torch, cfg3, 0))
+            in3 = units * n_freq * 16 * cfg3.n_ant
+            out3 = torch.empty(units * 8 * n_freq * cfg3.n_beams, dtype=torch.float32, device="cuda")
+            for i in range(10):
+                bf3.beamform(d_in[i % len(d_in)][:in3], units, out3, sptr)
+            ev3 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(100)]
+            for i, (a, b) in enumerate(ev3):
+                a.record(stream)
+                bf3.beamform(d_in[i % len(d_in)][:in3], units, out3, sptr)
+                b.record(stream)
+            torch.cuda.synchronize()
+            ms3 = sum(a.elapsed_time(b) for a, b in ev3) / len(ev3)
+            bytes3 = (cfg3.n_ant * 2 * n_freq + 4 * cfg3.n_beams * n_freq) * units * 8
+            out["debug_geometry"] = {"workload": "C2: BASELINE configs[1], N_TIME=16 (8 outputs x n_ipo 2), %d gemm-units per launch" % units,
+                                     "value": units * 8 / (ms3 * 1e-3), "unit": "beam-blocks/s", "kernel_ms_avg": ms3,
+                                     "kernel": bf3.kernel_info(units)["kernel"],
+                                     "roofline": {"bound": "hbm", "achieved": bytes3 / (ms3 * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                                                  "unit": "GB/s", "frac": bytes3 / (ms3 * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                                     "note": "not the headline; bit-exact parity on this geometry is what tests/ check"}
+            bf3.close()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, n_avg, n_out, args.cpu_seconds)
         print(json.dumps(out), flush=True)

@@ -883,7 +883,9 @@ LaunchShape fused_launch_shape(const Geometry& g, int n_units, int n_cus)
     const int groups_avail = ls.chunks_total / cpg;
     const int max_split = groups_avail >= 2 ? groups_avail / 2 : 1;
     int want = (groups_avail + 10) / 20;                                       // ~20 chunk-groups per workgroup
-    const int target_wgs_per_cu = 2 * (16 / kWaves16);
+    // short windows (n_ipo < 16) are store-bound: fewer, longer workgroups measured better (C2: 2 per CU 0.54 of the
+    // HBM peak, 8 per CU 0.49); the MFMA-bound shapes want ~2 resident sets of 4
+    const int target_wgs_per_cu = g.n_ipo < 16 ? 2 : 2 * (16 / kWaves16);
     int want_fill = (target_wgs_per_cu * n_cus + base - 1) / base;            // enough workgroups to fill the chip
     if (want_fill > max_split) want_fill = max_split;
     if (want < want_fill) want = want_fill;
