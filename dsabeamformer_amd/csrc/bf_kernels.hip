@@ -48,15 +48,14 @@
 #define DSABF_FASTADDR 1  // scalar chunk addressing in fused16_kernel when gemm-units are a multiple of the chunk span
 #endif
 #ifndef DSABF_OCC16
-#define DSABF_OCC16 3     // 147 VGPRs, no spills; 4 would spill 15 registers for no gain (the kernel is energy-bound)
+#define DSABF_OCC16 3     // register budget of the 64-antenna variants (168): the general kernel needs 153 VGPRs; the paired
+                          // one (101) reaches 4 workgroups per CU by itself; capping at 128 spills for no gain
 #endif
 
 namespace dsabf {
 
 typedef int v4i __attribute__((ext_vector_type(4)));
-typedef int v16i __attribute__((ext_vector_type(16)));
 typedef float v2f __attribute__((ext_vector_type(2)));
-typedef float v16f __attribute__((ext_vector_type(16)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 
 namespace {
@@ -77,7 +76,7 @@ struct FusedArgs {
     int T;                           // time samples per gemm-unit
     int t_shift;                     // log2(T) if T is a power of two, else -1
     unsigned S;                      // total time samples per frequency in this launch (n_units * T)
-    int chunks_total;                // ceil(tiles / 4)
+    int chunks_total;                // 128-sample chunks per frequency in this launch
     int n_tsplit;                    // workgroups along time
     int interleave;                  // beams are dealt to the column tiles of a wave 4 (pairs: 2) at a time: see beam_of_tile
 };
