@@ -67,24 +67,14 @@ class DetectedGather:
             self.full = [torch.empty((n_outputs, self.F, n_beams), dtype=f32, device=device) if self.rank == 0 else None
                          for _ in range(slots)]
         self.pending = [None] * slots
+        # On GPUs the wait for the collective and the re-layout into [o][f][b] run on a side stream, so the compute
+        # stream never waits for RCCL or for the (HBM-bound) permute copy of a step it is not about to overwrite.
+        self.on_gpu = str(device).startswith("cuda")
+        if self.on_gpu:
+            self.side = torch.cuda.Stream(device=device)
+            self.done = [torch.cuda.Event() for _ in range(slots)]
 
-    def start(self, slot: int, local_out):
-        """Launch the collective for `local_out` (flat or [n_outputs][f_local][n_beams]); returns immediately."""
-        assert self.pending[slot] is None, "finish(slot) before reusing it"
-        flat = local_out.reshape(-1)
-        if self.mode == "alltoall":
-            # chunk j of the send buffer = outputs j*n/R.. of MY frequencies -> rank j
-            self.pending[slot] = self.dist.all_to_all_single(self.recv[slot], flat, group=self.group, async_op=True)
-        else:
-            self.pending[slot] = self.dist.gather(flat, self.recv[slot] if self.rank == 0 else None, dst=0,
-                                                  group=self.group, async_op=True)
-
-    def finish(self, slot: int):
-        """Wait for the collective of `slot` and return the assembled tensor in the reference layout [o][f][b]."""
-        if self.pending[slot] is None:
-            return self.full[slot]
-        self.pending[slot].wait()
-        self.pending[slot] = None
+    def _assemble(self, slot: int):
         R = self.world
         if self.mode == "alltoall":
             # received [src rank = frequency shard][o_local][f_local][b] -> [o_local][shard][f_local][b]
@@ -94,6 +84,35 @@ class DetectedGather:
             dst = self.full[slot].view(self.no, R, self.fl, self.nb)
             for r in range(R):
                 dst[:, r].copy_(self.recv[slot][r].view(self.no, self.fl, self.nb))
+
+    def start(self, slot: int, local_out):
+        """Launch the collective for `local_out` (flat or [n_outputs][f_local][n_beams]); returns immediately."""
+        assert self.pending[slot] is None, "finish(slot) before reusing it"
+        flat = local_out.reshape(-1)
+        if self.mode == "alltoall":
+            # chunk j of the send buffer = outputs j*n/R.. of MY frequencies -> rank j
+            work = self.dist.all_to_all_single(self.recv[slot], flat, group=self.group, async_op=True)
+        else:
+            work = self.dist.gather(flat, self.recv[slot] if self.rank == 0 else None, dst=0,
+                                    group=self.group, async_op=True)
+        self.pending[slot] = work
+        if self.on_gpu:
+            with self.torch.cuda.stream(self.side):
+                work.wait()            # stream-level: the side stream waits for RCCL, the host does not block
+                self._assemble(slot)
+                self.done[slot].record(self.side)
+
+    def finish(self, slot: int):
+        """Make the caller's stream wait for the collective of `slot` and return the assembled tensor in the reference
+        layout [o][f][b] (also: `local_out` of that slot may be overwritten by work queued after this call)."""
+        if self.pending[slot] is None:
+            return self.full[slot]
+        if self.on_gpu:
+            self.torch.cuda.current_stream().wait_event(self.done[slot])
+        else:
+            self.pending[slot].wait()
+            self._assemble(slot)
+        self.pending[slot] = None
         return self.full[slot]
 
 
