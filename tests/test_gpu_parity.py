@@ -845,3 +845,30 @@ def test_wide_antenna_fast_detect_tolerance(torch, bfmod, orc):
     got = _run(torch, bf, packed, want.size).reshape(want.shape)
     rel = np.abs(got.astype(np.float64) - want) / np.maximum(want.astype(np.float64), 1e-30)
     assert rel.max() <= 4 * g.n_ipo * 2.0 ** -24
+
+
+@pytest.mark.parametrize("gpu", [0, 5])
+def test_grid_configuration_debug_flow_bit_identical(bfmod, orc, gpu):
+    """The reference's 2-D configuration end to end through the DEBUG flow (`beam -p grid_positions -d
+    grid_beam_directions -s grid_source_directions_4096 -g <gpu>`): 8x8 antenna grid, 16x16 beam grid (conjugate-
+    symmetric -> the paired kernel), 4096 point sources = 4 generator batches with re-generation gating
+    (src/test_data_generator.hh:44-61), a non-zero sub-band (-g 5: integer-division channel offset,
+    src/beamformer.cu:233).  The dedispersed table [4096][256] must equal the oracle's, row for row."""
+    from conftest import CFG
+    from dsabeamformer_amd import host
+
+    cfg = bfmod.debug_config()
+    pos_f, dir_f = os.path.join(CFG, "grid_positions.txt"), os.path.join(CFG, "grid_beam_directions.txt")
+    src_f = os.path.join(CFG, "grid_source_directions_4096.txt")
+    ded, ms = host.run_debug_observation(cfg, gpu=gpu, positions=pos_f, directions=dir_f, sources=src_f, max_sources=4096)
+    assert ded.shape == (4096, 256) and ms > 0
+    g = orc.DEBUG_GEOM
+    pos, dirs, src = orc.read_positions(pos_f, 64), orc.read_directions(dir_f, 256), orc.read_directions(src_f)
+    assert src.shape == (4096, 2)
+    w = orc.make_weights(g, pos, dirs, gpu)
+    for batch in range(4):
+        packed = orc.generate_test_data(g, pos, src, gpu, batch_counter=batch)
+        out = orc.beamform(g, w, packed)                                   # [1024 units][8][256][256]
+        for u in range(0, 1024, 37):                                       # every 37th source of the batch + the last
+            assert np.array_equal(ded[batch * 1024 + u], orc.dedisperse(g, out[u])), (batch, u)
+        assert np.array_equal(ded[batch * 1024 + 1023], orc.dedisperse(g, out[1023]))
