@@ -17,15 +17,19 @@ def test_nibble_to_int8_times_16():
     assert np.array_equal(((b.astype(np.uint32) << 4) & 0xF0).astype(np.uint8).astype(np.int8).astype(np.int32), 16 * im)
 
 
+N_MAX = 128 * 2 * 127 * 8   # largest |sum|: 128 antennas x (re, im) x |w| <= 127 x |v| <= 8  (64 antennas: half)
+
+
 def test_magic_seed_is_exact_int_to_float():
-    n = np.arange(-130048, 130049, dtype=np.int64)  # |sum| <= 64*2*127*8
+    n = np.arange(-N_MAX, N_MAX + 1, dtype=np.int64)
+    assert 16 * N_MAX < 2 ** 22                      # K + 16 n stays inside [2^23, 2^24): unit spacing
     bits = (K_BITS + 16 * n).astype(np.uint32)
     assert np.array_equal(bits.view(np.float32).astype(np.float64), 12582912.0 + 16.0 * n)
 
 
 def test_single_fma_equals_convert_then_scale():
     assert float(K) * float(C16) == float(np.float32(K * C16)), "K*alpha/16 must be exactly representable"
-    n = np.arange(-130048, 130049, dtype=np.int64)
+    n = np.arange(-N_MAX, N_MAX + 1, dtype=np.int64)
     m = (12582912.0 + 16.0 * n)                              # exact in float32 (previous test)
     # fma(m, c16, -K*c16): the double product and difference are exact (<= 49 significant bits), so one
     # rounding to float32 is exactly the fma result
@@ -33,6 +37,17 @@ def test_single_fma_equals_convert_then_scale():
     want = n.astype(np.float32) * C127                       # oracle: (float)n * alpha
     assert np.array_equal(fma.view(np.uint32) & 0x7FFFFFFF, want.view(np.uint32) & 0x7FFFFFFF)
     assert np.array_equal(fma == 0, want == 0)
+
+
+def test_conjugate_pair_combinations_stay_exact():
+    """Paired kernel: P1, P3 carry the seed K, P2, P4 do not; (K + 16 P1) -+ 16 P2 as int32 adds must still be the bit
+    pattern of the float K + 16 (P1 -+ P2), i.e. stay inside [2^23, 2^24) for every reachable pair.  |P1| + |P2| is
+    bounded by the same 128*2*127*8 as the full sum (they split its terms), so the extreme cases are enough."""
+    half = N_MAX // 2
+    for p1, p2 in ((half, half), (half, -half), (-half, half), (-half, -half), (N_MAX, 0), (-N_MAX, 0), (0, N_MAX), (0, -N_MAX)):
+        for sgn in (1, -1):
+            bits = np.uint32((K_BITS + 16 * p1 + sgn * 16 * p2) & 0xFFFFFFFF)
+            assert float(bits.view(np.float32)) == 12582912.0 + 16.0 * (p1 + sgn * p2)
 
 
 def _sext4x4(nib):
