@@ -57,9 +57,9 @@ for a, b in ev:
 torch.cuda.synchronize()
 ms = sorted(a.elapsed_time(b) for a, b in ev)
 alg = 4 * (n_t * 256 * 256 + len(dms) * n_t_out * 256)
-loads = 4 * len(dms) * n_t_out * 256 * 256
+loads = 4 * len(dms) * n_t_out * 256 * 256   # one value per (trial, time, freq, beam): what a kernel without reuse loads
 res["dedisperse_dm"] = {"n_t": n_t, "n_dm": len(dms), "max_delay": int(delays.max()), "n_t_out": n_t_out,
                         "ms_median": ms[len(ms) // 2], "algorithmic_bytes": alg,
                         "algorithmic_GBps": alg / (ms[len(ms) // 2] * 1e-3) / 1e9,
-                        "load_bytes_issued": loads, "load_GBps": loads / (ms[len(ms) // 2] * 1e-3) / 1e9}
+                        "bytes_summed": loads, "summed_GBps": loads / (ms[len(ms) // 2] * 1e-3) / 1e9}
 print(json.dumps(res))
