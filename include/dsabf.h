@@ -58,7 +58,7 @@ typedef struct bf_config {
 
 /* detect_mode.  CANONICAL evaluates the reference's `acc += x*x + y*y` (src/beamformer.cuh:150-152) literally: two
  * multiplies, one add, one accumulate add per sample, ascending time order -> bit-identical to the CPU restatement.
- * FAST (64-antenna geometries with n_pol*n_avg >= 16; ignored elsewhere) accumulates the unscaled integer voltages with
+ * FAST (geometries with n_pol*n_avg >= 16; ignored elsewhere) accumulates the unscaled integer voltages with
  * fused multiply-adds and applies (1/127)^2 once per output: 4 instead of 6 VALU ops per sample; the result is within
  * 4*n_ipo*2^-24 relative of the canonical one (it is the more accurate of the two w.r.t. exact arithmetic). */
 #define BF_DETECT_CANONICAL 0
@@ -91,7 +91,10 @@ int bf_get_config(const bf_handle *h, bf_config *cfg);
 
 /* Replaces the weight upload src/beamformer.cu:251,272.  `w` is a HOST array in the reference layout
  * [freq][ant][beam]{re,im} int8; the library re-lays it out once for the MFMA operand fragments.
- * Imaginary parts must be >= -127 (the reference's round(127*sin) never produces -128). */
+ * Imaginary parts must be >= -127 (the reference's round(127*sin) never produces -128).
+ * If W[f][a][n_beams-1-b] == conj(W[f][a][b]) for every f, a, b -- any beam set symmetric about the boresight, e.g. the
+ * reference's -- the library notices (checked on the device, exactly) and runs a kernel that forms each such beam pair
+ * from shared products: half the matrix-core work, identical results.  Nothing to configure. */
 int bf_set_weights(bf_handle *h, const int8_t *w);
 /* Same, from a DEVICE array (caller-owned HBM, e.g. weights computed on the GPU or a sharded slice). */
 int bf_set_weights_device(bf_handle *h, const int8_t *d_w, void *hip_stream);
