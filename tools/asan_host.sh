@@ -1,5 +1,5 @@
 #!/bin/bash
-# One-off sanitizer run of the host-side C++ (bf_host.cpp, bf_runtime.cpp) and of the oracle on the CPU
+# One-off sanitizer run of the host-side C++ (bf_host.cpp, bf_runtime.cpp, bf_shmring.cpp) and of the oracle on the CPU
 # (GPU AddressSanitizer is not available on this pool).  Temporarily swaps the built libraries; restores them afterwards.
 set -e
 cd "$(dirname "$0")/.."
@@ -7,7 +7,8 @@ CXX=/opt/rocm/lib/llvm/bin/clang++
 python -m dsabeamformer_amd.build >/dev/null
 $CXX -O1 -g -std=c++17 -fPIC -ffp-contract=off -fsanitize=address,undefined -fno-omit-frame-pointer -Iinclude \
     -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -shared -o /tmp/libhost_asan.so dsabeamformer_amd/csrc/bf_host.cpp \
-    dsabeamformer_amd/csrc/bf_runtime.cpp dsabeamformer_amd/build/bf_kernels.hip.o -lpthread
+    dsabeamformer_amd/csrc/bf_runtime.cpp dsabeamformer_amd/csrc/bf_shmring.cpp dsabeamformer_amd/build/bf_kernels.hip.o \
+    -lpthread -lrt
 cp dsabeamformer_amd/libdsabf.so /tmp/libdsabf_keep.so
 cp /tmp/libhost_asan.so dsabeamformer_amd/libdsabf.so
 ASAN_OPTIONS=detect_leaks=0:verify_asan_link_order=0 LD_PRELOAD=$($CXX -print-file-name=libclang_rt.asan-x86_64.so) \
