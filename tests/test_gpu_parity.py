@@ -445,7 +445,8 @@ def test_gemm_stage_many_chunks_bit_exact(torch, bfmod, orc, n_ant, n_avg, n_out
     assert np.array_equal(d_c.cpu().numpy().reshape(want.shape), want)
 
 
-@pytest.mark.parametrize("n_freq,n_beams,n_avg", [(8, 512, 16), (16, 288, 1), (24, 512, 8), (8, 32, 32)])
+@pytest.mark.parametrize("n_freq,n_beams,n_avg", [(8, 512, 16), (16, 288, 1), (24, 512, 8), (8, 32, 32), (3, 320, 16),
+                                                  (2, 576, 1), (4, 64, 4)])
 def test_xcd_block_map_and_beam_groups_bit_exact(torch, bfmod, orc, n_freq, n_beams, n_avg):
     """n_freq % 8 == 0 takes the XCD-aware block decode; n_beams > 256 gives several beam groups per frequency,
     n_beams = 288 a partially filled last group; several time splits and chunks per workgroup."""
@@ -542,7 +543,8 @@ def test_pairing_is_decided_per_weight_set(torch, bfmod, orc):
     assert "PAIRED" in bfd.kernel_info(1)["kernel"]
 
 
-@pytest.mark.parametrize("n_freq,n_beams,n_avg", [(8, 512, 16), (16, 288, 1), (24, 512, 8), (8, 32, 32), (5, 544, 16)])
+@pytest.mark.parametrize("n_freq,n_beams,n_avg", [(8, 512, 16), (16, 288, 1), (24, 512, 8), (8, 32, 32), (5, 544, 16),
+                                                  (3, 320, 16), (2, 576, 1), (4, 64, 4)])
 def test_conjugate_paired_beam_groups_bit_exact(torch, bfmod, orc, n_freq, n_beams, n_avg):
     """Paired kernel across several beam groups (base beams of one workgroup pair with the far end of the beam axis),
     a partially filled last group, and the XCD-aware block decode."""
