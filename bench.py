@@ -88,8 +88,13 @@ def pmc_traffic(args, world):
     """HBM bytes per launch of the fused kernel from the committed rocprofv3 PMC passes (tools/pmc.sh: FETCH_SIZE
     and WRITE_SIZE collected in separate passes, KiB units; FETCH_SIZE doubled per MI355X_MICROARCH.md section HBM --
     gfx950 tallies 128-B read requests at 64 B).  Only valid for the exact launch it was measured on."""
-    path = os.path.join(ROOT, "profiles", "r01_c3_pmc_summary.txt")
-    if not (args.workload == "c3" and args.units == 128 and world == 1 and os.path.exists(path)):
+    # (workload, units) each committed summary was measured on
+    measured = {("c3", 128): "r01_c3_pmc_summary.txt", ("c5", 16): "r01_c5_pmc_summary.txt"}
+    name = measured.get((args.workload, args.units))
+    if name is None or world != 1:
+        return None
+    path = os.path.join(ROOT, "profiles", name)
+    if not os.path.exists(path):
         return None
     vals = {}
     for line in open(path):
@@ -250,7 +255,7 @@ def main():
                      "kernel_ms_min": kern_ms[0], "algorithmic_ops_per_launch": launch_ops,
                      "algorithmic_bytes_per_launch": launch_bytes,
                      "note": "unit is int8 TOP/s (1 complex MAC = 8 ops); traffic = HBM bytes per launch from the "
-                             "committed PMC passes (profiles/r01_c3_pmc_summary.txt), null if this launch differs"})
+                             "committed PMC passes (profiles/r01_c3_pmc_summary.txt, r01_c5_pmc_summary.txt), null if this launch differs"})
         out = {
             "metric": "beam-blocks/sec (%d beams x %d freq x N_TIME)" % (cfg.n_beams, n_freq_total), "value": value,
             "unit": "beam-blocks/s",
