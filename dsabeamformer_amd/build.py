@@ -17,8 +17,10 @@ ROOT = os.path.dirname(PKG)
 HIPCC = os.environ.get("HIPCC") or shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 # -ffp-contract=off: the detect stage's x*x + y*y must be two multiplies and one add (bit-exact contract).
 # -fno-slp-vectorize: keep the detect epilogue on plain fp32 VALU ops (packed v_pk_*_f32 do not co-execute with MFMA).
+# -amdgpu-sched-strategy=max-ilp: the fused kernel's unrolled tile loop schedules 1-2 % faster than with the default
+#   occupancy-driven strategy (profiles/r01_variants_paired_log.txt); register counts stay inside every variant's budget.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize", "-Wall",
-         "-Wno-unused-function",
+         "-Wno-unused-function", "-mllvm", "-amdgpu-sched-strategy=max-ilp",
          "-I" + os.path.join(ROOT, "include")] + os.environ.get("DSABF_EXTRA_FLAGS", "").split()
 
 
