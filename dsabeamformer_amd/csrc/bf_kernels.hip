@@ -255,8 +255,9 @@ __global__ __launch_bounds__(kDmThreads) void dedisperse_dm_kernel(const float* 
 // halves the LDS fragment traffic per MFMA, and the detect of one tile interleaves with the MFMAs of the next in the
 // wave's own in-order stream.
 //
-// Mapping (K' = 128 = 64 re | 64 im, two k-steps of 64):
-//   A operand: 16 time rows; lane l supplies row l&15, bytes 16*(l>>4).. of the k-step (LDS chunk 4*s + (l>>4)).
+// Mapping, per group of 64 antennas (K' = 128 = 64 re | 64 im = two MFMAs of K = 64 chained through srcC):
+//   A operand: 16 time rows; lane l supplies row l&15, bytes 16*(l>>4).. of the re (s = 0) or im (s = 1) half (LDS piece
+//              4*s + (l>>4)).
 //   D tile   : lane (column c = l&15, group g = l>>4) holds rows 4g..4g+3 in 4 registers.  Row 4g+r of a tile is
 //              position 4*q + r of STREAM g, so every lane accumulates one output at a time, in time order, and a
 //              128-row chunk holds 4 streams x 32 positions (n_ipo >= 32) or 2 x 4 streams x 16 positions.
