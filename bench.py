@@ -229,6 +229,13 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    if args.force_dist and world == 1 and gather is not None:
+        # one rank: the gathered tensor must be the kernel's output of that slot, re-laid out as [o][f][b] (= unchanged)
+        for slot in (0, 1):
+            got = gather.full[slot]
+            if got is not None and not torch.equal(got.reshape(-1), d_out[slot]):
+                sys.exit("gather plumbing check failed: slot %d differs from the kernel output" % slot)
+
     kern_ms = sorted(a.elapsed_time(b) for a, b in events)
     kern_avg_ms = sum(kern_ms) / len(kern_ms)
 

@@ -874,3 +874,24 @@ def test_grid_configuration_debug_flow_bit_identical(bfmod, orc, gpu):
         for u in range(0, 1024, 37):                                       # every 37th source of the batch + the last
             assert np.array_equal(ded[batch * 1024 + u], orc.dedisperse(g, out[u])), (batch, u)
         assert np.array_equal(ded[batch * 1024 + 1023], orc.dedisperse(g, out[1023]))
+
+
+@pytest.mark.parametrize("mode", ["alltoall", "root"])
+def test_bench_rccl_gather_plumbing_on_one_gpu(mode):
+    """bench.py --force-dist: the multi-GPU path (RCCL process group, DetectedGather on its side stream, double
+    buffering) with world size 1 -- what can be exercised of it on a 1-GPU box.  The gathered result of the last steps
+    must be the kernel's output re-laid out as [o][f][b] (identity for one rank), and the JSON line must be well formed."""
+    import json
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29600 + (os.getpid() % 300)))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--force-dist", "--gather", mode, "--units", "16",
+                        "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--no-extras"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 1 and d["config"]["gather"] == mode and d["value"] > 0 and d["roofline"]["frac"] > 0.05
