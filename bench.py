@@ -132,6 +132,8 @@ def cpu_baseline(args, n_avg, n_out, seconds):
 
 def main():
     args = parse()
+    # the pool's host driver only supports dmabuf IPC; without this RCCL's cross-process handles fail
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
 
     rank = int(os.environ.get("RANK", "0"))
