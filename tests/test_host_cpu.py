@@ -370,3 +370,31 @@ def test_oracle_dedisperse_dm_properties(orc):
         pulse[5 + delays[1, f], f, :] = 1.0
     out = orc.dedisperse_dm(pulse, delays, n_t - int(delays.max()))
     assert out[1, 5, 0] == n_f and out[1].max() == n_f and out[0].max() < n_f and out[2].max() < n_f
+
+
+def test_sink_and_ring_error_paths(host, bfm, tmp_path):
+    """A sink on an unwritable path and a reader on a ring that does not exist fail with an error code, not a crash;
+    an oversized write to a ring is rejected."""
+    cfg = bfm.debug_config()
+    with pytest.raises(Exception):
+        host.FileSink(cfg, str(tmp_path / "no_such_dir" / "x.bin"))
+    lib = host.load()
+    import ctypes as C
+
+    h = C.c_void_p()
+    assert lib.bfh_shm_ring_attach(b"dsabf_no_such_ring", 50, C.byref(h)) < 0
+    name = _ring_name("e")
+    ring = host.ShmRing(name, n_blocks=2, block_size=1024)
+    try:
+        with pytest.raises(Exception):
+            ring.write(np.zeros(2048, np.uint8))       # larger than a block
+        assert host.ShmRing(name).block_size == 1024   # a second attach sees the same geometry
+        with pytest.raises(Exception):
+            host.ShmRing(name, n_blocks=host_max_blocks() + 1, block_size=64)
+    finally:
+        ring.detach()
+        ring.unlink()
+
+
+def host_max_blocks():
+    return 64   # dsabf::kMaxRingBlocks
