@@ -44,6 +44,9 @@
 #ifndef DSABF_INTERLEAVE
 #define DSABF_INTERLEAVE 1 // deal beams to a wave's column tiles 4 (pairs: 2) at a time -> 16- / 8-byte stores (beam_of_tile)
 #endif
+#ifndef DSABF_CLOCKPROBE
+#define DSABF_CLOCKPROBE 0 // diagnostic build only (tools/clock_probe.sh): every workgroup overwrites out[blockIdx.x] with its
+#endif                     // in-kernel shader clock in GHz (s_memtime / s_memrealtime around the chunk loop); results invalid
 #ifndef DSABF_FASTADDR
 #define DSABF_FASTADDR 1  // scalar chunk addressing in fused16_kernel when gemm-units are a multiple of the chunk span
 #endif
@@ -514,6 +517,9 @@ __global__ __launch_bounds__(kThreads16, AIN > 64 ? 2 : DSABF_OCC16) void fused1
     };
 
     if (c_begin >= c_end) return;
+#if DSABF_CLOCKPROBE
+    const unsigned long long probe_t0 = __builtin_amdgcn_s_memtime(), probe_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
 
     load_chunk(c_begin);
     write_chunk(smem);
@@ -698,6 +704,13 @@ __global__ __launch_bounds__(kThreads16, AIN > 64 ? 2 : DSABF_OCC16) void fused1
         __syncthreads();
     }
     flush_pending();
+#if DSABF_CLOCKPROBE
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned long long dt = __builtin_amdgcn_s_memtime() - probe_t0, dr = __builtin_amdgcn_s_memrealtime() - probe_r0;
+        a.out[blockIdx.x] = (float)((double)dt / (double)dr * 0.1);  // s_memrealtime ticks at 100 MHz
+    }
+#endif
 }
 
 // Conjugate-pair test: *flag stays 0 iff W[f][a][B-1-b] == conj(W[f][a][b]) for every f, a and b < B/2.
