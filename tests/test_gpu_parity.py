@@ -895,3 +895,25 @@ def test_bench_rccl_gather_plumbing_on_one_gpu(mode):
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 1 and d["config"]["gather"] == mode and d["value"] > 0 and d["roofline"]["frac"] > 0.05
+
+
+@pytest.mark.parametrize("n_ant", [100, 128])
+def test_observation_loop_wide_antenna_geometry_bit_exact(bfmod, orc, tmp_path, n_ant):
+    """The production observation loop (ring slots, 4 queues, sink) on a DSA100-style geometry: 100 / 128 antennas go
+    through the two-k-step kernel via bf_enqueue_gemm_unit, one gemm-unit per launch, straight from PSRDADA-style
+    blocks; the whole detected stream is checked against the oracle (default linear geometry -> the paired kernel)."""
+    from dsabeamformer_amd import host
+
+    cfg = bfmod.production_config(n_freq=4)
+    cfg.n_ant, cfg.n_beams, cfg.n_gemms_per_block, cfg.n_streams = n_ant, 128, 8, 4
+    n_blocks, ring_blocks = 5, 2
+    path = str(tmp_path / "wide.bin")
+    r = host.run_observation_junk_to_file(cfg, n_blocks, path, ring_blocks=ring_blocks, seed=n_ant)
+    assert r["gemms_written"] == n_blocks * 8
+    hdr, data = host.read_detected_file(path)
+    assert int(hdr["N_ANTENNAS"]) == n_ant
+    g = orc.Geom(n_beams=128, n_ant=n_ant, n_freq=4, n_avg=16, n_out_per_gemm=cfg.n_out_per_gemm)
+    w = orc.make_weights(g, orc.default_positions(n_ant), orc.default_directions(128), 0)
+    for blk in range(n_blocks):
+        want = orc.beamform(g, w, r["ring"][blk % ring_blocks])
+        assert np.array_equal(data[blk * 8:(blk + 1) * 8].reshape(want.shape), want), blk
