@@ -320,6 +320,9 @@ def test_shm_ring_in_process_backpressure(host):
         t.start()
         import time
 
+        deadline = time.time() + 20
+        while len(wrote) < 2 and time.time() < deadline:
+            time.sleep(0.01)
         time.sleep(0.3)
         assert wrote == [0, 1]  # two slots: the third write is blocked until a block is read
         for i in range(6):
