@@ -27,13 +27,13 @@ int main(int argc, char* argv[])
     bf_config cfg;
     bf_config_default(&cfg, /*debug=*/1);
     debug_run_options opt;
-    std::string positions, directions, sources, output = "bin/data.py", detected_path;
+    std::string positions, directions, sources, output = "bin/data.py", detected_path, out_ring;
     std::string ring_key;
     int core = -1;
     long junk_blocks = -1;
 
     int arg = 0;
-    while ((arg = getopt(argc, argv, "s:g:p:d:o:D:a:c:k:j:w:vh")) != -1) {  // src/beamformer.cu:41-43 (+ -o -D -a -v)
+    while ((arg = getopt(argc, argv, "s:g:p:d:o:D:a:c:k:K:j:w:vh")) != -1) {  // src/beamformer.cu:41-43 (+ -o -D -a -v)
         switch (arg) {
             case 's': sources = optarg; break;                 // :77-89
             case 'g': opt.gpu = atoi(optarg); break;           // :92-100
@@ -44,6 +44,7 @@ int main(int argc, char* argv[])
             case 'a': cfg.n_avg = atoi(optarg); break;
             case 'j': junk_blocks = atol(optarg); break;
             case 'w': detected_path = optarg; break;
+            case 'K': out_ring = optarg; break;
             case 'v': opt.verbose = true; cfg.verbose = 1; break;
             case 'c': core = atoi(optarg); break;              // :59-65
             case 'k': ring_key = optarg; break;                // :66-75 (a shared-memory ring name instead of a hex key)
@@ -93,18 +94,29 @@ int main(int argc, char* argv[])
         oopt.gpu = opt.gpu;
         oopt.device = opt.device;
         oopt.verbose = opt.verbose;
-        std::unique_ptr<file_sink> sink;
-        if (!detected_path.empty()) {  // -w: keep the detected stream (the reference drops it, README.md:149)
-            sink.reset(new file_sink(pcfg, detected_path.c_str(), opt.gpu));
-            if (!sink->ok() || !sink->is_open()) {
+        std::unique_ptr<detected_sink> sink;
+        std::string sink_name;
+        if (!out_ring.empty()) {  // -K: hand the detected stream to another process through a shared-memory ring
+            ring_sink* rs = new ring_sink(pcfg, out_ring.c_str(), 8, opt.gpu);
+            sink.reset(rs);
+            sink_name = "ring " + out_ring;
+            if (!rs->ok() || !rs->is_open()) {
+                fprintf(stderr, "beam: could not create ring %s\n", out_ring.c_str());
+                return EXIT_FAILURE;
+            }
+        } else if (!detected_path.empty()) {  // -w: keep the detected stream in a file (the reference drops it, README.md:149)
+            file_sink* fs = new file_sink(pcfg, detected_path.c_str(), opt.gpu);
+            sink.reset(fs);
+            sink_name = detected_path;
+            if (!fs->ok() || !fs->is_open()) {
                 fprintf(stderr, "beam: could not open %s\n", detected_path.c_str());
                 return EXIT_FAILURE;
             }
-            oopt.sink = sink.get();
         }
+        oopt.sink = sink.get();
         observation_result ores;
         int orc = run_observation(pcfg, oopt, *src, pos.data(), dir.data(), &ores, std::cout);
-        if (sink) std::cout << "Wrote " << sink->get_delivered() << " gemm-units of detected powers to " << detected_path << std::endl;
+        if (sink) std::cout << "Wrote " << sink->get_delivered() << " gemm-units of detected powers to " << sink_name << std::endl;
         if (orc != BF_OK) {
             fprintf(stderr, "GPUassert: %s (%d)\n", bf_last_error(), orc);
             return EXIT_FAILURE;

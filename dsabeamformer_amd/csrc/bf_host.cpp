@@ -17,6 +17,7 @@
 #include <memory>
 #include <sstream>
 #include <thread>
+#include <unistd.h>
 
 #include "../../include/dsabf_host.h"
 
@@ -820,6 +821,43 @@ void file_sink::finish()
     fp = nullptr;
 }
 
+ring_sink::ring_sink(const bf_config& cfg, const char* ring_name, uint64_t ring_blocks, int gpu, uint64_t slots)
+    : detected_sink(cfg, slots), name(ring_name ? ring_name : "")
+{
+    char header[kRingHeaderBytes];
+    ::snprintf(header, sizeof(header),
+               "HDR_VERSION 1.0\nHDR_SIZE %zu\nINSTRUMENT DSA\nCONTENT detected_power\nDTYPE float32\nENDIAN little\n"
+               "ORDER output,frequency,beam\nN_BEAMS %d\nN_FREQUENCIES %d\nN_OUTPUTS_PER_GEMM %d\nGPU %d\n",
+               kRingHeaderBytes, cfg.n_beams, cfg.n_freq, cfg.n_out_per_gemm, gpu);
+    out = shm_ring::create(name.c_str(), ring_blocks, get_floats_per_gemm() * sizeof(float), header);
+}
+
+ring_sink::~ring_sink()
+{
+    finish();
+}
+
+bool ring_sink::deliver(uint64_t, const float* data, size_t n_floats)
+{
+    if (!out) return false;
+    char* b = out->open_block_write();  // blocks while the consumer is behind by a whole ring
+    if (!b) return false;
+    ::memcpy(b, data, n_floats * sizeof(float));
+    out->close_block_write(n_floats * sizeof(float));
+    return true;
+}
+
+void ring_sink::finish()
+{
+    if (!out) return;
+    if (out->open_block_write()) out->close_block_write(0);  // short block: end of data
+    // wait for the consumer to drain, then remove the ring (dada_db -d)
+    for (int waited = 0; out->get_blocks_read() < out->get_blocks_written() && waited < 10000; waited += 5) ::usleep(5000);
+    delete out;
+    out = nullptr;
+    shm_ring::unlink(name.c_str());
+}
+
 // ---- production observation loop (src/beamformer.cu:364-534, #ifndef DEBUG branches) -------------------------------------
 int run_observation(const bf_config& cfg, const observation_options& opt, block_source& source, const antenna* pos,
                     const beam_direction* dir, observation_result* res, std::ostream& log)
@@ -1380,6 +1418,21 @@ int bfh_run_observation_shm(const bf_config* cfg, const char* name, int core, in
     if (rc != BF_OK) return rc;
     if (observation_ms) *observation_ms = res.observation_time_ms;
     if (gemms_written) *gemms_written = sink ? sink->get_delivered() : res.blocks * cfg->n_gemms_per_block;
+    return BF_OK;
+}
+
+int bfh_run_observation_junk_to_ring(const bf_config* cfg, uint64_t n_blocks, int ring_blocks, uint64_t seed, int gpu,
+                                     int device, const char* out_ring, uint64_t out_ring_blocks, float* observation_ms,
+                                     uint64_t* gemms_written, void* ring_copy)
+{
+    if (!cfg || !out_ring) return BF_ERR_INVALID;
+    ring_sink sink(*cfg, out_ring, out_ring_blocks, gpu);
+    if (!sink.ok() || !sink.is_open()) return BF_ERR_INVALID;
+    observation_result res;
+    int rc = run_junk(cfg, n_blocks, ring_blocks, seed, gpu, device, 0, 0, &sink, &res, ring_copy);
+    if (rc != BF_OK) return rc;
+    if (observation_ms) *observation_ms = res.observation_time_ms;
+    if (gemms_written) *gemms_written = sink.get_delivered();
     return BF_OK;
 }
 

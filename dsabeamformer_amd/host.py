@@ -252,6 +252,19 @@ def run_observation_junk_to_file(cfg: BfConfig, n_blocks: int, path: str, ring_b
     return {"ms": ms.value, "gemms_written": n.value, "ring": ring}
 
 
+def run_observation_junk_to_ring(cfg: BfConfig, n_blocks: int, out_ring: str, out_ring_blocks: int = 8,
+                                 ring_blocks: int = 4, seed: int = 0xD5A, gpu: int = 0, device: int = 0):
+    """Production observation loop with the detected stream handed to a consumer through the shared-memory ring
+    `out_ring` (dsabf::ring_sink).  Blocks until the consumer has drained the ring.  Returns dict(ms, gemms_written, ring)."""
+    lib = load()
+    n_time = cfg.n_out_per_gemm * cfg.n_pol * cfg.n_avg
+    ring = np.zeros((ring_blocks, cfg.n_gemms_per_block, cfg.n_freq, n_time, cfg.n_ant), np.uint8)
+    ms, n = C.c_float(), C.c_uint64()
+    check(lib.bfh_run_observation_junk_to_ring(C.byref(cfg), n_blocks, ring_blocks, seed, gpu, device, out_ring.encode(),
+                                               out_ring_blocks, C.byref(ms), C.byref(n), _p(ring)))
+    return {"ms": ms.value, "gemms_written": n.value, "ring": ring}
+
+
 class FileSink:
     """The sink's pinned ring + file writer on its own (dsabf::file_sink)."""
 

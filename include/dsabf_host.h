@@ -85,6 +85,13 @@ int bfh_run_observation_junk_to_file(const bf_config *cfg, uint64_t n_blocks, in
                                      int device, int burn_in, int verbose, const char *path, float *observation_ms,
                                      uint64_t *gemms_written, void *ring_copy);
 
+/* Same loop with the detected stream handed to another process through a shared-memory ring `out_ring` (dsabf::ring_sink:
+ * one block per gemm-unit, then a short block; the call creates the ring, blocks while it is full, and removes it once
+ * the consumer has drained it). */
+int bfh_run_observation_junk_to_ring(const bf_config *cfg, uint64_t n_blocks, int ring_blocks, uint64_t seed, int gpu,
+                                     int device, const char *out_ring, uint64_t out_ring_blocks, float *observation_ms,
+                                     uint64_t *gemms_written, void *ring_copy);
+
 /* The sink's ring on its own (tests; works without a device, the ring is then plain memory). */
 typedef struct bfh_sink bfh_sink;
 int bfh_file_sink_create(const bf_config *cfg, const char *path, int gpu, uint64_t slots, bfh_sink **out);

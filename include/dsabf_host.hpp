@@ -355,6 +355,24 @@ public:
     bool is_open() const { return fp != nullptr; }
 };
 
+// Hands every gemm-unit to another process through a shared-memory ring (one ring block per gemm-unit, then a short
+// block): the output side of the PSRDADA picture the reference left open ("writing out to the PSRDADA buffer has not yet
+// been implemented", README.md:149).  The sink creates the ring; a consumer attaches by name and reads until the short
+// block; like any PSRDADA writer the loop blocks while the ring is full.
+class ring_sink : public detected_sink {
+    shm_ring* out = nullptr;
+    std::string name;
+
+protected:
+    bool deliver(uint64_t gemm_index, const float* data, size_t n_floats) override;
+    void finish() override;
+
+public:
+    ring_sink(const bf_config& cfg, const char* ring_name, uint64_t ring_blocks, int gpu, uint64_t slots = 0);
+    ~ring_sink() override;
+    bool is_open() const { return out != nullptr; }
+};
+
 // Keeps everything in host memory (tests, small runs).
 class memory_sink : public detected_sink {
 protected:

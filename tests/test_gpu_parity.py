@@ -917,3 +917,50 @@ def test_observation_loop_wide_antenna_geometry_bit_exact(bfmod, orc, tmp_path, 
     for blk in range(n_blocks):
         want = orc.beamform(g, w, r["ring"][blk % ring_blocks])
         assert np.array_equal(data[blk * 8:(blk + 1) * 8].reshape(want.shape), want), blk
+
+
+def test_observation_detected_stream_to_output_ring(bfmod, orc):
+    """The output side of the PSRDADA picture (README.md:149 "not yet implemented" in the reference): the loop hands every
+    gemm-unit to a consumer through a shared-memory ring (dsabf::ring_sink, 3 slots for 40 gemm-units, so the loop also
+    blocks on a slow consumer); the consumer thread checks order, sizes, the end-of-data block and every value."""
+    import threading
+    import time
+
+    from dsabeamformer_amd import host
+
+    cfg = bfmod.production_config(n_freq=4)
+    cfg.n_beams, cfg.n_gemms_per_block, cfg.n_streams = 64, 8, 4
+    n_blocks, ring_blocks = 5, 2
+    name = "dsabf_out_%d" % os.getpid()
+    per = cfg.n_out_per_gemm * cfg.n_freq * cfg.n_beams
+    got, err = [], []
+
+    def consumer():
+        try:
+            ring = host.ShmRing(name, timeout_ms=20000)
+            assert ring.block_size == per * 4 and "detected_power" in ring.header
+            while True:
+                data, bid = ring.read()
+                if data.size < ring.block_size:
+                    break
+                assert bid == len(got)
+                got.append(data.view(np.float32).copy())
+                if bid == 7:
+                    time.sleep(0.2)   # let the 3-slot ring fill: the producer must wait, not drop
+            ring.detach()
+        except Exception as e:  # noqa: BLE001
+            err.append(e)
+
+    t = threading.Thread(target=consumer)
+    t.start()
+    r = host.run_observation_junk_to_ring(cfg, n_blocks, name, out_ring_blocks=3, ring_blocks=ring_blocks, seed=12)
+    t.join(timeout=60)
+    assert not err, err
+    assert r["gemms_written"] == n_blocks * 8 == len(got)
+    assert not os.path.exists("/dev/shm/" + name)   # the sink removed its ring after the consumer drained it
+    g = orc.Geom(n_beams=64, n_ant=64, n_freq=4, n_avg=16, n_out_per_gemm=cfg.n_out_per_gemm)
+    w = orc.make_weights(g, orc.default_positions(64), orc.default_directions(64), 0)
+    for blk in range(n_blocks):
+        want = orc.beamform(g, w, r["ring"][blk % ring_blocks]).reshape(8, per)
+        for u in range(8):
+            assert np.array_equal(got[blk * 8 + u], want[u]), (blk, u)
