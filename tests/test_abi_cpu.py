@@ -88,3 +88,15 @@ def test_product_does_not_reference_the_oracle():
 
     out = subprocess.run(["ldd", os.path.join(pkg, "libdsabf.so")], capture_output=True, text=True).stdout
     assert "liborc" not in out
+
+
+def test_headers_and_example_compile_as_plain_c(tmp_path):
+    """The boundary is a C ABI: dsabf.h / dsabf_host.h and the worked example must compile as pedantic C99 with gcc."""
+    import subprocess
+
+    from conftest import ROOT
+
+    obj = tmp_path / "minimal.o"
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I" + os.path.join(ROOT, "include"),
+                        "-c", os.path.join(ROOT, "examples", "minimal.c"), "-o", str(obj)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr

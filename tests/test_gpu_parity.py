@@ -964,3 +964,19 @@ def test_observation_detected_stream_to_output_ring(bfmod, orc):
         want = orc.beamform(g, w, r["ring"][blk % ring_blocks]).reshape(8, per)
         for u in range(8):
             assert np.array_equal(got[blk * 8 + u], want[u]), (blk, u)
+
+
+def test_plain_c_example_runs(tmp_path):
+    """examples/minimal.c (C99, streaming entry points of the C-ABI) built with hipcc against libdsabf.so and run."""
+    import subprocess
+
+    from conftest import ROOT
+
+    exe = str(tmp_path / "minimal")
+    pkg = os.path.join(ROOT, "dsabeamformer_amd")
+    b = subprocess.run(["/opt/rocm/bin/hipcc", "-x", "c", "-std=c99", "-I" + os.path.join(ROOT, "include"),
+                        os.path.join(ROOT, "examples", "minimal.c"), "-o", exe, "-L" + pkg, "-ldsabf",
+                        "-Wl,-rpath," + pkg], capture_output=True, text=True, timeout=300)
+    assert b.returncode == 0, b.stderr
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout + r.stderr
