@@ -60,7 +60,7 @@ typedef struct bf_config {
  * multiplies, one add, one accumulate add per sample, ascending time order -> bit-identical to the CPU restatement.
  * FAST (geometries with n_pol*n_avg >= 16; ignored elsewhere) accumulates the unscaled integer voltages with
  * fused multiply-adds and applies (1/127)^2 once per output: 4 instead of 6 VALU ops per sample; the result is within
- * 4*n_ipo*2^-24 relative of the canonical one (it is the more accurate of the two w.r.t. exact arithmetic). */
+ * 4*n_ipo*2^-24 relative of the canonical one; both are within 2*n_ipo*2^-24 relative of exact arithmetic (tested). */
 #define BF_DETECT_CANONICAL 0
 #define BF_DETECT_FAST 1
 

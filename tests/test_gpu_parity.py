@@ -400,6 +400,17 @@ def test_fast_detect_mode_within_stated_tolerance(torch, bfmod, orc, n_avg):
     rel = np.abs(got.astype(np.float64) - want) / np.maximum(want.astype(np.float64), 1e-30)
     assert rel.max() <= tol, (rel.max(), tol)
     assert not np.array_equal(got, want)  # it really is the other arithmetic
+    # against exact arithmetic (integer voltages, fl(1/127)^2 applied in double): both modes round the running fp32 sum
+    # once or twice per sample, so both stay within a few n_ipo * 2^-24 of the exact value
+    v = orc.expand(packed).astype(np.int64)                                  # [unit][f][t][a][2]
+    wc = w.astype(np.int64)
+    cre = np.einsum("ufta,fab->uftb", v[..., 0], wc[..., 0]) - np.einsum("ufta,fab->uftb", v[..., 1], wc[..., 1])
+    cim = np.einsum("ufta,fab->uftb", v[..., 0], wc[..., 1]) + np.einsum("ufta,fab->uftb", v[..., 1], wc[..., 0])
+    p = (cre * cre + cim * cim).reshape(3, g.n_freq, g.n_out_per_gemm, n_ipo, g.n_beams).sum(3)      # exact integers
+    exact = p.transpose(0, 2, 1, 3).astype(np.float64) * (float(np.float32(1.0 / 127.0)) ** 2)
+    e_fast = np.abs(got.astype(np.float64) - exact.reshape(want.shape)) / exact.reshape(want.shape)
+    e_canon = np.abs(want.astype(np.float64) - exact.reshape(want.shape)) / exact.reshape(want.shape)
+    assert e_fast.max() <= 2 * n_ipo * 2.0 ** -24 and e_canon.max() <= 2 * n_ipo * 2.0 ** -24
     # the default mode on the same input stays bit-exact
     bf0 = bfmod.Beamformer(_cfg(bfmod, g))
     bf0.set_weights(w)
