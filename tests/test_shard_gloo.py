@@ -77,15 +77,18 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def test_frequency_shard_and_gather_world2(tmp_path):
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_frequency_shard_and_gather(tmp_path, world):
+    """1 process per (pretend) GPU, gloo: world sizes of the driver's scaling runs (8 frequencies -> 4, 2, 1 per rank)."""
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
-    env = dict(os.environ, REPO_ROOT=ROOT, OMP_NUM_THREADS="2")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+    env = dict(os.environ, REPO_ROOT=ROOT, OMP_NUM_THREADS="1" if world > 2 else "2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
            "127.0.0.1", "--master-port", str(_free_port()), str(script)]
-    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
-    assert "rank 0 ok" in out.stdout and "rank 1 ok" in out.stdout
+    for r in range(world):
+        assert "rank %d ok" % r in out.stdout
 
 
 def test_freq_range_rules():
