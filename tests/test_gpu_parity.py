@@ -991,3 +991,48 @@ def test_plain_c_example_runs(tmp_path):
     assert b.returncode == 0, b.stderr
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout + r.stderr
+
+
+def test_device_resident_weights_and_host_registration(torch, bfmod, orc):
+    """bf_set_weights_device (weights already in HBM, e.g. a sharded slice): same image, same pairing decision, same
+    -128 rejection as the host path; bf_host_register / bf_host_unregister on caller-owned memory (the PSRDADA blocks'
+    dada_cuda_dbregister) feeding bf_submit_block."""
+    import ctypes as C
+
+    from dsabeamformer_amd import _lib
+
+    g = orc.Geom(n_beams=64, n_ant=64, n_freq=3, n_avg=16, n_out_per_gemm=2)
+    rng = np.random.default_rng(2718)
+    w = rng.integers(-127, 128, size=(g.n_freq, g.n_ant, g.n_beams, 2), dtype=np.int8)
+    packed = rng.integers(0, 256, size=(2, g.n_freq, g.n_time, g.n_ant), dtype=np.uint8)
+    bf = bfmod.Beamformer(_cfg(bfmod, g))
+    s = torch.cuda.current_stream().cuda_stream
+    for paired in (False, True):
+        ww = _conj_symmetric(w) if paired else w
+        bf.set_weights_device(torch.from_numpy(ww).cuda(), s)
+        assert ("PAIRED" in bf.kernel_info(2)["kernel"]) == paired
+        want = orc.beamform(g, ww, packed)
+        assert np.array_equal(_run(torch, bf, packed, want.size).reshape(want.shape), want)
+    bad = w.copy()
+    bad[1, 5, 7, 1] = -128
+    with pytest.raises(Exception):
+        bf.set_weights_device(torch.from_numpy(bad).cuda(), s)
+    with pytest.raises(Exception):
+        bf.beamform(torch.from_numpy(packed).cuda(), 2, torch.empty(want.size, device="cuda"), s)  # no valid weights now
+    # page-lock ordinary host memory and stream a block from it
+    lib = _lib.load()
+    cfg = _cfg(bfmod, g, n_gemms_per_block=2, n_blocks_on_gpu=2, n_streams=2)
+    bf2 = bfmod.Beamformer(cfg)
+    bf2.set_weights(w)
+    block = np.ascontiguousarray(packed)                        # exactly one block of 2 gemm-units
+    assert lib.bf_host_register(C.c_void_p(block.ctypes.data), block.nbytes) == 0
+    try:
+        out = np.zeros((2,) + (g.n_out_per_gemm, g.n_freq, g.n_beams), np.float32)
+        bf2.submit_block(0, block, block.nbytes)
+        for ts in range(2):
+            bf2.enqueue_gemm_unit(ts, 0, ts, out[ts])
+        bf2.sync(-1)
+        assert np.array_equal(out.reshape(-1), orc.beamform(g, w, packed).reshape(-1))
+    finally:
+        assert lib.bf_host_unregister(C.c_void_p(block.ctypes.data)) == 0
+    assert lib.bf_host_register(None, 16) < 0
