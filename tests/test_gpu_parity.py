@@ -1036,3 +1036,35 @@ def test_device_resident_weights_and_host_registration(torch, bfmod, orc):
     finally:
         assert lib.bf_host_unregister(C.c_void_p(block.ctypes.data)) == 0
     assert lib.bf_host_register(None, 16) < 0
+
+
+def test_remaining_abi_entry_points(torch, bfmod, orc):
+    """bf_device_name, bf_get_config, bf_record_transfer_event, bf_event_synchronize: the entry points the C++ host
+    mirror uses internally, called directly."""
+    import ctypes as C
+
+    from dsabeamformer_amd import _lib
+
+    lib = _lib.load()
+    buf = C.create_string_buffer(256)
+    assert lib.bf_device_name(0, buf, 256) == 0 and b"gfx950" in buf.value
+    assert lib.bf_device_name(99, buf, 256) < 0
+    g = orc.Geom(n_beams=64, n_ant=64, n_freq=2, n_avg=16, n_out_per_gemm=2)
+    cfg = _cfg(bfmod, g, n_gemms_per_block=1, n_blocks_on_gpu=2, n_streams=1)
+    bf = bfmod.Beamformer(cfg)
+    back = _lib.BfConfig()
+    assert lib.bf_get_config(bf._h, C.byref(back)) == 0
+    assert (back.n_beams, back.n_ant, back.n_freq, back.n_avg, back.n_out_per_gemm) == (64, 64, 2, 16, 2)
+    from dsabeamformer_amd import api
+
+    ev = api.event_create()
+    block = np.zeros(cfg.n_gemms_per_block * g.n_freq * g.n_time * g.n_ant, np.uint8)
+    pinned = C.c_void_p()
+    assert lib.bf_alloc_pinned(C.byref(pinned), block.nbytes) == 0
+    C.memmove(pinned, block.ctypes.data, block.nbytes)
+    bf.submit_block(1, pinned, block.nbytes)
+    assert lib.bf_record_transfer_event(bf._h, ev) == 0
+    assert lib.bf_event_synchronize(ev) == 0
+    assert api.event_query(ev) == 0            # BF_OK: complete
+    api.event_destroy(ev)
+    assert lib.bf_free_pinned(pinned) == 0
