@@ -29,6 +29,7 @@
 #define ORC_DEG2RAD(x) ((x) * ORC_PI / 180.0)
 
 static int g_threads = 0;
+static int g_contract = ORC_CONTRACT_NONE; /* how `x*x + y*y` of src/beamformer.cuh:151 is evaluated, see the header */
 
 void orc_set_threads(int n) { g_threads = n; }
 
@@ -175,6 +176,27 @@ static void cdot_column(int na, int nb, const int8_t *wf, const int8_t *v, int32
     }
 }
 
+
+/* One term of detect_sum's `shmem[beam_idx] += input[i].x*input[i].x + input[i].y*input[i].y` (src/beamformer.cuh:151)
+ * under the three ways a compiler may evaluate it (header: orc_set_detect_contract). */
+static inline float power_term(float x, float y, int contract)
+{
+    if (contract == ORC_CONTRACT_NVCC) {
+        const float yy = y * y;
+        return fmaf(x, x, yy);          /* mul t, y, y ; fma p, x, x, t */
+    }
+    if (contract == ORC_CONTRACT_NVCC_ALT) {
+        const float xx = x * x;
+        return fmaf(y, y, xx);          /* mul t, x, x ; fma p, y, y, t */
+    }
+    const float xx = x * x;
+    const float yy = y * y;
+    return xx + yy;
+}
+
+void orc_set_detect_contract(int mode) { g_contract = mode; }
+int orc_get_detect_contract(void) { return g_contract; }
+
 /* a2 -- src/beamformer.cu:470-477 with alpha = (float)(1.0/127) (:191), beta = 0 (:193-194). */
 void orc_gemm(const orc_geom *g, const int8_t *w, const int8_t *v, float *c)
 {
@@ -207,6 +229,7 @@ void orc_gemm(const orc_geom *g, const int8_t *w, const int8_t *v, float *c)
 void orc_detect(const orc_geom *g, const float *c, float *out)
 {
     const int nb = g->n_beams, nf = g->n_freq, no = g->n_out_per_gemm, n_avg = orc_n_ipo(g);
+    const int contract = g_contract;
 #ifdef _OPENMP
 #pragma omp parallel for collapse(2) num_threads(ORC_NT()) schedule(static)
 #endif
@@ -217,9 +240,7 @@ void orc_detect(const orc_geom *g, const float *c, float *out)
                 const size_t input_idx = (size_t)f * no * n_avg * nb + (size_t)o * n_avg * nb + b; /* :141-145 */
                 for (size_t i = input_idx; i < input_idx + (size_t)n_avg * nb; i += nb) {          /* :150 */
                     const float x = c[2 * i + 0], y = c[2 * i + 1];
-                    const float xx = x * x;
-                    const float yy = y * y;
-                    const float p = xx + yy;
+                    const float p = power_term(x, y, contract);
                     acc = acc + p; /* :151 */
                 }
                 out[(size_t)o * nf * nb + (size_t)f * nb + b] = acc; /* :147,154 */
@@ -236,6 +257,7 @@ void orc_beamform(const orc_geom *g, const int8_t *w, const uint8_t *packed, int
     const float alpha = 1.0 / ORC_MAX_VAL;
     const size_t per_gemm = orc_bytes_per_gemm(g);
     const size_t out_per_gemm = (size_t)no * nf * nb;
+    const int contract = g_contract;
 #ifdef _OPENMP
 #pragma omp parallel num_threads(ORC_NT())
 #endif
@@ -260,14 +282,60 @@ void orc_beamform(const orc_geom *g, const int8_t *w, const uint8_t *packed, int
                         for (int b = 0; b < nb; b++) {
                             const float x = (float)ar[b] * alpha;
                             const float y = (float)ai[b] * alpha;
-                            const float xx = x * x;
-                            const float yy = y * y;
-                            const float p = xx + yy;
+                            const float p = power_term(x, y, contract);
                             acc[b] = acc[b] + p;
                         }
                     }
                     memcpy(out + (size_t)u * out_per_gemm + (size_t)o * nf * nb + (size_t)f * nb, acc,
                            sizeof(float) * (size_t)nb);
+                }
+            }
+        }
+        free(col);
+        free(acc);
+        free(ar);
+    }
+}
+
+/* The same path with NO floating-point rounding until the end: out = alpha^2 * sum_i (re_i^2 + im_i^2), the integer sum
+ * exact in int64 (< 2^41), alpha = (float)(1.0/127) as a double, product rounded once to double (2^-53).  This is the
+ * value every float evaluation order of src/beamformer.cuh:150-152 approximates; tests bound canonical / nvcc-contracted /
+ * fast results against it. */
+void orc_beamform_exact(const orc_geom *g, const int8_t *w, const uint8_t *packed, int n_units, double *out)
+{
+    const int nb = g->n_beams, na = g->n_ant, nf = g->n_freq, no = g->n_out_per_gemm;
+    const int n_ipo = orc_n_ipo(g), nt = orc_n_time(g);
+    const float alpha = 1.0 / ORC_MAX_VAL;
+    const double a2 = (double)alpha * (double)alpha;
+    const size_t per_gemm = orc_bytes_per_gemm(g);
+    const size_t out_per_gemm = (size_t)no * nf * nb;
+#ifdef _OPENMP
+#pragma omp parallel num_threads(ORC_NT())
+#endif
+    {
+        int32_t *ar = (int32_t *)malloc(sizeof(int32_t) * (size_t)nb * 2);
+        int32_t *ai = ar + nb;
+        int64_t *acc = (int64_t *)malloc(sizeof(int64_t) * (size_t)nb);
+        int8_t *col = (int8_t *)malloc((size_t)na * 2);
+#ifdef _OPENMP
+#pragma omp for collapse(2) schedule(static)
+#endif
+        for (int u = 0; u < n_units; u++) {
+            for (int f = 0; f < nf; f++) {
+                const int8_t *wf = w + 2 * (size_t)f * na * nb;
+                for (int o = 0; o < no; o++) {
+                    for (int b = 0; b < nb; b++)
+                        acc[b] = 0;
+                    for (int i = 0; i < n_ipo; i++) {
+                        const int t = o * n_ipo + i;
+                        orc_expand(packed + (size_t)u * per_gemm + ((size_t)f * nt + t) * na, (size_t)na, col);
+                        cdot_column(na, nb, wf, col, ar, ai);
+                        for (int b = 0; b < nb; b++)
+                            acc[b] += (int64_t)ar[b] * ar[b] + (int64_t)ai[b] * ai[b];
+                    }
+                    double *o_ = out + (size_t)u * out_per_gemm + (size_t)o * nf * nb + (size_t)f * nb;
+                    for (int b = 0; b < nb; b++)
+                        o_[b] = (double)acc[b] * a2;
                 }
             }
         }

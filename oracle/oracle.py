@@ -97,6 +97,9 @@ def lib() -> C.CDLL:
         L.orc_gemm.argtypes = [G, P, P, P]
         L.orc_detect.argtypes = [G, P, P]
         L.orc_beamform.argtypes = [G, P, P, C.c_int, P]
+        L.orc_beamform_exact.argtypes = [G, P, P, C.c_int, P]
+        L.orc_set_detect_contract.argtypes = [C.c_int]
+        L.orc_get_detect_contract.restype = C.c_int
         L.orc_dedisperse.argtypes = [G, P, P]
         L.orc_read_positions.argtypes = [C.c_char_p, C.c_int, P]
         L.orc_read_positions.restype = C.c_int
@@ -219,6 +222,44 @@ def beamform(g: Geom, w: np.ndarray, packed: np.ndarray) -> np.ndarray:
     out = np.empty((n_units, g.n_out_per_gemm, g.n_freq, g.n_beams), np.float32)
     cg = g.c()
     lib().orc_beamform(C.byref(cg), _p(np.ascontiguousarray(w, np.int8)), _p(packed), n_units, _p(out))
+    return out
+
+
+CONTRACT_NONE, CONTRACT_NVCC, CONTRACT_NVCC_ALT = 0, 1, 2
+
+
+def set_detect_contract(mode: int) -> None:
+    """How detect's `x*x + y*y` is evaluated: CONTRACT_NONE (g++, default), CONTRACT_NVCC fma(x,x,y*y), CONTRACT_NVCC_ALT."""
+    lib().orc_set_detect_contract(int(mode))
+
+
+def get_detect_contract() -> int:
+    return int(lib().orc_get_detect_contract())
+
+
+class detect_contract:
+    """with orc.detect_contract(orc.CONTRACT_NVCC): ...  (restores the previous mode)"""
+
+    def __init__(self, mode: int):
+        self.mode = mode
+
+    def __enter__(self):
+        self.prev = get_detect_contract()
+        set_detect_contract(self.mode)
+        return self
+
+    def __exit__(self, *exc):
+        set_detect_contract(self.prev)
+        return False
+
+
+def beamform_exact(g: Geom, w: np.ndarray, packed: np.ndarray) -> np.ndarray:
+    """a1+a2+a3 without intermediate rounding: float64 [unit][o][f][b] = alpha^2 * exact integer power sum."""
+    packed = np.ascontiguousarray(packed, np.uint8).reshape(-1, g.n_freq, g.n_time, g.n_ant)
+    n_units = packed.shape[0]
+    out = np.empty((n_units, g.n_out_per_gemm, g.n_freq, g.n_beams), np.float64)
+    cg = g.c()
+    lib().orc_beamform_exact(C.byref(cg), _p(np.ascontiguousarray(w, np.int8)), _p(packed), n_units, _p(out))
     return out
 
 

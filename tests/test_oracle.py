@@ -6,7 +6,10 @@ Sources of truth, in order of strength:
   * SURVEY.md 8c's values measured from the reference compiled in this container (weight sums, first generator
     bytes, dedispersed source 0) and the committed hashes of the byte-identical probe run (tests/golden);
   * an independent numpy restatement of each stage on small random cases;
-  * the notebook's all-double formula (sandbox/2D Beamformer.ipynb cells 5, 8, 17) as a loose statistical bound.
+  * the reference's Python notebooks EXECUTED cell by cell (tests/golden/make_notebook_golden.py ->
+    tests/golden/notebook_linear.npz): the reference's own acceptance statistics (README.md:202-211) are held on them;
+  * the exact (integer) value of every output, which every float evaluation order must approximate within the stated
+    tolerance (the FMA-contraction question, oracle/dsabf_oracle.h).
 """
 import json
 import os
@@ -175,26 +178,113 @@ def test_linear_debug_detected_and_dedispersed(orc, linear_inputs, linear_weight
     assert np.allclose(ded0, out[0, 0].astype(np.float64).sum(0), rtol=1e-6)
 
 
-def test_against_notebook_formula_statistics(orc, linear_inputs, linear_weights):
-    """sandbox/2D Beamformer.ipynb cells 5, 8, 17 restated in float64; README.md:211 reports mean 0.03 %,
-    max 0.8 %; the notebook prints RMS 9.1e-4 and mean 0.0435 % over all 1024 sources."""
+NOTEBOOK = os.path.join(GOLDEN, "notebook_linear.npz")   # written by tests/golden/make_notebook_golden.py, which EXECUTES
+                                                          # the cells of the reference's notebooks (nothing re-typed)
+
+
+def _acceptance(nb_out_beam_src, table_src_beam):
+    """The statistic of sandbox/2D Beamformer.ipynb cell 17 / Beamformer Theory.ipynb cell 7:
+    b = |(out.T - da) / out.T|; prints sqrt(sum(b^2) / (1024*256)) and mean(b) * 100."""
+    b = np.abs((nb_out_beam_src.T - table_src_beam) / nb_out_beam_src.T)
+    return float(np.sqrt(np.sum(b ** 2) / b.size)), float(np.mean(b) * 100), float(np.max(b) * 100)
+
+
+def test_reference_acceptance_against_executed_notebook(orc):
+    """The reference's own acceptance test (README.md:202-211): bin/data.py, the dedispersed [source][beam] table its GPU
+    path writes, against the `out` array of its Python notebook.  Published for the reference's GPU: RMS 9.10e-4, mean
+    0.0435 % (2D notebook cell 17 output), RMS 8.41e-4, mean 0.0387 % (Theory notebook cell 7 output), "max 0.8 %"
+    (README.md:211).  The oracle's table has to pass at least as well; measured 8.18e-4 / 0.0375 % / 1.09 %."""
+    nb = np.load(NOTEBOOK)
+    table = np.load(os.path.join(GOLDEN, "linear_debug.npz"))["dedispersed"].astype(np.float64)   # oracle output, re-derived
+    rms, mean_pct, max_pct = _acceptance(nb["nb2d_out"], table)                                  # in the test above
+    assert rms <= 9.10e-4 and mean_pct <= 0.0435, (rms, mean_pct)
+    assert max_pct <= 1.2, max_pct   # README.md:211's "0.8 %" is for the authors' CUDA build; ours peaks at 1.09 % on a
+    #                                  low-power (far side-lobe) pixel
+    rms_t, mean_t, max_t = _acceptance(nb["theory_out"].astype(np.float64), table)
+    assert rms_t <= 9.10e-4 and mean_t <= 0.0435 and max_t <= 1.2, (rms_t, mean_t, max_t)
+    # the two notebooks agree with each other far better than either agrees with the quantised pipeline
+    assert np.abs(nb["theory_out"] / nb["nb2d_out"] - 1).max() < 1e-5
+    # the brightest beam of every source is the same beam
+    assert np.array_equal(nb["nb2d_out"].argmax(0), table.argmax(1))
+
+
+def test_executed_notebook_pins_weights_and_generator(orc, linear_inputs, linear_weights):
+    nb = np.load(NOTEBOOK)
+    # cell 6 of the committed notebook prints np.sum(A) = 13295.149606299225 (SURVEY.md 8c): the executed cells reproduce it
+    assert nb["nb2d_sum_A"][0] == 13295.149606299225 and nb["nb2d_sum_A"][1] == 0.0
+    # a5: A*127 of the notebook (all double) vs the C++ path (float wavelength, src/beamformer.cu:233-235): unit flips only
+    w = linear_weights                                           # [f][a][b][2]
+    n_bad = 0
+    for f, key in ((0, "nb2d_A127_f0"), (128, "nb2d_A127_f128"), (255, "nb2d_A127_f255")):
+        a127 = nb[key].transpose(1, 0, 2).astype(np.int32)       # [beam][ant][2] -> [ant][beam][2]
+        d = a127 - w[f].astype(np.int32)
+        assert np.abs(d).max() <= 1
+        n_bad += int(np.count_nonzero(d))
+    assert n_bad <= 12, n_bad                                    # measured: 4 + 0 + 0 of 98,304
+    # the whole matrix: sum(re)/127 differs from np.sum(A) by the net of those flips (a handful of units in 4.2 M entries)
+    assert abs(int(w[..., 0].astype(np.int64).sum()) - 127 * nb["nb2d_sum_A"][0]) <= 32
+    # geometry the notebook derives (cells 3, 5) == the reference's config files / frequency table
     pos, dirs, src = linear_inputs
-    gold = np.load(os.path.join(GOLDEN, "linear_debug.npz"))
-    pick = np.arange(0, 1024, 16)
-    c = 299792458.0
-    freq = np.array([1.53 - (0 + i) * ((1.53 - 1.28) / 2048) for i in range(256)])
-    lam = c / (freq * 1e9)
-    x = pos[:, 0].astype(np.float64)
-    theta = np.linspace(-3.5 * np.pi / 180, 3.5 * np.pi / 180, 256)
-    ang = np.linspace(-3.5 * np.pi / 180, 3.5 * np.pi / 180, 1024)[pick]
-    out = np.zeros((len(pick), 256))
-    for k in range(256):
-        A = np.round(127.0 * np.exp(-2.0j * np.pi * (x[None, :] * np.sin(theta[:, None])) / lam[k])) / 127.0
-        sig = np.round(7 * np.exp(2j * np.pi * (x[None, :] * np.sin(ang[:, None])) / lam[k]))
-        out += 2 * 1 * np.abs(sig @ A.T) ** 2
-    b = np.abs((out - gold["dedispersed"][pick]) / out)
-    rms = np.sqrt(np.sum(b ** 2) / b.size)
-    assert rms < 3e-3 and b.mean() * 100 < 0.15 and b.max() < 0.05, (rms, b.mean(), b.max())
+    assert np.allclose(nb["nb2d_pos"], pos, atol=2e-5) and np.allclose(nb["nb2d_theta"], dirs[:, 0], atol=1e-9)
+    assert np.allclose(nb["nb2d_source_angles"], src[:, 0], atol=1e-9)
+    assert np.allclose(nb["nb2d_freq"], [orc.freq_weights(0, i) for i in range(256)], rtol=1e-7)
+    # a6: the notebook's quantised signal of its last loop iteration (source 1023, frequency 255) == the generator's bytes
+    unit = orc.generate_test_data(orc.DEBUG_GEOM, pos, src[[1023]], 0, 0, 1)
+    sig = orc.expand(unit[0, 255, 0])
+    assert np.array_equal(sig, nb["nb2d_signal_src1023_f255"])
+
+
+def _fast_restatement(g, w, packed):
+    """BF_DETECT_FAST (include/dsabf.h) restated: d = 16 n exact; acc = fma(d, d, acc) for re then im, in time order;
+    one (alpha/16)^2 scale per output.  fma is emulated exactly: d^2 < 2^43 and acc + d^2 < 2^53 are exact in float64."""
+    pb = packed.astype(np.int8)
+    v = np.stack([pb >> 4, (packed << 4).astype(np.uint8).astype(np.int8) >> 4], -1).astype(np.int64)
+    W = w.astype(np.int64)
+    a16 = np.float32(np.float32(1.0 / 127) * np.float32(0.0625))
+    scale = np.float32(a16 * a16)
+    outs = []
+    for u in range(packed.shape[0]):
+        re = np.einsum("fab,fta->ftb", W[..., 0], v[u, ..., 0]) - np.einsum("fab,fta->ftb", W[..., 1], v[u, ..., 1])
+        im = np.einsum("fab,fta->ftb", W[..., 0], v[u, ..., 1]) + np.einsum("fab,fta->ftb", W[..., 1], v[u, ..., 0])
+        dr = (16 * re).astype(np.float64).reshape(g.n_freq, g.n_out_per_gemm, g.n_ipo, g.n_beams)
+        di = (16 * im).astype(np.float64).reshape(g.n_freq, g.n_out_per_gemm, g.n_ipo, g.n_beams)
+        acc = np.zeros((g.n_freq, g.n_out_per_gemm, g.n_beams), np.float32)
+        for i in range(g.n_ipo):
+            acc = (acc.astype(np.float64) + dr[:, :, i] * dr[:, :, i]).astype(np.float32)
+            acc = (acc.astype(np.float64) + di[:, :, i] * di[:, :, i]).astype(np.float32)
+        outs.append((acc * scale).transpose(1, 0, 2))
+    return np.stack(outs)
+
+
+@pytest.mark.parametrize("n_avg,n_out", [(1, 8), (4, 2), (16, 2), (32, 1)])
+def test_every_detect_reading_within_stated_tolerance_of_exact(orc, n_avg, n_out):
+    """Nobody here can run nvcc: whether the reference's device code evaluates `x*x + y*y` (src/beamformer.cuh:151) as
+    two multiplies and an add (the g++ reading, the oracle's default) or as fma(x, x, y*y) (nvcc's default -fmad=true,
+    makefile:13-16) cannot be settled.  What can: every reading, and the product's fast mode, is within the tolerance
+    include/dsabf.h states of the exact value alpha^2 * sum |n|^2."""
+    g = orc.Geom(n_beams=64, n_ant=64, n_freq=3, n_avg=n_avg, n_out_per_gemm=n_out)
+    rng = np.random.default_rng(1000 + n_avg)
+    w = rng.integers(-127, 128, size=(g.n_freq, g.n_ant, g.n_beams, 2), dtype=np.int8)
+    packed = rng.integers(0, 256, size=(2, g.n_freq, g.n_time, g.n_ant), dtype=np.uint8)
+    packed[0, 0, :, :] = 0x88    # extremes: all (-8, -8) against ...
+    w[0, :, :, :] = 127          # ... the largest weights
+    exact = orc.beamform_exact(g, w, packed)
+    assert exact.min() > 0
+    tol = (g.n_ipo + 4) * 2.0 ** -24
+    readings = {}
+    for name, mode in (("g++", orc.CONTRACT_NONE), ("nvcc", orc.CONTRACT_NVCC), ("nvcc-alt", orc.CONTRACT_NVCC_ALT)):
+        with orc.detect_contract(mode):
+            readings[name] = orc.beamform(g, w, packed)
+        assert np.abs(readings[name] / exact - 1).max() <= tol, name
+    assert orc.get_detect_contract() == orc.CONTRACT_NONE
+    assert np.array_equal(readings["g++"], _np_beamform(g, w, packed))
+    fast = _fast_restatement(g, w, packed)
+    assert np.abs(fast / exact - 1).max() <= (g.n_ipo + 1) * 2.0 ** -23
+    # the readings are different functions (this is why "bit-identical to the reference's GPU" is not claimed) ...
+    assert (readings["g++"] != readings["nvcc"]).any()
+    # ... but never further apart than the sum of their bounds, and in practice a few units in the last place
+    assert np.abs(readings["nvcc"] / readings["g++"] - 1).max() <= 2 * tol
+    assert np.abs(readings["nvcc"] / readings["g++"] - 1).max() <= 8 * 2.0 ** -24
 
 
 def test_python_file_writer_format(orc, tmp_path):
