@@ -9,6 +9,8 @@ LIB_PATH = os.path.join(PKG, "libdsabf.so")
 
 BF_OK = 0
 BF_NOT_READY = 1
+BF_ERR_INVALID, BF_ERR_DEVICE, BF_ERR_NO_DEVICE, BF_ERR_STATE = -1, -2, -3, -4
+BF_DETECT_CANONICAL, BF_DETECT_FAST, BF_DETECT_CONTRACTED = 0, 1, 2
 
 
 class BfConfig(C.Structure):
@@ -16,6 +18,17 @@ class BfConfig(C.Structure):
 
     _fields_ = [(n, C.c_int) for n in ("n_beams", "n_ant", "n_freq", "n_pol", "n_avg", "n_out_per_gemm",
                                        "n_gemms_per_block", "n_blocks_on_gpu", "n_streams", "verbose", "detect_mode")]
+
+
+class BfhEventOps(C.Structure):
+    """Mirror of ``bfh_event_ops`` (include/dsabf_host.h): an event backend as a table of C callbacks."""
+
+    CREATE = C.CFUNCTYPE(C.c_void_p, C.c_void_p)
+    DESTROY = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p)
+    RECORD = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p)
+    QUERY = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p)
+    _fields_ = [("user", C.c_void_p), ("create", CREATE), ("destroy", DESTROY), ("record_transfer", RECORD),
+                ("record_analysis", RECORD), ("query", QUERY)]
 
 
 class DsabfError(RuntimeError):
@@ -54,6 +67,7 @@ SIGNATURES = {
     "bf_submit_block": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     "bf_record_transfer_event": (C.c_int, [C.c_void_p, C.c_void_p]),
     "bf_enqueue_gemm_unit": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "bf_enqueue_block": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "bf_enqueue_dedisperse": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "bf_record_analysis_event": (C.c_int, [C.c_void_p, C.c_void_p]),
     "bf_stream_sync": (C.c_int, [C.c_void_p, C.c_int]),
@@ -106,7 +120,9 @@ SIGNATURES = {
     "bfh_obs_get_next_gpu_analysis_block": (C.c_uint64, [C.c_void_p]),
     "bfh_obs_get_next_gpu_transfer_block": (C.c_uint64, [C.c_void_p]),
     "bfh_obs_describe": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t]),
-    "bfh_obs_fake_complete": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "bfh_obs_create_custom": (C.c_int, [C.c_uint64, C.c_uint64, C.POINTER(BfConfig), C.POINTER(BfhEventOps), C.c_int,
+                                        C.POINTER(C.c_void_p)]),
+    "bfh_obs_status": (C.c_int, [C.c_void_p]),
     "bfh_run_observation_junk": (C.c_int, [C.POINTER(BfConfig), C.c_uint64, C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_int,
                                            C.c_int, C.POINTER(C.c_float), C.c_void_p, C.c_void_p, C.c_void_p]),
     "bfh_run_observation_junk_to_file": (C.c_int, [C.POINTER(BfConfig), C.c_uint64, C.c_int, C.c_uint64, C.c_int, C.c_int,

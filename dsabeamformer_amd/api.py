@@ -105,6 +105,13 @@ class Beamformer:
     def enqueue_gemm_unit(self, stream_idx: int, slot: int, time_slice: int, host_out=None) -> None:
         check(self._lib.bf_enqueue_gemm_unit(self._h, stream_idx, slot, time_slice, _ptr(host_out)))
 
+    def enqueue_block(self, stream_idx: int, slot: int, first_unit: int, n_units: int, host_outs=None) -> None:
+        """One launch over n_units consecutive gemm-units of a ring slot; host_outs: n_units host pointers (or None)."""
+        arr = None
+        if host_outs is not None:
+            arr = (C.c_void_p * n_units)(*[_ptr(p).value for p in host_outs])
+        check(self._lib.bf_enqueue_block(self._h, stream_idx, slot, first_unit, n_units, arr))
+
     def enqueue_dedisperse(self, stream_idx: int, host_out_row=None) -> None:
         check(self._lib.bf_enqueue_dedisperse(self._h, stream_idx, _ptr(host_out_row)))
 

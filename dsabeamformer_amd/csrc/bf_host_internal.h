@@ -1,0 +1,10 @@
+// bf_host_internal.h -- helpers shared by the host-mirror translation units (not installed, not part of the ABI).
+#pragma once
+#include <functional>
+
+namespace dsabf {
+// Splits [0, n) over the machine's hardware threads (std::thread; OpenMP is not assumed in the product build).
+void parallel_for(long n, const std::function<void(long, long)>& body);
+// Sets the calling thread's bf_last_error() text; returns `code` (bf_runtime.cpp).
+int set_error(int code, const char* msg);
+}  // namespace dsabf

@@ -13,9 +13,10 @@ constexpr int kBeamsPerWg = 256;     // 4 waves x 4 column tiles x 16 beams
 
 struct Geometry {
     int n_beams, n_ant, n_freq, n_ipo, n_out, n_time;  // n_time = n_out * n_ipo (per gemm-unit)
-    int n_btiles;                                       // n_beams / 32
+    int n_ctiles;                                       // 16-beam column tiles: ceil(n_beams / 16)
     int n_bgroups;                                      // workgroups along the beam axis: ceil(n_beams / 256)
     bool fast_detect;                                   // BF_DETECT_FAST requested (honoured by fused16_kernel, n_ipo >= 16)
+    bool contracted_detect = false;                     // BF_DETECT_CONTRACTED requested
     bool paired = false;                                // weights verified conjugate-symmetric: beam B-1-b = conj(beam b)
 };
 

@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "bf_kernels.h"
+#include "bf_host_internal.h"
 
 struct bf_event {
     hipEvent_t ev = nullptr;
@@ -35,6 +36,7 @@ struct bf_handle {
     uint8_t* d_data = nullptr;    // ring: n_blocks_on_gpu x bytes_per_block
     float* d_out = nullptr;       // n_streams x floats_per_detect
     float* d_ded = nullptr;       // n_streams x n_beams
+    std::vector<float*> d_out_blk;  // per compute queue, n_gemms_per_block x floats_per_detect: bf_enqueue_block (lazy)
     hipStream_t h2d = nullptr;
     std::vector<hipStream_t> streams;
     std::vector<hipEvent_t> join;  // one per compute queue, for bf_record_analysis_event
@@ -71,8 +73,8 @@ int check_cfg(const bf_config* c)
         return fail(BF_ERR_INVALID, "every geometry field must be positive");
     if (c->n_beams % 4) return fail(BF_ERR_INVALID, "N_BEAMS must be divisible by 4");       // src/beamformer.hh:155
     if (c->n_ant % 4) return fail(BF_ERR_INVALID, "N_ANTENNAS must be divisible by 4");      // src/beamformer.hh:156
-    if (c->detect_mode != BF_DETECT_CANONICAL && c->detect_mode != BF_DETECT_FAST)
-        return fail(BF_ERR_INVALID, "detect_mode must be BF_DETECT_CANONICAL or BF_DETECT_FAST");
+    if (c->detect_mode != BF_DETECT_CANONICAL && c->detect_mode != BF_DETECT_FAST && c->detect_mode != BF_DETECT_CONTRACTED)
+        return fail(BF_ERR_INVALID, "detect_mode must be BF_DETECT_CANONICAL, BF_DETECT_CONTRACTED or BF_DETECT_FAST");
     return BF_OK;
 }
 
@@ -85,20 +87,50 @@ dsabf::Geometry make_geom(const bf_config& c)
     g.n_ipo = c.n_pol * c.n_avg;
     g.n_out = c.n_out_per_gemm;
     g.n_time = g.n_out * g.n_ipo;
-    g.n_btiles = c.n_beams / 32;
+    g.n_ctiles = (c.n_beams + 15) / 16;
     g.n_bgroups = (c.n_beams + dsabf::kBeamsPerWg - 1) / dsabf::kBeamsPerWg;
     g.fast_detect = c.detect_mode == BF_DETECT_FAST;
+    g.contracted_detect = c.detect_mode == BF_DETECT_CONTRACTED;
     return g;
 }
 
 hipStream_t as_stream(void* s) { return static_cast<hipStream_t>(s); }
 
+// Makes `device` current for the duration of one entry point and puts the caller's device back afterwards: a library
+// call must not change the current device of a multi-device host process (torch's included).
+struct DeviceScope {
+    int prev = -1;
+    hipError_t err = hipSuccess;
+    explicit DeviceScope(int device)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != device) err = hipSetDevice(device);
+    }
+    ~DeviceScope()
+    {
+        int cur = -1;
+        if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev);
+    }
+};
+#define ON_DEVICE(h_)                                                                                       \
+    DeviceScope dev_scope_((h_)->device);                                                                   \
+    if (dev_scope_.err != hipSuccess)                                                                       \
+        return fail(BF_ERR_DEVICE, "hipSetDevice(%d) failed: %s", (h_)->device, hipGetErrorString(dev_scope_.err))
+
 }  // namespace
+
+namespace dsabf {
+int set_error(int code, const char* msg)
+{
+    g_err = msg ? msg : "";
+    return code;
+}
+}  // namespace dsabf
 
 extern "C" {
 
 const char* bf_last_error(void) { return g_err.c_str(); }
-const char* bf_version(void) { return "dsabf 0.1 (gfx950, fused expand+int8 MFMA+detect)"; }
+const char* bf_version(void) { return "dsabf 0.2 (gfx950, fused expand+int8 MFMA+detect)"; }
 
 int bf_config_default(bf_config* cfg, int debug)
 {
@@ -164,7 +196,8 @@ int bf_create(const bf_config* cfg, int device, bf_handle** out)
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
         return fail(BF_ERR_NO_DEVICE, "no HIP device visible (libdsabf has no CPU fallback)");
     if (device < 0 || device >= n) return fail(BF_ERR_INVALID, "device %d out of range (0..%d)", device, n - 1);
-    HIP_TRY(hipSetDevice(device));
+    DeviceScope dev_scope_(device);
+    if (dev_scope_.err != hipSuccess) return fail(BF_ERR_DEVICE, "hipSetDevice(%d) failed: %s", device, hipGetErrorString(dev_scope_.err));
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device));
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
@@ -215,7 +248,7 @@ int bf_create(const bf_config* cfg, int device, bf_handle** out)
 int bf_destroy(bf_handle* h)
 {
     if (!h) return BF_OK;
-    (void)hipSetDevice(h->device);
+    DeviceScope dev_scope_(h->device);
     for (auto s : h->streams)
         if (s) (void)hipStreamSynchronize(s);
     if (h->h2d) (void)hipStreamSynchronize(h->h2d);
@@ -232,6 +265,7 @@ int bf_destroy(bf_handle* h)
     (void)hipFree(h->d_data);
     (void)hipFree(h->d_out);
     (void)hipFree(h->d_ded);
+    for (float* p : h->d_out_blk) (void)hipFree(p);
     delete h;
     return BF_OK;
 }
@@ -266,7 +300,7 @@ static int finish_weights(bf_handle* h, const int8_t* d_w, hipStream_t s)
 int bf_set_weights(bf_handle* h, const int8_t* w)
 {
     if (!h || !w) return fail(BF_ERR_INVALID, "NULL argument");
-    HIP_TRY(hipSetDevice(h->device));
+    ON_DEVICE(h);
     const size_t n = (size_t)h->cfg.n_freq * h->cfg.n_ant * h->cfg.n_beams * 2;
     int8_t* d_w = nullptr;
     HIP_TRY(hipMalloc((void**)&d_w, n));
@@ -283,7 +317,7 @@ int bf_set_weights(bf_handle* h, const int8_t* w)
 int bf_set_weights_device(bf_handle* h, const int8_t* d_w, void* hip_stream)
 {
     if (!h || !d_w) return fail(BF_ERR_INVALID, "NULL argument");
-    HIP_TRY(hipSetDevice(h->device));
+    ON_DEVICE(h);
     return finish_weights(h, d_w, as_stream(hip_stream));
 }
 
@@ -362,7 +396,7 @@ int bf_submit_block(bf_handle* h, int slot, const void* host, size_t nbytes, bf_
     if (slot < 0 || slot >= h->cfg.n_blocks_on_gpu) return fail(BF_ERR_INVALID, "slot %d out of range", slot);
     const size_t block = bf_bytes_per_block(&h->cfg);
     if (nbytes > block) return fail(BF_ERR_INVALID, "nbytes %zu exceeds the block size %zu", nbytes, block);
-    HIP_TRY(hipSetDevice(h->device));
+    ON_DEVICE(h);
     HIP_TRY(hipMemcpyAsync(h->d_data + block * (size_t)slot, host, nbytes, hipMemcpyHostToDevice, h->h2d));
     if (ev) {
         HIP_TRY(hipEventRecord(ev->ev, h->h2d));
@@ -374,7 +408,7 @@ int bf_submit_block(bf_handle* h, int slot, const void* host, size_t nbytes, bf_
 int bf_record_transfer_event(bf_handle* h, bf_event* ev)
 {
     if (!h || !ev) return fail(BF_ERR_INVALID, "NULL argument");
-    HIP_TRY(hipSetDevice(h->device));
+    ON_DEVICE(h);
     HIP_TRY(hipEventRecord(ev->ev, h->h2d));
     ev->recorded = true;
     return BF_OK;
@@ -388,7 +422,7 @@ int bf_enqueue_gemm_unit(bf_handle* h, int stream_idx, int slot, int time_slice,
     if (slot < 0 || slot >= h->cfg.n_blocks_on_gpu) return fail(BF_ERR_INVALID, "slot %d out of range", slot);
     if (time_slice < 0 || time_slice >= h->cfg.n_gemms_per_block)
         return fail(BF_ERR_INVALID, "time_slice %d out of range", time_slice);
-    HIP_TRY(hipSetDevice(h->device));
+    ON_DEVICE(h);
     const size_t per_gemm = bf_bytes_per_gemm(&h->cfg);
     const size_t per_det = bf_floats_per_detect(&h->cfg);
     // src/beamformer.cu:464: &d_data[N_BYTES_PRE_EXPANSION_PER_GEMM*(N_GEMMS_PER_BLOCK*block + timeSlice)]
@@ -400,11 +434,37 @@ int bf_enqueue_gemm_unit(bf_handle* h, int stream_idx, int slot, int time_slice,
     return BF_OK;
 }
 
+int bf_enqueue_block(bf_handle* h, int stream_idx, int slot, int first_unit, int n_units, float* const* host_out)
+{
+    if (!h) return fail(BF_ERR_INVALID, "handle is NULL");
+    if (!h->weights_set) return fail(BF_ERR_STATE, "bf_set_weights has not been called");
+    if (stream_idx < 0 || stream_idx >= h->cfg.n_streams) return fail(BF_ERR_INVALID, "stream %d out of range", stream_idx);
+    if (slot < 0 || slot >= h->cfg.n_blocks_on_gpu) return fail(BF_ERR_INVALID, "slot %d out of range", slot);
+    if (first_unit < 0 || n_units <= 0 || first_unit + n_units > h->cfg.n_gemms_per_block)
+        return fail(BF_ERR_INVALID, "gemm-units [%d, %d) are not inside a block of %d", first_unit, first_unit + n_units,
+                    h->cfg.n_gemms_per_block);
+    ON_DEVICE(h);
+    const size_t per_gemm = bf_bytes_per_gemm(&h->cfg);
+    const size_t per_det = bf_floats_per_detect(&h->cfg);
+    if (h->d_out_blk.empty()) h->d_out_blk.assign((size_t)h->cfg.n_streams, nullptr);
+    if (!h->d_out_blk[stream_idx])
+        HIP_TRY(hipMalloc((void**)&h->d_out_blk[stream_idx], per_det * sizeof(float) * (size_t)h->cfg.n_gemms_per_block));
+    const uint8_t* in = h->d_data + per_gemm * ((size_t)h->cfg.n_gemms_per_block * slot + first_unit);
+    float* out = h->d_out_blk[stream_idx] + per_det * (size_t)first_unit;
+    hipStream_t s = h->streams[stream_idx];
+    HIP_TRY(dsabf::launch_fused(h->geom, h->d_wimage, h->d_wimage_p, in, n_units, out, h->n_cus, s));
+    if (host_out)
+        for (int u = 0; u < n_units; u++)
+            if (host_out[u])
+                HIP_TRY(hipMemcpyAsync(host_out[u], out + per_det * (size_t)u, per_det * sizeof(float), hipMemcpyDeviceToHost, s));
+    return BF_OK;
+}
+
 int bf_enqueue_dedisperse(bf_handle* h, int stream_idx, float* host_out_row)
 {
     if (!h) return fail(BF_ERR_INVALID, "handle is NULL");
     if (stream_idx < 0 || stream_idx >= h->cfg.n_streams) return fail(BF_ERR_INVALID, "stream %d out of range", stream_idx);
-    HIP_TRY(hipSetDevice(h->device));
+    ON_DEVICE(h);
     hipStream_t s = h->streams[stream_idx];
     const float* out = h->d_out + bf_floats_per_detect(&h->cfg) * (size_t)stream_idx;
     float* ded = h->d_ded + (size_t)h->cfg.n_beams * stream_idx;
@@ -417,7 +477,7 @@ int bf_enqueue_dedisperse(bf_handle* h, int stream_idx, float* host_out_row)
 int bf_record_analysis_event(bf_handle* h, bf_event* ev)
 {
     if (!h || !ev) return fail(BF_ERR_INVALID, "NULL argument");
-    HIP_TRY(hipSetDevice(h->device));
+    ON_DEVICE(h);
     const int last = h->cfg.n_streams - 1;
     for (int i = 0; i < last; i++) {
         HIP_TRY(hipEventRecord(h->join[i], h->streams[i]));
@@ -431,7 +491,7 @@ int bf_record_analysis_event(bf_handle* h, bf_event* ev)
 int bf_stream_sync(bf_handle* h, int stream_idx)
 {
     if (!h) return fail(BF_ERR_INVALID, "handle is NULL");
-    HIP_TRY(hipSetDevice(h->device));
+    ON_DEVICE(h);
     if (stream_idx < 0) {
         HIP_TRY(hipStreamSynchronize(h->h2d));
         for (auto s : h->streams) HIP_TRY(hipStreamSynchronize(s));
@@ -445,7 +505,7 @@ int bf_stream_sync(bf_handle* h, int stream_idx)
 int bf_timer_start(bf_handle* h)
 {
     if (!h) return fail(BF_ERR_INVALID, "handle is NULL");
-    HIP_TRY(hipSetDevice(h->device));
+    ON_DEVICE(h);
     if (!h->t0) HIP_TRY(hipEventCreate(&h->t0));
     if (!h->t1) HIP_TRY(hipEventCreate(&h->t1));
     HIP_TRY(hipEventRecord(h->t0, nullptr));
@@ -467,8 +527,10 @@ int bf_beamform_device(bf_handle* h, const void* d_packed, int n_units, float* d
     if (!h || !d_packed || !d_out) return fail(BF_ERR_INVALID, "NULL argument");
     if (n_units <= 0) return fail(BF_ERR_INVALID, "n_units must be positive");
     if (!h->weights_set) return fail(BF_ERR_STATE, "bf_set_weights has not been called");
-    if (((uintptr_t)d_packed & 15) || ((uintptr_t)d_out & 3)) return fail(BF_ERR_INVALID, "misaligned device pointer");
-    HIP_TRY(hipSetDevice(h->device));
+    if (((uintptr_t)d_packed & 15) || ((uintptr_t)d_out & 15))
+        return fail(BF_ERR_INVALID, "misaligned device pointer: d_packed and d_out must be 16-byte aligned (the kernel loads "
+                                    "16-byte pieces and stores 16-byte groups of beams)");
+    ON_DEVICE(h);
     HIP_TRY(dsabf::launch_fused(h->geom, h->d_wimage, h->d_wimage_p, d_packed, n_units, d_out, h->n_cus, as_stream(hip_stream)));
     return BF_OK;
 }
@@ -478,7 +540,7 @@ int bf_expand_device(bf_handle* h, const void* d_in, size_t nbytes, void* d_out,
     if (!h || !d_in || !d_out) return fail(BF_ERR_INVALID, "NULL argument");
     if (nbytes % 16 || ((uintptr_t)d_in & 15) || ((uintptr_t)d_out & 15))
         return fail(BF_ERR_INVALID, "expand needs 16-byte aligned pointers and a multiple of 16 bytes");
-    HIP_TRY(hipSetDevice(h->device));
+    ON_DEVICE(h);
     HIP_TRY(dsabf::launch_expand(d_in, nbytes, d_out, as_stream(hip_stream)));
     return BF_OK;
 }
@@ -487,7 +549,7 @@ int bf_gemm_device(bf_handle* h, const void* d_packed_unit, float* d_c, void* hi
 {
     if (!h || !d_packed_unit || !d_c) return fail(BF_ERR_INVALID, "NULL argument");
     if (!h->weights_set) return fail(BF_ERR_STATE, "bf_set_weights has not been called");
-    HIP_TRY(hipSetDevice(h->device));
+    ON_DEVICE(h);
     HIP_TRY(dsabf::launch_gemm_only(h->geom, h->d_wimage, d_packed_unit, d_c, h->n_cus, as_stream(hip_stream)));
     return BF_OK;
 }
@@ -495,7 +557,7 @@ int bf_gemm_device(bf_handle* h, const void* d_packed_unit, float* d_c, void* hi
 int bf_dedisperse_device(bf_handle* h, const float* d_out_unit, float* d_ded, void* hip_stream)
 {
     if (!h || !d_out_unit || !d_ded) return fail(BF_ERR_INVALID, "NULL argument");
-    HIP_TRY(hipSetDevice(h->device));
+    ON_DEVICE(h);
     HIP_TRY(dsabf::launch_dedisperse(h->geom, d_out_unit, d_ded, as_stream(hip_stream)));
     return BF_OK;
 }
@@ -505,7 +567,7 @@ int bf_dedisperse_dm_device(bf_handle* h, const float* d_series, int n_t, const 
 {
     if (!h || !d_series || !d_delays || !d_out) return fail(BF_ERR_INVALID, "NULL argument");
     if (n_t <= 0 || n_dm < 0 || n_t_out < 0 || n_t_out > n_t) return fail(BF_ERR_INVALID, "need 0 <= n_t_out <= n_t, n_dm >= 0");
-    HIP_TRY(hipSetDevice(h->device));
+    ON_DEVICE(h);
     HIP_TRY(dsabf::launch_dedisperse_dm(h->geom, d_series, n_t, d_delays, n_dm, n_t_out, d_out, as_stream(hip_stream)));
     return BF_OK;
 }

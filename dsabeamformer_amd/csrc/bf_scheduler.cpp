@@ -1,0 +1,538 @@
+// bf_scheduler.cpp -- host mirror, part 3: observation_loop_state (src/observation_loop.hh:1-177) on an
+// event backend, and the two branches of the reference's main loop (src/beamformer.cu:364-534) on the C-ABI of dsabf.h:
+// run_debug_observation (DEBUG) and run_observation (production).
+#include "../../include/dsabf_host.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <functional>
+#include <iostream>
+#include <memory>
+#include <sstream>
+#include <thread>
+#include <unistd.h>
+
+#include "../../include/dsabf_host.h"
+#include "bf_host_internal.h"
+
+namespace dsabf {
+
+// ---- event backends ---------------------------------------------------------------------------------------------
+namespace {
+
+struct hip_backend : event_backend {
+    bf_handle* h;
+    explicit hip_backend(bf_handle* hh) : h(hh) {}
+    void* create() override
+    {
+        bf_event* e = nullptr;
+        if (bf_event_create(&e) != BF_OK) return nullptr;
+        return e;
+    }
+    void destroy(void* ev) override { bf_event_destroy(static_cast<bf_event*>(ev)); }
+    int record_transfer(void* ev) override { return ev ? bf_record_transfer_event(h, static_cast<bf_event*>(ev)) : BF_ERR_INVALID; }
+    int record_analysis(void* ev) override { return ev ? bf_record_analysis_event(h, static_cast<bf_event*>(ev)) : BF_ERR_INVALID; }
+    int query(void* ev) override { return ev ? bf_event_query(static_cast<bf_event*>(ev)) : BF_ERR_INVALID; }
+};
+
+}  // namespace
+
+event_backend* make_hip_event_backend(bf_handle* h) { return new hip_backend(h); }
+
+// ---- observation_loop_state (src/observation_loop.hh:54-176) -------------------------------------------------------
+observation_loop_state::observation_loop_state(uint64_t max_tsep, uint64_t max_totsep, const bf_config& cfg,
+                                               event_backend* backend, bool debug)
+    : maximum_transfer_seperation(max_tsep), maximum_total_seperation(max_totsep), debug_mode(debug),
+      verbose(cfg.verbose != 0), n_gemms_per_block(cfg.n_gemms_per_block), n_blocks_on_gpu(cfg.n_blocks_on_gpu),
+      n_events(5 * cfg.n_blocks_on_gpu), ev(backend)
+{
+    BlockTransferredSync.resize(n_events);
+    BlockAnalyzedSync.resize(n_events);
+    for (int i = 0; i < n_events; i++) {  // :58-61
+        BlockTransferredSync[i] = ev->create();
+        BlockAnalyzedSync[i] = ev->create();
+        if (!BlockTransferredSync[i] || !BlockAnalyzedSync[i]) fail(BF_ERR_DEVICE);
+    }
+}
+
+void observation_loop_state::fail(int code)
+{
+    if (error == BF_OK) {
+        error = code < 0 ? code : BF_ERR_DEVICE;
+        std::cerr << "observation_loop_state: event backend failed (" << error << "): " << bf_last_error() << std::endl;
+    }
+}
+
+observation_loop_state::~observation_loop_state()
+{
+    for (int event = 0; event < n_events; event++) {  // :65-68
+        if (BlockAnalyzedSync[event]) ev->destroy(BlockAnalyzedSync[event]);
+        if (BlockTransferredSync[event]) ev->destroy(BlockTransferredSync[event]);
+    }
+}
+
+void observation_loop_state::generate_transfer_event()
+{
+    if (error != BF_OK) return;
+    void* e = BlockTransferredSync[blocks_transfer_queue % n_events];
+    const int rc = e ? ev->record_transfer(e) : BF_ERR_DEVICE;  // :73
+    if (rc != BF_OK) return fail(rc);
+    blocks_transfer_queue++;
+}
+
+void observation_loop_state::generate_analysis_event()
+{
+    if (error != BF_OK) return;
+    void* e = BlockAnalyzedSync[blocks_analysis_queue % n_events];
+    const int rc = e ? ev->record_analysis(e) : BF_ERR_DEVICE;  // :79
+    if (rc != BF_OK) return fail(rc);
+    blocks_analysis_queue++;
+}
+
+void observation_loop_state::check_transfer_events()
+{
+    if (error != BF_OK) return;
+    for (uint64_t event = blocks_transferred; event < blocks_transfer_queue; event++) {  // :85
+        const int rc = ev->query(BlockTransferredSync[event % n_events]);
+        if (rc == BF_OK) {
+            if (verbose) std::cout << "Block " << event << " transfered to GPU" << std::endl;
+            blocks_transferred++;
+            ev->destroy(BlockTransferredSync[event % n_events]);  // :95-96 destroy and recreate
+            BlockTransferredSync[event % n_events] = ev->create();
+            if (!BlockTransferredSync[event % n_events]) return fail(BF_ERR_DEVICE);
+        } else if (rc < 0) {
+            return fail(rc);  // the reference dies in gpuErrchk here; never treat an error as "not ready yet"
+        } else {
+            break;  // :98
+        }
+    }
+}
+
+void observation_loop_state::check_analysis_events()
+{
+    if (error != BF_OK) return;
+    for (uint64_t event = blocks_analyzed; event < blocks_analysis_queue; event++) {  // :104
+        const int rc = ev->query(BlockAnalyzedSync[event % n_events]);
+        if (rc == BF_OK) {
+            blocks_analyzed++;
+            if (verbose) std::cout << "Block " << event << " Analyzed" << std::endl;
+            ev->destroy(BlockAnalyzedSync[event % n_events]);  // :112-113
+            BlockAnalyzedSync[event % n_events] = ev->create();
+            if (!BlockAnalyzedSync[event % n_events]) return fail(BF_ERR_DEVICE);
+        } else if (rc < 0) {
+            return fail(rc);
+        } else {
+            break;  // :116
+        }
+    }
+}
+
+uint64_t observation_loop_state::get_current_analysis_gemm(int time_slice)
+{
+    most_recent_gemm = (int)(blocks_analysis_queue * n_gemms_per_block + time_slice);  // :122
+    return most_recent_gemm;
+}
+
+uint64_t observation_loop_state::get_current_transfer_gemm() const { return blocks_transfer_queue * n_gemms_per_block; }
+
+bool observation_loop_state::check_ready_for_transfer() const
+{
+    return ((blocks_transfer_queue - blocks_analyzed < maximum_total_seperation) &&
+            (blocks_transfer_queue - blocks_transferred < maximum_transfer_seperation) && !transfers_complete);  // :131-133
+}
+
+bool observation_loop_state::check_ready_for_dh2_transfer(int time_slice)
+{
+    int current_gemm = (int)get_current_analysis_gemm(time_slice);  // :137
+    return (current_gemm < n_pt_sources);
+}
+
+bool observation_loop_state::check_ready_for_analysis() const { return (blocks_analysis_queue < blocks_transferred); }
+
+bool observation_loop_state::check_observations_complete()
+{
+    if (debug_mode) {  // :146-151
+        if ((most_recent_gemm >= n_pt_sources - 1) && (blocks_analyzed == blocks_transfer_queue) && transfers_complete) {
+            std::cout << "obs Complete" << std::endl;
+            return true;
+        }
+        return false;
+    }
+    if ((blocks_analyzed == blocks_transfer_queue) && transfers_complete) {  // :153-157
+        std::cout << "obs Complete" << std::endl;
+        return true;
+    }
+    return false;
+}
+
+bool observation_loop_state::check_transfers_complete()
+{
+    if (blocks_transfer_queue * n_gemms_per_block >= (uint64_t)std::max(n_pt_sources, 0)) {  // :163
+        transfers_complete = 1;
+        return true;
+    }
+    return false;
+}
+
+std::ostream& operator<<(std::ostream& out, const observation_loop_state& a)
+{
+    return out << "A: " << a.blocks_analyzed << ", AQ: " << a.blocks_analysis_queue << ", T: " << a.blocks_transferred
+               << ", TQ: " << a.blocks_transfer_queue << "\n"
+               << "current_gemm: " << a.most_recent_gemm << ", transfers_complete: " << a.transfers_complete;
+}
+
+// ---- the DEBUG main() flow (src/beamformer.cu:12-621 with -DDEBUG) ----------------------------------------------------
+int run_debug_observation(const bf_config& cfg, const debug_run_options& opt, debug_run_result* res,
+                          std::vector<float>* dedispersed_result, std::ostream& log)
+{
+    const int n_streams = cfg.n_streams;
+    if (cfg.n_gemms_per_block % n_streams) {
+        log << "N_GEMMS_PER_BLOCK must be divisible by N_STREAMS" << std::endl;
+        return BF_ERR_INVALID;
+    }
+    if (kSourcesPerBatch % cfg.n_gemms_per_block) {  // static_assert src/beamformer.hh:151
+        log << "N_SOURCES_PER_BATCH must be divisible by N_GEMMS_PER_BLOCK" << std::endl;
+        return BF_ERR_INVALID;
+    }
+    std::vector<antenna> pos((size_t)cfg.n_ant);
+    std::vector<beam_direction> dir((size_t)cfg.n_beams);
+    bool pos_set = false, dir_set = false;
+
+    test_data_generator input_data_generator(cfg);
+    if (!input_data_generator.get_data()) return BF_ERR_DEVICE;
+    if (opt.sources && input_data_generator.read_in_source_directions(opt.sources) != 0) {
+        log << "beam: could not read source direction file " << opt.sources << std::endl;
+        return BF_ERR_INVALID;
+    }
+    if (opt.positions) {
+        if (read_in_position_locations(opt.positions, cfg.n_ant, pos.data()) != 0) return BF_ERR_INVALID;
+        pos_set = true;
+    }
+    if (opt.directions) {
+        if (read_in_beam_directions(opt.directions, cfg.n_beams, dir.data()) != 0) return BF_ERR_INVALID;
+        dir_set = true;
+    }
+    if (!pos_set) default_positions(cfg.n_ant, pos.data());    // :135-140
+    if (!dir_set) default_directions(cfg.n_beams, dir.data());  // :142-147
+    if (opt.verbose) print_all_defines(cfg, log);
+
+    bf_handle* h = nullptr;
+    int rc = bf_create(&cfg, opt.device, &h);
+    if (rc != BF_OK) {
+        log << "GPUassert: " << bf_last_error() << std::endl;
+        return rc;
+    }
+    struct guard {
+        bf_handle* h;
+        std::vector<void*> pinned;
+        ~guard()
+        {
+            if (h) bf_stream_sync(h, -1);
+            for (void* p : pinned) bf_free_pinned(p);
+            bf_destroy(h);
+        }
+    } g{h, {}};
+
+    const int n_src = input_data_generator.get_n_pt_sources();
+    const size_t n_f_per_detect = bf_floats_per_detect(&cfg);
+    float *beam_out = nullptr, *dedispersed_out = nullptr;
+    void* p = nullptr;
+    if ((rc = bf_alloc_pinned(&p, n_f_per_detect * n_streams * sizeof(float))) != BF_OK) return rc;  // :249
+    g.pinned.push_back(p);
+    beam_out = static_cast<float*>(p);
+    if ((rc = bf_alloc_pinned(&p, (size_t)cfg.n_beams * std::max(n_src, 1) * sizeof(float))) != BF_OK) return rc;  // :212
+    g.pinned.push_back(p);
+    dedispersed_out = static_cast<float*>(p);
+    ::memset(dedispersed_out, 0, (size_t)cfg.n_beams * std::max(n_src, 1) * sizeof(float));
+
+    {  // :230-241, :251, :272
+        std::vector<int8_t> fourier_coefficients((size_t)cfg.n_freq * cfg.n_ant * cfg.n_beams * 2);
+        generate_fourier_coefficients(cfg.n_beams, cfg.n_ant, cfg.n_freq, 0, opt.gpu, pos.data(), dir.data(),
+                                      fourier_coefficients.data());
+        if ((rc = bf_set_weights(h, fourier_coefficients.data())) != BF_OK) {
+            log << "GPUassert: " << bf_last_error() << std::endl;
+            return rc;
+        }
+    }
+
+    std::vector<int> timeSlice((size_t)n_streams);
+    for (int i = 0; i < n_streams; i++) timeSlice[i] = i;  // :319
+
+    hip_backend backend(h);
+    observation_loop_state obs_state(kMaxTransferSep, kMaxTotalSep, cfg, &backend, /*debug_mode=*/true);  // :322
+    obs_state.set_n_pt_sources(n_src);                                                                  // :325
+
+    if (opt.verbose) {
+        log << "Executing beamformer.cu" << "\n";
+        log << "MAX_TOTAL_SEP: " << kMaxTotalSep << "\n";
+        log << "MAX_TRANSFER_SEP: " << kMaxTransferSep << std::endl;
+    }
+
+    float time_accumulator_ms = 0, observation_time_ms = 0;
+    bf_timer_start(h);  // :358
+    const size_t block_bytes = bf_bytes_per_block(&cfg);
+    const size_t input_data_size = input_data_generator.input_data_size();
+
+    while (!obs_state.check_observations_complete()) {  // :364
+        if (opt.verbose) {
+            log << "##########################################" << std::endl;
+            log << obs_state << std::endl;
+        }
+        if (obs_state.check_ready_for_transfer()) {  // :378
+            if (input_data_generator.check_need_to_generate_more_input_data((int)obs_state.get_blocks_transferred())) {
+                log << "Generating new source data" << std::endl;
+                bf_timer_stop(h, &time_accumulator_ms);  // :408-409
+                observation_time_ms += time_accumulator_ms;
+                input_data_generator.generate_test_data(pos.data(), opt.gpu);
+                bf_timer_start(h);
+                log << "done generating test data" << std::endl;
+            }
+            if (input_data_generator.check_data_ready_for_transfer((int)obs_state.get_blocks_transfer_queue())) {  // :421
+                char* input_data = input_data_generator.get_data();
+                rc = bf_submit_block(h, (int)obs_state.get_next_gpu_transfer_block(),
+                                     &input_data[(block_bytes * obs_state.get_blocks_transfer_queue()) % input_data_size],
+                                     block_bytes, nullptr);  // :425-429
+                if (rc != BF_OK) {
+                    log << "GPUassert: " << bf_last_error() << std::endl;
+                    return rc;
+                }
+                obs_state.generate_transfer_event();  // :431
+            }
+            obs_state.check_transfers_complete();  // :438
+        }
+        obs_state.check_transfer_events();  // :446
+
+        if (obs_state.check_ready_for_analysis()) {  // :452
+            for (int part = 0; part < cfg.n_gemms_per_block / n_streams; part++) {
+                if (opt.verbose)
+                    log << "Queueing Beamforming. Start Dir = " << obs_state.get_current_analysis_gemm(timeSlice[0])
+                        << std::endl;
+                for (int st = 0; st < n_streams; st++) {
+                    rc = bf_enqueue_gemm_unit(h, st, (int)obs_state.get_next_gpu_analysis_block(), timeSlice[st],
+                                              &beam_out[(size_t)st * n_f_per_detect]);  // :464-488
+                    if (rc != BF_OK) {
+                        log << "GPUassert: " << bf_last_error() << std::endl;
+                        return rc;
+                    }
+                    if (obs_state.check_ready_for_dh2_transfer(timeSlice[st])) {  // :492
+                        int current_gemm = (int)obs_state.get_current_analysis_gemm(timeSlice[st]);
+                        if (opt.verbose) log << "Current GEMM: " << current_gemm << std::endl;
+                        rc = bf_enqueue_dedisperse(h, st, &dedispersed_out[(size_t)current_gemm * cfg.n_beams]);  // :498-510
+                        if (rc != BF_OK) {
+                            log << "GPUassert: " << bf_last_error() << std::endl;
+                            return rc;
+                        }
+                    }
+                    timeSlice[st] += n_streams;  // :515
+                    if (timeSlice[st] >= cfg.n_gemms_per_block) timeSlice[st] -= cfg.n_gemms_per_block;
+                }
+            }
+            obs_state.generate_analysis_event();  // :525
+        }
+        obs_state.check_analysis_events();  // :532
+        if (obs_state.status() != BF_OK) {  // a failed record / query: the reference exits in gpuErrchk, never keep polling
+            log << "GPUassert: event backend failed: " << bf_last_error() << std::endl;
+            return obs_state.status();
+        }
+    }
+
+    bf_timer_stop(h, &time_accumulator_ms);  // :540
+    observation_time_ms += time_accumulator_ms;
+    const long long chunks = (long long)n_src * cfg.n_out_per_gemm;
+    log << "Observation ran in " << observation_time_ms << "milliseconds.\n";
+    log << "Code produced outputs for " << chunks << " data chunks.\n";
+    log << "Time per data chunk: " << observation_time_ms / chunks << " milliseconds.\n";
+    log << "Approximate datarate: " << bf_bytes_per_gemm(&cfg) * (double)n_src / observation_time_ms / 1e6 << "GB/s"
+        << std::endl;
+
+    bf_stream_sync(h, -1);  // :560-562
+    log << "Synchronized" << std::endl;
+
+    if (opt.output && opt.output[0])
+        if (write_array_to_disk_as_python_file(dedispersed_out, n_src, cfg.n_beams, opt.output) != 0)  // :568-571
+            log << "could not write " << opt.output << std::endl;
+    if (dedispersed_result) dedispersed_result->assign(dedispersed_out, dedispersed_out + (size_t)n_src * cfg.n_beams);
+    if (res) {
+        res->observation_time_ms = observation_time_ms;
+        res->n_pt_sources = n_src;
+        res->data_chunks = chunks;
+    }
+    return BF_OK;
+}
+
+// ---- production observation loop (src/beamformer.cu:364-534, #ifndef DEBUG branches) -------------------------------------
+int run_observation(const bf_config& cfg, const observation_options& opt, block_source& source, const antenna* pos,
+                    const beam_direction* dir, observation_result* res, std::ostream& log)
+{
+    const int n_streams = cfg.n_streams;
+    if (cfg.n_gemms_per_block % n_streams) return BF_ERR_INVALID;
+    const size_t block_bytes = bf_bytes_per_block(&cfg);
+    if (source.get_block_size() != block_bytes) {
+        // The reference prints this (src/beamformer.cu:336-339) and carries on; every ring block is then copied with the
+        // GEOMETRY's size: a smaller ring block is read past its end (past the mapping on the last one), a larger one is
+        // silently truncated.  Neither can produce a meaningful beam: refuse.
+        log << "ERROR: block size " << source.get_block_size() << ", Should also be " << block_bytes << std::endl;
+        return set_error(BF_ERR_INVALID, "run_observation: the source's block size does not match bf_bytes_per_block(cfg)");
+    }
+
+    bf_handle* h = nullptr;
+    int rc = bf_create(&cfg, opt.device, &h);
+    if (rc != BF_OK) {
+        log << "GPUassert: " << bf_last_error() << std::endl;
+        return rc;
+    }
+    struct guard {
+        bf_handle* h;
+        void* pinned;
+        ~guard()
+        {
+            if (h) bf_stream_sync(h, -1);
+            bf_free_pinned(pinned);
+            bf_destroy(h);
+        }
+    } g{h, nullptr};
+
+    const size_t n_f_per_detect = bf_floats_per_detect(&cfg);
+    if ((rc = bf_alloc_pinned(&g.pinned, n_f_per_detect * n_streams * sizeof(float))) != BF_OK) return rc;  // :249
+    float* beam_out = static_cast<float*>(g.pinned);
+    ::memset(beam_out, 0, n_f_per_detect * n_streams * sizeof(float));
+    {
+        std::vector<int8_t> fourier_coefficients((size_t)cfg.n_freq * cfg.n_ant * cfg.n_beams * 2);
+        generate_fourier_coefficients(cfg.n_beams, cfg.n_ant, cfg.n_freq, opt.rank * cfg.n_freq, opt.gpu, pos, dir,
+                                      fourier_coefficients.data());
+        if ((rc = bf_set_weights(h, fourier_coefficients.data())) != BF_OK) return rc;
+    }
+    std::vector<int> timeSlice((size_t)n_streams);
+    for (int i = 0; i < n_streams; i++) timeSlice[i] = i;  // :319
+    std::vector<long long> last_gemm((size_t)n_streams, -1);
+    std::vector<float*> unit_dst;
+
+    hip_backend backend(h);
+    observation_loop_state obs_state(kMaxTransferSep, kMaxTotalSep, cfg, &backend, /*debug_mode=*/false);  // :322
+    source.read_headers();  // :334
+    if (opt.burn_in > 0) {  // :348-355
+        log << "Burning IN" << std::endl;
+        for (int i = 0; i < opt.burn_in; i++) {
+            source.read();
+            source.close();
+        }
+        log << "Done Burn in" << std::endl;
+    }
+    uint64_t sink_committed = 0;
+    const char* unit_env = getenv("DSABF_UNIT_LAUNCH");   // measurement / test switch: the reference's per-gemm-unit launches
+    const bool block_launch = opt.block_launch && !(unit_env && unit_env[0] == '1');
+    bf_timer_start(h);  // :358
+    while (!obs_state.check_observations_complete()) {  // :364
+        if (opt.verbose) {
+            log << "##########################################" << std::endl;
+            log << obs_state << std::endl;
+        }
+        if (obs_state.check_ready_for_transfer()) {  // :378
+            char* block = source.read();             // :384
+            if (!source.check_transfers_complete()) {  // :386
+                rc = bf_submit_block(h, (int)obs_state.get_next_gpu_transfer_block(), block, block_bytes, nullptr);  // :389-393
+                if (rc != BF_OK) {
+                    log << "GPUassert: " << bf_last_error() << std::endl;
+                    return rc;
+                }
+                obs_state.generate_transfer_event();  // :396
+                if (source.close_releases_block())      // not in the reference: see block_source::close_releases_block
+                    while (obs_state.status() == BF_OK &&
+                           obs_state.get_blocks_transferred() < obs_state.get_blocks_transfer_queue())
+                        obs_state.check_transfer_events();
+            } else {
+                obs_state.set_transfers_complete(true);  // :398
+            }
+            source.close();  // :401
+        }
+        obs_state.check_transfer_events();  // :446
+        if (obs_state.check_ready_for_analysis()) {  // :452
+            const long long block_index = (long long)obs_state.get_blocks_analysis_queue();
+            if (block_launch) {
+                // one launch for the whole block; unit u's powers go where the per-unit loop below would send them:
+                // its sink slot, or beam_out[u % n_streams] (later units of the same queue overwrite earlier ones, in order)
+                const int n_units = cfg.n_gemms_per_block;
+                unit_dst.assign((size_t)n_units, nullptr);
+                for (int u = 0; u < n_units; u++) {
+                    const int st = u % n_streams;
+                    unit_dst[u] = &beam_out[(size_t)st * n_f_per_detect];
+                    if (opt.sink) {
+                        unit_dst[u] = opt.sink->acquire((uint64_t)block_index * n_units + u);
+                        if (!unit_dst[u]) {
+                            log << "ERROR: detected sink has no free slot" << std::endl;
+                            return BF_ERR_STATE;
+                        }
+                    }
+                    last_gemm[st] = block_index * n_units + u;
+                }
+                rc = bf_enqueue_block(h, (int)(block_index % n_streams), (int)obs_state.get_next_gpu_analysis_block(), 0,
+                                      n_units, unit_dst.data());
+                if (rc != BF_OK) {
+                    log << "GPUassert: " << bf_last_error() << std::endl;
+                    return rc;
+                }
+            } else {  // the reference's launch pattern: one gemm-unit per launch, round-robin over the compute queues
+                for (int part = 0; part < cfg.n_gemms_per_block / n_streams; part++) {
+                    for (int st = 0; st < n_streams; st++) {
+                        float* dst = &beam_out[(size_t)st * n_f_per_detect];  // the reference's destination, :485-488
+                        if (opt.sink) {
+                            dst = opt.sink->acquire((uint64_t)block_index * cfg.n_gemms_per_block + timeSlice[st]);
+                            if (!dst) {
+                                log << "ERROR: detected sink has no free slot" << std::endl;
+                                return BF_ERR_STATE;
+                            }
+                        }
+                        rc = bf_enqueue_gemm_unit(h, st, (int)obs_state.get_next_gpu_analysis_block(), timeSlice[st], dst);  // :464-488
+                        if (rc != BF_OK) {
+                            log << "GPUassert: " << bf_last_error() << std::endl;
+                            return rc;
+                        }
+                        last_gemm[st] = block_index * cfg.n_gemms_per_block + timeSlice[st];
+                        timeSlice[st] += n_streams;  // :515-519
+                        if (timeSlice[st] >= cfg.n_gemms_per_block) timeSlice[st] -= cfg.n_gemms_per_block;
+                    }
+                }
+            }
+            obs_state.generate_analysis_event();  // :525
+        }
+        obs_state.check_analysis_events();  // :532
+        if (obs_state.status() != BF_OK) {  // a failed record / query: the reference exits in gpuErrchk, never keep polling
+            log << "GPUassert: event backend failed: " << bf_last_error() << std::endl;
+            return obs_state.status();
+        }
+        if (opt.sink) {  // every D2H copy of an analysed block has landed: hand its gemm-units over, in order
+            for (; sink_committed < obs_state.get_blocks_analyzed() * (uint64_t)cfg.n_gemms_per_block; sink_committed++)
+                if (!opt.sink->commit(sink_committed)) {
+                    log << "ERROR: detected sink failed at gemm-unit " << sink_committed << std::endl;
+                    return BF_ERR_STATE;
+                }
+        }
+    }
+    float ms = 0;
+    bf_timer_stop(h, &ms);
+    bf_stream_sync(h, -1);  // :560-562
+    if (opt.sink) opt.sink->close();
+    const uint64_t blocks = obs_state.get_blocks_analyzed();
+    const uint64_t chunks = obs_state.get_current_transfer_gemm() * cfg.n_out_per_gemm;  // :552
+    const double rate = (double)source.get_block_size() * obs_state.get_blocks_transfer_queue() / ms / 1e6;  // :554
+    log << "Observation ran in " << ms << "milliseconds.\n";
+    log << "Code produced outputs for " << chunks << " data chunks.\n";
+    log << "Time per data chunk: " << ms / (chunks ? chunks : 1) << " milliseconds.\n";
+    log << "Approximate datarate: " << rate << "GB/s" << std::endl;
+    log << "Synchronized" << std::endl;
+    if (res) {
+        res->observation_time_ms = ms;
+        res->blocks = blocks;
+        res->data_chunks = chunks;
+        res->gbytes_per_s = rate;
+        res->beam_out.assign(beam_out, beam_out + n_f_per_detect * n_streams);
+        res->last_gemm = last_gemm;
+    }
+    return BF_OK;
+}
+
+}  // namespace dsabf

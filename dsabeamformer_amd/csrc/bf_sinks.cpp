@@ -1,0 +1,128 @@
+// bf_sinks.cpp -- host mirror, part 4: consumers of the detected stream: detected_sink and its file /
+// shared-memory-ring implementations.
+#include "../../include/dsabf_host.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <functional>
+#include <iostream>
+#include <memory>
+#include <sstream>
+#include <thread>
+#include <unistd.h>
+
+#include "../../include/dsabf_host.h"
+#include "bf_host_internal.h"
+
+namespace dsabf {
+
+// ---- detected-stream sinks ------------------------------------------------------------------------------------------
+detected_sink::detected_sink(const bf_config& cfg, uint64_t slots)
+    : floats_per_gemm(bf_floats_per_detect(&cfg)), n_slots(slots ? slots : slots_for(cfg))
+{
+    const size_t bytes = floats_per_gemm * n_slots * sizeof(float);
+    void* p = nullptr;
+    if (bf_alloc_pinned(&p, bytes) == BF_OK)
+        pinned = true;
+    else
+        p = ::malloc(bytes);  // no device (CPU tests of the ring logic)
+    ring = static_cast<float*>(p);
+}
+
+detected_sink::~detected_sink()
+{
+    if (!ring) return;
+    if (pinned)
+        bf_free_pinned(ring);
+    else
+        ::free(ring);
+}
+
+float* detected_sink::acquire(uint64_t gemm_index)
+{
+    if (!ring || gemm_index < next_commit || gemm_index >= next_commit + n_slots) return nullptr;
+    return ring + (size_t)(gemm_index % n_slots) * floats_per_gemm;
+}
+
+bool detected_sink::commit(uint64_t gemm_index)
+{
+    if (!ring || gemm_index != next_commit) return false;
+    if (!deliver(gemm_index, ring + (size_t)(gemm_index % n_slots) * floats_per_gemm, floats_per_gemm)) failed = true;
+    next_commit++;
+    delivered++;
+    return !failed;
+}
+
+file_sink::file_sink(const bf_config& cfg, const char* path, int gpu, uint64_t slots) : detected_sink(cfg, slots)
+{
+    fp = ::fopen(path, "wb");
+    if (!fp) return;
+    char header[kHeaderBytes];
+    ::memset(header, 0, sizeof(header));
+    ::snprintf(header, sizeof(header),
+               "HDR_VERSION 1.0\nHDR_SIZE %zu\nINSTRUMENT DSA\nCONTENT detected_power\nDTYPE float32\nENDIAN little\n"
+               "ORDER gemm,output,frequency,beam\nN_BEAMS %d\nN_FREQUENCIES %d\nN_OUTPUTS_PER_GEMM %d\nN_ANTENNAS %d\n"
+               "N_POL %d\nN_AVERAGING %d\nN_GEMMS_PER_BLOCK %d\nGPU %d\nFLOATS_PER_GEMM %zu\n",
+               kHeaderBytes, cfg.n_beams, cfg.n_freq, cfg.n_out_per_gemm, cfg.n_ant, cfg.n_pol, cfg.n_avg,
+               cfg.n_gemms_per_block, gpu, get_floats_per_gemm());
+    if (::fwrite(header, 1, sizeof(header), fp) != sizeof(header)) {
+        ::fclose(fp);
+        fp = nullptr;
+    }
+}
+
+file_sink::~file_sink() { finish(); }
+
+bool file_sink::deliver(uint64_t, const float* data, size_t n_floats)
+{
+    return fp && ::fwrite(data, sizeof(float), n_floats, fp) == n_floats;
+}
+
+void file_sink::finish()
+{
+    if (fp) ::fclose(fp);
+    fp = nullptr;
+}
+
+ring_sink::ring_sink(const bf_config& cfg, const char* ring_name, uint64_t ring_blocks, int gpu, uint64_t slots)
+    : detected_sink(cfg, slots), name(ring_name ? ring_name : "")
+{
+    char header[kRingHeaderBytes];
+    ::snprintf(header, sizeof(header),
+               "HDR_VERSION 1.0\nHDR_SIZE %zu\nINSTRUMENT DSA\nCONTENT detected_power\nDTYPE float32\nENDIAN little\n"
+               "ORDER output,frequency,beam\nN_BEAMS %d\nN_FREQUENCIES %d\nN_OUTPUTS_PER_GEMM %d\nGPU %d\n",
+               kRingHeaderBytes, cfg.n_beams, cfg.n_freq, cfg.n_out_per_gemm, gpu);
+    out = shm_ring::create(name.c_str(), ring_blocks, get_floats_per_gemm() * sizeof(float), header);
+}
+
+ring_sink::~ring_sink()
+{
+    finish();
+}
+
+bool ring_sink::deliver(uint64_t, const float* data, size_t n_floats)
+{
+    if (!out) return false;
+    char* b = out->open_block_write();  // blocks while the consumer is behind by a whole ring
+    if (!b) return false;
+    ::memcpy(b, data, n_floats * sizeof(float));
+    out->close_block_write(n_floats * sizeof(float));
+    return true;
+}
+
+void ring_sink::finish()
+{
+    if (!out) return;
+    if (out->open_block_write()) out->close_block_write(0);  // short block: end of data
+    // wait for the consumer to drain, then remove the ring (dada_db -d)
+    for (int waited = 0; out->get_blocks_read() < out->get_blocks_written() && waited < 10000; waited += 5) ::usleep(5000);
+    delete out;
+    out = nullptr;
+    shm_ring::unlink(name.c_str());
+}
+
+}  // namespace dsabf

@@ -6,7 +6,7 @@ import ctypes as C
 
 import numpy as np
 
-from ._lib import BfConfig, check, load
+from ._lib import BfhEventOps, BfConfig, check, load
 
 
 def _p(a: np.ndarray) -> C.c_void_p:
@@ -116,13 +116,24 @@ class TestDataGenerator:
 
 
 class ObservationLoopState:
-    """observation_loop_state (src/observation_loop.hh:1-177).  handle=None -> fake events (CPU tests)."""
+    """observation_loop_state (src/observation_loop.hh:1-177) on HIP events of `handle`'s queues, or -- event_ops given --
+    on a caller-supplied event backend (``BfhEventOps``; the CPU tests drive the scheduler that way)."""
 
-    def __init__(self, cfg: BfConfig, handle=None, max_transfer_sep: int = 2, max_total_sep: int = 4, debug: bool = True):
+    def __init__(self, cfg: BfConfig, handle=None, max_transfer_sep: int = 2, max_total_sep: int = 4, debug: bool = True,
+                 event_ops=None):
         self._lib = load()
         self._o = C.c_void_p()
-        check(self._lib.bfh_obs_create(max_transfer_sep, max_total_sep, C.byref(cfg), handle, 1 if debug else 0,
-                                       C.byref(self._o)))
+        self._ops = event_ops   # keep the callback table (and the Python callables behind it) alive
+        if event_ops is not None:
+            check(self._lib.bfh_obs_create_custom(max_transfer_sep, max_total_sep, C.byref(cfg), C.byref(event_ops),
+                                                  1 if debug else 0, C.byref(self._o)))
+        else:
+            check(self._lib.bfh_obs_create(max_transfer_sep, max_total_sep, C.byref(cfg), handle, 1 if debug else 0,
+                                           C.byref(self._o)))
+
+    def status(self) -> int:
+        """BF_OK or the first (sticky) error an event operation reported."""
+        return int(self._lib.bfh_obs_status(self._o))
 
     def counters(self) -> dict:
         v = [C.c_uint64() for _ in range(4)]
@@ -178,9 +189,6 @@ class ObservationLoopState:
         buf = C.create_string_buffer(512)
         check(self._lib.bfh_obs_describe(self._o, buf, 512))
         return buf.value.decode()
-
-    def fake_complete(self, n_transfers: int = 0, n_analyses: int = 0):
-        check(self._lib.bfh_obs_fake_complete(self._o, n_transfers, n_analyses))
 
     def close(self):
         if self._o:

@@ -43,26 +43,39 @@ extern "C" {
  * because BASELINE config 5 needs 100 ant / 512 beams / 1024 freq.  bf_config_default fills the reference's
  * values (debug != 0: `make debug`, n_avg = 1; debug == 0: production, n_avg = 16). */
 typedef struct bf_config {
-    int n_beams;           /* N_BEAMS            src/beamformer.hh:47   multiple of 32 */
-    int n_ant;             /* N_ANTENNAS         src/beamformer.hh:48   multiple of 4 (:156) */
+    int n_beams;           /* N_BEAMS            src/beamformer.hh:47   multiple of 4 (:155) */
+    int n_ant;             /* N_ANTENNAS         src/beamformer.hh:48   multiple of 4 (:156), at most 128 */
     int n_freq;            /* N_FREQUENCIES      src/beamformer.hh:49   frequencies owned by THIS handle/GPU */
     int n_pol;             /* N_POL              src/beamformer.hh:52 */
-    int n_avg;             /* N_AVERAGING        src/beamformer.hh:55-60 */
+    int n_avg;             /* N_AVERAGING        src/beamformer.hh:55-60  n_pol*n_avg in {2,4,8,16,32,64} */
     int n_out_per_gemm;    /* N_OUTPUTS_PER_GEMM src/beamformer.hh:111 */
     int n_gemms_per_block; /* N_GEMMS_PER_BLOCK  src/beamformer.hh:114 */
     int n_blocks_on_gpu;   /* N_BLOCKS_ON_GPU    src/beamformer.hh:124 */
     int n_streams;         /* N_STREAMS          src/beamformer.hh:83 */
     int verbose;           /* -DVERBOSE as a runtime flag */
-    int detect_mode;       /* BF_DETECT_CANONICAL (0, default) or BF_DETECT_FAST */
+    int detect_mode;       /* BF_DETECT_CANONICAL (0, default), BF_DETECT_CONTRACTED or BF_DETECT_FAST */
 } bf_config;
 
-/* detect_mode.  CANONICAL evaluates the reference's `acc += x*x + y*y` (src/beamformer.cuh:150-152) literally: two
- * multiplies, one add, one accumulate add per sample, ascending time order -> bit-identical to the CPU restatement.
- * FAST (geometries with n_pol*n_avg >= 16; ignored elsewhere) accumulates the unscaled integer voltages with
- * fused multiply-adds and applies (1/127)^2 once per output: 4 instead of 6 VALU ops per sample; the result is within
- * 4*n_ipo*2^-24 relative of the canonical one; both are within 2*n_ipo*2^-24 relative of exact arithmetic (tested). */
+/* detect_mode: how the power term of detect_sum, `acc += x*x + y*y` (src/beamformer.cuh:150-152), is evaluated.  x, y are
+ * the float32 real / imaginary parts fl(n * (float)(1/127)) of one beam sample, n the exact integer dot product.
+ *   BF_DETECT_CANONICAL   xx = x*x; yy = y*y; p = xx + yy; acc = acc + p -- two multiplies, an add and the accumulate add,
+ *                         ascending time order: what the reference's source says when no contraction happens (g++ on
+ *                         x86-64, the CPU restatement in oracle/).  Bit-identical to that restatement for every geometry.
+ *   BF_DETECT_CONTRACTED  yy = y*y; p = fma(x, x, yy); acc = acc + p -- what nvcc makes of the same source with its
+ *                         default -fmad=true (the reference's makefile:13-16 never turns it off), i.e. most likely the
+ *                         bits the reference's GPU build produces.  5 instead of 6 VALU ops per sample.  Bit-identical to
+ *                         the restatement's ORC_CONTRACT_NVCC reading.
+ *   BF_DETECT_FAST        (n_pol*n_avg >= 16; canonical elsewhere) d = 16 n exactly; acc = fma(d, d, acc) for re then im;
+ *                         one (alpha/16)^2 scale per output: 4 VALU ops per sample.
+ * Which of the first two the reference's device code really computes cannot be decided without NVIDIA hardware; the
+ * stated tolerance covers all three: with E = alpha^2 * sum over the n_ipo samples of |n|^2 evaluated exactly,
+ *   |canonical - E|, |contracted - E| <= (n_ipo + 4) * 2^-24 * E        |fast - E| <= (n_ipo + 1) * 2^-23 * E
+ * (at most 4 roundings per term -- x, x^2 or the fma, y^2, the pair sum -- plus n_ipo - 1 accumulate roundings of
+ * non-negative terms; fast: 2 n_ipo fma roundings, the scale and its constant).  tests/test_oracle.py and
+ * tests/test_gpu_parity.py hold all modes to these bounds; measured errors are a few units of 2^-24. */
 #define BF_DETECT_CANONICAL 0
 #define BF_DETECT_FAST 1
+#define BF_DETECT_CONTRACTED 2
 
 typedef struct bf_handle bf_handle; /* owns device memory, 1 transfer queue + n_streams compute queues */
 typedef struct bf_event bf_event;
@@ -132,6 +145,14 @@ int bf_record_transfer_event(bf_handle *h, bf_event *ev);
  * be pinned). */
 int bf_enqueue_gemm_unit(bf_handle *h, int stream_idx, int slot, int time_slice, float *host_out);
 
+/* Block-granular form of the same: ONE kernel launch over the n_units consecutive gemm-units [first_unit, first_unit +
+ * n_units) of ring slot `slot` on compute queue `stream_idx` (the reference launches K1-K3 once per gemm-unit,
+ * src/beamformer.cu:454-519; a whole PSRDADA block of 32 units keeps the chip filled where one unit cannot).  The detected
+ * powers land in a per-queue device buffer of n_gemms_per_block units; host_out, if not NULL, is an array of n_units host
+ * pointers (pinned; NULL entries are skipped): unit first_unit + i is copied to host_out[i] asynchronously, behind the
+ * launch, on the same queue.  Results are identical to n_units calls of bf_enqueue_gemm_unit. */
+int bf_enqueue_block(bf_handle *h, int stream_idx, int slot, int first_unit, int n_units, float *const *host_out);
+
 /* Replaces K5, the DEBUG dedisperse, src/beamformer.cu:498-510: sums output 0 of the unit last enqueued on
  * `stream_idx` over frequency (ascending f, fp32) and copies the n_beams floats to host_out_row. */
 int bf_enqueue_dedisperse(bf_handle *h, int stream_idx, float *host_out_row);
@@ -153,7 +174,9 @@ int bf_timer_stop(bf_handle *h, float *ms);
  * These are what bench.py and the multi-GPU path call; `hip_stream` is a hipStream_t (NULL = default). */
 
 /* Fused a1+a2+a3 over n_units gemm-units: d_packed [n_units][freq][time][ant] -> d_out
- * [n_units][output][freq][beam].  One kernel launch. */
+ * [n_units][output][freq][beam].  One kernel launch.  Both pointers must be 16-byte aligned (16-byte loads; groups of
+ * four beams are stored with one 16-byte store).  Like every entry point, the call leaves the caller's current HIP
+ * device as it found it. */
 int bf_beamform_device(bf_handle *h, const void *d_packed, int n_units, float *d_out, void *hip_stream);
 
 /* a1 alone (expand_input, src/beamformer.cuh:66-109): nbytes packed bytes -> 2*nbytes int8 (re, im pairs in

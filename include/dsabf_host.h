@@ -38,11 +38,25 @@ int bfh_gen_n_pt_sources(bfh_generator *g);
 int bfh_gen_need_more(bfh_generator *g, int blocks_transferred);
 int bfh_gen_ready(bfh_generator *g, int blocks_transfer_queue);
 
-/* observation_loop_state.  backend: handle == NULL -> fake events completed by bfh_obs_fake_complete (tests);
- * handle != NULL -> HIP events on that handle's queues. */
+/* observation_loop_state on HIP events of handle `h`'s queues (src/observation_loop.hh:54-176). */
 typedef struct bfh_obs bfh_obs;
 int bfh_obs_create(uint64_t max_transfer_sep, uint64_t max_total_sep, const bf_config *cfg, bf_handle *h, int debug_mode,
                    bfh_obs **out);
+/* The same scheduler on caller-supplied events (another runtime's, or a test's: the CPU tests drive the state machine
+ * with events they complete -- or fail -- by hand).  create returns NULL on failure; record_* return BF_OK or < 0;
+ * query returns BF_OK (done), BF_NOT_READY or < 0.  The table is copied; `user` must outlive the bfh_obs. */
+typedef struct bfh_event_ops {
+    void *user;
+    void *(*create)(void *user);
+    void (*destroy)(void *user, void *ev);
+    int (*record_transfer)(void *user, void *ev);
+    int (*record_analysis)(void *user, void *ev);
+    int (*query)(void *user, void *ev);
+} bfh_event_ops;
+int bfh_obs_create_custom(uint64_t max_transfer_sep, uint64_t max_total_sep, const bf_config *cfg, const bfh_event_ops *ops,
+                          int debug_mode, bfh_obs **out);
+/* BF_OK, or the first error an event operation reported (sticky): stop polling and return it. */
+int bfh_obs_status(bfh_obs *o);
 int bfh_obs_destroy(bfh_obs *o);
 int bfh_obs_generate_transfer_event(bfh_obs *o);
 int bfh_obs_generate_analysis_event(bfh_obs *o);
@@ -61,7 +75,6 @@ uint64_t bfh_obs_get_current_transfer_gemm(bfh_obs *o);
 uint64_t bfh_obs_get_next_gpu_analysis_block(bfh_obs *o);
 uint64_t bfh_obs_get_next_gpu_transfer_block(bfh_obs *o);
 int bfh_obs_describe(bfh_obs *o, char *buf, size_t buflen); /* operator<<, src/observation_loop.hh:172-176 */
-int bfh_obs_fake_complete(bfh_obs *o, int n_transfers, int n_analyses); /* fake backend only */
 
 /* The reference's `make debug` run end to end (generate -> H2D -> beamform -> dedisperse -> data.py).
  * Paths may be NULL (defaults src/beamformer.cu:135-147 and BOGUS_DATA).  ded_out (optional) receives

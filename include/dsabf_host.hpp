@@ -109,14 +109,16 @@ public:
 };
 
 // ---- observation_loop_state (src/observation_loop.hh:1-177) ----------------------------------------------
-// Event backend: the real one records/queries bf_event (HIP events); tests inject a fake to exercise the
-// scheduler on a machine with no GPU.
+// Event backend: the real one records/queries bf_event (HIP events); bfh_obs_create_custom (dsabf_host.h) plugs in any
+// other implementation through a table of C callbacks (the CPU tests drive the scheduler that way, with no GPU).
+// Every operation reports failure: the reference exits inside gpuErrchk (src/beamformer.cuh:19-29); here the error
+// becomes the state's sticky status() and the loops return it instead of polling a dead device forever.
 struct event_backend {
     virtual ~event_backend() {}
-    virtual void* create() = 0;
+    virtual void* create() = 0;                  // nullptr on failure
     virtual void destroy(void* ev) = 0;
-    virtual void record_transfer(void* ev) = 0;  // behind the last bf_submit_block
-    virtual void record_analysis(void* ev) = 0;  // behind all compute queues
+    virtual int record_transfer(void* ev) = 0;   // behind the last bf_submit_block; BF_OK or < 0
+    virtual int record_analysis(void* ev) = 0;   // behind all compute queues; BF_OK or < 0
     virtual int query(void* ev) = 0;             // BF_OK done, BF_NOT_READY, < 0 error
 };
 event_backend* make_hip_event_backend(bf_handle* h);  // caller deletes
@@ -138,6 +140,8 @@ private:
     bool verbose;
     int n_gemms_per_block, n_blocks_on_gpu, n_events;
     event_backend* ev;
+    int error = 0;  // first backend failure (BF_ERR_*), sticky; 0 = BF_OK
+    void fail(int code);
 
 public:
     observation_loop_state(uint64_t maximum_transfer_seperation, uint64_t maximum_total_seperation,
@@ -169,6 +173,9 @@ public:
     bool check_ready_for_dh2_transfer(int time_slice);
 
     bool check_observations_complete();
+    // BF_OK, or the first error any event operation reported (a failed record / create, a query that returned < 0).
+    // Once set, no counter advances any more: callers must stop polling and return it.
+    int status() const { return error; }
     void set_n_pt_sources(int val) { n_pt_sources = val; }  // DEBUG only in the reference
     bool check_transfers_complete();                        // DEBUG only in the reference
 
@@ -394,6 +401,13 @@ struct observation_options {
     bool verbose = false;
     detected_sink* sink = nullptr;  // optional consumer of every gemm-unit's detected powers; replaces beam_out as
                                     // the D2H destination (beam_out then stays zero)
+    // launch granularity: true = ONE kernel launch per PSRDADA block (bf_enqueue_block: 32 gemm-units keep the chip
+    // filled), the compute queue rotating with the block; false = the reference's own pattern, one launch per gemm-unit
+    // round-robin over the queues (src/beamformer.cu:454-519).  Identical outputs, destinations and completion order.
+    bool block_launch = true;
+    // -R / -r: this process beamforms frequencies [rank * n_freq, (rank + 1) * n_freq) of a world x n_freq sub-band (cfg.n_freq
+    // is the LOCAL count).  The weights are generated for those channels; the input blocks are the rank's own slice.
+    int world = 1, rank = 0;
 };
 struct observation_result {
     float observation_time_ms = 0;

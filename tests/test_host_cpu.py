@@ -7,6 +7,8 @@ import os
 import numpy as np
 import pytest
 
+from fake_events import make_obs
+
 from conftest import CFG, GOLDEN
 
 
@@ -163,7 +165,7 @@ def _simulate(obs, gen_blocks, per_block=32, n_streams=8, transfer_lag=1, analys
 @pytest.mark.parametrize("n_src,tl,al", [(1024, 1, 2), (1024, 3, 1), (100, 1, 5), (33, 2, 2)])
 def test_observation_loop_scheduler(host, bfm, n_src, tl, al):
     cfg = bfm.debug_config()
-    obs = host.ObservationLoopState(cfg, handle=None, debug=True)
+    obs = make_obs(host, cfg, debug=True)
     obs.set_n_pt_sources(n_src)
     assert obs.describe() == "A: 0, AQ: 0, T: 0, TQ: 0\ncurrent_gemm: 0, transfers_complete: 0"
     assert obs.check_ready_for_transfer() and not obs.check_ready_for_analysis()
@@ -183,7 +185,7 @@ def test_observation_loop_scheduler(host, bfm, n_src, tl, al):
 
 
 def test_observation_loop_backpressure_rules(host, bfm):
-    obs = host.ObservationLoopState(bfm.debug_config(), handle=None, debug=False)
+    obs = make_obs(host, bfm.debug_config(), debug=False)
     # transfer separation: at most 2 un-transferred blocks in flight
     obs.generate_transfer_event()
     assert obs.check_ready_for_transfer()
@@ -218,6 +220,55 @@ def test_observation_loop_backpressure_rules(host, bfm):
     assert obs.check_observations_complete()
     assert obs.get_current_transfer_gemm() == 4 * 32
     obs.close()
+
+
+def test_observation_loop_event_errors_are_sticky_not_polled_forever(host, bfm):
+    """A failed query / record / create must surface as an error, never as "not ready yet" (the reference exits inside
+    gpuErrchk, src/beamformer.cuh:19-29; a loop that treats errors as not-ready spins forever on a dead device)."""
+    from dsabeamformer_amd._lib import BF_ERR_DEVICE, BF_OK, DsabfError
+
+    cfg = bfm.debug_config()
+    # (1) a query that fails
+    obs = make_obs(host, cfg, debug=False)
+    obs.generate_transfer_event()
+    assert obs.status() == BF_OK
+    obs.fake.fail_query = True
+    with pytest.raises(DsabfError) as e:
+        obs.check_transfer_events()
+    assert e.value.code == BF_ERR_DEVICE and obs.status() == BF_ERR_DEVICE
+    obs.fake.fail_query = False
+    before = obs.counters()
+    with pytest.raises(DsabfError):      # sticky: nothing advances any more, every later call reports it
+        obs.generate_transfer_event()
+    with pytest.raises(DsabfError):
+        obs.check_analysis_events()
+    assert obs.counters() == before
+    obs.close()
+    # (2) a record that fails does not count as queued
+    obs = make_obs(host, cfg, debug=False)
+    obs.fake.fail_record = True
+    with pytest.raises(DsabfError):
+        obs.generate_analysis_event()
+    assert obs.counters()["AQ"] == 0 and obs.status() == BF_ERR_DEVICE
+    obs.close()
+    # (3) the destroy-and-recreate step of check_*_events cannot create a new event
+    obs = make_obs(host, cfg, debug=False)
+    obs.generate_transfer_event()
+    obs.fake_complete(1, 0)
+    obs.fake.fail_create = True
+    with pytest.raises(DsabfError):
+        obs.check_transfer_events()
+    assert obs.status() == BF_ERR_DEVICE
+    obs.fake.fail_create = False
+    obs.close()
+    # (4) construction with a backend that cannot create events
+    fake_cfg = bfm.debug_config()
+    from fake_events import FakeEvents
+    f = FakeEvents()
+    f.fail_create = True
+    o = host.ObservationLoopState(fake_cfg, debug=False, event_ops=f.ops)
+    assert o.status() == BF_ERR_DEVICE
+    o.close()
 
 
 def test_detected_sink_ring_and_file_format(host, bfm, tmp_path):
@@ -401,3 +452,23 @@ def test_sink_and_ring_error_paths(host, bfm, tmp_path):
 
 def host_max_blocks():
     return 64   # dsabf::kMaxRingBlocks
+
+
+def test_observation_refuses_a_ring_of_the_wrong_block_size(host, bfm):
+    """A ring built for another geometry: the reference prints "ERROR: block size ..." and carries on
+    (src/beamformer.cu:336-339), copying the geometry's block size out of every ring block -- past the end of a smaller
+    block, a prefix of a larger one.  run_observation refuses before it touches a device."""
+    from dsabeamformer_amd._lib import BF_ERR_INVALID, DsabfError
+
+    cfg = bfm.debug_config(n_freq=8, n_beams=64)
+    want = cfg.n_ant * cfg.n_freq * cfg.n_out_per_gemm * cfg.n_pol * cfg.n_avg * cfg.n_gemms_per_block
+    for wrong in (want // 2, want * 2):
+        name = _ring_name("m")
+        ring = host.ShmRing(name, n_blocks=2, block_size=wrong, header="HDR_SIZE 4096\n")
+        try:
+            with pytest.raises(DsabfError) as e:
+                host.run_observation_shm(cfg, name)
+            assert e.value.code == BF_ERR_INVALID and "block size" in str(e.value)
+        finally:
+            ring.detach()
+            ring.unlink()
