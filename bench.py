@@ -8,12 +8,19 @@ Workload (BASELINE.json configs[2] geometry, "C3" in SURVEY.md section 8d): 64 a
 256 beams, N_TIME = 512 voltage columns per gemm-unit (16 detected outputs x n_ipo 32), input = uniform random
 nibbles (all 16 codes) already resident in HBM.  One *step* = one launch over `--units` gemm-units (default 128 =
 the MAX_TOTAL_SEP = 4 PSRDADA blocks of 32 gemm-units that the reference's scheduler keeps in flight,
-src/beamformer.hh:85,114) = units*16 beam-blocks.  The metric unit is the
-beam-block: one detected [256 freq][256 beams] float32 output.
+src/beamformer.hh:85,114) = units*16 beam-blocks.  The metric unit is the beam-block: one detected [256 freq][256 beams]
+float32 output.
 
-N > 1 (strong scaling, BASELINE.json configs[3]): rank r owns frequencies [r*256/N, (r+1)*256/N) of every
-gemm-unit; the only collective is the detected-power gather (RCCL all_to_all_single: every rank becomes the owner of
-the full band for 1/N of the outputs; `--gather root` gathers everything on rank 0 instead, `--gather none` skips it).
+Order of work (so that the GPU is busy for seconds around the timed region and nothing long runs before it):
+  warm-up (W steps, then more of the same until >= 1 s has passed: DVFS settles, the smi sampler sees the burst)
+  -> the timed K steps (barrier + synchronize on both sides, max over ranks) -> supplementary GPU records
+  -> the CPU baselines, LAST (announced on stderr; ~20 s of host work).
+
+N > 1 (strong scaling, BASELINE.json configs[3]): rank r owns frequencies [r*256/N, (r+1)*256/N) of every gemm-unit; the
+only collective is the gather of the detected powers, through the C-ABI (bf_comm_create / bf_gather_detected: RCCL
+point-to-point over xGMI, include/dsabf.h).  `--gather` picks the headline mode (default alltoall = distributed owners);
+every mode -- none, root, alltoall, each in both layouts -- is then timed side by side under "gather_modes", so a scaling
+run separates kernel scaling from xGMI.
 """
 from __future__ import annotations
 
@@ -45,19 +52,27 @@ def parse():
                     help="c3: N_TIME 512 (16 outputs x n_ipo 32); prod: reference production N_TIME 256; "
                          "c2: DEBUG geometry N_TIME 16 (n_ipo 2, parity config; HBM-write bound); "
                          "c5: DSA100 scale-up, 100 ant x 512 beams x 1024 freq, N_TIME 256 (use --units 4)")
-    ap.add_argument("--gather", default="alltoall", choices=["alltoall", "root", "none"])
-    ap.add_argument("--detect", default="canonical", choices=["canonical", "fast"],
-                    help="canonical (default): bit-exact detect; fast: opt-in fma-contracted detect (tolerance mode)")
+    ap.add_argument("--gather", default="alltoall", choices=["alltoall", "root", "none"],
+                    help="N > 1: the headline's gather mode (all modes are also timed side by side)")
+    ap.add_argument("--layout", default="rank", choices=["rank", "freq"],
+                    help="gathered layout: rank = sub-band-major [rank][row][f_local][b], one message per sender; "
+                         "freq = the reference's [row][f over the band][b], one message per (row, sender)")
+    ap.add_argument("--detect", default="canonical", choices=["canonical", "contracted", "fast"],
+                    help="canonical (default): x*x + y*y as written; contracted: nvcc's fma(x,x,y*y); fast: tolerance mode")
     ap.add_argument("--input", default="random", choices=["random", "zeros", "const"],
                     help="experiment only: voltage bit patterns (MFMA power depends on operand toggling)")
     ap.add_argument("--force-dist", action="store_true",
-                    help="single process: still create the RCCL process group (world size 1) and run the gather path "
-                         "(plumbing check on a 1-GPU box; the driver's multi-GPU runs use torch.distributed.run)")
+                    help="single process: still create the process group and a one-rank RCCL communicator and run the "
+                         "gather path (plumbing check on a 1-GPU box)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
-                    help="skip the supplementary runs (fast detect, general kernel): profiling passes see one kernel")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+                    help="skip the supplementary records: profiling passes see one kernel")
+    ap.add_argument("--min-warm-seconds", type=float, default=1.0)
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
     return ap.parse_args()
+
+
+DETECT = {"canonical": 0, "fast": 1, "contracted": 2}
 
 
 def geometry(workload):
@@ -65,53 +80,78 @@ def geometry(workload):
     return {"c3": (16, 16), "prod": (16, 8), "c2": (1, 8), "c5": (16, 8)}[workload]
 
 
-def product_weights(torch, cfg, f0):
-    """Steering weights for the linear DSA geometry, computed by the product's own host code (a5)."""
-    import ctypes as C
+def grid_100():
+    """c5: 10x10 antenna grid, 32x16 beam grid (the notebook's formulas)."""
+    import numpy as np
 
+    ax = np.linspace(-250, 250, 10)
+    pos = np.zeros((100, 3), np.float32)
+    pos[:, 0], pos[:, 1] = [v.ravel() for v in np.meshgrid(ax, ax)]
+    th, ph = np.meshgrid(np.linspace(-3.5, 3.5, 32) * np.pi / 180, np.linspace(-3.5, 3.5, 16) * np.pi / 180)
+    return pos, np.stack([th.ravel(), ph.ravel()], 1).astype(np.float32)
+
+
+def product_weights(cfg, f0):
+    """Steering weights computed by the product's own host code (a5)."""
     import numpy as np
 
     from dsabeamformer_amd import host
 
-    if cfg.n_ant == 100:  # c5: 10x10 grid, 32x16 beam grid (notebook formulas; SURVEY.md section 4)
-        ax = np.linspace(-250, 250, 10)
-        pos = np.zeros((100, 3), np.float32)
-        pos[:, 0], pos[:, 1] = [v.ravel() for v in np.meshgrid(ax, ax)]
-        th, ph = np.meshgrid(np.linspace(-3.5, 3.5, 32) * np.pi / 180, np.linspace(-3.5, 3.5, 16) * np.pi / 180)
-        dirs = np.stack([th.ravel(), ph.ravel()], 1).astype(np.float32)
+    if cfg.n_ant == 100:
+        pos, dirs = grid_100()
         return host.make_weights(pos, dirs, cfg.n_freq, chan0=f0, gpu=0)
     w = host.make_weights_default(n_beams=cfg.n_beams, n_ant=cfg.n_ant, n_freq_total=256, gpu=0)
     return np.ascontiguousarray(w[f0:f0 + cfg.n_freq])
 
 
-def pmc_traffic(args, world):
-    """HBM bytes per launch of the fused kernel from the committed rocprofv3 PMC passes (tools/pmc.sh: FETCH_SIZE
-    and WRITE_SIZE collected in separate passes, KiB units; FETCH_SIZE doubled per MI355X_MICROARCH.md section HBM --
-    gfx950 tallies 128-B read requests at 64 B).  Only valid for the exact launch it was measured on."""
-    # (workload, units) each committed summary was measured on
-    measured = {("c3", 128): "r01_c3_pmc_summary.txt", ("c5", 16): "r01_c5_pmc_summary.txt",
-                ("c2", 128): "r01_c2_pmc_summary.txt"}
-    name = measured.get((args.workload, args.units))
-    if name is None or world != 1:
-        return None
+def pmc_summary(name):
+    """Counter means of one committed rocprofv3 PMC summary (tools/pmc.sh), {} if absent."""
     path = os.path.join(ROOT, "profiles", name)
-    if not os.path.exists(path):
-        return None
     vals = {}
-    for line in open(path):
-        parts = line.split()
-        if len(parts) >= 3 and parts[1] == "mean":
-            vals[parts[0]] = float(parts[2])
+    if os.path.exists(path):
+        for line in open(path):
+            parts = line.split()
+            if len(parts) >= 3 and parts[1] == "mean":
+                vals[parts[0]] = float(parts[2])
+    return vals
+
+
+def pmc_traffic(vals):
+    """HBM bytes per launch: FETCH_SIZE and WRITE_SIZE (KiB) come from separate passes; FETCH_SIZE doubled per
+    MI355X_MICROARCH.md section HBM (gfx950 tallies 128-B read requests at 64 B)."""
     if "FETCH_SIZE" not in vals or "WRITE_SIZE" not in vals:
         return None
     return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
 
 
-def cpu_baseline(args, n_avg, n_out, seconds):
-    """Oracle (C restatement, OpenMP, all host cores) on a bounded sample of the SAME workload."""
+def pmc_mfma_busy(vals):
+    """Fraction of SIMD cycles the matrix pipe is busy: SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs)."""
+    if "SQ_VALU_MFMA_BUSY_CYCLES" not in vals or "GRBM_GUI_ACTIVE" not in vals:
+        return None
+    return vals["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * vals["GRBM_GUI_ACTIVE"] / 8.0)
+
+
+def time_launches(torch, fn, n, stream):
+    """Average duration (ms) of n launches of fn(i), HIP events on the launch stream around each."""
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+    for i, (a, b) in enumerate(ev):
+        a.record(stream)
+        fn(i)
+        b.record(stream)
+    torch.cuda.synchronize()
+    ms = sorted(a.elapsed_time(b) for a, b in ev)
+    return sum(ms) / len(ms), ms[len(ms) // 2], ms[0]
+
+
+def cpu_baselines(n_avg, n_out, seconds):
+    """Host-side baselines, on a bounded sample: (1) the oracle's beamform port (expand + GEMM + detect, OpenMP, all cores)
+    on gemm-units of the bench workload; (2) the reference's only CPU code on the path, generate_test_data
+    (src/test_data_generator.hh:63-95): the PRODUCT's generator for one 1024-unit DEBUG batch on 1 core and on all cores,
+    and the oracle's literal restatement of the reference loop (trig for every time column, as `make fast_debug` runs it)."""
     import numpy as np
 
     import oracle as orc
+    from dsabeamformer_amd import debug_config, host
 
     g = orc.Geom(n_avg=n_avg, n_out_per_gemm=n_out)
     pos, dirs = orc.default_positions(g.n_ant), orc.default_directions(g.n_beams)
@@ -126,9 +166,38 @@ def cpu_baseline(args, n_avg, n_out, seconds):
         el = time.perf_counter() - t0
         if el >= seconds or n >= 4096:
             break
-    return {"value": n * g.n_out_per_gemm / el, "unit": "beam-blocks/s", "cores": orc.get_threads(), "kind": "port",
-            "sample": "%d gemm-unit(s) of the bench workload (%d beam-blocks), oracle/dsabf_oracle.c -O3 -mavx2 "
-                      "-fopenmp, %.1f s" % (n, n * g.n_out_per_gemm, el)}
+    out = {"value": n * g.n_out_per_gemm / el, "unit": "beam-blocks/s", "cores": orc.get_threads(), "kind": "port",
+           "sample": "%d gemm-unit(s) of the bench workload (%d beam-blocks), oracle/dsabf_oracle.c -O3 -mavx2 "
+                     "-fopenmp, %.1f s" % (n, n * g.n_out_per_gemm, el)}
+    # (2) the generator
+    dbg = debug_config()
+    src = host.read_directions(os.path.join(ROOT, "tests", "golden", "config", "linear_source_directions_1024.txt"))
+    gen_rec = {"unit": "s per 1024-gemm-unit DEBUG batch (256 MiB)", "reference": "src/test_data_generator.hh:63-95"}
+    ncores = os.cpu_count() or 1
+    for label, nt in (("product_1_core", 1), ("product_all_cores", ncores)):
+        os.environ["DSABF_THREADS"] = str(nt)
+        gen = host.TestDataGenerator(dbg, 1024, pin=False)
+        gen.set_source_directions(src)
+        ppos = host.default_positions(64)
+        gen.generate_test_data(ppos, 0)          # first touch of the 256 MiB buffer
+        t0 = time.perf_counter()
+        gen.generate_test_data(ppos, 0)
+        gen_rec[label] = {"value": time.perf_counter() - t0, "cores": nt}
+        gen.close()
+    os.environ.pop("DSABF_THREADS", None)
+    gen_rec["product_note"] = ("dsabf::test_data_generator evaluates the trig once per (source, frequency, antenna) and "
+                               "replicates it over the time columns (the reference's expression has no column index)")
+    # the reference's loop as written (trig for every column), OpenMP over sources like `make fast_debug` (makefile:16):
+    # a bounded 128-unit sample, scaled to the 1024-unit batch
+    gd = orc.DEBUG_GEOM
+    opos = orc.default_positions(gd.n_ant)
+    t0 = time.perf_counter()
+    orc.generate_test_data(gd, opos, src, 0, 0, 128, literal=True)
+    el = time.perf_counter() - t0
+    gen_rec["reference_loop_all_cores"] = {"value": el * 8.0, "cores": orc.get_threads(), "kind": "port",
+                                           "sample": "128 of 1024 gemm-units, literal restatement, x8"}
+    out["generator"] = gen_rec
+    return out
 
 
 def main():
@@ -158,6 +227,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     import dsabeamformer_amd as bfm
+    from dsabeamformer_amd import api
 
     n_avg, n_out = geometry(args.workload)
     n_freq_total = 1024 if args.workload == "c5" else 256
@@ -166,10 +236,10 @@ def main():
     cfg = bfm.production_config(n_avg=n_avg, n_out_per_gemm=n_out, n_freq=n_freq)
     if args.workload == "c5":
         cfg.n_ant, cfg.n_beams = 100, 512
-    cfg.detect_mode = 1 if args.detect == "fast" else 0
+    cfg.detect_mode = DETECT[args.detect]
     n_ipo, n_time = cfg.n_pol * cfg.n_avg, n_out * cfg.n_pol * cfg.n_avg
     bf = bfm.Beamformer(cfg, device=local)
-    bf.set_weights(product_weights(torch, cfg, rank * n_freq))
+    bf.set_weights(product_weights(cfg, rank * n_freq))
 
     units = args.units
     blocks_per_step = units * n_out                      # beam-blocks per step (whole job)
@@ -185,62 +255,141 @@ def main():
     stream = torch.cuda.current_stream()
     sptr = stream.cuda_stream
 
-    # ---- gather plumbing (N > 1): dsabeamformer_amd/shard.py, covered by tests/test_shard_gloo.py ------------
-    og = units * n_out
-    gather = None
-    if dist is not None and args.gather != "none":
-        from dsabeamformer_amd.shard import DetectedGather
+    # ---- the gather (N > 1 or --force-dist): bf_comm / bf_gather_detected behind the C-ABI -------------------------------
+    n_rows, row_floats = units * n_out, n_freq * cfg.n_beams
+    comm, comm_note = None, None
+    if dist is not None:
+        try:
+            idt = torch.zeros(128, dtype=torch.uint8, device="cuda")
+            if rank == 0:
+                idt.copy_(torch.frombuffer(bytearray(api.comm_unique_id()), dtype=torch.uint8))
+            dist.broadcast(idt, 0)
+            comm = api.Comm(rank, world, bytes(idt.cpu().numpy().tobytes()), device=local)
+        except Exception as e:  # pragma: no cover -- keep a scaling run alive: fall back to the torch.distributed gather
+            comm_note = "C-ABI communicator failed (%s); gather runs through torch.distributed (dsabeamformer_amd/shard.py)" % e
+    side = torch.cuda.Stream() if dist is not None else None
 
-        gather = DetectedGather(torch, dist, args.gather, og, n_freq, cfg.n_beams, torch.device("cuda", local))
+    class GatherMode:
+        """One way of bringing the shards together, double-buffered: the collective of step i runs on a side stream and
+        overlaps the kernel of step i+1; the compute stream waits for it only before it overwrites that slot again."""
 
-    def step(i, ev_pair=None):
+        def __init__(self, mode, layout):
+            self.mode, self.layout = mode, layout
+            self.root = {"root": 0, "alltoall": api.GATHER_ROOT_DISTRIBUTED}.get(mode)
+            self.lay = api.GATHER_RANK_MAJOR if layout == "rank" else api.GATHER_FREQ_MAJOR
+            self.kernel_done = [torch.cuda.Event() for _ in range(2)]
+            self.gather_done = [None, None]
+            self.full = [None, None]
+            self.torch_gather = None
+            if mode == "none":
+                return
+            if comm is not None:
+                held = comm.rows_held(n_rows, self.root)
+                if held:
+                    self.full = [torch.empty(held * world * row_floats, dtype=torch.float32, device="cuda") for _ in range(2)]
+            else:
+                from dsabeamformer_amd.shard import DetectedGather
+
+                self.torch_gather = DetectedGather(torch, dist, mode, n_rows, n_freq, cfg.n_beams, torch.device("cuda", local))
+
+        def before_kernel(self, slot):
+            if self.torch_gather is not None:
+                self.torch_gather.finish(slot)
+            elif self.gather_done[slot] is not None:
+                stream.wait_event(self.gather_done[slot])
+                self.gather_done[slot] = None
+
+        def after_kernel(self, slot):
+            if self.mode == "none":
+                return
+            if self.torch_gather is not None:
+                self.torch_gather.start(slot, d_out[slot])
+                return
+            self.kernel_done[slot].record(stream)
+            side.wait_event(self.kernel_done[slot])
+            comm.gather(d_out[slot], n_rows, row_floats, self.root, self.lay, self.full[slot], side.cuda_stream)
+            ev = torch.cuda.Event()
+            ev.record(side)
+            self.gather_done[slot] = ev
+
+        def drain(self):
+            for slot in (0, 1):
+                self.before_kernel(slot)
+            torch.cuda.synchronize()
+
+    headline_mode = GatherMode(args.gather if dist is not None else "none", args.layout)
+
+    def step(i, gm, ev_pair=None):
         slot = i & 1
-        if gather is not None:
-            gather.finish(slot)  # the output buffer about to be overwritten must have left (and been re-laid out)
+        gm.before_kernel(slot)  # the output buffer about to be overwritten must have left
         if ev_pair:
             ev_pair[0].record(stream)
         bf.beamform(d_in[i % len(d_in)], units, d_out[slot], sptr)
         if ev_pair:
             ev_pair[1].record(stream)
-        if gather is not None:
-            gather.start(slot, d_out[slot])  # RCCL runs on its own stream, overlapping the next step's kernel
+        gm.after_kernel(slot)
 
-    def drain():
-        if gather is not None:
-            gather.finish(0)
-            gather.finish(1)
+    def timed_region(gm, n_steps, with_events):
+        events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_steps)] if with_events else None
+        if dist is not None:
+            dist.barrier()
         torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(n_steps):
+            step(i, gm, events[i] if events else None)
+        gm.drain()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed, events
 
+    # ---- warm-up: W steps, then keep stepping until the chip has been busy for min-warm-seconds -------------------------
+    t_w = time.perf_counter()
     for i in range(args.warmup):
-        step(i)
-    drain()
+        step(i, headline_mode)
+    extra_warm = 0
+    while True:
+        headline_mode.drain()
+        go = torch.tensor([1.0 if time.perf_counter() - t_w < args.min_warm_seconds else 0.0], device="cuda")
+        if dist is not None:
+            dist.all_reduce(go, op=dist.ReduceOp.MAX)   # every rank takes the same number of extra steps
+        if go.item() == 0.0:
+            break
+        for i in range(32):
+            step(i, headline_mode)
+        extra_warm += 32
 
-    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i, events[i])
-    drain()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed, events = timed_region(headline_mode, args.steps, True)
 
-    if args.force_dist and world == 1 and gather is not None:
-        # one rank: the gathered tensor must be the kernel's output of that slot, re-laid out as [o][f][b] (= unchanged)
+    if args.force_dist and world == 1 and headline_mode.mode != "none":
+        # one rank: the gathered tensor must be the kernel's output of that slot (both layouts are the identity)
         for slot in (0, 1):
-            got = gather.full[slot]
+            got = headline_mode.full[slot] if headline_mode.torch_gather is None else headline_mode.torch_gather.full[slot]
             if got is not None and not torch.equal(got.reshape(-1), d_out[slot]):
                 sys.exit("gather plumbing check failed: slot %d differs from the kernel output" % slot)
 
     kern_ms = sorted(a.elapsed_time(b) for a, b in events)
     kern_avg_ms = sum(kern_ms) / len(kern_ms)
+
+    # ---- every gather mode side by side (N > 1) ----------------------------------------------------------------------------
+    gather_modes = None
+    if dist is not None and (world > 1 or args.force_dist) and not args.no_extras:
+        gather_modes = {}
+        n_side = max(5, min(args.steps, 50))
+        for mode, layout in (("none", "rank"), ("root", "rank"), ("root", "freq"), ("alltoall", "rank"), ("alltoall", "freq")):
+            gm = GatherMode(mode, layout)
+            for i in range(4):
+                step(i, gm)
+            gm.drain()
+            el, _ = timed_region(gm, n_side, False)
+            gather_modes[mode if mode == "none" else "%s_%s_major" % (mode, layout)] = {
+                "value": n_side * blocks_per_step / el, "unit": "beam-blocks/s", "ms_per_step": el / n_side * 1e3, "steps": n_side}
+            del gm
 
     if rank == 0:
         total_blocks = args.steps * blocks_per_step
@@ -251,21 +400,36 @@ def main():
         launch_ops = ops_per_block * blocks_per_step / world    # per launch (this rank's kernel)
         launch_bytes = bytes_per_block * blocks_per_step / world
         mfma_bound = args.workload != "c2"
+        info = bf.kernel_info(units)
+        paired = "PAIRED" in info["kernel"]
+        # committed rocprofv3 PMC summaries of exactly this launch (tools/pmc.sh), if any
+        pmc_name = {("c3", 128, True): "r02_c3_paired_pmc_summary.txt", ("c3", 128, False): "r02_c3_general_pmc_summary.txt",
+                    ("c5", 16, True): "r01_c5_pmc_summary.txt", ("c2", 128, True): "r01_c2_pmc_summary.txt"}.get(
+            (args.workload, units, paired))
+        pmc = pmc_summary(pmc_name) if (pmc_name and world == 1 and args.detect == "canonical") else {}
         if mfma_bound:
             achieved = launch_ops / (kern_avg_ms * 1e-3) / 1e12
-            roof = {"bound": "mfma", "achieved": achieved, "peak": INT8_DENSE_PEAK_TOPS, "unit": "TFLOP/s",
-                    "frac": achieved / INT8_DENSE_PEAK_TOPS, "traffic": pmc_traffic(args, world)}
+            roof = {"bound": "mfma", "achieved": achieved, "peak": INT8_DENSE_PEAK_TOPS, "unit": "TOP/s",
+                    "frac": achieved / INT8_DENSE_PEAK_TOPS, "traffic": pmc_traffic(pmc)}
         else:
             achieved = launch_bytes / (kern_avg_ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args, world)}
-        info = bf.kernel_info(units)
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(pmc)}
+        executed = launch_ops / 2 if paired else launch_ops
         roof.update({"kernel": info["kernel"],
                      "kernel_ms_avg": kern_avg_ms, "kernel_ms_median": kern_ms[len(kern_ms) // 2],
                      "kernel_ms_min": kern_ms[0], "algorithmic_ops_per_launch": launch_ops,
                      "algorithmic_bytes_per_launch": launch_bytes,
-                     "note": "unit is int8 TOP/s (1 complex MAC = 8 ops); traffic = HBM bytes per launch from the "
-                             "committed PMC passes (profiles/r01_c3_pmc_summary.txt, r01_c5_pmc_summary.txt), null if this launch differs"})
+                     "executed_mfma_ops_per_launch": executed,
+                     "executed_frac": (executed / (kern_avg_ms * 1e-3) / 1e12 / INT8_DENSE_PEAK_TOPS) if mfma_bound else None,
+                     "mfma_busy_frac": pmc_mfma_busy(pmc),
+                     "pmc_source": ("profiles/" + pmc_name) if pmc else None,
+                     "note": "int8 ops: 1 complex MAC = 8 ops.  frac = ALGORITHMIC ops / kernel time / peak; executed_frac = "
+                             "the int8 ops the MFMA pipe really executes / time / peak (the conjugate-pair kernel forms two "
+                             "beams from shared products: half the algorithmic ops, same bits); mfma_busy_frac = "
+                             "SQ_VALU_MFMA_BUSY_CYCLES / SIMD cycles from the committed rocprofv3 PMC pass of this launch "
+                             "(profiled passes clock lower); traffic = HBM bytes per launch from the same passes (FETCH_SIZE "
+                             "doubled per the guide), null if this launch has no committed pass"})
         out = {
             "metric": "beam-blocks/sec (%d beams x %d freq x N_TIME)" % (cfg.n_beams, n_freq_total), "value": value,
             "unit": "beam-blocks/s",
@@ -280,85 +444,138 @@ def main():
                                     "c5": "C5 DSA100 scale-up: 100 ant x 2 pol, 1024 freq, 512 beams, N_TIME=256; the "
                                           "unit is a 512-beam x 1024-freq block"}[args.workload],
                        "gemm_units_per_step": units, "beam_blocks_per_step": blocks_per_step,
-                       "freq_per_gpu": n_freq, "gather": args.gather if dist is not None else "n/a",
-                       "detect_mode": args.detect,
+                       "freq_per_gpu": n_freq,
+                       "gather": ("%s, %s-major layout, %s" % (args.gather, args.layout,
+                                                               "bf_gather_detected (RCCL p2p behind the C-ABI)" if comm is not None
+                                                               else "torch.distributed")) if dist is not None else "n/a",
+                       "detect_mode": args.detect, "extra_warmup_steps": extra_warm,
                        "launch": info},
             "roofline": roof,
         }
-        paired = "PAIRED" in info["kernel"]
-        roof["executed_mfma_ops_per_launch"] = launch_ops / 2 if paired else launch_ops
-        if paired:
-            roof["note"] += ("; the beam set is symmetric about the boresight, so the conjugate-pair kernel executes half "
-                             "the algorithmic int8 ops on the MFMA pipe (same bits) -- achieved/frac stay ALGORITHMIC "
-                             "ops over time, the general kernel on the same input is reported under general_kernel")
-        if world == 1 and args.detect == "canonical" and args.workload in ("c3", "prod") and not args.no_extras:
-            def supplementary(detect_mode, env=None):
-                old = os.environ.get("DSABF_PAIRED")
-                if env is not None:
-                    os.environ["DSABF_PAIRED"] = env
-                try:
-                    cfg2 = bfm.production_config(n_avg=n_avg, n_out_per_gemm=n_out, n_freq=n_freq, detect_mode=detect_mode)
-                    bf2 = bfm.Beamformer(cfg2, device=local)
-                    bf2.set_weights(product_weights(torch, cfg2, 0))
-                finally:
-                    if env is not None:
-                        if old is None:
-                            del os.environ["DSABF_PAIRED"]
-                        else:
-                            os.environ["DSABF_PAIRED"] = old
-                n2 = max(10, args.steps // 4)
-                for i in range(5):
-                    bf2.beamform(d_in[i % len(d_in)], units, d_out[i & 1], sptr)
-                torch.cuda.synchronize()
-                t2 = time.perf_counter()
-                for i in range(n2):
-                    bf2.beamform(d_in[i % len(d_in)], units, d_out[i & 1], sptr)
-                torch.cuda.synchronize()
-                el2 = time.perf_counter() - t2
-                name = bf2.kernel_info(units)["kernel"]
-                bf2.close()
-                v2 = n2 * blocks_per_step / el2
-                return {"value": v2, "unit": "beam-blocks/s", "frac": v2 * ops_per_block / 1e12 / INT8_DENSE_PEAK_TOPS,
-                        "kernel": name}
+        if comm_note:
+            out["config"]["gather_note"] = comm_note
+        if gather_modes is not None:
+            out["gather_modes"] = gather_modes
+            out["gather_modes"]["note"] = ("the same kernel and inputs, only the collective differs; rank-major = one message "
+                                           "per sender, freq-major = the reference's [o][f][b], one message per (row, sender); "
+                                           "root = everything to rank 0, alltoall = rank j owns rows j*n/N.. of the whole band")
 
-            # supplementary, never the headline: the opt-in tolerance mode (BF_DETECT_FAST) on the same inputs ...
-            out["fast_detect_mode"] = supplementary(1)
-            out["fast_detect_mode"].update({"tolerance": "4*n_ipo*2^-24 relative to the canonical (bit-exact) result",
-                                            "note": "opt-in bf_config.detect_mode = BF_DETECT_FAST; not the headline"})
+        def variant(detect_mode, paired_env=None, wl=None, n_units=None, reps=None):
+            """Kernel-time record of another variant / workload on this GPU (HIP events around every launch)."""
+            old = os.environ.get("DSABF_PAIRED")
+            if paired_env is not None:
+                os.environ["DSABF_PAIRED"] = paired_env
+            try:
+                na, no = geometry(wl) if wl else (n_avg, n_out)
+                c2 = bfm.production_config(n_avg=na, n_out_per_gemm=no, n_freq=n_freq, detect_mode=detect_mode)
+                if wl == "c5":
+                    c2.n_ant, c2.n_beams, c2.n_freq = 100, 512, 128
+                b2 = bfm.Beamformer(c2, device=local)
+                b2.set_weights(product_weights(c2, 0))
+            finally:
+                if paired_env is not None:
+                    if old is None:
+                        del os.environ["DSABF_PAIRED"]
+                    else:
+                        os.environ["DSABF_PAIRED"] = old
+            nu = n_units or units
+            nt2 = no * c2.n_pol * c2.n_avg
+            in2 = nu * c2.n_freq * nt2 * c2.n_ant
+            of2 = nu * no * c2.n_freq * c2.n_beams
+            src = d_in if in2 <= in_bytes else [torch.randint(0, 256, (in2,), dtype=torch.uint8, device="cuda", generator=gen)
+                                                for _ in range(2)]
+            dst = d_out if of2 <= out_floats else [torch.empty(of2, dtype=torch.float32, device="cuda") for _ in range(2)]
+            fn = lambda i: b2.beamform(src[i % len(src)][:in2], nu, dst[i & 1][:of2], sptr)  # noqa: E731
+            for i in range(5):
+                fn(i)
+            avg, med, mn = time_launches(torch, fn, reps or max(20, args.steps // 4), stream)
+            name = b2.kernel_info(nu)["kernel"]
+            li = b2.kernel_info(nu)
+            b2.close()
+            n_ipo2 = c2.n_pol * c2.n_avg
+            ops = 8 * c2.n_beams * c2.n_ant * n_ipo2 * c2.n_freq * nu * no
+            byts = (c2.n_ant * n_ipo2 * c2.n_freq + 4 * c2.n_beams * c2.n_freq) * nu * no
+            return {"kernel": name, "kernel_ms_avg": avg, "kernel_ms_median": med, "kernel_ms_min": mn,
+                    "grid": li["grid"], "vgprs": li["vgprs"], "gemm_units_per_launch": nu,
+                    "value": nu * no / (avg * 1e-3), "unit": "beam-blocks/s (of this record's geometry)",
+                    "tops": ops / (avg * 1e-3) / 1e12, "frac": ops / (avg * 1e-3) / 1e12 / INT8_DENSE_PEAK_TOPS,
+                    "gbs": byts / (avg * 1e-3) / 1e9}
+
+        if world == 1 and args.detect == "canonical" and args.workload in ("c3", "prod") and not args.no_extras:
+            # supplementary, never the headline, same inputs:
             if paired:
-                # ... and the general kernel (what weights without the conjugate symmetry run), same inputs, same bits
-                out["general_kernel"] = supplementary(0, env="0")
-                out["general_kernel"]["note"] = ("DSABF_PAIRED=0: every int8 op of the algorithmic count executes on "
-                                                 "the MFMA pipe; not the headline")
+                g = variant(0, "0")
+                gp = pmc_summary("r02_c3_general_pmc_summary.txt") if args.workload == "c3" and units == 128 else {}
+                g.update({"mfma_busy_frac": pmc_mfma_busy(gp), "note": "DSABF_PAIRED=0: the kernel any weight set without the "
+                          "conjugate symmetry runs; every algorithmic int8 op executes on the MFMA pipe; same bits"})
+                out["general_kernel"] = g
+            c = variant(2)
+            c["note"] = ("bf_config.detect_mode = BF_DETECT_CONTRACTED: acc + fma(x,x,y*y), nvcc's default reading of "
+                         "src/beamformer.cuh:151; 5 instead of 6 VALU ops per sample; bit-identical to the oracle's "
+                         "ORC_CONTRACT_NVCC; within (n_ipo+4)*2^-24 of exact like the canonical mode")
+            out["contracted_detect_mode"] = c
+            if paired:
+                out["contracted_detect_mode_general_kernel"] = variant(2, "0")
+            f = variant(1)
+            f["tolerance"] = "(n_ipo+1)*2^-23 relative to the exact value (include/dsabf.h); canonical: (n_ipo+4)*2^-24"
+            f["note"] = "opt-in bf_config.detect_mode = BF_DETECT_FAST; not the headline"
+            out["fast_detect_mode"] = f
         if world == 1 and args.workload == "c3" and not args.no_extras:
-            # supplementary: BASELINE configs[1], the reference's DEBUG geometry (N_TIME 16, n_ipo 2) -- the parity
-            # configuration; HBM-write-bound (4 B out per 0.125 B in per beam), so its roofline is the HBM one
-            cfg3 = bfm.production_config(n_avg=1, n_out_per_gemm=8, n_freq=n_freq)
-            bf3 = bfm.Beamformer(cfg3, device=local)
-            bf3.set_weights(product_weights(torch, cfg3, 0))
-            in3 = units * n_freq * 16 * cfg3.n_ant
-            out3 = torch.empty(units * 8 * n_freq * cfg3.n_beams, dtype=torch.float32, device="cuda")
-            for i in range(10):
-                bf3.beamform(d_in[i % len(d_in)][:in3], units, out3, sptr)
-            ev3 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(100)]
-            for i, (a, b) in enumerate(ev3):
-                a.record(stream)
-                bf3.beamform(d_in[i % len(d_in)][:in3], units, out3, sptr)
-                b.record(stream)
-            torch.cuda.synchronize()
-            ms3 = sum(a.elapsed_time(b) for a, b in ev3) / len(ev3)
-            bytes3 = (cfg3.n_ant * 2 * n_freq + 4 * cfg3.n_beams * n_freq) * units * 8
+            # BASELINE configs[1], the reference's DEBUG geometry (N_TIME 16, n_ipo 2): the parity configuration;
+            # HBM-write-bound (4 B out per 0.125 B in per beam), so its roofline is the HBM one
+            d = variant(0, wl="c2", reps=100)
             out["debug_geometry"] = {"workload": "C2: BASELINE configs[1], N_TIME=16 (8 outputs x n_ipo 2), %d gemm-units per launch" % units,
-                                     "value": units * 8 / (ms3 * 1e-3), "unit": "beam-blocks/s", "kernel_ms_avg": ms3,
-                                     "kernel": bf3.kernel_info(units)["kernel"],
-                                     "roofline": {"bound": "hbm", "achieved": bytes3 / (ms3 * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-                                                  "unit": "GB/s", "frac": bytes3 / (ms3 * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                                     "value": d["value"], "unit": "beam-blocks/s", "kernel_ms_avg": d["kernel_ms_avg"],
+                                     "kernel": d["kernel"],
+                                     "roofline": {"bound": "hbm", "achieved": d["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                  "frac": d["gbs"] / HBM_PEAK_GBS},
                                      "note": "not the headline; bit-exact parity on this geometry is what tests/ check"}
-            bf3.close()
+            # one rank's share of BASELINE configs[4]: 128 of 1024 freq x 512 beams x 100 ant, n_ipo 32, 16 gemm-units
+            s5 = variant(0, wl="c5", n_units=16, reps=30)
+            s5["workload"] = ("C5 shard: one of 8 ranks of BASELINE configs[4] = 128 freq x 512 beams x 100 ant x 2 pol, "
+                              "N_TIME 256, 16 gemm-units per launch; beam-blocks here are 512 beams x 128 freq")
+            s5["pmc_source"] = "profiles/r01_c5_pmc_summary.txt (whole-band launch of round 1)"
+            out["c5_shard"] = s5
+            # launch granularity: what one launch over 1 / 8 / 32 gemm-units costs per beam-block (input resident)
+            ls = {}
+            for nu in (1, 8, 32, 128):
+                r = variant(0, n_units=nu, reps=60)
+                ls["%d_units" % nu] = {"kernel_us_per_beam_block": r["kernel_ms_avg"] * 1e3 / (nu * n_out), "grid": r["grid"],
+                                       "kernel_ms_avg": r["kernel_ms_avg"], "frac": r["frac"]}
+            ls["note"] = ("bf_enqueue_gemm_unit launches 1 unit (the reference's pattern, src/beamformer.cu:454-519), "
+                          "bf_enqueue_block 32 (one PSRDADA block), the headline step 128")
+            out["launch_size"] = ls
+            # the production loop end to end, PCIe included: junk source -> H2D -> kernel -> D2H, as the reference's
+            # "Time per data chunk" (src/beamformer.cu:539-546)
+            from dsabeamformer_amd import host
+
+            pc = bfm.production_config()
+            n_blk = 64
+            st = {}
+            for label, env in (("block_launches", None), ("unit_launches", "1")):
+                if env:
+                    os.environ["DSABF_UNIT_LAUNCH"] = env
+                try:
+                    r = host.run_observation_junk(pc, n_blk, ring_blocks=4, device=local, burn_in=4)
+                finally:
+                    os.environ.pop("DSABF_UNIT_LAUNCH", None)
+                chunks = n_blk * pc.n_gemms_per_block * pc.n_out_per_gemm
+                in_b = n_blk * pc.n_gemms_per_block * pc.n_ant * pc.n_freq * pc.n_out_per_gemm * pc.n_pol * pc.n_avg
+                out_b = chunks * pc.n_freq * pc.n_beams * 4
+                st[label] = {"ms_per_beam_block": r["ms"] / chunks, "input_gbs": in_b / (r["ms"] * 1e-3) / 1e9,
+                             "output_gbs": out_b / (r["ms"] * 1e-3) / 1e9, "observation_ms": r["ms"], "blocks": n_blk}
+            st["note"] = ("run_observation, production geometry (N_AVERAGING 16, 128 MiB blocks), in-memory junk source, "
+                          "pinned host buffers: H2D of every block and D2H of every gemm-unit's detected powers included -- the "
+                          "reference's 'Time per data chunk'; never the headline.  Real-time budget: 0.131 ms per beam-block")
+            out["streaming"] = st
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args, n_avg, n_out, args.cpu_seconds)
+            print("bench.py: GPU part done; timing the CPU baselines on the host cores (~%.0f s) ..." % (args.cpu_seconds + 12),
+                  file=sys.stderr, flush=True)
+            out["cpu_baseline"] = cpu_baselines(n_avg, n_out, args.cpu_seconds)
         print(json.dumps(out), flush=True)
     bf.close()
+    if comm is not None:
+        comm.close()
     if dist is not None:
         dist.destroy_process_group()
 

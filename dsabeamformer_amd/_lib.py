@@ -31,6 +31,13 @@ class BfhEventOps(C.Structure):
                 ("record_analysis", RECORD), ("query", QUERY)]
 
 
+class BfGatherMsg(C.Structure):
+    """Mirror of ``bf_gather_msg`` (include/dsabf.h)."""
+
+    _fields_ = [("kind", C.c_int), ("peer", C.c_int), ("local_offset", C.c_size_t), ("full_offset", C.c_size_t),
+                ("count", C.c_size_t)]
+
+
 class DsabfError(RuntimeError):
     def __init__(self, code: int, msg: str):
         super().__init__("libdsabf error %d: %s" % (code, msg))
@@ -79,6 +86,20 @@ SIGNATURES = {
     "bf_dedisperse_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bf_dedisperse_dm_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
                                           C.c_void_p]),
+    "bf_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "bf_comm_create": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
+    "bf_comm_destroy": (C.c_int, [C.c_void_p]),
+    "bf_comm_rank": (C.c_int, [C.c_void_p]),
+    "bf_comm_world": (C.c_int, [C.c_void_p]),
+    "bf_gather_detected": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "bf_gather_offset": (C.c_size_t, [C.c_int, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_size_t]),
+    "bf_gather_rows_held": (C.c_size_t, [C.c_size_t, C.c_int, C.c_int, C.c_int]),
+    "bf_gather_plan": (C.c_size_t, [C.c_int, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_int, C.POINTER(BfGatherMsg),
+                                    C.c_size_t]),
+    "bf_block_output_device": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
+    "bf_queue_stream": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
+    "bf_block_gather_device": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "bf_enqueue_d2h": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]),
     "bf_kernel_info": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
                                  C.POINTER(C.c_int)]),
     "bf_kernel_name": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t]),
@@ -157,6 +178,7 @@ SIGNATURES = {
 
 
 _hip = None
+_rccl_path = None
 
 
 def _preload_hip_runtime():
@@ -180,6 +202,15 @@ def _preload_hip_runtime():
             continue
         try:
             _hip = C.CDLL(c, mode=C.RTLD_GLOBAL)
+            # RCCL must come from the same place as the HIP runtime (bf_comm.cpp binds it with dlopen at first use):
+            # torch's bundled librccl.so next to torch's libamdhip64.so, ROCm's next to ROCm's.
+            global _rccl_path
+            for r in ("librccl.so", "librccl.so.1"):
+                rp = os.path.join(os.path.dirname(c), r) if os.path.sep in c else r
+                if os.path.sep not in rp or os.path.exists(rp):
+                    _rccl_path = rp
+                    os.environ.setdefault("DSABF_RCCL_LIB", rp)
+                    break
             return _hip
         except OSError as e:  # pragma: no cover
             errs.append("%s: %s" % (c, e))

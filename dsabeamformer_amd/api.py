@@ -156,6 +156,46 @@ class Beamformer:
 
 
 # events / pinned memory as free functions (they are not tied to a handle in the C-ABI)
+GATHER_FREQ_MAJOR, GATHER_RANK_MAJOR = 0, 1
+GATHER_ROOT_ALL, GATHER_ROOT_DISTRIBUTED = -1, -2
+
+
+def comm_unique_id() -> bytes:
+    """Rank 0: the 128-byte RCCL unique id to hand to the other ranks (bf_comm_unique_id)."""
+    buf = C.create_string_buffer(128)
+    check(load().bf_comm_unique_id(buf))
+    return buf.raw
+
+
+class Comm:
+    """bf_comm: this rank's place in the frequency partition + the RCCL communicator behind bf_gather_detected."""
+
+    def __init__(self, rank: int, world: int, unique_id: bytes | None = None, device: int = 0):
+        self._lib = load()
+        self._c = C.c_void_p()
+        idbuf = C.create_string_buffer(unique_id, 128) if unique_id is not None else None
+        check(self._lib.bf_comm_create(rank, world, idbuf, device, C.byref(self._c)))
+        self.rank, self.world = rank, world
+
+    def rows_held(self, n_rows: int, root: int) -> int:
+        return self._lib.bf_gather_rows_held(n_rows, self.world, self.rank, root)
+
+    def gather(self, d_local, n_rows: int, row_floats: int, root: int, layout: int, d_full, stream: int = 0) -> None:
+        check(self._lib.bf_gather_detected(self._c, _ptr(d_local), n_rows, row_floats, root, layout, _ptr(d_full),
+                                           C.c_void_p(stream)))
+
+    def close(self) -> None:
+        if self._c:
+            self._lib.bf_comm_destroy(self._c)
+            self._c = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def event_create() -> C.c_void_p:
     ev = C.c_void_p()
     check(load().bf_event_create(C.byref(ev)))

@@ -28,7 +28,9 @@ BEAM = os.path.join(PKG, "beam")                      # the `beam` CLI driver (r
 BEAM_SRC = os.path.join(CSRC, "beam_main.cpp")
 JUNKDB = os.path.join(PKG, "junkdb")                  # writer side of the shared-memory input ring (dada_db + dada_junkdb)
 JUNKDB_SRC = os.path.join(CSRC, "junkdb_main.cpp")
-MAINS = {BEAM: BEAM_SRC, JUNKDB: JUNKDB_SRC}
+REPLICAS = os.path.join(PKG, "beam_replicas")          # one `beam` per GPU: the reference's 8 replicas, or one sharded sub-band
+REPLICAS_SRC = os.path.join(CSRC, "beam_replicas_main.cpp")
+MAINS = {BEAM: BEAM_SRC, JUNKDB: JUNKDB_SRC, REPLICAS: REPLICAS_SRC}
 
 
 def sources() -> list[str]:
@@ -87,8 +89,11 @@ def build(force: bool = False, verbose: bool = False) -> str:
     subprocess.check_call(cmd)
     # the CLI programs are ordinary HIP applications: they link libdsabf.so AND the HIP runtime
     for exe, src in MAINS.items():
-        cmd = [HIPCC, "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "include"), src, "-o", exe, "-L" + PKG, "-ldsabf",
-               "-Wl,-rpath,$ORIGIN"]
+        if src == REPLICAS_SRC:   # a plain launcher: no HIP, no libdsabf (it must not initialise a GPU before exec)
+            cmd = [shutil.which("g++") or "g++", "-O2", "-std=c++17", src, "-o", exe]
+        else:
+            cmd = [HIPCC, "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "include"), src, "-o", exe, "-L" + PKG, "-ldsabf",
+                   "-Wl,-rpath,$ORIGIN"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

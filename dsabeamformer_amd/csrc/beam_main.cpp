@@ -4,6 +4,13 @@
 //   beam [-g gpu] [-p position_file] [-d direction_file] [-s source_file] [-o data.py] [-D device] [-a n_avg] [-v] [-h]
 //   beam -j n_blocks [-g gpu] [-p ...] [-d ...]     production geometry, observation loop fed by the in-memory
 //                                                   dada_junkdb stand-in (soak / data-rate run, makefile:28-29)
+//   beam -j n_blocks -R world -r rank -I idfile     one frequency SHARD of a sub-band: this process beamforms channels
+//                                                   [rank * 256/world, (rank+1) * 256/world); after every block the
+//                                                   shards' detected powers are gathered to rank 0 (RCCL over xGMI), which
+//                                                   alone writes -w / -K.  idfile: rank 0 publishes the 128-byte RCCL
+//                                                   unique id there, the others wait for it.  beam_replicas -S starts
+//                                                   the `world` processes.  (The reference's own scaling -- 8 independent
+//                                                   sub-bands selected by -g, README.md:168 -- is beam_replicas without -S.)
 //
 // With the reference's `make debug` geometry (default) it generates synthetic point-source voltages on the CPU,
 // streams them through the observation loop and writes bin/data.py (dedispersed beam responses, one row per source)
@@ -11,7 +18,10 @@
 // not part of this build; the options are accepted and reported.
 #include <unistd.h>
 
+#include <chrono>
 #include <cstdio>
+#include <fstream>
+#include <thread>
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
@@ -31,9 +41,11 @@ int main(int argc, char* argv[])
     std::string ring_key;
     int core = -1;
     long junk_blocks = -1;
+    int world = 1, rank = 0;
+    std::string id_file;
 
     int arg = 0;
-    while ((arg = getopt(argc, argv, "s:g:p:d:o:D:a:c:k:K:j:w:vh")) != -1) {  // src/beamformer.cu:41-43 (+ -o -D -a -v)
+    while ((arg = getopt(argc, argv, "s:g:p:d:o:D:a:c:k:K:j:w:R:r:I:vh")) != -1) {  // src/beamformer.cu:41-43 (+ -o -D -a -v)
         switch (arg) {
             case 's': sources = optarg; break;                 // :77-89
             case 'g': opt.gpu = atoi(optarg); break;           // :92-100
@@ -45,6 +57,9 @@ int main(int argc, char* argv[])
             case 'j': junk_blocks = atol(optarg); break;
             case 'w': detected_path = optarg; break;
             case 'K': out_ring = optarg; break;
+            case 'R': world = atoi(optarg); break;
+            case 'r': rank = atoi(optarg); break;
+            case 'I': id_file = optarg; break;
             case 'v': opt.verbose = true; cfg.verbose = 1; break;
             case 'c': core = atoi(optarg); break;              // :59-65
             case 'k': ring_key = optarg; break;                // :66-75 (a shared-memory ring name instead of a hex key)
@@ -69,6 +84,49 @@ int main(int argc, char* argv[])
         bf_config pcfg;
         bf_config_default(&pcfg, /*debug=*/0);
         pcfg.verbose = cfg.verbose;
+        if (world < 1 || rank < 0 || rank >= world || pcfg.n_freq % world) {
+            fprintf(stderr, "beam: -R %d -r %d: need 0 <= rank < world and world dividing %d channels\n", world, rank, pcfg.n_freq);
+            return EXIT_FAILURE;
+        }
+        bf_config full_cfg = pcfg;        // the whole sub-band (what the gather root's sink receives)
+        pcfg.n_freq /= world;             // this rank's shard
+        bf_comm* comm = nullptr;
+        if (world > 1 || !id_file.empty()) {
+            char id[BF_COMM_ID_BYTES];
+            if (id_file.empty()) {
+                fprintf(stderr, "beam: -R needs -I idfile (where rank 0 publishes the RCCL unique id)\n");
+                return EXIT_FAILURE;
+            }
+            if (rank == 0) {
+                if (bf_comm_unique_id(id) != BF_OK) {
+                    fprintf(stderr, "GPUassert: %s\n", bf_last_error());
+                    return EXIT_FAILURE;
+                }
+                const std::string tmp = id_file + ".tmp";
+                std::ofstream(tmp, std::ios::binary).write(id, sizeof id);
+                if (rename(tmp.c_str(), id_file.c_str()) != 0) {
+                    perror("beam: publishing the unique id");
+                    return EXIT_FAILURE;
+                }
+            } else {
+                bool got = false;
+                for (int tries = 0; tries < 1200 && !got; tries++) {   // up to 2 minutes
+                    std::ifstream in(id_file, std::ios::binary);
+                    got = in && in.read(id, sizeof id) && in.gcount() == (std::streamsize)sizeof id;
+                    if (!got) std::this_thread::sleep_for(std::chrono::milliseconds(100));
+                }
+                if (!got) {
+                    fprintf(stderr, "beam: rank %d never saw the unique id in %s\n", rank, id_file.c_str());
+                    return EXIT_FAILURE;
+                }
+            }
+            if (bf_comm_create(rank, world, id, opt.device, &comm) != BF_OK) {
+                fprintf(stderr, "GPUassert: %s\n", bf_last_error());
+                return EXIT_FAILURE;
+            }
+            std::cout << "Shard " << rank << " of " << world << ": channels " << rank * pcfg.n_freq << " .. "
+                      << (rank + 1) * pcfg.n_freq - 1 << std::endl;
+        }
         std::vector<antenna> pos((size_t)pcfg.n_ant);
         std::vector<beam_direction> dir((size_t)pcfg.n_beams);
         if (!opt.positions || read_in_position_locations(opt.positions, pcfg.n_ant, pos.data()) != 0)
@@ -94,10 +152,18 @@ int main(int argc, char* argv[])
         oopt.gpu = opt.gpu;
         oopt.device = opt.device;
         oopt.verbose = opt.verbose;
+        oopt.world = world;
+        oopt.rank = rank;
+        oopt.comm = comm;
+        const bf_config& sink_cfg = comm ? full_cfg : pcfg;
+        if (comm && rank != 0) {          // only the gather root has a consumer
+            out_ring.clear();
+            detected_path.clear();
+        }
         std::unique_ptr<detected_sink> sink;
         std::string sink_name;
         if (!out_ring.empty()) {  // -K: hand the detected stream to another process through a shared-memory ring
-            ring_sink* rs = new ring_sink(pcfg, out_ring.c_str(), 8, opt.gpu);
+            ring_sink* rs = new ring_sink(sink_cfg, out_ring.c_str(), 8, opt.gpu);
             sink.reset(rs);
             sink_name = "ring " + out_ring;
             if (!rs->ok() || !rs->is_open()) {
@@ -105,7 +171,7 @@ int main(int argc, char* argv[])
                 return EXIT_FAILURE;
             }
         } else if (!detected_path.empty()) {  // -w: keep the detected stream in a file (the reference drops it, README.md:149)
-            file_sink* fs = new file_sink(pcfg, detected_path.c_str(), opt.gpu);
+            file_sink* fs = new file_sink(sink_cfg, detected_path.c_str(), opt.gpu);
             sink.reset(fs);
             sink_name = detected_path;
             if (!fs->ok() || !fs->is_open()) {
@@ -117,6 +183,7 @@ int main(int argc, char* argv[])
         observation_result ores;
         int orc = run_observation(pcfg, oopt, *src, pos.data(), dir.data(), &ores, std::cout);
         if (sink) std::cout << "Wrote " << sink->get_delivered() << " gemm-units of detected powers to " << sink_name << std::endl;
+        bf_comm_destroy(comm);
         if (orc != BF_OK) {
             fprintf(stderr, "GPUassert: %s (%d)\n", bf_last_error(), orc);
             return EXIT_FAILURE;

@@ -1,0 +1,298 @@
+// bf_comm.cpp -- the one collective of the path: gathering the detected powers of the frequency shards.
+// RCCL point-to-point over xGMI, behind the C-ABI (include/dsabf.h, "Multi-GPU").  One process per GPU; a bf_comm is one
+// RCCL communicator + the rank's place in the frequency partition.
+//
+// The layout arithmetic (which floats of which rank land where) is a pure host function, bf_gather_plan /
+// bf_gather_offset, so that it is tested on the CPU for any world size; the device part only walks that plan with
+// grouped ncclSend / ncclRecv -- every message is received straight at its final position, there is no staging buffer
+// and no re-layout pass.
+//
+// RCCL is bound at run time (dlopen): libdsabf.so must not drag a second HIP runtime into a process that already has
+// one (torch bundles its own librccl.so + libamdhip64.so; a C++ application links ROCm's) -- the same rule as for the HIP
+// runtime itself.  Resolution order: a librccl already loaded in the process, $DSABF_RCCL_LIB,
+// librccl.so.1, librccl.so.
+#include "../../include/dsabf.h"
+
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "bf_host_internal.h"
+
+namespace {
+
+// The few RCCL declarations this file needs (rccl/rccl.h:40-43,187,220,260,339,466,700,722,923,929), bound with dlsym.
+struct rccl_unique_id {
+    char internal[128];
+};
+typedef void* rccl_comm_t;
+constexpr int kNcclFloat32 = 7;
+struct rccl_api {
+    void* lib = nullptr;
+    int (*GetUniqueId)(rccl_unique_id*) = nullptr;
+    int (*CommInitRank)(rccl_comm_t*, int, rccl_unique_id, int) = nullptr;
+    int (*CommDestroy)(rccl_comm_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*Send)(const void*, size_t, int, int, rccl_comm_t, hipStream_t) = nullptr;
+    int (*Recv)(void*, size_t, int, int, rccl_comm_t, hipStream_t) = nullptr;
+    std::string error;
+};
+
+rccl_api& rccl()
+{
+    static rccl_api api;
+    if (api.lib || !api.error.empty()) return api;
+    std::vector<std::string> names;
+    if (const char* e = getenv("DSABF_RCCL_LIB")) names.push_back(e);
+    names.push_back("librccl.so.1");
+    names.push_back("librccl.so");
+    for (int pass = 0; pass < 2 && !api.lib; pass++)      // pass 0: only a copy that is already in the process
+        for (const std::string& n : names) {
+            api.lib = dlopen(n.c_str(), RTLD_NOW | RTLD_GLOBAL | (pass == 0 ? RTLD_NOLOAD : 0));
+            if (api.lib) break;
+        }
+    if (!api.lib) {
+        api.error = std::string("librccl could not be loaded: ") + (dlerror() ? dlerror() : "not found");
+        return api;
+    }
+#define BIND(field, sym)                                                            \
+    *reinterpret_cast<void**>(&api.field) = dlsym(api.lib, sym);                     \
+    if (!api.field) api.error = std::string("librccl lacks ") + sym;
+    BIND(GetUniqueId, "ncclGetUniqueId")
+    BIND(CommInitRank, "ncclCommInitRank")
+    BIND(CommDestroy, "ncclCommDestroy")
+    BIND(GetErrorString, "ncclGetErrorString")
+    BIND(GroupStart, "ncclGroupStart")
+    BIND(GroupEnd, "ncclGroupEnd")
+    BIND(Send, "ncclSend")
+    BIND(Recv, "ncclRecv")
+#undef BIND
+    return api;
+}
+
+int comm_fail(int code, const std::string& msg) { return dsabf::set_error(code, msg.c_str()); }
+
+}  // namespace
+
+struct bf_comm {
+    int rank = 0, world = 1, device = 0;
+    rccl_comm_t comm = nullptr;
+};
+
+extern "C" {
+
+size_t bf_gather_offset(int layout, size_t n_rows, size_t row_floats, int world, int rank, size_t row)
+{
+    if (layout == BF_GATHER_LAYOUT_RANK_MAJOR) return ((size_t)rank * n_rows + row) * row_floats;
+    return (row * (size_t)world + (size_t)rank) * row_floats;   // [row][rank][row_floats] == [o][f][b], f = rank * F/R + f_local
+}
+
+// owner of gathered row `row`: the root, everybody (-1: returned as -1), or -- distributed -- rank row / (n_rows / world)
+static int row_owner(size_t n_rows, int world, int root, size_t row)
+{
+    if (root == BF_GATHER_ROOT_DISTRIBUTED) return (int)(row / (n_rows / (size_t)world));
+    return root;
+}
+
+size_t bf_gather_rows_held(size_t n_rows, int world, int rank, int root)
+{
+    if (world <= 0 || rank < 0 || rank >= world) return 0;
+    if (root == BF_GATHER_ROOT_DISTRIBUTED) return n_rows % (size_t)world ? 0 : n_rows / (size_t)world;
+    return (root < 0 || root == rank) ? n_rows : 0;
+}
+
+size_t bf_gather_plan(int layout, size_t n_rows, size_t row_floats, int world, int rank, int root, bf_gather_msg* msgs,
+                      size_t capacity)
+{
+    // Messages this rank takes part in, in issue order (ascending row, then ascending receiver, then ascending sender:
+    // the same order on every rank, which is what matches sends with receives between a pair of ranks).
+    // A receiver holds `held` rows [first, first + held) of every sender; its array is [held][world][row_floats]
+    // (freq-major) or [world][held][row_floats] (rank-major).  Rows that are contiguous on both sides travel as one
+    // message: rank-major = one message per (sender, receiver); freq-major = one message per (row, sender).
+    if (world <= 0 || rank < 0 || rank >= world || root >= world || root < BF_GATHER_ROOT_DISTRIBUTED) return 0;
+    if (root == BF_GATHER_ROOT_DISTRIBUTED && n_rows % (size_t)world) return 0;
+    const size_t held = root == BF_GATHER_ROOT_DISTRIBUTED ? n_rows / (size_t)world : n_rows;   // rows per receiver
+    const size_t run_rows = layout == BF_GATHER_LAYOUT_RANK_MAJOR ? held : 1;
+    size_t n = 0;
+    auto emit = [&](int kind, int peer, size_t local_off, size_t full_off, size_t count) {
+        if (msgs && n < capacity) msgs[n] = bf_gather_msg{kind, peer, local_off, full_off, count};
+        n++;
+    };
+    for (size_t row0 = 0; row0 < n_rows; row0 += run_rows) {
+        const size_t count = run_rows * row_floats;
+        const int owner = row_owner(n_rows, world, root, row0);
+        const size_t first = root == BF_GATHER_ROOT_DISTRIBUTED ? (size_t)owner * held : 0;   // first row the owner holds
+        for (int dst = 0; dst < world; dst++) {
+            if (owner >= 0 && dst != owner) continue;
+            if (rank == dst) {                                // this rank receives from every rank, itself included
+                for (int src = 0; src < world; src++) {
+                    const size_t off = bf_gather_offset(layout, held, row_floats, world, src, row0 - first);
+                    emit(src == rank ? BF_GATHER_COPY : BF_GATHER_RECV, src, row0 * row_floats, off, count);
+                }
+            } else {
+                emit(BF_GATHER_SEND, dst, row0 * row_floats, 0, count);
+            }
+        }
+    }
+    return n;
+}
+
+int bf_comm_unique_id(void* id128)
+{
+    if (!id128) return comm_fail(BF_ERR_INVALID, "id buffer is NULL");
+    rccl_api& r = rccl();
+    if (!r.error.empty()) return comm_fail(BF_ERR_DEVICE, r.error);
+    rccl_unique_id id;
+    const int rc = r.GetUniqueId(&id);
+    if (rc != 0) return comm_fail(BF_ERR_DEVICE, std::string("ncclGetUniqueId: ") + r.GetErrorString(rc));
+    memcpy(id128, &id, sizeof id);
+    return BF_OK;
+}
+
+int bf_comm_create(int rank, int world, const void* id128, int device, bf_comm** out)
+{
+    if (!out) return comm_fail(BF_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (world < 1 || rank < 0 || rank >= world) return comm_fail(BF_ERR_INVALID, "need 0 <= rank < world");
+    bf_comm* c = new (std::nothrow) bf_comm();
+    if (!c) return comm_fail(BF_ERR_DEVICE, "out of host memory");
+    c->rank = rank;
+    c->world = world;
+    c->device = device;
+    if (world > 1 || id128) {   // a unique id with world == 1 still builds a real (one-rank) RCCL communicator
+        if (!id128) {
+            delete c;
+            return comm_fail(BF_ERR_INVALID, "a unique id (bf_comm_unique_id of rank 0) is needed when world > 1");
+        }
+        rccl_api& r = rccl();
+        if (!r.error.empty()) {
+            delete c;
+            return comm_fail(BF_ERR_DEVICE, r.error);
+        }
+        int prev = -1;
+        (void)hipGetDevice(&prev);
+        if (hipSetDevice(device) != hipSuccess) {
+            delete c;
+            return comm_fail(BF_ERR_DEVICE, "hipSetDevice failed");
+        }
+        rccl_unique_id id;
+        memcpy(&id, id128, sizeof id);
+        const int rc = r.CommInitRank(&c->comm, world, id, rank);
+        if (prev >= 0 && prev != device) (void)hipSetDevice(prev);
+        if (rc != 0) {
+            delete c;
+            return comm_fail(BF_ERR_DEVICE, std::string("ncclCommInitRank: ") + r.GetErrorString(rc));
+        }
+    }
+    *out = c;
+    return BF_OK;
+}
+
+int bf_comm_destroy(bf_comm* c)
+{
+    if (!c) return BF_OK;
+    if (c->comm) (void)rccl().CommDestroy(c->comm);
+    delete c;
+    return BF_OK;
+}
+
+int bf_comm_rank(const bf_comm* c) { return c ? c->rank : BF_ERR_INVALID; }
+int bf_comm_world(const bf_comm* c) { return c ? c->world : BF_ERR_INVALID; }
+
+int bf_gather_detected(bf_comm* c, const float* d_local, size_t n_rows, size_t row_floats, int root, int layout,
+                       float* d_full, void* hip_stream)
+{
+    if (!c || !d_local) return comm_fail(BF_ERR_INVALID, "NULL argument");
+    if (root >= c->world || root < BF_GATHER_ROOT_DISTRIBUTED) return comm_fail(BF_ERR_INVALID, "root out of range");
+    if (root == BF_GATHER_ROOT_DISTRIBUTED && n_rows % (size_t)c->world)
+        return comm_fail(BF_ERR_INVALID, "distributed owners need n_rows divisible by the number of ranks");
+    if (layout != BF_GATHER_LAYOUT_FREQ_MAJOR && layout != BF_GATHER_LAYOUT_RANK_MAJOR)
+        return comm_fail(BF_ERR_INVALID, "unknown gather layout");
+    const size_t held = bf_gather_rows_held(n_rows, c->world, c->rank, root);
+    const bool receives = held > 0;
+    if (receives && !d_full) return comm_fail(BF_ERR_INVALID, "this rank receives: d_full must not be NULL");
+    if (n_rows == 0 || row_floats == 0) return BF_OK;
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    const size_t n = bf_gather_plan(layout, n_rows, row_floats, c->world, c->rank, root, nullptr, 0);
+    std::vector<bf_gather_msg> plan(n);
+    bf_gather_plan(layout, n_rows, row_floats, c->world, c->rank, root, plan.data(), n);
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    if (prev != c->device && hipSetDevice(c->device) != hipSuccess) return comm_fail(BF_ERR_DEVICE, "hipSetDevice failed");
+    int result = BF_OK;
+    // own rows: a strided device-to-device copy (one call for the freq-major layout), not through RCCL -- unless
+    // DSABF_GATHER_SELF_RCCL=1 asks for it (test switch: lets ONE GPU exercise the grouped ncclSend / ncclRecv path)
+    const char* self_env = getenv("DSABF_GATHER_SELF_RCCL");
+    const bool self_rccl = c->comm && self_env && self_env[0] == '1';
+    if (!self_rccl && receives) {
+        const size_t first = root == BF_GATHER_ROOT_DISTRIBUTED ? (size_t)c->rank * held : 0;   // my own rows that I keep
+        const size_t off0 = bf_gather_offset(layout, held, row_floats, c->world, c->rank, 0);
+        const float* src = d_local + first * row_floats;
+        hipError_t e;
+        if (layout == BF_GATHER_LAYOUT_RANK_MAJOR)
+            e = hipMemcpyAsync(d_full + off0, src, held * row_floats * sizeof(float), hipMemcpyDeviceToDevice, s);
+        else
+            e = hipMemcpy2DAsync(d_full + off0, (size_t)c->world * row_floats * sizeof(float), src, row_floats * sizeof(float),
+                                 row_floats * sizeof(float), held, hipMemcpyDeviceToDevice, s);
+        if (e != hipSuccess) result = comm_fail(BF_ERR_DEVICE, std::string("gather self-copy: ") + hipGetErrorString(e));
+    }
+    if (result == BF_OK && (c->world > 1 || self_rccl)) {
+        rccl_api& r = rccl();
+        // One ncclGroup per range of rows, the SAME ranges on every rank (symmetric groups: each group is a complete
+        // exchange of its rows), sized so that a group stays below ~2048 messages on the busiest rank.
+        const size_t rows_per_group = layout == BF_GATHER_LAYOUT_RANK_MAJOR ? n_rows : (2048 / (size_t)c->world ? 2048 / (size_t)c->world : 1);
+        size_t group_end_row = 0;
+        bool open = false;
+        auto close_group = [&]() {
+            if (!open) return 0;
+            open = false;
+            return r.GroupEnd();
+        };
+        for (const bf_gather_msg& m : plan) {
+            if (m.kind == BF_GATHER_COPY && !self_rccl) continue;
+            const size_t row = m.local_offset / row_floats;
+            if (open && row >= group_end_row) {
+                const int rc2 = close_group();
+                if (rc2 != 0) {
+                    result = comm_fail(BF_ERR_DEVICE, std::string("ncclGroupEnd: ") + r.GetErrorString(rc2));
+                    break;
+                }
+            }
+            if (!open) {
+                int rc = r.GroupStart();
+                if (rc != 0) {
+                    result = comm_fail(BF_ERR_DEVICE, std::string("ncclGroupStart: ") + r.GetErrorString(rc));
+                    break;
+                }
+                open = true;
+                group_end_row = (row / rows_per_group + 1) * rows_per_group;
+            }
+            int rc = 0;
+            if (m.kind == BF_GATHER_SEND || m.kind == BF_GATHER_COPY)
+                rc = r.Send(d_local + m.local_offset, m.count, kNcclFloat32, m.peer, c->comm, s);
+            if (rc == 0 && (m.kind == BF_GATHER_RECV || m.kind == BF_GATHER_COPY))
+                rc = r.Recv(d_full + m.full_offset, m.count, kNcclFloat32, m.peer, c->comm, s);
+            if (rc != 0) {
+                (void)close_group();
+                result = comm_fail(BF_ERR_DEVICE, std::string("ncclSend/Recv: ") + r.GetErrorString(rc));
+                break;
+            }
+        }
+        if (result == BF_OK) {
+            const int rc = close_group();
+            if (rc != 0) result = comm_fail(BF_ERR_DEVICE, std::string("ncclGroupEnd: ") + r.GetErrorString(rc));
+        }
+    }
+    if (prev >= 0 && prev != c->device) (void)hipSetDevice(prev);
+    return result;
+}
+
+}  // extern "C"

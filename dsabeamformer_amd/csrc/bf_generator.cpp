@@ -90,7 +90,7 @@ void test_data_generator::generate_test_data(const antenna pos[], int gpu)
                 char* slab = data + (size_t)direction * per_gemm + (size_t)i * nt * na;
                 for (int k = 0; k < na; k++) {
                     char byte = 0;  // :85
-                    if (source_look_up < n_pt_sources) {
+                    if (source_look_up < n_pt_sources && source_look_up < (int)sources.size()) {  // (no catalogue: zero bytes)
                         const double proj = (double)pos[k].x * ::sin((double)sources[source_look_up].theta) +
                                             (double)pos[k].y * ::sin((double)sources[source_look_up].phi);
                         const char high = (char)::round(kSigMaxVal * ::cos(2 * kPi * proj / (double)wavelength));  // :80

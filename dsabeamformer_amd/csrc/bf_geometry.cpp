@@ -190,6 +190,8 @@ float channel_frequency_generator(int gpu, int chan)
 void parallel_for(long n, const std::function<void(long, long)>& body)
 {
     unsigned nt = std::thread::hardware_concurrency();
+    if (const char* e = getenv("DSABF_THREADS"))   // like OMP_NUM_THREADS for the reference's -fopenmp build (makefile:16)
+        if (atoi(e) > 0) nt = (unsigned)atoi(e);
     if (nt == 0) nt = 1;
     if ((long)nt > n) nt = (unsigned)std::max<long>(1, n);
     if (nt <= 1) {

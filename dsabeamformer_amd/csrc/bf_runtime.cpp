@@ -37,6 +37,8 @@ struct bf_handle {
     float* d_out = nullptr;       // n_streams x floats_per_detect
     float* d_ded = nullptr;       // n_streams x n_beams
     std::vector<float*> d_out_blk;  // per compute queue, n_gemms_per_block x floats_per_detect: bf_enqueue_block (lazy)
+    std::vector<float*> d_full_blk; // per compute queue, the gathered block (world x as large): bf_block_gather_device (lazy)
+    int full_world = 0;
     hipStream_t h2d = nullptr;
     std::vector<hipStream_t> streams;
     std::vector<hipEvent_t> join;  // one per compute queue, for bf_record_analysis_event
@@ -266,6 +268,7 @@ int bf_destroy(bf_handle* h)
     (void)hipFree(h->d_out);
     (void)hipFree(h->d_ded);
     for (float* p : h->d_out_blk) (void)hipFree(p);
+    for (float* p : h->d_full_blk) (void)hipFree(p);
     delete h;
     return BF_OK;
 }
@@ -457,6 +460,52 @@ int bf_enqueue_block(bf_handle* h, int stream_idx, int slot, int first_unit, int
         for (int u = 0; u < n_units; u++)
             if (host_out[u])
                 HIP_TRY(hipMemcpyAsync(host_out[u], out + per_det * (size_t)u, per_det * sizeof(float), hipMemcpyDeviceToHost, s));
+    return BF_OK;
+}
+
+int bf_block_output_device(bf_handle* h, int stream_idx, float** d_out)
+{
+    if (!h || !d_out) return fail(BF_ERR_INVALID, "NULL argument");
+    if (stream_idx < 0 || stream_idx >= h->cfg.n_streams) return fail(BF_ERR_INVALID, "stream %d out of range", stream_idx);
+    ON_DEVICE(h);
+    if (h->d_out_blk.empty()) h->d_out_blk.assign((size_t)h->cfg.n_streams, nullptr);
+    if (!h->d_out_blk[stream_idx])
+        HIP_TRY(hipMalloc((void**)&h->d_out_blk[stream_idx],
+                          bf_floats_per_detect(&h->cfg) * sizeof(float) * (size_t)h->cfg.n_gemms_per_block));
+    *d_out = h->d_out_blk[stream_idx];
+    return BF_OK;
+}
+
+int bf_block_gather_device(bf_handle* h, int stream_idx, int world, float** d_full)
+{
+    if (!h || !d_full) return fail(BF_ERR_INVALID, "NULL argument");
+    if (stream_idx < 0 || stream_idx >= h->cfg.n_streams) return fail(BF_ERR_INVALID, "stream %d out of range", stream_idx);
+    if (world < 1) return fail(BF_ERR_INVALID, "world must be positive");
+    if (h->full_world && h->full_world != world) return fail(BF_ERR_STATE, "the gather buffers were sized for world %d", h->full_world);
+    ON_DEVICE(h);
+    h->full_world = world;
+    if (h->d_full_blk.empty()) h->d_full_blk.assign((size_t)h->cfg.n_streams, nullptr);
+    if (!h->d_full_blk[stream_idx])
+        HIP_TRY(hipMalloc((void**)&h->d_full_blk[stream_idx],
+                          bf_floats_per_detect(&h->cfg) * sizeof(float) * (size_t)h->cfg.n_gemms_per_block * (size_t)world));
+    *d_full = h->d_full_blk[stream_idx];
+    return BF_OK;
+}
+
+int bf_enqueue_d2h(bf_handle* h, int stream_idx, const float* d_src, float* host_dst, size_t n_floats)
+{
+    if (!h || !d_src || !host_dst) return fail(BF_ERR_INVALID, "NULL argument");
+    if (stream_idx < 0 || stream_idx >= h->cfg.n_streams) return fail(BF_ERR_INVALID, "stream %d out of range", stream_idx);
+    ON_DEVICE(h);
+    HIP_TRY(hipMemcpyAsync(host_dst, d_src, n_floats * sizeof(float), hipMemcpyDeviceToHost, h->streams[stream_idx]));
+    return BF_OK;
+}
+
+int bf_queue_stream(bf_handle* h, int stream_idx, void** hip_stream)
+{
+    if (!h || !hip_stream) return fail(BF_ERR_INVALID, "NULL argument");
+    if (stream_idx < 0 || stream_idx >= h->cfg.n_streams) return fail(BF_ERR_INVALID, "stream %d out of range", stream_idx);
+    *hip_stream = h->streams[stream_idx];
     return BF_OK;
 }
 

@@ -370,6 +370,15 @@ int run_observation(const bf_config& cfg, const observation_options& opt, block_
 {
     const int n_streams = cfg.n_streams;
     if (cfg.n_gemms_per_block % n_streams) return BF_ERR_INVALID;
+    if (opt.world < 1 || opt.rank < 0 || opt.rank >= opt.world || opt.gather_root < 0 || opt.gather_root >= opt.world)
+        return set_error(BF_ERR_INVALID, "run_observation: need 0 <= rank, gather_root < world");
+    if (opt.comm && (bf_comm_rank(opt.comm) != opt.rank || bf_comm_world(opt.comm) != opt.world))
+        return set_error(BF_ERR_INVALID, "run_observation: the communicator's rank / world differ from the options'");
+    if (opt.comm && !opt.block_launch)
+        return set_error(BF_ERR_INVALID, "run_observation: the sharded gather needs block-granular launches");
+    if (opt.comm && opt.sink && opt.rank != opt.gather_root)
+        return set_error(BF_ERR_INVALID, "run_observation: only the gather root may have a sink");
+    source.read_headers();  // :334 (before the device exists here: the block-size check below needs no GPU)
     const size_t block_bytes = bf_bytes_per_block(&cfg);
     if (source.get_block_size() != block_bytes) {
         // The reference prints this (src/beamformer.cu:336-339) and carries on; every ring block is then copied with the
@@ -397,9 +406,11 @@ int run_observation(const bf_config& cfg, const observation_options& opt, block_
     } g{h, nullptr};
 
     const size_t n_f_per_detect = bf_floats_per_detect(&cfg);
-    if ((rc = bf_alloc_pinned(&g.pinned, n_f_per_detect * n_streams * sizeof(float))) != BF_OK) return rc;  // :249
+    // beam_out: the reference's pinned D2H destination (:249); the root of a sharded run receives the whole band there
+    const size_t beam_out_stride = n_f_per_detect * (size_t)(opt.comm ? opt.world : 1);
+    if ((rc = bf_alloc_pinned(&g.pinned, beam_out_stride * n_streams * sizeof(float))) != BF_OK) return rc;
     float* beam_out = static_cast<float*>(g.pinned);
-    ::memset(beam_out, 0, n_f_per_detect * n_streams * sizeof(float));
+    ::memset(beam_out, 0, beam_out_stride * n_streams * sizeof(float));
     {
         std::vector<int8_t> fourier_coefficients((size_t)cfg.n_freq * cfg.n_ant * cfg.n_beams * 2);
         generate_fourier_coefficients(cfg.n_beams, cfg.n_ant, cfg.n_freq, opt.rank * cfg.n_freq, opt.gpu, pos, dir,
@@ -413,7 +424,6 @@ int run_observation(const bf_config& cfg, const observation_options& opt, block_
 
     hip_backend backend(h);
     observation_loop_state obs_state(kMaxTransferSep, kMaxTotalSep, cfg, &backend, /*debug_mode=*/false);  // :322
-    source.read_headers();  // :334
     if (opt.burn_in > 0) {  // :348-355
         log << "Burning IN" << std::endl;
         for (int i = 0; i < opt.burn_in; i++) {
@@ -425,6 +435,7 @@ int run_observation(const bf_config& cfg, const observation_options& opt, block_
     uint64_t sink_committed = 0;
     const char* unit_env = getenv("DSABF_UNIT_LAUNCH");   // measurement / test switch: the reference's per-gemm-unit launches
     const bool block_launch = opt.block_launch && !(unit_env && unit_env[0] == '1');
+    if (opt.comm && !block_launch) return set_error(BF_ERR_INVALID, "run_observation: the sharded gather needs block-granular launches");
     bf_timer_start(h);  // :358
     while (!obs_state.check_observations_complete()) {  // :364
         if (opt.verbose) {
@@ -459,7 +470,7 @@ int run_observation(const bf_config& cfg, const observation_options& opt, block_
                 unit_dst.assign((size_t)n_units, nullptr);
                 for (int u = 0; u < n_units; u++) {
                     const int st = u % n_streams;
-                    unit_dst[u] = &beam_out[(size_t)st * n_f_per_detect];
+                    unit_dst[u] = &beam_out[(size_t)st * beam_out_stride];
                     if (opt.sink) {
                         unit_dst[u] = opt.sink->acquire((uint64_t)block_index * n_units + u);
                         if (!unit_dst[u]) {
@@ -469,8 +480,24 @@ int run_observation(const bf_config& cfg, const observation_options& opt, block_
                     }
                     last_gemm[st] = block_index * n_units + u;
                 }
-                rc = bf_enqueue_block(h, (int)(block_index % n_streams), (int)obs_state.get_next_gpu_analysis_block(), 0,
-                                      n_units, unit_dst.data());
+                const int q = (int)(block_index % n_streams);
+                rc = bf_enqueue_block(h, q, (int)obs_state.get_next_gpu_analysis_block(), 0, n_units,
+                                      opt.comm ? nullptr : unit_dst.data());
+                if (rc == BF_OK && opt.comm) {
+                    // sharded: bring the shards' powers together on the root, in [unit][o][f over the band][b], behind the
+                    // launch on the same queue; only the root copies to the host
+                    float *d_blk = nullptr, *d_full = nullptr;
+                    void* qs = nullptr;
+                    const size_t full_det = n_f_per_detect * (size_t)opt.world;
+                    const bool root = opt.rank == opt.gather_root;
+                    if ((rc = bf_block_output_device(h, q, &d_blk)) == BF_OK && (rc = bf_queue_stream(h, q, &qs)) == BF_OK &&
+                        (!root || (rc = bf_block_gather_device(h, q, opt.world, &d_full)) == BF_OK))
+                        rc = bf_gather_detected(opt.comm, d_blk, (size_t)n_units * cfg.n_out_per_gemm,
+                                                (size_t)cfg.n_freq * cfg.n_beams, opt.gather_root, BF_GATHER_LAYOUT_FREQ_MAJOR,
+                                                d_full, qs);
+                    for (int u = 0; rc == BF_OK && root && u < n_units; u++)
+                        rc = bf_enqueue_d2h(h, q, d_full + full_det * (size_t)u, unit_dst[u], full_det);
+                }
                 if (rc != BF_OK) {
                     log << "GPUassert: " << bf_last_error() << std::endl;
                     return rc;
@@ -529,7 +556,7 @@ int run_observation(const bf_config& cfg, const observation_options& opt, block_
         res->blocks = blocks;
         res->data_chunks = chunks;
         res->gbytes_per_s = rate;
-        res->beam_out.assign(beam_out, beam_out + n_f_per_detect * n_streams);
+        res->beam_out.assign(beam_out, beam_out + beam_out_stride * n_streams);
         res->last_gemm = last_gemm;
     }
     return BF_OK;

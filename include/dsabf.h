@@ -198,6 +198,64 @@ int bf_dedisperse_device(bf_handle *h, const float *d_out_unit, float *d_ded, vo
 int bf_dedisperse_dm_device(bf_handle *h, const float *d_series, int n_t, const int32_t *d_delays, int n_dm, int n_t_out,
                             float *d_out, void *hip_stream);
 
+/* ---- Multi-GPU: frequency shards and the gather of their detected powers -------------------------------
+ * The reference runs 8 independent processes, one sub-band per GPU (`-g`, src/beamformer.cu:92-100,233; README.md:168)
+ * and never brings their outputs together.  Here a handle may own any contiguous range of frequencies (bf_config.n_freq
+ * = the LOCAL count; weights generated for those channels), one process per GPU, and the ONE collective of the path is
+ * the gather of the detected powers -- RCCL point-to-point over xGMI, received straight at the final position.
+ * The input voltages are never exchanged: [freq][time][ant] is frequency-major, every rank reads its own slice.
+ *
+ * Row = one detected beam-block of one rank = row_floats = n_freq_local * n_beams consecutive floats; a launch over
+ * n_units gemm-units produces n_rows = n_units * n_out_per_gemm rows per rank.  Layout of the gathered array:
+ *   BF_GATHER_LAYOUT_FREQ_MAJOR  [row][world * n_freq_local][beam] -- the reference's [o][f][b] over the whole band: rank r's
+ *                                row o sits at ((o * world + r) * row_floats): one message per (row, sender)
+ *   BF_GATHER_LAYOUT_RANK_MAJOR  [rank][row][n_freq_local][beam]   -- sub-band-major (the reference's own 8-stream shape):
+ *                                one contiguous message per sender
+ * Who receives (root): a rank >= 0: only that rank (d_full may be NULL elsewhere); BF_GATHER_ROOT_ALL: every rank receives
+ * everything; BF_GATHER_ROOT_DISTRIBUTED: rank j becomes the owner of rows [j * n_rows/world, (j+1) * n_rows/world) of
+ * the WHOLE band (n_rows % world == 0) -- an all-to-all that loads every xGMI link of every GPU in both directions
+ * instead of funnelling world-1 shards into one GPU's links, and leaves all frequencies of a time range on one device,
+ * which is what a dedispersion search wants.  In the layouts above `row` then counts from the owner's first row and
+ * n_rows is the number of rows the receiver holds (bf_gather_rows_held). */
+#define BF_GATHER_ROOT_ALL (-1)
+#define BF_GATHER_ROOT_DISTRIBUTED (-2)
+typedef struct bf_comm bf_comm;
+#define BF_COMM_ID_BYTES 128
+#define BF_GATHER_LAYOUT_FREQ_MAJOR 0
+#define BF_GATHER_LAYOUT_RANK_MAJOR 1
+int bf_comm_unique_id(void *id128);                 /* rank 0: ncclGetUniqueId; hand the 128 bytes to the other ranks */
+int bf_comm_create(int rank, int world, const void *id128, int device, bf_comm **out); /* world == 1 needs no id / RCCL */
+int bf_comm_destroy(bf_comm *c);
+int bf_comm_rank(const bf_comm *c);
+int bf_comm_world(const bf_comm *c);
+int bf_gather_detected(bf_comm *c, const float *d_local, size_t n_rows, size_t row_floats, int root, int layout,
+                       float *d_full, void *hip_stream);
+/* The layout arithmetic as plain host functions (no device, no RCCL): float offset of (rank, row) in the gathered array,
+ * and the list of messages one rank issues (kind: send to peer, receive from peer, or copy its own rows). */
+size_t bf_gather_offset(int layout, size_t n_rows_held, size_t row_floats, int world, int rank, size_t row);
+size_t bf_gather_rows_held(size_t n_rows, int world, int rank, int root); /* rows `rank` ends up holding (0: it only sends) */
+#define BF_GATHER_SEND 0
+#define BF_GATHER_RECV 1
+#define BF_GATHER_COPY 2
+typedef struct bf_gather_msg {
+    int kind, peer;
+    size_t local_offset; /* floats into d_local (send / copy source; for a receive: the sender's offset) */
+    size_t full_offset;  /* floats into d_full (receive / copy destination) */
+    size_t count;        /* floats */
+} bf_gather_msg;
+size_t bf_gather_plan(int layout, size_t n_rows, size_t row_floats, int world, int rank, int root, bf_gather_msg *msgs,
+                      size_t capacity); /* returns the number of messages (call with capacity 0 to size the array) */
+
+/* Device pointer of the per-queue block buffer bf_enqueue_block fills ([n_gemms_per_block][output][freq][beam]) and the
+ * hipStream_t of compute queue `stream_idx`: what a caller needs to chain bf_gather_detected behind a block launch. */
+int bf_block_output_device(bf_handle *h, int stream_idx, float **d_out);
+int bf_queue_stream(bf_handle *h, int stream_idx, void **hip_stream);
+/* A handle-owned device buffer for the gathered block of compute queue `stream_idx`: n_gemms_per_block * world *
+ * bf_floats_per_detect floats ([unit][output][world * n_freq][beam] with the freq-major layout); allocated on first use. */
+int bf_block_gather_device(bf_handle *h, int stream_idx, int world, float **d_full);
+/* Asynchronous device-to-host copy of n_floats on compute queue `stream_idx` (behind whatever was enqueued there). */
+int bf_enqueue_d2h(bf_handle *h, int stream_idx, const float *d_src, float *host_dst, size_t n_floats);
+
 /* Introspection for benchmarks/roofline reports. */
 int bf_kernel_info(const bf_handle *h, int n_units, int *grid, int *block, int *lds_bytes, int *vgprs);
 int bf_kernel_name(const bf_handle *h, char *buf, size_t buflen); /* which fused kernel this geometry runs */

@@ -408,6 +408,12 @@ struct observation_options {
     // -R / -r: this process beamforms frequencies [rank * n_freq, (rank + 1) * n_freq) of a world x n_freq sub-band (cfg.n_freq
     // is the LOCAL count).  The weights are generated for those channels; the input blocks are the rank's own slice.
     int world = 1, rank = 0;
+    // Sharded run: the communicator of the frequency partition (bf_comm_create; rank / world above must agree with it).
+    // After every block the detected powers of all shards are gathered to rank `gather_root` in the reference's
+    // [unit][output][freq over the whole band][beam] layout; only that rank copies to the host / feeds `sink` (which
+    // must then be built for the whole band: cfg.n_freq * world) -- the others pass sink = nullptr.  Needs block_launch.
+    bf_comm* comm = nullptr;
+    int gather_root = 0;
 };
 struct observation_result {
     float observation_time_ms = 0;

@@ -888,10 +888,12 @@ def test_grid_configuration_debug_flow_bit_identical(bfmod, orc, gpu):
 
 
 @pytest.mark.parametrize("mode", ["alltoall", "root"])
-def test_bench_rccl_gather_plumbing_on_one_gpu(mode):
-    """bench.py --force-dist: the multi-GPU path (RCCL process group, DetectedGather on its side stream, double
-    buffering) with world size 1 -- what can be exercised of it on a 1-GPU box.  The gathered result of the last steps
-    must be the kernel's output re-laid out as [o][f][b] (identity for one rank), and the JSON line must be well formed."""
+@pytest.mark.parametrize("layout", ["rank", "freq"])
+def test_bench_rccl_gather_plumbing_on_one_gpu(mode, layout):
+    """bench.py --force-dist: the multi-GPU path (process group, a one-rank RCCL communicator behind bf_comm_create,
+    bf_gather_detected on its side stream, double buffering) with world size 1 -- what can be exercised of it on a 1-GPU
+    box.  The gathered result of the last steps must be the kernel's output (identity for one rank), the JSON line well
+    formed, and every gather mode reported side by side."""
     import json
     import subprocess
     import sys
@@ -899,13 +901,16 @@ def test_bench_rccl_gather_plumbing_on_one_gpu(mode):
     from conftest import ROOT
 
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29600 + (os.getpid() % 300)))
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--force-dist", "--gather", mode, "--units", "16",
-                        "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--no-extras"],
-                       capture_output=True, text=True, timeout=300, env=env)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--force-dist", "--gather", mode, "--layout", layout,
+                        "--units", "16", "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--min-warm-seconds", "0.2"],
+                       capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
-    assert d["n_gpus"] == 1 and d["config"]["gather"] == mode and d["value"] > 0 and d["roofline"]["frac"] > 0.05
+    assert d["n_gpus"] == 1 and d["config"]["gather"].startswith(mode) and "C-ABI" in d["config"]["gather"]
+    assert "gather_note" not in d["config"]          # the C-ABI communicator was created (no torch.distributed fallback)
+    assert d["value"] > 0 and d["roofline"]["frac"] > 0.05 and d["roofline"]["unit"] == "TOP/s"
+    assert set(d["gather_modes"]) >= {"none", "root_rank_major", "root_freq_major", "alltoall_rank_major", "alltoall_freq_major"}
 
 
 @pytest.mark.parametrize("n_ant", [100, 128])

@@ -393,3 +393,84 @@ def test_config5_debug_flow_on_the_named_catalogue(bfmod, orc, tmp_path):
     d_th = np.abs(d32[best, 0] - s32[:, 0])
     d_ph = np.abs(d32[best, 1] - s32[:, 1])
     assert (d_th <= 7.0 / 31 * np.pi / 180 * 0.75).all() and (d_ph <= 7.0 / 15 * np.pi / 180 * 0.75).all()
+
+
+# ---- the gather behind the C-ABI, on one GPU ---------------------------------------------------------------------------------
+@pytest.mark.parametrize("layout", [0, 1])
+@pytest.mark.parametrize("root", [0, -1, -2])
+@pytest.mark.parametrize("through_rccl", [False, True])
+def test_gather_detected_world_one(torch, bfmod, orc, monkeypatch, layout, root, through_rccl):
+    """bf_comm / bf_gather_detected with one rank.  through_rccl: a real one-rank RCCL communicator (unique id) and
+    DSABF_GATHER_SELF_RCCL=1, so the rank's own rows travel through grouped ncclSend / ncclRecv -- the code path every
+    message of a multi-GPU run takes -- instead of the device-to-device copy."""
+    from dsabeamformer_amd import api
+
+    g = orc.Geom(n_beams=64, n_ant=64, n_freq=4, n_avg=16, n_out_per_gemm=2)
+    rng = np.random.default_rng(91)
+    w = rng.integers(-127, 128, size=(g.n_freq, g.n_ant, g.n_beams, 2), dtype=np.int8)
+    packed = rng.integers(0, 256, size=(3, g.n_freq, g.n_time, g.n_ant), dtype=np.uint8)
+    bf = bfmod.Beamformer(_cfg(bfmod, g))
+    bf.set_weights(w)
+    want = orc.beamform(g, w, packed)
+    d_in = torch.from_numpy(packed).cuda()
+    d_local = torch.empty(want.size, dtype=torch.float32, device="cuda")
+    d_full = torch.full((want.size,), float("nan"), dtype=torch.float32, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    if through_rccl:
+        monkeypatch.setenv("DSABF_GATHER_SELF_RCCL", "1")
+        comm = api.Comm(0, 1, api.comm_unique_id(), device=0)
+    else:
+        comm = api.Comm(0, 1)
+    n_rows, row_floats = 3 * g.n_out_per_gemm, g.n_freq * g.n_beams
+    assert comm.rows_held(n_rows, root) == n_rows
+    bf.beamform(d_in, 3, d_local, s)
+    comm.gather(d_local, n_rows, row_floats, root, layout, d_full, s)
+    torch.cuda.synchronize()
+    assert np.array_equal(d_full.cpu().numpy().reshape(want.shape), want)   # one rank: both layouts are the identity
+    comm.close()
+    bf.close()
+
+
+def _beam(*args, timeout=600):
+    import subprocess
+
+    from dsabeamformer_amd import build
+
+    r = subprocess.run([build.BEAM] + [str(a) for a in args], capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stdout + r.stderr
+    return r.stdout
+
+
+def test_beam_sharded_mode_and_replica_launcher_on_one_gpu(tmp_path):
+    """`beam -R 1 -r 0 -I id` (a one-rank frequency partition: real RCCL communicator, gather path, root-side D2H) writes
+    the same detected file as the unsharded run; `beam_replicas -n 1` (the reference's replica deployment) and
+    `beam_replicas -n 1 -S` (the sharded one) drive the same binary."""
+    import subprocess
+
+    from dsabeamformer_amd import build
+
+    plain, shard = tmp_path / "plain.bin", tmp_path / "shard.bin"
+    _beam("-j", 3, "-w", plain)
+    out = _beam("-j", 3, "-w", shard, "-R", 1, "-r", 0, "-I", tmp_path / "id")
+    assert "Shard 0 of 1: channels 0 .. 255" in out
+    a, b = open(plain, "rb").read(), open(shard, "rb").read()
+    assert len(a) == len(b) and a == b
+    for extra, name in (([], "rep_{i}.bin"), (["-S"], "shd_{i}.bin")):
+        r = subprocess.run([build.REPLICAS, "-n", "1"] + extra + ["-j", "3", "-w", str(tmp_path / name)],
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert open(tmp_path / name.replace("{i}", "0"), "rb").read() == a
+    r = subprocess.run([build.REPLICAS], capture_output=True, text=True)
+    assert r.returncode == 2 and "usage" in r.stderr
+
+
+def test_beam_sharded_argument_errors(tmp_path):
+    import subprocess
+
+    from dsabeamformer_amd import build
+
+    for args in (["-j", "1", "-R", "3", "-r", "0", "-I", str(tmp_path / "i")],      # 256 channels do not split 3 ways
+                 ["-j", "1", "-R", "2", "-r", "2", "-I", str(tmp_path / "i")],      # rank out of range
+                 ["-j", "1", "-R", "2", "-r", "0"]):                               # no id file
+        r = subprocess.run([build.BEAM] + args, capture_output=True, text=True, timeout=120)
+        assert r.returncode != 0 and "beam:" in r.stderr, args
