@@ -179,9 +179,9 @@ def cpu_baselines(n_avg, n_out, seconds):
         gen = host.TestDataGenerator(dbg, 1024, pin=False)
         gen.set_source_directions(src)
         ppos = host.default_positions(64)
-        gen.generate_test_data(ppos, 0)          # first touch of the 256 MiB buffer
+        gen.data()[:] = 0                        # first touch of the 256 MiB buffer outside the timed call
         t0 = time.perf_counter()
-        gen.generate_test_data(ppos, 0)
+        gen.generate_test_data(ppos, 0)          # batch 0 = sources 0..1023 of the catalogue
         gen_rec[label] = {"value": time.perf_counter() - t0, "cores": nt}
         gen.close()
     os.environ.pop("DSABF_THREADS", None)

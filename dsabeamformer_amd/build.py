@@ -39,8 +39,15 @@ def sources() -> list[str]:
                   if os.path.abspath(p) not in [os.path.abspath(m) for m in MAINS.values()])
 
 
+STAMP = os.path.join(PKG, "build", "flags.stamp")   # the flag set the in-tree library was built with
+
+
 def _stale() -> bool:
     if not os.path.exists(LIB):
+        return True
+    # a library built with other flags (an experiment's DSABF_EXTRA_FLAGS, tools/variants.sh) is stale even if it is newer
+    # than every source: never let tests / bench / profiles silently run a variant build
+    if not os.path.exists(STAMP) or open(STAMP).read() != " ".join(FLAGS):
         return True
     t = os.path.getmtime(LIB)
     if not all(os.path.exists(b) for b in MAINS):
@@ -61,7 +68,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
     for src in sources():
         obj = os.path.join(objdir, os.path.basename(src) + ".o")
         objs.append(obj)
-        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(
+        flags_same = os.path.exists(STAMP) and open(STAMP).read() == " ".join(FLAGS)
+        if not force and flags_same and os.path.exists(obj) and os.path.getmtime(obj) > max(
                 [os.path.getmtime(src)] + [os.path.getmtime(p) for p in glob.glob(os.path.join(CSRC, "*.h*"))] +
                 [os.path.getmtime(p) for p in glob.glob(os.path.join(ROOT, "include", "*.h*"))]):
             continue
@@ -87,6 +95,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    with open(STAMP, "w") as fp:
+        fp.write(" ".join(FLAGS))
     # the CLI programs are ordinary HIP applications: they link libdsabf.so AND the HIP runtime
     for exe, src in MAINS.items():
         if src == REPLICAS_SRC:   # a plain launcher: no HIP, no libdsabf (it must not initialise a GPU before exec)

@@ -587,6 +587,7 @@ hipError_t launch_fused16_t(const FusedArgs& args, const LaunchShape& ls, hipStr
                                            ls.lds_bytes);
         if (e != hipSuccess) return e;
     }
+    (void)hipGetLastError();   // clear what earlier, unrelated calls left behind: return this launch's own status
     hipLaunchKernelGGL(kern, dim3(ls.grid), dim3(ls.block), ls.lds_bytes, s, args);
     return hipGetLastError();
 }

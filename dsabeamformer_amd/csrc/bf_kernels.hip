@@ -343,11 +343,16 @@ LaunchShape fused_launch_shape(const Geometry& g, int n_units, int n_cus)
     // of the launch is fine-grained); small launches still get ~2 workgroups per resident slot, but never fewer
     // than 2 chunks each.
     const int groups_avail = ls.chunks_total / cpg;
-    const int max_split = groups_avail >= 2 ? groups_avail / 2 : 1;
+    // at least 2 chunk-groups per workgroup (the weight-fragment load and the prologue are paid per workgroup) -- unless
+    // that leaves fewer than 4 workgroups per CU: a single gemm-unit is 4 chunks per frequency, 1 chunk each is then
+    // 6 % faster (profiles/r02_launch_size.txt)
+    int max_split = groups_avail >= 2 ? groups_avail / 2 : 1;
+    if ((long long)base * max_split < 4LL * n_cus) max_split = groups_avail >= 1 ? groups_avail : 1;
     int want = (groups_avail + 10) / 20;                                       // ~20 chunk-groups per workgroup
     // short windows (n_ipo < 16) are store-bound: fewer, longer workgroups measured better (C2: 2 per CU 0.54 of the
-    // HBM peak, 8 per CU 0.49); the MFMA-bound shapes want ~2 resident sets of 4
-    const int target_wgs_per_cu = g.n_ipo < 16 ? 2 : 2 * (16 / kWaves16);
+    // HBM peak, 8 per CU 0.49); the MFMA-bound shapes want ~4 resident sets of 4: a 32-unit block (one PSRDADA block,
+    // bf_enqueue_block) runs 4 % faster on 4096 workgroups than on 2048 (profiles/r02_launch_size.txt)
+    const int target_wgs_per_cu = g.n_ipo < 16 ? 2 : 4 * (16 / kWaves16);
     int want_fill = (target_wgs_per_cu * n_cus + base - 1) / base;            // enough workgroups to fill the chip
     if (want_fill > max_split) want_fill = max_split;
     if (want < want_fill) want = want_fill;
@@ -404,9 +409,14 @@ hipError_t launch_gemm_only(const Geometry& g, const void* d_image, const void* 
     return dispatch_fused(gg, true, a, ls, s);
 }
 
+// hipGetLastError() also returns errors left behind by EARLIER, unrelated calls of the thread (a failed
+// hipGetDeviceProperties of a caller, say): every launcher clears the slot first so that what it returns is its own.
+static inline void clear_stale_error() { (void)hipGetLastError(); }
+
 hipError_t launch_weight_relayout(const Geometry& g, const int8_t* d_w, void* d_image, void* d_pair_image, int* d_bad,
                                   hipStream_t s)
 {
+    clear_stale_error();
     const size_t total = weight_image_bytes(g) / 16;
     int grid = (int)((total + 255) / 256);
     if (grid > 4096) grid = 4096;
@@ -427,6 +437,7 @@ hipError_t launch_weight_relayout(const Geometry& g, const int8_t* d_w, void* d_
 
 hipError_t launch_expand(const void* d_in, size_t nbytes, void* d_out, hipStream_t s)
 {
+    clear_stale_error();
     const size_t n_vec = nbytes / 16;
     if (n_vec == 0) return hipSuccess;
     size_t grid = (n_vec + 255) / 256;
@@ -438,6 +449,7 @@ hipError_t launch_expand(const void* d_in, size_t nbytes, void* d_out, hipStream
 
 hipError_t launch_dedisperse(const Geometry& g, const float* d_out_unit, float* d_ded, hipStream_t s)
 {
+    clear_stale_error();
     hipLaunchKernelGGL(dedisperse_kernel, dim3((g.n_beams + 63) / 64), dim3(64), 0, s, d_out_unit, d_ded, g.n_freq,
                        g.n_beams);
     return hipGetLastError();
@@ -447,6 +459,7 @@ hipError_t launch_dedisperse_dm(const Geometry& g, const float* d_series, int n_
                                 int n_t_out, float* d_out, hipStream_t s)
 {
     if (n_dm <= 0 || n_t_out <= 0) return hipSuccess;
+    clear_stale_error();
     const dim3 grid((unsigned)((n_dm + kDmBlock - 1) / kDmBlock), (unsigned)((n_t_out + kDmTb - 1) / kDmTb),
                     (unsigned)((g.n_beams + kDmThreads - 1) / kDmThreads));
     if (grid.y > 65535u || grid.z > 65535u) return hipErrorInvalidValue;

@@ -436,6 +436,12 @@ int run_observation(const bf_config& cfg, const observation_options& opt, block_
     const char* unit_env = getenv("DSABF_UNIT_LAUNCH");   // measurement / test switch: the reference's per-gemm-unit launches
     const bool block_launch = opt.block_launch && !(unit_env && unit_env[0] == '1');
     if (opt.comm && !block_launch) return set_error(BF_ERR_INVALID, "run_observation: the sharded gather needs block-granular launches");
+    if (block_launch)   // the per-queue block buffers are allocated on first use: do that here, not inside the timed loop
+        for (int q = 0; q < n_streams; q++) {
+            float* unused = nullptr;
+            if ((rc = bf_block_output_device(h, q, &unused)) != BF_OK) return rc;
+            if (opt.comm && opt.rank == opt.gather_root && (rc = bf_block_gather_device(h, q, opt.world, &unused)) != BF_OK) return rc;
+        }
     bf_timer_start(h);  // :358
     while (!obs_state.check_observations_complete()) {  // :364
         if (opt.verbose) {

@@ -4,7 +4,10 @@
 # out[blockIdx.x] with the ratio in GHz), two seconds of back-to-back launches on random data, median over workgroups.
 # Restores the product build afterwards.  usage (GPU box, repo root): tools/clock_probe.sh [workload] [units]
 WL=${1:-c3}; UNITS=${2:-128}
+restore() { DSABF_EXTRA_FLAGS="" python -m dsabeamformer_amd.build --force > /dev/null 2>&1; }
+trap restore EXIT     # the probe build corrupts out[blockIdx.x]: never leave it in place, however the script ends
 DSABF_EXTRA_FLAGS="-DDSABF_CLOCKPROBE=1" python -m dsabeamformer_amd.build --force > /dev/null 2>&1 || exit 1
+export DSABF_EXTRA_FLAGS="-DDSABF_CLOCKPROBE=1"   # the python below must see the same flag set (build/flags.stamp)
 python - "$WL" "$UNITS" <<'PY'
 import sys, time, json
 import numpy as np, torch
@@ -21,7 +24,7 @@ for label, env in (("paired", None), ("general", "0")):
     if wl == "c5":
         cfg.n_ant, cfg.n_beams = 100, 512
     bf = bfm.Beamformer(cfg)
-    bf.set_weights(bench.product_weights(torch, cfg, 0))
+    bf.set_weights(bench.product_weights(cfg, 0))
     n_time = n_out * cfg.n_pol * cfg.n_avg
     d_in = [torch.randint(0, 256, (units * cfg.n_freq * n_time * cfg.n_ant,), dtype=torch.uint8, device="cuda") for _ in range(2)]
     d_out = torch.empty(units * n_out * cfg.n_freq * cfg.n_beams, dtype=torch.float32, device="cuda")
@@ -37,4 +40,3 @@ for label, env in (("paired", None), ("general", "0")):
         "median": float(np.median(ghz)), "p10": float(np.percentile(ghz, 10)), "p90": float(np.percentile(ghz, 90))}}))
     bf.close()
 PY
-python -m dsabeamformer_amd.build --force > /dev/null 2>&1

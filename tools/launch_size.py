@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Kernel time per beam-block of one launch over 1 / 2 / 8 / 32 / 128 gemm-units (input resident in HBM), for the time
+splits DSABF_TSPLIT can force -- how fused_launch_shape's choice compares with the alternatives.  GPU box, repo root:
+python tools/launch_size.py [workload] > gpurun_out/r02_launch_size.txt"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, ".")
+import bench  # noqa: E402
+import dsabeamformer_amd as bfm  # noqa: E402
+
+wl = sys.argv[1] if len(sys.argv) > 1 else "c3"
+n_avg, n_out = bench.geometry(wl)
+cfg = bfm.production_config(n_avg=n_avg, n_out_per_gemm=n_out)
+bf = bfm.Beamformer(cfg)
+bf.set_weights(bench.product_weights(cfg, 0))
+n_time = n_out * cfg.n_pol * cfg.n_avg
+stream = torch.cuda.current_stream()
+print("workload %s: kernel %s" % (wl, bf.kernel_info(1)["kernel"]))
+for units in (1, 2, 4, 8, 32, 128):
+    d_in = [torch.randint(0, 256, (units * cfg.n_freq * n_time * cfg.n_ant,), dtype=torch.uint8, device="cuda") for _ in range(4)]
+    d_out = torch.empty(units * n_out * cfg.n_freq * cfg.n_beams, dtype=torch.float32, device="cuda")
+    chunks = units * n_time // 128
+    rows = []
+    for ts in [None] + [t for t in (1, 2, 4, 8, 16, 32, 64) if t <= chunks]:
+        if ts is None:
+            os.environ.pop("DSABF_TSPLIT", None)
+        else:
+            os.environ["DSABF_TSPLIT"] = str(ts)
+        info = bf.kernel_info(units)
+        fn = lambda i: bf.beamform(d_in[i % 4], units, d_out, stream.cuda_stream)  # noqa: E731
+        for i in range(10):
+            fn(i)
+        avg, med, mn = bench.time_launches(torch, fn, 200 if units <= 8 else 60, stream)
+        rows.append((ts, info["grid"], avg, mn))
+    os.environ.pop("DSABF_TSPLIT", None)
+    print("units %3d (%4d chunks per frequency)" % (units, chunks))
+    for ts, grid, avg, mn in rows:
+        print("   tsplit %-7s grid %5d  kernel avg %8.2f us  min %8.2f us  = %6.3f us per beam-block%s"
+              % ("default" if ts is None else ts, grid, avg * 1e3, mn * 1e3, avg * 1e3 / (units * n_out),
+                 "   <- fused_launch_shape" if ts is None else ""))
+bf.close()
