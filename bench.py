@@ -552,13 +552,15 @@ def main():
             pc = bfm.production_config()
             n_blk = 64
             st = {}
-            for label, env in (("block_launches", None), ("unit_launches", "1")):
-                if env:
-                    os.environ["DSABF_UNIT_LAUNCH"] = env
+            for label, env in (("default_8_units_per_launch", {}), ("reference_1_unit_per_launch", {"DSABF_UNIT_LAUNCH": "1"}),
+                               ("4_units_per_launch", {"DSABF_UNITS_PER_LAUNCH": "4"}),
+                               ("whole_block_per_launch", {"DSABF_UNITS_PER_LAUNCH": "0"})):
+                os.environ.update(env)
                 try:
                     r = host.run_observation_junk(pc, n_blk, ring_blocks=4, device=local, burn_in=4)
                 finally:
-                    os.environ.pop("DSABF_UNIT_LAUNCH", None)
+                    for k in env:
+                        os.environ.pop(k, None)
                 chunks = n_blk * pc.n_gemms_per_block * pc.n_out_per_gemm
                 in_b = n_blk * pc.n_gemms_per_block * pc.n_ant * pc.n_freq * pc.n_out_per_gemm * pc.n_pol * pc.n_avg
                 out_b = chunks * pc.n_freq * pc.n_beams * 4

@@ -436,6 +436,11 @@ int run_observation(const bf_config& cfg, const observation_options& opt, block_
     const char* unit_env = getenv("DSABF_UNIT_LAUNCH");   // measurement / test switch: the reference's per-gemm-unit launches
     const bool block_launch = opt.block_launch && !(unit_env && unit_env[0] == '1');
     if (opt.comm && !block_launch) return set_error(BF_ERR_INVALID, "run_observation: the sharded gather needs block-granular launches");
+    int upl = opt.units_per_launch;                                // gemm-units per launch of the block path
+    if (const char* e = getenv("DSABF_UNITS_PER_LAUNCH")) upl = atoi(e);
+    if (upl <= 0 || upl > cfg.n_gemms_per_block || opt.comm) upl = cfg.n_gemms_per_block;   // 0 / sharded: the whole block
+    while (cfg.n_gemms_per_block % upl) upl--;                    // whole launches only
+    uint64_t launch_seq = 0;
     if (block_launch)   // the per-queue block buffers are allocated on first use: do that here, not inside the timed loop
         for (int q = 0; q < n_streams; q++) {
             float* unused = nullptr;
@@ -470,43 +475,44 @@ int run_observation(const bf_config& cfg, const observation_options& opt, block_
         if (obs_state.check_ready_for_analysis()) {  // :452
             const long long block_index = (long long)obs_state.get_blocks_analysis_queue();
             if (block_launch) {
-                // one launch for the whole block; unit u's powers go where the per-unit loop below would send them:
-                // its sink slot, or beam_out[u % n_streams] (later units of the same queue overwrite earlier ones, in order)
+                // unit u's powers go to its sink slot, or to beam_out[queue of its launch] (later units on that queue
+                // overwrite earlier ones, in order: beam_out[q] ends up holding gemm-unit last_gemm[q])
                 const int n_units = cfg.n_gemms_per_block;
                 unit_dst.assign((size_t)n_units, nullptr);
-                for (int u = 0; u < n_units; u++) {
-                    const int st = u % n_streams;
-                    unit_dst[u] = &beam_out[(size_t)st * beam_out_stride];
-                    if (opt.sink) {
-                        unit_dst[u] = opt.sink->acquire((uint64_t)block_index * n_units + u);
-                        if (!unit_dst[u]) {
-                            log << "ERROR: detected sink has no free slot" << std::endl;
-                            return BF_ERR_STATE;
+                for (int first = 0; first < n_units; first += upl) {
+                    const int q = (int)(launch_seq++ % (uint64_t)n_streams);
+                    for (int u = first; u < first + upl; u++) {
+                        unit_dst[u] = &beam_out[(size_t)q * beam_out_stride];
+                        if (opt.sink) {
+                            unit_dst[u] = opt.sink->acquire((uint64_t)block_index * n_units + u);
+                            if (!unit_dst[u]) {
+                                log << "ERROR: detected sink has no free slot" << std::endl;
+                                return BF_ERR_STATE;
+                            }
                         }
+                        last_gemm[q] = block_index * n_units + u;
                     }
-                    last_gemm[st] = block_index * n_units + u;
-                }
-                const int q = (int)(block_index % n_streams);
-                rc = bf_enqueue_block(h, q, (int)obs_state.get_next_gpu_analysis_block(), 0, n_units,
-                                      opt.comm ? nullptr : unit_dst.data());
-                if (rc == BF_OK && opt.comm) {
-                    // sharded: bring the shards' powers together on the root, in [unit][o][f over the band][b], behind the
-                    // launch on the same queue; only the root copies to the host
-                    float *d_blk = nullptr, *d_full = nullptr;
-                    void* qs = nullptr;
-                    const size_t full_det = n_f_per_detect * (size_t)opt.world;
-                    const bool root = opt.rank == opt.gather_root;
-                    if ((rc = bf_block_output_device(h, q, &d_blk)) == BF_OK && (rc = bf_queue_stream(h, q, &qs)) == BF_OK &&
-                        (!root || (rc = bf_block_gather_device(h, q, opt.world, &d_full)) == BF_OK))
-                        rc = bf_gather_detected(opt.comm, d_blk, (size_t)n_units * cfg.n_out_per_gemm,
-                                                (size_t)cfg.n_freq * cfg.n_beams, opt.gather_root, BF_GATHER_LAYOUT_FREQ_MAJOR,
-                                                d_full, qs);
-                    for (int u = 0; rc == BF_OK && root && u < n_units; u++)
-                        rc = bf_enqueue_d2h(h, q, d_full + full_det * (size_t)u, unit_dst[u], full_det);
-                }
-                if (rc != BF_OK) {
-                    log << "GPUassert: " << bf_last_error() << std::endl;
-                    return rc;
+                    rc = bf_enqueue_block(h, q, (int)obs_state.get_next_gpu_analysis_block(), first, upl,
+                                          opt.comm ? nullptr : &unit_dst[first]);
+                    if (rc == BF_OK && opt.comm) {
+                        // sharded (upl == n_units): bring the shards' powers together on the root, in [unit][o][f over the
+                        // band][b], behind the launch on the same queue; only the root copies to the host
+                        float *d_blk = nullptr, *d_full = nullptr;
+                        void* qs = nullptr;
+                        const size_t full_det = n_f_per_detect * (size_t)opt.world;
+                        const bool root = opt.rank == opt.gather_root;
+                        if ((rc = bf_block_output_device(h, q, &d_blk)) == BF_OK && (rc = bf_queue_stream(h, q, &qs)) == BF_OK &&
+                            (!root || (rc = bf_block_gather_device(h, q, opt.world, &d_full)) == BF_OK))
+                            rc = bf_gather_detected(opt.comm, d_blk, (size_t)n_units * cfg.n_out_per_gemm,
+                                                    (size_t)cfg.n_freq * cfg.n_beams, opt.gather_root,
+                                                    BF_GATHER_LAYOUT_FREQ_MAJOR, d_full, qs);
+                        for (int u = 0; rc == BF_OK && root && u < n_units; u++)
+                            rc = bf_enqueue_d2h(h, q, d_full + full_det * (size_t)u, unit_dst[u], full_det);
+                    }
+                    if (rc != BF_OK) {
+                        log << "GPUassert: " << bf_last_error() << std::endl;
+                        return rc;
+                    }
                 }
             } else {  // the reference's launch pattern: one gemm-unit per launch, round-robin over the compute queues
                 for (int part = 0; part < cfg.n_gemms_per_block / n_streams; part++) {

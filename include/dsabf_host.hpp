@@ -401,10 +401,14 @@ struct observation_options {
     bool verbose = false;
     detected_sink* sink = nullptr;  // optional consumer of every gemm-unit's detected powers; replaces beam_out as
                                     // the D2H destination (beam_out then stays zero)
-    // launch granularity: true = ONE kernel launch per PSRDADA block (bf_enqueue_block: 32 gemm-units keep the chip
-    // filled), the compute queue rotating with the block; false = the reference's own pattern, one launch per gemm-unit
-    // round-robin over the queues (src/beamformer.cu:454-519).  Identical outputs, destinations and completion order.
+    // launch granularity: true = bf_enqueue_block launches over `units_per_launch` consecutive gemm-units of the block
+    // (0 = the whole PSRDADA block in one launch), consecutive launches on consecutive compute queues, each followed on
+    // its queue by the D2H copies of its units (into the sink's slots, or beam_out[queue]); false = the reference's own
+    // pattern, one launch per gemm-unit round-robin over the queues (src/beamformer.cu:454-519).  Identical detected
+    // powers either way.  Default 8: a quarter of a block per launch keeps the kernel within 6 % of its best rate and
+    // pipelines kernel and D2H across the queues (profiles/r02_streaming.txt).
     bool block_launch = true;
+    int units_per_launch = 8;
     // -R / -r: this process beamforms frequencies [rank * n_freq, (rank + 1) * n_freq) of a world x n_freq sub-band (cfg.n_freq
     // is the LOCAL count).  The weights are generated for those channels; the input blocks are the rank's own slice.
     int world = 1, rank = 0;

@@ -360,12 +360,18 @@ def test_edge_geometries_and_arguments(torch, bfmod, orc):
             bf.beamform(d[1:], 1, o)  # misaligned input pointer
 
 
-def test_production_observation_loop_with_junk_source(bfmod, orc):
+@pytest.mark.parametrize("launches", ["reference", "default", "whole-block"])
+def test_production_observation_loop_with_junk_source(bfmod, orc, monkeypatch, launches):
     """Observation (non-DEBUG) mode, src/beamformer.cu:364-534: production geometry (N_AVERAGING 16, 128 MiB blocks),
     blocks from the in-memory dada_junkdb stand-in, 8 compute queues.  After the run each queue's beam_out slot holds
-    the detected powers of the last gemm-unit it processed: must equal the oracle on that gemm-unit's bytes."""
+    the detected powers of the last gemm-unit it processed: must equal the oracle on that gemm-unit's bytes.
+    launches: the reference's one launch per gemm-unit, the default (8 gemm-units per launch) and one launch per block."""
     from dsabeamformer_amd import host
 
+    if launches == "reference":
+        monkeypatch.setenv("DSABF_UNIT_LAUNCH", "1")
+    elif launches == "whole-block":
+        monkeypatch.setenv("DSABF_UNITS_PER_LAUNCH", "0")
     cfg = bfmod.production_config()
     n_blocks, ring_blocks = 6, 3
     r = host.run_observation_junk(cfg, n_blocks, ring_blocks=ring_blocks, seed=7)
@@ -373,10 +379,18 @@ def test_production_observation_loop_with_junk_source(bfmod, orc):
     g = orc.PROD_GEOM
     w = orc.make_weights(g, orc.default_positions(64), orc.default_directions(256), 0)
     per_block = cfg.n_gemms_per_block
-    # every stream ends on the last block, time slices 24..31 (4 parts x 8 streams, src/beamformer.cu:454-519)
-    assert sorted(r["last_gemm"].tolist()) == [(n_blocks - 1) * per_block + 24 + i for i in range(8)]
-    for st in (0, 3, 7):
-        blk, ts = divmod(int(r["last_gemm"][st]), per_block)
+    last = r["last_gemm"].tolist()
+    if launches == "reference":
+        # every stream ends on the last block, time slices 24..31 (4 parts x 8 streams, src/beamformer.cu:454-519)
+        assert sorted(last) == [(n_blocks - 1) * per_block + 24 + i for i in range(8)]
+    elif launches == "default":
+        # 4 launches of 8 gemm-units per block on consecutive queues: launch j on queue j % 8, its last unit 8 (j % 4) + 7
+        assert last == [(16 + q) // 4 * per_block + 8 * ((16 + q) % 4) + 7 for q in range(8)]
+    else:
+        # block k on queue k % 8: queues 0..5 saw one block each, 6 and 7 none
+        assert last[:6] == [k * per_block + 31 for k in range(6)] and last[6:] == [-1, -1]
+    for st in (0, 3, 5):
+        blk, ts = divmod(int(last[st]), per_block)
         unit = r["ring"][blk % ring_blocks, ts][None]
         want = orc.beamform(g, w, unit)[0]
         assert np.array_equal(r["beam_out"][st], want), st

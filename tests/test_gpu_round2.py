@@ -264,19 +264,21 @@ def test_enqueue_block_equals_per_unit_launches(torch, bfmod, orc):
 
 
 def test_observation_loop_block_launches_equal_unit_launches(bfmod, orc, tmp_path):
-    """The production loop with one launch per PSRDADA block (default) and with the reference's one launch per gemm-unit:
-    the same detected stream, byte for byte, and the same final beam_out."""
+    """The production loop with the default launch granularity (quarter blocks), with one launch per PSRDADA block and with
+    the reference's one launch per gemm-unit: the same detected stream, byte for byte."""
     from dsabeamformer_amd import host
 
     cfg = bfmod.production_config(n_freq=8, n_beams=64, n_out_per_gemm=2, n_gemms_per_block=8, n_blocks_on_gpu=4, n_streams=4)
     a = host.run_observation_junk_to_file(cfg, 6, str(tmp_path / "blk.bin"), ring_blocks=3)
-    os.environ["DSABF_UNIT_LAUNCH"] = "1"
-    try:
-        b = host.run_observation_junk_to_file(cfg, 6, str(tmp_path / "unit.bin"), ring_blocks=3)
-    finally:
-        os.environ.pop("DSABF_UNIT_LAUNCH")
-    assert a["gemms_written"] == b["gemms_written"] == 6 * 8
-    assert open(tmp_path / "blk.bin", "rb").read() == open(tmp_path / "unit.bin", "rb").read()
+    for env, val, name in (("DSABF_UNIT_LAUNCH", "1", "unit.bin"), ("DSABF_UNITS_PER_LAUNCH", "0", "whole.bin"),
+                           ("DSABF_UNITS_PER_LAUNCH", "2", "two.bin")):
+        os.environ[env] = val
+        try:
+            b = host.run_observation_junk_to_file(cfg, 6, str(tmp_path / name), ring_blocks=3)
+        finally:
+            os.environ.pop(env)
+        assert a["gemms_written"] == b["gemms_written"] == 6 * 8
+        assert open(tmp_path / "blk.bin", "rb").read() == open(tmp_path / name, "rb").read(), name
     # and against the oracle
     g = orc.Geom(n_beams=64, n_ant=64, n_freq=8, n_avg=16, n_out_per_gemm=2)
     pos = host.default_positions(64)
@@ -388,11 +390,8 @@ def test_config5_debug_flow_on_the_named_catalogue(bfmod, orc, tmp_path):
     out = orc.beamform(g, w, units)
     want = np.stack([orc.dedisperse(g, out[u]) for u in range(160)])
     assert np.array_equal(ded, want)
-    # every source lights up the beam nearest to it
-    best = ded.argmax(1)
-    d_th = np.abs(d32[best, 0] - s32[:, 0])
-    d_ph = np.abs(d32[best, 1] - s32[:, 1])
-    assert (d_th <= 7.0 / 31 * np.pi / 180 * 0.75).all() and (d_ph <= 7.0 / 15 * np.pi / 180 * 0.75).all()
+    assert ded.max() > 0 and np.isfinite(ded).all()
+    # (no 'brightest beam = nearest beam' check: a 10 x 10 grid at 55 m spacing has grating lobes every 0.2 degrees)
 
 
 # ---- the gather behind the C-ABI, on one GPU ---------------------------------------------------------------------------------
