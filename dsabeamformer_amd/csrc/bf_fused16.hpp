@@ -557,8 +557,8 @@ __global__ __launch_bounds__(kThreads16, ant_two_ksteps<AIN>() ? 2 : DSABF_OCC16
                 v4i a0[KS], a1[KS];
                 read_frag(t8, a0, a1);
 #pragma unroll
-                for (int t = 0; t < NT; t++) {
-                    v4i re[SPS], im[SPS];
+                for (int t = 0; t < NT; t++) {   // (the compiler issues the first MFMAs of all chains before the dependent
+                    v4i re[SPS], im[SPS];        //  second ones by itself; forcing that order changed nothing, r02 variants log)
                     issue(a0, a1, t, re, im);
                     consume(t8, t, re, im);
                 }

@@ -402,13 +402,14 @@ struct observation_options {
     detected_sink* sink = nullptr;  // optional consumer of every gemm-unit's detected powers; replaces beam_out as
                                     // the D2H destination (beam_out then stays zero)
     // launch granularity: true = bf_enqueue_block launches over `units_per_launch` consecutive gemm-units of the block
-    // (0 = the whole PSRDADA block in one launch), consecutive launches on consecutive compute queues, each followed on
-    // its queue by the D2H copies of its units (into the sink's slots, or beam_out[queue]); false = the reference's own
-    // pattern, one launch per gemm-unit round-robin over the queues (src/beamformer.cu:454-519).  Identical detected
-    // powers either way.  Default 8: a quarter of a block per launch keeps the kernel within 6 % of its best rate and
-    // pipelines kernel and D2H across the queues (profiles/r02_streaming.txt).
+    // (0 = the whole PSRDADA block in one launch, the default), consecutive launches on consecutive compute queues, each
+    // followed on its queue by the D2H copies of its units (into the sink's slots, or beam_out[queue]); false = the
+    // reference's own pattern, one launch per gemm-unit round-robin over the queues (src/beamformer.cu:454-519).
+    // Identical detected powers either way.  End to end the loop is PCIe-bound and the granularity does not matter
+    // (9.7-10.5 us per beam-block for 1 ... 32 units per launch, profiles/r02_streaming.txt); the whole block per launch
+    // is what keeps the kernel at its best rate once the input is resident (profiles/r02_launch_size.txt).
     bool block_launch = true;
-    int units_per_launch = 8;
+    int units_per_launch = 0;
     // -R / -r: this process beamforms frequencies [rank * n_freq, (rank + 1) * n_freq) of a world x n_freq sub-band (cfg.n_freq
     // is the LOCAL count).  The weights are generated for those channels; the input blocks are the rank's own slice.
     int world = 1, rank = 0;

@@ -360,18 +360,18 @@ def test_edge_geometries_and_arguments(torch, bfmod, orc):
             bf.beamform(d[1:], 1, o)  # misaligned input pointer
 
 
-@pytest.mark.parametrize("launches", ["reference", "default", "whole-block"])
+@pytest.mark.parametrize("launches", ["reference", "quarter-block", "default"])
 def test_production_observation_loop_with_junk_source(bfmod, orc, monkeypatch, launches):
     """Observation (non-DEBUG) mode, src/beamformer.cu:364-534: production geometry (N_AVERAGING 16, 128 MiB blocks),
     blocks from the in-memory dada_junkdb stand-in, 8 compute queues.  After the run each queue's beam_out slot holds
     the detected powers of the last gemm-unit it processed: must equal the oracle on that gemm-unit's bytes.
-    launches: the reference's one launch per gemm-unit, the default (8 gemm-units per launch) and one launch per block."""
+    launches: the reference's one launch per gemm-unit, 8 gemm-units per launch, and the default: one launch per block."""
     from dsabeamformer_amd import host
 
     if launches == "reference":
         monkeypatch.setenv("DSABF_UNIT_LAUNCH", "1")
-    elif launches == "whole-block":
-        monkeypatch.setenv("DSABF_UNITS_PER_LAUNCH", "0")
+    elif launches == "quarter-block":
+        monkeypatch.setenv("DSABF_UNITS_PER_LAUNCH", "8")
     cfg = bfmod.production_config()
     n_blocks, ring_blocks = 6, 3
     r = host.run_observation_junk(cfg, n_blocks, ring_blocks=ring_blocks, seed=7)
@@ -383,7 +383,7 @@ def test_production_observation_loop_with_junk_source(bfmod, orc, monkeypatch, l
     if launches == "reference":
         # every stream ends on the last block, time slices 24..31 (4 parts x 8 streams, src/beamformer.cu:454-519)
         assert sorted(last) == [(n_blocks - 1) * per_block + 24 + i for i in range(8)]
-    elif launches == "default":
+    elif launches == "quarter-block":
         # 4 launches of 8 gemm-units per block on consecutive queues: launch j on queue j % 8, its last unit 8 (j % 4) + 7
         assert last == [(16 + q) // 4 * per_block + 8 * ((16 + q) % 4) + 7 for q in range(8)]
     else:

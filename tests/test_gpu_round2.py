@@ -264,13 +264,13 @@ def test_enqueue_block_equals_per_unit_launches(torch, bfmod, orc):
 
 
 def test_observation_loop_block_launches_equal_unit_launches(bfmod, orc, tmp_path):
-    """The production loop with the default launch granularity (quarter blocks), with one launch per PSRDADA block and with
-    the reference's one launch per gemm-unit: the same detected stream, byte for byte."""
+    """The production loop with the default launch granularity (one launch per PSRDADA block), with quarter / sixteenth
+    blocks and with the reference's one launch per gemm-unit: the same detected stream, byte for byte."""
     from dsabeamformer_amd import host
 
     cfg = bfmod.production_config(n_freq=8, n_beams=64, n_out_per_gemm=2, n_gemms_per_block=8, n_blocks_on_gpu=4, n_streams=4)
     a = host.run_observation_junk_to_file(cfg, 6, str(tmp_path / "blk.bin"), ring_blocks=3)
-    for env, val, name in (("DSABF_UNIT_LAUNCH", "1", "unit.bin"), ("DSABF_UNITS_PER_LAUNCH", "0", "whole.bin"),
+    for env, val, name in (("DSABF_UNIT_LAUNCH", "1", "unit.bin"), ("DSABF_UNITS_PER_LAUNCH", "8", "quarter.bin"),
                            ("DSABF_UNITS_PER_LAUNCH", "2", "two.bin")):
         os.environ[env] = val
         try:
