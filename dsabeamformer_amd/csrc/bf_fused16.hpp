@@ -11,9 +11,6 @@
 #ifndef DSABF_PAIR_MFMA
 #define DSABF_PAIR_MFMA 4 // MFMAs per conjugate pair tile: 4 (+-P2, +-P4 on the VALU), 5 (real part chained on the MFMA), 6
 #endif
-#ifndef DSABF_LDS_PREFETCH
-#define DSABF_LDS_PREFETCH 0 // request row-tile t8+1's LDS fragments while tile t8 computes (8 more VGPRs per k-step)
-#endif
 #ifndef DSABF_CLOCKPROBE
 #define DSABF_CLOCKPROBE 0 // diagnostic build only (tools/clock_probe.sh): every workgroup overwrites out[blockIdx.x] with its
 #endif                     // in-kernel shader clock in GHz (s_memtime / s_memrealtime around the chunk loop); results invalid
@@ -555,22 +552,10 @@ __global__ __launch_bounds__(kThreads16, ant_two_ksteps<AIN>() ? 2 : DSABF_OCC16
                     if (c + 2 < c_end) load_chunk(c + 2);
                 }
             };
-#if DSABF_LDS_PREFETCH
-            // The LDS fragments of row-tile t8 + 1 are requested while tile t8 computes: read just in time, every tile
-            // started with the wave parked for an LDS round trip (SQ_WAIT_ANY 17 % of the wave cycles, r02 PMC summary).
-            v4i fa0[2][KS], fa1[2][KS];
-            read_frag(0, fa0[0], fa1[0]);
 #pragma unroll
-            for (int t8 = 0; t8 < 8; t8++) {
-                if (t8 + 1 < 8) read_frag(t8 + 1, fa0[(t8 + 1) & 1], fa1[(t8 + 1) & 1]);
-                const v4i(&a0)[KS] = fa0[t8 & 1];
-                const v4i(&a1)[KS] = fa1[t8 & 1];
-#else
-#pragma unroll
-            for (int t8 = 0; t8 < 8; t8++) {
-                v4i a0[KS], a1[KS];
+            for (int t8 = 0; t8 < 8; t8++) {   // (requesting tile t8+1's LDS fragments one tile early was tried: pair kernel
+                v4i a0[KS], a1[KS];            //  -2 % (129 VGPRs: 3 instead of 4 waves per SIMD), general +-0, r02 variants log)
                 read_frag(t8, a0, a1);
-#endif
 #pragma unroll
                 for (int t = 0; t < NT; t++) {   // (the compiler issues the first MFMAs of all chains before the dependent
                     v4i re[SPS], im[SPS];        //  second ones by itself; forcing that order changed nothing, r02 variants log)
