@@ -100,3 +100,17 @@ def test_headers_and_example_compile_as_plain_c(tmp_path):
     r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I" + os.path.join(ROOT, "include"),
                         "-c", os.path.join(ROOT, "examples", "minimal.c"), "-o", str(obj)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+def test_product_library_ships_no_test_double_and_no_hard_runtime_dependencies():
+    """libdsabf.so exports what the headers declare and nothing test-only (round 1 shipped a fake event backend);
+    it has no DT_NEEDED on a HIP runtime or on RCCL (both bind to what the process already has)."""
+    import subprocess
+
+    lib = os.path.join(ROOT, "dsabeamformer_amd", "libdsabf.so")
+    syms = subprocess.run(["nm", "-D", "--defined-only", lib], capture_output=True, text=True).stdout
+    assert "fake" not in syms.lower()
+    exported_c = set(re.findall(r" T (bfh?_[a-z0-9_]+)$", syms, flags=re.M))
+    assert exported_c == set(_declared_symbols())
+    needed = subprocess.run(["readelf", "-d", lib], capture_output=True, text=True).stdout
+    assert "amdhip" not in needed and "rccl" not in needed
