@@ -382,14 +382,19 @@ def main():
         gather_modes = {}
         n_side = max(5, min(args.steps, 50))
         for mode, layout in (("none", "rank"), ("root", "rank"), ("root", "freq"), ("alltoall", "rank"), ("alltoall", "freq")):
-            gm = GatherMode(mode, layout)
-            for i in range(4):
-                step(i, gm)
-            gm.drain()
-            el, _ = timed_region(gm, n_side, False)
-            gather_modes[mode if mode == "none" else "%s_%s_major" % (mode, layout)] = {
-                "value": n_side * blocks_per_step / el, "unit": "beam-blocks/s", "ms_per_step": el / n_side * 1e3, "steps": n_side}
-            del gm
+            key = mode if mode == "none" else "%s_%s_major" % (mode, layout)
+            try:   # a supplementary record must never cost the headline line
+                gm = GatherMode(mode, layout)
+                for i in range(4):
+                    step(i, gm)
+                gm.drain()
+                el, _ = timed_region(gm, n_side, False)
+                gather_modes[key] = {"value": n_side * blocks_per_step / el, "unit": "beam-blocks/s",
+                                     "ms_per_step": el / n_side * 1e3, "steps": n_side}
+                del gm
+            except Exception as e:  # pragma: no cover
+                gather_modes[key] = {"error": str(e)[:300]}
+                torch.cuda.synchronize()
 
     if rank == 0:
         total_blocks = args.steps * blocks_per_step
@@ -501,7 +506,18 @@ def main():
                     "tops": ops / (avg * 1e-3) / 1e12, "frac": ops / (avg * 1e-3) / 1e12 / INT8_DENSE_PEAK_TOPS,
                     "gbs": byts / (avg * 1e-3) / 1e9}
 
-        if world == 1 and args.detect == "canonical" and args.workload in ("c3", "prod") and not args.no_extras:
+        def guarded(name, fn):
+            """A supplementary record must never cost the headline line: an exception becomes {"error": ...}."""
+            try:
+                fn()
+            except Exception as e:  # pragma: no cover
+                out[name] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+                try:
+                    torch.cuda.synchronize()
+                except Exception:
+                    pass
+
+        def extras_variants():
             # supplementary, never the headline, same inputs:
             if paired:
                 g = variant(0, "0")
@@ -520,7 +536,8 @@ def main():
             f["tolerance"] = "(n_ipo+1)*2^-23 relative to the exact value (include/dsabf.h); canonical: (n_ipo+4)*2^-24"
             f["note"] = "opt-in bf_config.detect_mode = BF_DETECT_FAST; not the headline"
             out["fast_detect_mode"] = f
-        if world == 1 and args.workload == "c3" and not args.no_extras:
+
+        def extras_geometries():
             # BASELINE configs[1], the reference's DEBUG geometry (N_TIME 16, n_ipo 2): the parity configuration;
             # HBM-write-bound (4 B out per 0.125 B in per beam), so its roofline is the HBM one
             d = variant(0, wl="c2", reps=100)
@@ -545,6 +562,8 @@ def main():
             ls["note"] = ("bf_enqueue_gemm_unit launches 1 unit (the reference's pattern, src/beamformer.cu:454-519), "
                           "bf_enqueue_block 32 (one PSRDADA block), the headline step 128")
             out["launch_size"] = ls
+
+        def extras_streaming():
             # the production loop end to end, PCIe included: junk source -> H2D -> kernel -> D2H, as the reference's
             # "Time per data chunk" (src/beamformer.cu:539-546)
             from dsabeamformer_amd import host
@@ -570,10 +589,16 @@ def main():
                           "reference's 'Time per data chunk'; never the headline.  Real-time budget: 0.131 ms per beam-block.  "
                           "PCIe-bound either way; interleaved sweep over the launch granularities: profiles/r02_streaming.txt")
             out["streaming"] = st
+
+        if world == 1 and args.detect == "canonical" and args.workload in ("c3", "prod") and not args.no_extras:
+            guarded("general_kernel", extras_variants)
+        if world == 1 and args.workload == "c3" and not args.no_extras:
+            guarded("debug_geometry", extras_geometries)
+            guarded("streaming", extras_streaming)
         if world == 1 and not args.no_cpu_baseline:
             print("bench.py: GPU part done; timing the CPU baselines on the host cores (~%.0f s) ..." % (args.cpu_seconds + 12),
                   file=sys.stderr, flush=True)
-            out["cpu_baseline"] = cpu_baselines(n_avg, n_out, args.cpu_seconds)
+            guarded("cpu_baseline", lambda: out.__setitem__("cpu_baseline", cpu_baselines(n_avg, n_out, args.cpu_seconds)))
         print(json.dumps(out), flush=True)
     bf.close()
     if comm is not None:
