@@ -343,16 +343,20 @@ LaunchShape fused_launch_shape(const Geometry& g, int n_units, int n_cus)
     // of the launch is fine-grained); small launches still get ~2 workgroups per resident slot, but never fewer
     // than 2 chunks each.
     const int groups_avail = ls.chunks_total / cpg;
-    // at least 2 chunk-groups per workgroup (the weight-fragment load and the prologue are paid per workgroup) -- unless
-    // that leaves fewer than 4 workgroups per CU: a single gemm-unit is 4 chunks per frequency, 1 chunk each is then
-    // 6 % faster (profiles/r02_launch_size.txt)
-    int max_split = groups_avail >= 2 ? groups_avail / 2 : 1;
-    if ((long long)base * max_split < 4LL * n_cus) max_split = groups_avail >= 1 ? groups_avail : 1;
+    // At least 2 chunk-groups per workgroup (the weight-fragment load and the prologue are paid per workgroup; two
+    // k-steps = twice the fragments: at least 4) -- unless that leaves fewer than 4 (2) workgroups per CU: a single
+    // gemm-unit is 4 chunks per frequency, 1 chunk each is then 6 % faster (profiles/r02_launch_size.txt).
+    const bool two_k = ksteps16(g) == 2;
+    const int min_groups = two_k ? 4 : 2;
+    int max_split = groups_avail >= min_groups ? groups_avail / min_groups : 1;
+    if ((long long)base * max_split < (two_k ? 2LL : 4LL) * n_cus) max_split = groups_avail >= 1 ? groups_avail : 1;
     int want = (groups_avail + 10) / 20;                                       // ~20 chunk-groups per workgroup
-    // short windows (n_ipo < 16) are store-bound: fewer, longer workgroups measured better (C2: 2 per CU 0.54 of the
-    // HBM peak, 8 per CU 0.49); the MFMA-bound shapes want ~4 resident sets of 4: a 32-unit block (one PSRDADA block,
-    // bf_enqueue_block) runs 4 % faster on 4096 workgroups than on 2048 (profiles/r02_launch_size.txt)
-    const int target_wgs_per_cu = g.n_ipo < 16 ? 2 : 4 * (16 / kWaves16);
+    // Short windows (n_ipo < 16) are store-bound: fewer, longer workgroups measured better (C2: 2 per CU 0.54 of the
+    // HBM peak, 8 per CU 0.49).  The MFMA-bound one-k-step shapes want ~4 resident sets of 4: a 32-unit block (one
+    // PSRDADA block, bf_enqueue_block) runs 4 % faster on 4096 workgroups than on 2048 (profiles/r02_launch_size.txt);
+    // two-k-step shapes (2 resident per CU, 128 KiB of weight fragments each) want 2 sets of 2: a 16-unit launch of a
+    // BASELINE-config-5 rank shard is 14 % faster on 1024 workgroups than on 4096 (profiles/r02_launch_size_c5shard.txt).
+    const int target_wgs_per_cu = g.n_ipo < 16 ? 2 : (two_k ? 4 : 4 * (16 / kWaves16));
     int want_fill = (target_wgs_per_cu * n_cus + base - 1) / base;            // enough workgroups to fill the chip
     if (want_fill > max_split) want_fill = max_split;
     if (want < want_fill) want = want_fill;

@@ -1,5 +1,5 @@
 """ctypes access to the C++ host mirror (include/dsabf_host.h): weights, config readers, the data.py writer,
-test_data_generator and observation_loop_state.  Thin wrappers only; the logic is C++ (csrc/bf_host.cpp)."""
+test_data_generator and observation_loop_state.  Thin wrappers only; the logic is C++ (csrc/bf_geometry.cpp, bf_generator.cpp, bf_scheduler.cpp, bf_sinks.cpp; C wrappers bf_host_c.cpp)."""
 from __future__ import annotations
 
 import ctypes as C

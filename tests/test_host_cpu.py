@@ -1,4 +1,4 @@
-"""CPU tests of the C++ host mirror (dsabeamformer_amd/csrc/bf_host.cpp) -- the product's own weight generator,
+"""CPU tests of the C++ host mirror (dsabeamformer_amd/csrc/bf_geometry.cpp, bf_generator.cpp, bf_scheduler.cpp, bf_sinks.cpp) -- the product's own weight generator,
 config readers, data.py writer, test_data_generator and observation_loop_state -- against the oracle and the
 reference's documented scheduler rules (README.md:122-140, src/observation_loop.hh)."""
 import json

@@ -12,14 +12,19 @@ import bench  # noqa: E402
 import dsabeamformer_amd as bfm  # noqa: E402
 
 wl = sys.argv[1] if len(sys.argv) > 1 else "c3"
+shard = wl == "c5shard"          # one rank's share of BASELINE configs[4]: 128 of 1024 freq x 512 beams x 100 ant
+if shard:
+    wl = "c5"
 n_avg, n_out = bench.geometry(wl)
 cfg = bfm.production_config(n_avg=n_avg, n_out_per_gemm=n_out)
+if wl == "c5":
+    cfg.n_ant, cfg.n_beams, cfg.n_freq = 100, 512, 128 if shard else 1024
 bf = bfm.Beamformer(cfg)
 bf.set_weights(bench.product_weights(cfg, 0))
 n_time = n_out * cfg.n_pol * cfg.n_avg
 stream = torch.cuda.current_stream()
 print("workload %s: kernel %s" % (wl, bf.kernel_info(1)["kernel"]))
-for units in (1, 2, 4, 8, 32, 128):
+for units in ((1, 4, 16, 64) if wl == "c5" else (1, 2, 4, 8, 32, 128)):
     d_in = [torch.randint(0, 256, (units * cfg.n_freq * n_time * cfg.n_ant,), dtype=torch.uint8, device="cuda") for _ in range(4)]
     d_out = torch.empty(units * n_out * cfg.n_freq * cfg.n_beams, dtype=torch.float32, device="cuda")
     chunks = units * n_time // 128
