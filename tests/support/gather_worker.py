@@ -1,0 +1,63 @@
+"""Worker of tests/test_gpu_multirank.py: ONE rank of a frequency partition, as its own process (TEST INFRASTRUCTURE).
+usage: gather_worker.py rank world workdir          (DSABF_RCCL_LIB must point at tests/support/libfakerccl.so)
+
+Every rank builds the same seeded full-band problem, beamforms ITS frequency shard on GPU 0 and takes part in
+bf_gather_detected for every receiver mode and layout; what it received is saved for the parent to compare with the
+oracle's full-band result."""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+rank, world, work = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
+import torch  # noqa: E402
+
+import dsabeamformer_amd as bfm  # noqa: E402
+from dsabeamformer_amd import api  # noqa: E402
+
+F, B, A, n_avg, n_out, n_units = 8 * world, 64, 64, 16, 2, 4
+fl = F // world
+rng = np.random.default_rng(2026)
+w = rng.integers(-127, 128, size=(F, A, B, 2), dtype=np.int8)
+n_time = n_out * 2 * n_avg
+packed = rng.integers(0, 256, size=(n_units, F, n_time, A), dtype=np.uint8)
+np.savez(os.path.join(work, "problem.npz"), w=w, packed=packed) if rank == 0 else None
+
+idfile = os.path.join(work, "id")
+if rank == 0:
+    uid = api.comm_unique_id()
+    open(idfile + ".tmp", "wb").write(uid)
+    os.rename(idfile + ".tmp", idfile)
+else:
+    t0 = time.time()
+    while not os.path.exists(idfile):
+        assert time.time() - t0 < 120
+        time.sleep(0.05)
+    uid = open(idfile, "rb").read()
+comm = api.Comm(rank, world, uid, device=0)
+
+cfg = bfm.production_config(n_beams=B, n_ant=A, n_freq=fl, n_avg=n_avg, n_out_per_gemm=n_out)
+bf = bfm.Beamformer(cfg)
+bf.set_weights(np.ascontiguousarray(w[rank * fl:(rank + 1) * fl]))
+d_in = torch.from_numpy(np.ascontiguousarray(packed[:, rank * fl:(rank + 1) * fl])).cuda()
+n_rows, row_floats = n_units * n_out, fl * B
+d_local = torch.empty(n_rows * row_floats, dtype=torch.float32, device="cuda")
+s = torch.cuda.current_stream().cuda_stream
+bf.beamform(d_in, n_units, d_local, s)
+res = {}
+for root in (0, world - 1, api.GATHER_ROOT_ALL, api.GATHER_ROOT_DISTRIBUTED):
+    for layout in (api.GATHER_FREQ_MAJOR, api.GATHER_RANK_MAJOR):
+        held = comm.rows_held(n_rows, root)
+        d_full = torch.full((max(held, 1) * world * row_floats,), float("nan"), dtype=torch.float32, device="cuda")
+        comm.gather(d_local, n_rows, row_floats, root, layout, d_full if held else None, s)
+        torch.cuda.synchronize()
+        if held:
+            res["root%d_layout%d" % (root, layout)] = d_full.cpu().numpy()
+np.savez(os.path.join(work, "rank%d.npz" % rank), local=d_local.cpu().numpy(), **res)
+comm.close()
+bf.close()
+print("rank", rank, "done")

@@ -1,0 +1,98 @@
+"""GPU tests (-m gpu) of the multi-rank paths with MORE THAN ONE RANK -- on one GPU.  RCCL refuses two ranks on one
+device and the pool has 1-GPU boxes, so the ranks (separate processes, as in production: one process per shard) time-share
+GPU 0 and their point-to-point messages travel through tests/support/fake_rccl.cpp, a loopback stand-in for the eight
+RCCL entry points csrc/bf_comm.cpp binds (selected with DSABF_RCCL_LIB; same matching rules: per-pair issue order,
+concurrent progress inside a group, sizes must agree).  Everything else is the product: bf_comm_create,
+bf_gather_detected's plan walk and grouping, `beam -R world -r rank`, the gather inside run_observation."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+SUPPORT = os.path.join(ROOT, "tests", "support")
+FAKE = os.path.join(SUPPORT, "libfakerccl.so")
+
+
+@pytest.fixture(scope="module")
+def fake_rccl():
+    """Builds the loopback stand-in (no DT_NEEDED on a HIP runtime: it binds to the one already in the process)."""
+    src = os.path.join(SUPPORT, "fake_rccl.cpp")
+    if not os.path.exists(FAKE) or os.path.getmtime(FAKE) < os.path.getmtime(src):
+        from dsabeamformer_amd import build
+
+        obj = os.path.join(SUPPORT, "fake_rccl.o")
+        subprocess.check_call([build.HIPCC, "-O2", "-std=c++17", "-fPIC", "-c", src, "-o", obj])
+        cxx = os.path.join(os.path.dirname(os.path.realpath(build.HIPCC)), "..", "lib", "llvm", "bin", "clang++")
+        subprocess.check_call([cxx if os.path.exists(cxx) else "g++", "-shared", "-fPIC", "-o", FAKE, obj, "-lpthread", "-lrt"])
+    return FAKE
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_gather_detected_with_several_ranks_on_one_gpu(orc, fake_rccl, tmp_path, world):
+    env = dict(os.environ, DSABF_RCCL_LIB=fake_rccl)
+    procs = [subprocess.Popen([sys.executable, os.path.join(SUPPORT, "gather_worker.py"), str(r), str(world), str(tmp_path)],
+                              env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    prob = np.load(tmp_path / "problem.npz")
+    w, packed = prob["w"], prob["packed"]
+    F, B = w.shape[0], w.shape[2]
+    fl = F // world
+    g = orc.Geom(n_beams=B, n_ant=64, n_freq=F, n_avg=16, n_out_per_gemm=2)
+    want = orc.beamform(g, w, packed)                              # [unit][o][F][b]: the whole band
+    n_rows = want.shape[0] * want.shape[1]
+    full = want.reshape(n_rows, F, B)
+    ranks = [np.load(tmp_path / ("rank%d.npz" % r)) for r in range(world)]
+    for r in range(world):                                          # every shard's own kernel output
+        assert np.array_equal(ranks[r]["local"].reshape(n_rows, fl, B), full[:, r * fl:(r + 1) * fl])
+    shards = np.stack([full[:, r * fl:(r + 1) * fl] for r in range(world)])      # [rank][row][f_local][b]
+    for root in (0, world - 1, -1, -2):
+        receivers = [root] if root >= 0 else list(range(world))
+        for r in range(world):
+            keys = [k for k in ranks[r].files if k.startswith("root%d_" % root)]
+            assert bool(keys) == (r in receivers), (root, r, keys)
+        for r in receivers:
+            held = n_rows // world if root == -2 else n_rows
+            first = r * held if root == -2 else 0
+            got_f = ranks[r]["root%d_layout0" % root].reshape(held, F, B)          # the reference's [o][f][b]
+            got_r = ranks[r]["root%d_layout1" % root].reshape(world, held, fl, B)  # sub-band-major
+            assert np.array_equal(got_f, full[first:first + held]), (root, r)
+            assert np.array_equal(got_r, shards[:, first:first + held]), (root, r)
+
+
+def test_beam_sharded_over_two_ranks_gathers_the_whole_band(orc, fake_rccl, tmp_path):
+    """`beam -j 28 -R 2 -r i -I id` (25 burn-in reads + 3 analysed blocks): two shard processes, the detected powers of both gathered to shard 0 after every
+    block (bf_gather_detected on the block's compute queue inside run_observation), shard 0 alone writes -w: the file
+    holds [gemm][o][256 freq][beam] = shard 0's channels 0..127 next to shard 1's 128..255, bit for bit the oracle's."""
+    from dsabeamformer_amd import build, host
+
+    import dsabeamformer_amd as bfm
+
+    env = dict(os.environ, DSABF_RCCL_LIB=fake_rccl)
+    out = tmp_path / "band.bin"
+    cmd = lambda r: [build.BEAM, "-j", "28", "-R", "2", "-r", str(r), "-D", "0", "-I", str(tmp_path / "id")] + (["-w", str(out)] if r == 0 else [])  # noqa: E731
+    procs = [subprocess.Popen(cmd(r), env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in (0, 1)]
+    outs = [p.communicate(timeout=900)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    assert "Shard 0 of 2: channels 0 .. 127" in outs[0] and "Shard 1 of 2: channels 128 .. 255" in outs[1]
+    assert "Wrote 96 gemm-units" in outs[0]
+    cfg = bfm.production_config(n_freq=128)                     # one shard's geometry
+    n_time = cfg.n_out_per_gemm * cfg.n_pol * cfg.n_avg
+    # both shards read the same junk bytes (same seed, same local geometry); their weights are their own channels
+    ring = host.junk_bytes(cfg.n_ant * cfg.n_freq * n_time * cfg.n_gemms_per_block, 4, 0xD5A, cfg).reshape(
+        4, cfg.n_gemms_per_block, cfg.n_freq, n_time, cfg.n_ant)
+    pos, dirs = host.default_positions(64), host.default_directions(256)
+    raw = np.fromfile(out, np.float32, offset=4096).reshape(3 * 32, cfg.n_out_per_gemm, 256, 256)
+    g = orc.Geom(n_beams=256, n_ant=64, n_freq=128, n_avg=16, n_out_per_gemm=8)
+    for gemm in (0, 31, 40, 95):
+        blk, ts = divmod(gemm, 32)
+        unit = ring[(25 + blk) % 4, ts][None]               # the first 25 blocks of the source went to the burn-in reads
+        for r in (0, 1):
+            w = host.make_weights(pos, dirs, 128, chan0=128 * r, gpu=0)
+            want = orc.beamform(g, w, unit)[0]                  # [o][128][256]
+            assert np.array_equal(raw[gemm][:, 128 * r:128 * (r + 1)], want), (gemm, r)

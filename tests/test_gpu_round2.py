@@ -449,13 +449,13 @@ def test_beam_sharded_mode_and_replica_launcher_on_one_gpu(tmp_path):
     from dsabeamformer_amd import build
 
     plain, shard = tmp_path / "plain.bin", tmp_path / "shard.bin"
-    _beam("-j", 3, "-w", plain)
-    out = _beam("-j", 3, "-w", shard, "-R", 1, "-r", 0, "-I", tmp_path / "id")
-    assert "Shard 0 of 1: channels 0 .. 255" in out
+    assert "Wrote 64 gemm-units" in _beam("-j", 27, "-w", plain)      # 25 burn-in reads (BURNIN) + 2 analysed blocks
+    out = _beam("-j", 27, "-w", shard, "-R", 1, "-r", 0, "-I", tmp_path / "id")
+    assert "Shard 0 of 1: channels 0 .. 255" in out and "Wrote 64 gemm-units" in out
     a, b = open(plain, "rb").read(), open(shard, "rb").read()
-    assert len(a) == len(b) and a == b
+    assert len(a) == len(b) == 4096 + 64 * 8 * 256 * 256 * 4 and a == b
     for extra, name in (([], "rep_{i}.bin"), (["-S"], "shd_{i}.bin")):
-        r = subprocess.run([build.REPLICAS, "-n", "1"] + extra + ["-j", "3", "-w", str(tmp_path / name)],
+        r = subprocess.run([build.REPLICAS, "-n", "1"] + extra + ["-j", "27", "-w", str(tmp_path / name)],
                            capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stdout + r.stderr
         assert open(tmp_path / name.replace("{i}", "0"), "rb").read() == a
