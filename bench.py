@@ -64,6 +64,9 @@ def parse():
     ap.add_argument("--force-dist", action="store_true",
                     help="single process: still create the process group and a one-rank RCCL communicator and run the "
                          "gather path (plumbing check on a 1-GPU box)")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend for the barrier / max-over-ranks / id broadcast (gloo: tests that run "
+                         "several ranks on ONE GPU, with DSABF_BENCH_ONE_GPU=1 and a loopback DSABF_RCCL_LIB)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the supplementary records: profiling passes see one kernel")
@@ -214,7 +217,10 @@ def main():
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
                      % (args.gpus, args.gpus))
         args.gpus = world
+    if os.environ.get("DSABF_BENCH_ONE_GPU") == "1":
+        local = 0          # test mode: every rank time-shares GPU 0
     torch.cuda.set_device(local)
+    dist_dev = "cuda" if args.dist_backend == "nccl" else "cpu"
     dist = None
     if world > 1 or args.force_dist:
         import torch.distributed as dist
@@ -224,7 +230,10 @@ def main():
             os.environ.setdefault("MASTER_PORT", "29541")
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group("gloo")
 
     import dsabeamformer_amd as bfm
     from dsabeamformer_amd import api
@@ -260,7 +269,7 @@ def main():
     comm, comm_note = None, None
     if dist is not None:
         try:
-            idt = torch.zeros(128, dtype=torch.uint8, device="cuda")
+            idt = torch.zeros(128, dtype=torch.uint8, device=dist_dev)
             if rank == 0:
                 idt.copy_(torch.frombuffer(bytearray(api.comm_unique_id()), dtype=torch.uint8))
             dist.broadcast(idt, 0)
@@ -343,7 +352,7 @@ def main():
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
         if dist is not None:
-            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dist_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         return elapsed, events
@@ -355,7 +364,7 @@ def main():
     extra_warm = 0
     while True:
         headline_mode.drain()
-        go = torch.tensor([1.0 if time.perf_counter() - t_w < args.min_warm_seconds else 0.0], device="cuda")
+        go = torch.tensor([1.0 if time.perf_counter() - t_w < args.min_warm_seconds else 0.0], device=dist_dev)
         if dist is not None:
             dist.all_reduce(go, op=dist.ReduceOp.MAX)   # every rank takes the same number of extra steps
         if go.item() == 0.0:

@@ -9,7 +9,7 @@
 //
 // RCCL is bound at run time (dlopen): libdsabf.so must not drag a second HIP runtime into a process that already has
 // one (torch bundles its own librccl.so + libamdhip64.so; a C++ application links ROCm's) -- the same rule as for the HIP
-// runtime itself.  Resolution order: a librccl already loaded in the process, $DSABF_RCCL_LIB,
+// runtime itself.  Resolution order: $DSABF_RCCL_LIB, a librccl already loaded in the process,
 // librccl.so.1, librccl.so.
 #include "../../include/dsabf.h"
 
@@ -50,13 +50,20 @@ rccl_api& rccl()
 {
     static rccl_api api;
     if (api.lib || !api.error.empty()) return api;
-    std::vector<std::string> names;
-    if (const char* e = getenv("DSABF_RCCL_LIB")) names.push_back(e);
-    names.push_back("librccl.so.1");
-    names.push_back("librccl.so");
+    // $DSABF_RCCL_LIB wins outright (Python callers get it set to the librccl next to the HIP runtime they preloaded,
+    // dsabeamformer_amd/_lib.py; tests point it at a loopback stand-in); otherwise a copy that is already in the process,
+    // then the system's.
+    if (const char* e = getenv("DSABF_RCCL_LIB")) {
+        if (e[0]) api.lib = dlopen(e, RTLD_NOW | RTLD_GLOBAL);
+        if (e[0] && !api.lib) {
+            api.error = std::string("DSABF_RCCL_LIB=") + e + " could not be loaded: " + (dlerror() ? dlerror() : "?");
+            return api;
+        }
+    }
+    const char* names[] = {"librccl.so.1", "librccl.so"};
     for (int pass = 0; pass < 2 && !api.lib; pass++)      // pass 0: only a copy that is already in the process
-        for (const std::string& n : names) {
-            api.lib = dlopen(n.c_str(), RTLD_NOW | RTLD_GLOBAL | (pass == 0 ? RTLD_NOLOAD : 0));
+        for (const char* n : names) {
+            api.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL | (pass == 0 ? RTLD_NOLOAD : 0));
             if (api.lib) break;
         }
     if (!api.lib) {
