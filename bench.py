@@ -500,9 +500,14 @@ def main():
                                                 for _ in range(2)]
             dst = d_out if of2 <= out_floats else [torch.empty(of2, dtype=torch.float32, device="cuda") for _ in range(2)]
             fn = lambda i: b2.beamform(src[i % len(src)][:in2], nu, dst[i & 1][:of2], sptr)  # noqa: E731
-            for i in range(5):
+            t_w2 = time.perf_counter()     # the handle was just built (idle GPU): warm the clock back up before timing
+            i = 0
+            while i < 8 or time.perf_counter() - t_w2 < 0.15:
                 fn(i)
-            avg, med, mn = time_launches(torch, fn, reps or max(20, args.steps // 4), stream)
+                i += 1
+                if i % 16 == 0:
+                    torch.cuda.synchronize()
+            avg, med, mn = time_launches(torch, fn, reps or max(40, args.steps // 2), stream)
             name = b2.kernel_info(nu)["kernel"]
             li = b2.kernel_info(nu)
             b2.close()
