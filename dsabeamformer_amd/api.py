@@ -98,6 +98,14 @@ class Beamformer:
         check(self._lib.bf_dedisperse_dm_device(self._h, _ptr(d_series), int(n_t), _ptr(d_delays), int(n_dm),
                                                 int(n_t_out), _ptr(d_out), C.c_void_p(stream)))
 
+    def dedisperse_band(self, d_out_unit, n_freq_total: int, d_ded, stream: int = 0) -> None:
+        check(self._lib.bf_dedisperse_band_device(self._h, _ptr(d_out_unit), n_freq_total, _ptr(d_ded), C.c_void_p(stream)))
+
+    def dedisperse_dm_band(self, d_series, n_t: int, n_freq_total: int, d_delays, n_dm: int, n_t_out: int, d_out,
+                           stream: int = 0) -> None:
+        check(self._lib.bf_dedisperse_dm_band_device(self._h, _ptr(d_series), n_t, n_freq_total, _ptr(d_delays), n_dm, n_t_out,
+                                                     _ptr(d_out), C.c_void_p(stream)))
+
     # -- streaming entry points (the reference's observation loop) ---------------------------------------------
     def submit_block(self, slot: int, host, nbytes: int, event=None) -> None:
         check(self._lib.bf_submit_block(self._h, slot, _ptr(host), nbytes, _ptr(event)))

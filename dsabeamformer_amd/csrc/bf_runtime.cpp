@@ -621,6 +621,30 @@ int bf_dedisperse_dm_device(bf_handle* h, const float* d_series, int n_t, const 
     return BF_OK;
 }
 
+int bf_dedisperse_band_device(bf_handle* h, const float* d_out_unit, int n_freq_total, float* d_ded, void* hip_stream)
+{
+    if (!h || !d_out_unit || !d_ded) return fail(BF_ERR_INVALID, "NULL argument");
+    if (n_freq_total <= 0) return fail(BF_ERR_INVALID, "n_freq_total must be positive");
+    ON_DEVICE(h);
+    dsabf::Geometry g = h->geom;
+    g.n_freq = n_freq_total;
+    HIP_TRY(dsabf::launch_dedisperse(g, d_out_unit, d_ded, as_stream(hip_stream)));
+    return BF_OK;
+}
+
+int bf_dedisperse_dm_band_device(bf_handle* h, const float* d_series, int n_t, int n_freq_total, const int32_t* d_delays,
+                                 int n_dm, int n_t_out, float* d_out, void* hip_stream)
+{
+    if (!h || !d_series || !d_delays || !d_out) return fail(BF_ERR_INVALID, "NULL argument");
+    if (n_freq_total <= 0 || n_t <= 0 || n_dm < 0 || n_t_out < 0 || n_t_out > n_t)
+        return fail(BF_ERR_INVALID, "need n_freq_total > 0, 0 <= n_t_out <= n_t, n_dm >= 0");
+    ON_DEVICE(h);
+    dsabf::Geometry g = h->geom;
+    g.n_freq = n_freq_total;
+    HIP_TRY(dsabf::launch_dedisperse_dm(g, d_series, n_t, d_delays, n_dm, n_t_out, d_out, as_stream(hip_stream)));
+    return BF_OK;
+}
+
 int bf_kernel_info(const bf_handle* h, int n_units, int* grid, int* block, int* lds_bytes, int* vgprs)
 {
     if (!h) return fail(BF_ERR_INVALID, "handle is NULL");

@@ -256,6 +256,13 @@ int bf_block_gather_device(bf_handle *h, int stream_idx, int world, float **d_fu
 /* Asynchronous device-to-host copy of n_floats on compute queue `stream_idx` (behind whatever was enqueued there). */
 int bf_enqueue_d2h(bf_handle *h, int stream_idx, const float *d_src, float *host_dst, size_t n_floats);
 
+/* The two dedispersion entry points above on a gathered band: the same kernels over n_freq_total = world * n_freq
+ * channels of a [row][n_freq_total][beam] array (BF_GATHER_LAYOUT_FREQ_MAJOR on the receiving rank) -- ascending f over the
+ * WHOLE band, i.e. the bits one GPU holding all channels would produce. */
+int bf_dedisperse_band_device(bf_handle *h, const float *d_out_unit, int n_freq_total, float *d_ded, void *hip_stream);
+int bf_dedisperse_dm_band_device(bf_handle *h, const float *d_series, int n_t, int n_freq_total, const int32_t *d_delays,
+                                 int n_dm, int n_t_out, float *d_out, void *hip_stream);
+
 /* Introspection for benchmarks/roofline reports. */
 int bf_kernel_info(const bf_handle *h, int n_units, int *grid, int *block, int *lds_bytes, int *vgprs);
 int bf_kernel_name(const bf_handle *h, char *buf, size_t buflen); /* which fused kernel this geometry runs */

@@ -57,6 +57,19 @@ for root in (0, world - 1, api.GATHER_ROOT_ALL, api.GATHER_ROOT_DISTRIBUTED):
         torch.cuda.synchronize()
         if held:
             res["root%d_layout%d" % (root, layout)] = d_full.cpu().numpy()
+# rank 0: DM-0 sum and a DM ladder over the WHOLE band, on the freq-major gathered series (rows = time samples)
+comm.gather(d_local, n_rows, row_floats, 0, api.GATHER_FREQ_MAJOR,
+            d_band := (torch.empty(n_rows * world * row_floats, dtype=torch.float32, device="cuda") if rank == 0 else None), s)
+if rank == 0:
+    d_ded = torch.empty(B, dtype=torch.float32, device="cuda")
+    bf.dedisperse_band(d_band, F, d_ded, s)                      # unit 0, output 0 = row 0
+    delays = np.load(os.path.join(work, "delays.npy"))         # [n_dm][F], written by the parent
+    n_dm, n_t_out = delays.shape[0], n_rows - int(delays.max())
+    d_dm = torch.empty(n_dm * n_t_out * B, dtype=torch.float32, device="cuda")
+    bf.dedisperse_dm_band(d_band, n_rows, F, torch.from_numpy(delays).cuda(), n_dm, n_t_out, d_dm, s)
+    torch.cuda.synchronize()
+    res["band_ded0"] = d_ded.cpu().numpy()
+    res["band_dm"] = d_dm.cpu().numpy().reshape(n_dm, n_t_out, B)
 np.savez(os.path.join(work, "rank%d.npz" % rank), local=d_local.cpu().numpy(), **res)
 comm.close()
 bf.close()

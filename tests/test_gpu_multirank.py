@@ -35,6 +35,10 @@ def fake_rccl():
 @pytest.mark.parametrize("world", [2, 4])
 def test_gather_detected_with_several_ranks_on_one_gpu(orc, fake_rccl, tmp_path, world):
     env = dict(os.environ, DSABF_RCCL_LIB=fake_rccl)
+    rng = np.random.default_rng(5)
+    delays = np.sort(rng.integers(0, 3, size=(3, 8 * world)), axis=1)[:, ::-1].astype(np.int32).copy()   # [dm][F], falling with f
+    delays[0] = 0
+    np.save(tmp_path / "delays.npy", delays)
     procs = [subprocess.Popen([sys.executable, os.path.join(SUPPORT, "gather_worker.py"), str(r), str(world), str(tmp_path)],
                               env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
     outs = [p.communicate(timeout=600)[0] for p in procs]
@@ -63,6 +67,11 @@ def test_gather_detected_with_several_ranks_on_one_gpu(orc, fake_rccl, tmp_path,
             got_r = ranks[r]["root%d_layout1" % root].reshape(world, held, fl, B)  # sub-band-major
             assert np.array_equal(got_f, full[first:first + held]), (root, r)
             assert np.array_equal(got_r, shards[:, first:first + held]), (root, r)
+    # dedispersion of the gathered band on rank 0 (bf_dedisperse_band_device / bf_dedisperse_dm_band_device): ascending f over
+    # ALL channels = the bits a single GPU holding the whole band produces = the oracle's
+    assert np.array_equal(ranks[0]["band_ded0"], orc.dedisperse(g, want[0]))
+    n_t_out = n_rows - int(delays.max())
+    assert np.array_equal(ranks[0]["band_dm"], orc.dedisperse_dm(full, delays, n_t_out))
 
 
 def test_beam_sharded_over_two_ranks_gathers_the_whole_band(orc, fake_rccl, tmp_path):
