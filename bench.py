@@ -418,7 +418,7 @@ def main():
         paired = "PAIRED" in info["kernel"]
         # committed rocprofv3 PMC summaries of exactly this launch (tools/pmc.sh), if any
         pmc_name = {("c3", 128, True): "r02_c3_paired_pmc_summary.txt", ("c3", 128, False): "r02_c3_general_pmc_summary.txt",
-                    ("c5", 16, True): "r01_c5_pmc_summary.txt", ("c2", 128, True): "r01_c2_pmc_summary.txt"}.get(
+                    ("c5", 16, True): "r02_c5_pmc_summary.txt", ("c2", 128, True): "r02_c2_pmc_summary.txt"}.get(
             (args.workload, units, paired))
         pmc = pmc_summary(pmc_name) if (pmc_name and world == 1 and args.detect == "canonical") else {}
         if mfma_bound:
