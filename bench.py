@@ -68,6 +68,9 @@ def parse():
                     help="torch.distributed backend for the barrier / max-over-ranks / id broadcast (gloo: tests that run "
                          "several ranks on ONE GPU, with DSABF_BENCH_ONE_GPU=1 and a loopback DSABF_RCCL_LIB)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--budget-seconds", type=float, default=900.0,
+                    help="wall-clock limit for everything AFTER the headline measurement (supplementary records, gather modes, "
+                         "CPU baselines): when it expires the line is printed with what is there and the process exits 0")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the supplementary records: profiling passes see one kernel")
     ap.add_argument("--min-warm-seconds", type=float, default=1.0)
@@ -201,6 +204,46 @@ def cpu_baselines(n_avg, n_out, seconds):
                                            "sample": "128 of 1024 gemm-units, literal restatement, x8"}
     out["generator"] = gen_rec
     return out
+
+
+class Watchdog:
+    """Prints the JSON line exactly once: normally through finish(); if the budget expires first (a supplementary record or a
+    gather mode hangs), from a timer thread with whatever has been recorded, then ends the process with status 0."""
+
+    def __init__(self, out, seconds):
+        import threading
+
+        self.out, self.lock, self.printed = out, threading.Lock(), False
+        self.timer = threading.Timer(seconds, self._expired)
+        self.timer.daemon = True
+        self.timer.start()
+
+    def _emit(self, note=None):
+        with self.lock:
+            if self.printed:
+                return
+            self.printed = True
+            if self.out is not None:
+                if note:
+                    self.out["truncated"] = note
+                try:
+                    line = json.dumps(self.out)
+                except Exception:   # a record half-written by the main thread
+                    line = json.dumps({k: v for k, v in self.out.items() if k in (
+                        "metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                        "vs_baseline", "dtype", "data", "config", "roofline", "truncated")})
+                print(line, flush=True)
+
+    def _expired(self):
+        self._emit("the budget for supplementary records (--budget-seconds) expired; the headline and roofline are complete")
+        os._exit(0)
+
+    def finish(self):
+        self.timer.cancel()
+        self._emit()
+
+    def cancel(self):
+        self.timer.cancel()
 
 
 def main():
@@ -385,26 +428,7 @@ def main():
     kern_ms = sorted(a.elapsed_time(b) for a, b in events)
     kern_avg_ms = sum(kern_ms) / len(kern_ms)
 
-    # ---- every gather mode side by side (N > 1) ----------------------------------------------------------------------------
-    gather_modes = None
-    if dist is not None and (world > 1 or args.force_dist) and not args.no_extras:
-        gather_modes = {}
-        n_side = max(5, min(args.steps, 50))
-        for mode, layout in (("none", "rank"), ("root", "rank"), ("root", "freq"), ("alltoall", "rank"), ("alltoall", "freq")):
-            key = mode if mode == "none" else "%s_%s_major" % (mode, layout)
-            try:   # a supplementary record must never cost the headline line
-                gm = GatherMode(mode, layout)
-                for i in range(4):
-                    step(i, gm)
-                gm.drain()
-                el, _ = timed_region(gm, n_side, False)
-                gather_modes[key] = {"value": n_side * blocks_per_step / el, "unit": "beam-blocks/s",
-                                     "ms_per_step": el / n_side * 1e3, "steps": n_side}
-                del gm
-            except Exception as e:  # pragma: no cover
-                gather_modes[key] = {"error": str(e)[:300]}
-                torch.cuda.synchronize()
-
+    out = None
     if rank == 0:
         total_blocks = args.steps * blocks_per_step
         value = total_blocks / elapsed
@@ -468,8 +492,32 @@ def main():
         }
         if comm_note:
             out["config"]["gather_note"] = comm_note
-        if gather_modes is not None:
-            out["gather_modes"] = gather_modes
+
+    # ---- from here on nothing may cost the headline: a watchdog prints the line with what is there when the budget expires
+    # (a collective that never returns cannot be caught as an exception) -------------------------------------------------
+    watchdog = Watchdog(out, args.budget_seconds + (0.0 if rank == 0 else 5.0))
+
+    # ---- every gather mode side by side (N > 1) ----------------------------------------------------------------------------
+    if dist is not None and (world > 1 or args.force_dist) and not args.no_extras:
+        gather_modes = {} if out is None else out.setdefault("gather_modes", {})
+        n_side = max(5, min(args.steps, 50))
+        for mode, layout in (("none", "rank"), ("root", "rank"), ("root", "freq"), ("alltoall", "rank"), ("alltoall", "freq")):
+            key = mode if mode == "none" else "%s_%s_major" % (mode, layout)
+            try:   # a supplementary record must never cost the headline line
+                gm = GatherMode(mode, layout)
+                for i in range(4):
+                    step(i, gm)
+                gm.drain()
+                el, _ = timed_region(gm, n_side, False)
+                gather_modes[key] = {"value": n_side * blocks_per_step / el, "unit": "beam-blocks/s",
+                                     "ms_per_step": el / n_side * 1e3, "steps": n_side}
+                del gm
+            except Exception as e:  # pragma: no cover
+                gather_modes[key] = {"error": str(e)[:300]}
+                torch.cuda.synchronize()
+
+    if rank == 0:
+        if "gather_modes" in out:
             out["gather_modes"]["note"] = ("the same kernel and inputs, only the collective differs; rank-major = one message "
                                            "per sender, freq-major = the reference's [o][f][b], one message per (row, sender); "
                                            "root = everything to rank 0, alltoall = rank j owns rows j*n/N.. of the whole band")
@@ -565,7 +613,7 @@ def main():
             s5 = variant(0, wl="c5", n_units=16, reps=30)
             s5["workload"] = ("C5 shard: one of 8 ranks of BASELINE configs[4] = 128 freq x 512 beams x 100 ant x 2 pol, "
                               "N_TIME 256, 16 gemm-units per launch; beam-blocks here are 512 beams x 128 freq")
-            s5["pmc_source"] = "profiles/r01_c5_pmc_summary.txt (whole-band launch of round 1)"
+            s5["pmc_source"] = "profiles/r02_c5_pmc_summary.txt is the whole-band launch (16 gemm-units x 1024 freq), not this shard"
             out["c5_shard"] = s5
             # launch granularity: what one launch over 1 / 8 / 32 gemm-units costs per beam-block (input resident)
             ls = {}
@@ -613,7 +661,9 @@ def main():
             print("bench.py: GPU part done; timing the CPU baselines on the host cores (~%.0f s) ..." % (args.cpu_seconds + 12),
                   file=sys.stderr, flush=True)
             guarded("cpu_baseline", lambda: out.__setitem__("cpu_baseline", cpu_baselines(n_avg, n_out, args.cpu_seconds)))
-        print(json.dumps(out), flush=True)
+        watchdog.finish()
+    else:
+        watchdog.cancel()
     bf.close()
     if comm is not None:
         comm.close()

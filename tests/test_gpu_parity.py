@@ -927,6 +927,26 @@ def test_bench_rccl_gather_plumbing_on_one_gpu(mode, layout):
     assert set(d["gather_modes"]) >= {"none", "root_rank_major", "root_freq_major", "alltoall_rank_major", "alltoall_freq_major"}
 
 
+def test_bench_watchdog_prints_the_headline_when_the_supplementary_records_overrun():
+    """bench.py --budget-seconds: whatever happens after the headline measurement (a gather mode that never returns on a real
+    8-GPU node, a supplementary record that overruns), the ONE JSON line still appears, complete up to the roofline, marked
+    truncated, exit status 0."""
+    import json
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "2", "--min-warm-seconds", "0.2",
+                        "--budget-seconds", "0.05"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert "truncated" in d and d["value"] > 0 and d["roofline"]["frac"] > 0.05 and d["n_gpus"] == 1
+    assert "cpu_baseline" not in d      # it comes last and takes 20 s: the budget expired long before
+
+
 @pytest.mark.parametrize("n_ant", [100, 128])
 def test_observation_loop_wide_antenna_geometry_bit_exact(bfmod, orc, tmp_path, n_ant):
     """The production observation loop (ring slots, 4 queues, sink) on a DSA100-style geometry: 100 / 128 antennas go
