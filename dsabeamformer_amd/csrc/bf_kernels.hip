@@ -109,22 +109,38 @@ __global__ void dedisperse_kernel(const float* __restrict__ out_unit, float* __r
 // every trial of the block adds its kDmTb values out of that window: 24 coalesced row loads instead of 64 per frequency.
 // The trial's offset into the window is only known at run time, and registers cannot be indexed dynamically, so the
 // window lives in LDS -- as a PRIVATE column per thread ([row][thread]: conflict-free, no barrier: a thread only ever
-// reads what it wrote).  The next frequency's rows are already in flight while the current window is consumed.  A
-// trial whose delay falls outside the window (widely spaced or non-monotonic trials) reads its rows directly.
-// Measured (profiles/r01_stage_kernels.json): 0.78 ms for 64 trials x 901 samples x 256 x 256 vs 1.09 ms for the
-// one-trial-per-workgroup version it replaced; tile shapes (8,4,8) ... (16,8,16) were within +-20 % of this one.
+// reads what it wrote).  The next frequency's rows are already in flight while the current window is consumed.
+// Round 2 (0.76 -> 0.46 ms for 64 trials x 901 samples x 256 x 256, profiles/r02_dm_*): the round-1 loop was bound by
+// instruction issue -- 258 scalar + 257 vector instructions per (wave, frequency) around 64 useful adds: 64-bit flat
+// addresses per row, a range test per row, a scalar delay load + test per trial.  Now the loads are buffer loads (one
+// descriptor per frequency, the row in the 32-bit offset, the series' end enforced by the descriptor's range check),
+// the trials' window offsets are tabulated in LDS once per tile, and a tile whose trials all stay inside their windows
+// (any fine DM ladder) runs a loop without a data-dependent branch; tiles are ordered so that the ones sharing rows run
+// on one XCD (L2 hits 64 % -> 85 %, Infinity Cache / HBM fetches 2.0 -> 0.4 GB).  What binds now is LDS bandwidth
+// (24 rows written + 56 read per 64 adds).  Tiles with widely spaced / non-monotonic trials or negative delays take
+// the general loop (direct loads for a trial outside the window).
 constexpr int kDmTb = 8, kDmBlock = 8, kDmSpan = 16, kDmWin = kDmTb + kDmSpan, kDmThreads = 256;
+constexpr int kDmMaxTableFreq = 1024;   // the trials' window offsets of a tile ([f][trial] ints) live in LDS up to this many channels
 
-__global__ __launch_bounds__(kDmThreads) void dedisperse_dm_kernel(const float* __restrict__ series,
+__global__ __launch_bounds__(kDmThreads, 4) void dedisperse_dm_kernel(const float* __restrict__ series,
                                                                    const int* __restrict__ delays, float* __restrict__ out,
                                                                    int n_t, int n_freq, int n_beams, int n_t_out, int n_dm)
 {
     __shared__ float win[kDmWin][kDmThreads];
-    const int dm0 = blockIdx.x * kDmBlock;
-    const int t0 = blockIdx.y * kDmTb;
+    // XCD-aware tile order: workgroup L runs on XCD L % 8 (round-robin dispatch), and each XCD has its own L2.  The trial
+    // blocks of one time tile and the neighbouring time tiles read the same rows, so consecutive tiles (trial block
+    // fastest, then time tile, then beam group) go to ONE XCD: the rows are fetched from Infinity Cache / HBM once, not once
+    // per XCD, and the chain of dependent row loads runs at L2-hit latency.
+    const int n_x = (n_dm + kDmBlock - 1) / kDmBlock, n_y = (n_t_out + kDmTb - 1) / kDmTb;
+    const int per_xcd = gridDim.x / 8;
+    const int v = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+    if (v >= n_x * n_y * ((n_beams + kDmThreads - 1) / kDmThreads)) return;
+    const int dm0 = (v % n_x) * kDmBlock;
+    const int t0 = ((v / n_x) % n_y) * kDmTb;
     const int tid = threadIdx.x;
-    const int b = blockIdx.z * kDmThreads + tid;
-    if (b >= n_beams) return;
+    const int b_raw = (v / (n_x * n_y)) * kDmThreads + tid;
+    const bool live = b_raw < n_beams;
+    const int b = live ? b_raw : n_beams - 1;
     float acc[kDmBlock][kDmTb];
 #pragma unroll
     for (int k = 0; k < kDmBlock; k++)
@@ -133,41 +149,111 @@ __global__ __launch_bounds__(kDmThreads) void dedisperse_dm_kernel(const float* 
     const size_t row_stride = (size_t)n_freq * n_beams;
     const int* dl0 = delays + (size_t)dm0 * n_freq;
     float nxt[kDmWin];
-    auto load_window = [&](int f) {
-        const float* p = series + (size_t)f * n_beams + b;
-        const int first = t0 + __builtin_amdgcn_readfirstlane(dl0[f]);
+    // Addressing stays on the scalar unit: per frequency ONE buffer descriptor whose base is the first row of the window
+    // (wave-uniform), the row as an SGPR offset (j * row stride), the beam as the one per-lane 32-bit offset -- a load
+    // costs no VALU instruction (flat loads need a 64-bit v_mad per row).
+    const int lane_bytes = b * 4;
+    const unsigned stride_bytes = (unsigned)row_stride * 4u;   // launch_dedisperse_dm checks kDmWin * stride < 4 GiB
+
+    // Is this tile REGULAR -- every window starting inside the series and every trial inside its window, for every
+    // frequency?  (Always, except for widely spaced or non-monotonic trials or negative delays.)  One cooperative pass
+    // over the block's delays decides, and leaves the trials' window offsets in LDS ([f][trial], bytes).  A regular tile
+    // then runs a loop without a data-dependent branch and without a scalar load between its LDS reads (SMEM and LDS
+    // share one counter and SMEM returns out of order: a delay fetched by s_load inside the trial loop forces
+    // s_waitcnt lgkmcnt(0) per trial, which serialises the LDS round trips).  The kernel is bound by instruction issue
+    // and by these latencies, and -- all workgroups being resident at once -- by its SLOWEST tile, so the ends of the
+    // series must not be a slow path: rows past the end are dropped by the buffer descriptor's range check (they read as
+    // +0, which is what the definition asks for), a partial trial block repeats its last trial (never stored).
+    extern __shared__ int trial_off[];   // [n_freq][kDmBlock]; only filled / used when the table fits (see the launcher)
+    const int* dlk[kDmBlock];
 #pragma unroll
-        for (int j = 0; j < kDmWin; j++) {
-            const int r = first + j;
-            nxt[j] = (r >= 0 && r < n_t) ? p[(size_t)r * row_stride] : 0.0f;
+    for (int k = 0; k < kDmBlock; k++) dlk[k] = delays + (size_t)min(dm0 + k, n_dm - 1) * n_freq;
+    int irregular = n_freq > kDmMaxTableFreq;
+    if (!irregular)
+        for (int f = tid; f < n_freq; f += kDmThreads) {
+            const int base = dl0[f];
+            irregular |= t0 + base < 0;
+#pragma unroll
+            for (int k = 0; k < kDmBlock; k++) {
+                const int d = dlk[k][f] - base;
+                irregular |= d < 0 || d > kDmSpan;
+                trial_off[f * kDmBlock + k] = d * (kDmThreads * 4);
+            }
         }
-    };
-    load_window(0);
-    for (int f = 0; f < n_freq; f++) {
+    irregular = __syncthreads_or(irregular);
+
+    if (!irregular) {
+        static_assert(kDmBlock == 8, "two 16-byte table reads per frequency");
+        const char* my_col = reinterpret_cast<const char*>(&win[0][tid]);
+        const size_t series_floats = (size_t)n_t * row_stride;
+        auto load_window = [&](int first, int f) {
+            // descriptor: base = row `first` of channel f, records = what is left of the series from there (capped: rows
+            // of a window are < 4 GiB apart); the per-lane offset carries the row so that the range check sees it
+            const size_t at = (size_t)first * row_stride + (size_t)f * n_beams;
+            const size_t left = at < series_floats ? (series_floats - at) * 4 : 0;   // a window wholly past the end reads +0
+            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float*>(series + (left ? at : 0)), 0, (int)(left < 0xfffffff0u ? left : 0xfffffff0u), 0x00020000);
 #pragma unroll
-        for (int j = 0; j < kDmWin; j++) win[j][tid] = nxt[j];
-        const int base = __builtin_amdgcn_readfirstlane(dl0[f]);
-        if (f + 1 < n_freq) load_window(f + 1);
+            for (int j = 0; j < kDmWin; j++)
+                nxt[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, lane_bytes + (int)(j * stride_bytes), 0, 0));
+        };
+        load_window(t0 + __builtin_amdgcn_readfirstlane(dl0[0]), 0);
+        for (int f = 0; f < n_freq; f++) {
+            const int fn = min(f + 1, n_freq - 1);   // the last iteration re-reads its own window: no branch
+            const int first_next = t0 + __builtin_amdgcn_readfirstlane(dl0[fn]);
 #pragma unroll
-        for (int k = 0; k < kDmBlock; k++) {
-            if (dm0 + k >= n_dm) break;
-            const int dl = __builtin_amdgcn_readfirstlane(delays[(size_t)(dm0 + k) * n_freq + f]);
-            const int d = dl - base;  // wave-uniform
-            if (d >= 0 && d <= kDmSpan) {
-                const float* w = &win[d][tid];
+            for (int j = 0; j < kDmWin; j++) win[j][tid] = nxt[j];
+#pragma unroll
+            for (int i = 0; i < kDmTb; i++) acc[0][i] = acc[0][i] + nxt[i];   // trial 0 sits at offset 0: from registers
+            load_window(first_next, fn);
+            const v4i o0 = *reinterpret_cast<const v4i*>(&trial_off[f * kDmBlock]);
+            const v4i o1 = *reinterpret_cast<const v4i*>(&trial_off[f * kDmBlock + 4]);
+            const int off[kDmBlock] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w};
+#pragma unroll
+            for (int k = 1; k < kDmBlock; k++) {
+                const float* w = reinterpret_cast<const float*>(my_col + off[k]);
 #pragma unroll
                 for (int i = 0; i < kDmTb; i++) acc[k][i] = acc[k][i] + w[i * kDmThreads];
-            } else {  // outside the window: direct loads
-                const float* p = series + (size_t)f * n_beams + b;
+            }
+        }
+    } else {
+        auto load_window = [&](int f) {
+            const float* col = series + (size_t)f * n_beams;   // uniform
+            const int first = t0 + __builtin_amdgcn_readfirstlane(dl0[f]);
 #pragma unroll
-                for (int i = 0; i < kDmTb; i++) {
-                    const int r = t0 + dl + i;
-                    const float v = (r >= 0 && r < n_t) ? p[(size_t)r * row_stride] : 0.0f;
-                    acc[k][i] = acc[k][i] + v;
+            for (int j = 0; j < kDmWin; j++) {
+                const int r = first + j;
+                nxt[j] = (r >= 0 && r < n_t) ? (col + (size_t)r * row_stride)[b] : 0.0f;
+            }
+        };
+        load_window(0);
+        for (int f = 0; f < n_freq; f++) {
+#pragma unroll
+            for (int j = 0; j < kDmWin; j++) win[j][tid] = nxt[j];
+            const int base = __builtin_amdgcn_readfirstlane(dl0[f]);
+            if (f + 1 < n_freq) load_window(f + 1);
+#pragma unroll
+            for (int k = 0; k < kDmBlock; k++) {
+                if (dm0 + k >= n_dm) break;
+                const int dl = __builtin_amdgcn_readfirstlane(delays[(size_t)(dm0 + k) * n_freq + f]);
+                const int d = dl - base;  // wave-uniform
+                if (d >= 0 && d <= kDmSpan) {
+                    const float* w = &win[d][tid];
+#pragma unroll
+                    for (int i = 0; i < kDmTb; i++) acc[k][i] = acc[k][i] + w[i * kDmThreads];
+                } else {  // outside the window: direct loads
+                    const float* p = series + (size_t)f * n_beams + b;
+#pragma unroll
+                    for (int i = 0; i < kDmTb; i++) {
+                        const int r = t0 + dl + i;
+                        const float x = (r >= 0 && r < n_t) ? p[(size_t)r * row_stride] : 0.0f;
+                        acc[k][i] = acc[k][i] + x;
+                    }
                 }
             }
         }
     }
+    if (!live) return;
 #pragma unroll
     for (int k = 0; k < kDmBlock; k++)
 #pragma unroll
@@ -464,10 +550,13 @@ hipError_t launch_dedisperse_dm(const Geometry& g, const float* d_series, int n_
 {
     if (n_dm <= 0 || n_t_out <= 0) return hipSuccess;
     clear_stale_error();
-    const dim3 grid((unsigned)((n_dm + kDmBlock - 1) / kDmBlock), (unsigned)((n_t_out + kDmTb - 1) / kDmTb),
-                    (unsigned)((g.n_beams + kDmThreads - 1) / kDmThreads));
-    if (grid.y > 65535u || grid.z > 65535u) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(dedisperse_dm_kernel, grid, dim3(kDmThreads), 0, s, d_series, d_delays, d_out, n_t, g.n_freq,
+    if ((size_t)kDmWin * g.n_freq * g.n_beams * 4 >= ((size_t)1 << 32)) return hipErrorInvalidValue;   // SGPR row offsets are 32-bit
+    const size_t tiles = (size_t)((n_dm + kDmBlock - 1) / kDmBlock) * (size_t)((n_t_out + kDmTb - 1) / kDmTb) *
+                         (size_t)((g.n_beams + kDmThreads - 1) / kDmThreads);
+    if (tiles > (size_t)1 << 30) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)((tiles + 7) / 8 * 8));    // a multiple of the 8 XCDs (see the kernel's tile order)
+    const size_t table = g.n_freq <= kDmMaxTableFreq ? (size_t)g.n_freq * kDmBlock * sizeof(int) : 0;
+    hipLaunchKernelGGL(dedisperse_dm_kernel, grid, dim3(kDmThreads), table, s, d_series, d_delays, d_out, n_t, g.n_freq,
                        g.n_beams, n_t_out, n_dm);
     return hipGetLastError();
 }

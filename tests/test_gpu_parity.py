@@ -791,6 +791,44 @@ def test_dedisperse_dm_bit_exact(torch, bfmod, orc, n_t, n_f, n_b, n_dm, tsamp):
         assert np.array_equal(d_out.cpu().numpy(), want), n_t_out
 
 
+@pytest.mark.parametrize("case", ["fine_ladder", "negative_delays", "many_channels", "one_wide_gap"])
+def test_dedisperse_dm_regular_and_irregular_tiles_bit_exact(torch, bfmod, orc, case):
+    """The kernel has a branch-free loop for regular tiles (every trial of a block inside the block's window at every
+    channel: a fine DM ladder) and a general loop for the rest; both must give the oracle's bits, including where regular
+    tiles meet the end of the series (windows partly and wholly past the last row, dropped by the buffer range check), a
+    partial trial block, a partial beam group, delays that go negative (reference channel mid-band), more channels than the
+    in-LDS offset table holds, and a ladder that is fine except for one gap."""
+    from dsabeamformer_amd import host
+
+    n_t, n_f, n_b, n_dm = 160, 64, 96, 13
+    if case == "many_channels":
+        n_t, n_f, n_b, n_dm = 40, 1040, 32, 9
+    g = orc.Geom(n_beams=n_b, n_ant=64, n_freq=n_f if n_f <= 256 else 256, n_avg=1, n_out_per_gemm=8)
+    cfg = _cfg(bfmod, g)
+    cfg.n_freq = n_f
+    bf = bfmod.Beamformer(cfg)
+    rng = np.random.default_rng(7)
+    series = (rng.random((n_t, n_f, n_b), dtype=np.float32) * 1e5).astype(np.float32)
+    freq = np.linspace(1.53, 1.28, n_f).astype(np.float32)
+    dms = np.arange(n_dm) * 0.25                        # neighbouring trials: <= 2 samples apart per channel
+    if case == "one_wide_gap":
+        dms[7:] += 15.0
+    ref = float(freq[n_f // 2]) if case == "negative_delays" else float(freq[0])
+    delays = host.dm_delays(dms, freq, ref, 0.131 if case != "many_channels" else 1.0)
+    if case == "negative_delays":
+        assert delays.min() < 0
+    if case == "fine_ladder":
+        assert (delays[1:] - delays[:-1]).max() <= 2 and (delays[7] - delays[0]).max() <= 16 and delays.max() > 8
+    d_series = torch.from_numpy(series).cuda()
+    d_delays = torch.from_numpy(delays).cuda()
+    for n_t_out in (max(1, n_t - int(delays.max())), n_t):
+        d_out = torch.full((n_dm, n_t_out, n_b), float("nan"), dtype=torch.float32, device="cuda")
+        bf.dedisperse_dm(d_series, n_t, d_delays, n_dm, n_t_out, d_out, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        want = orc.dedisperse_dm(series, delays, n_t_out)
+        assert np.array_equal(d_out.cpu().numpy(), want), (case, n_t_out)
+
+
 def test_dedisperse_dm_recovers_dispersed_pulse_from_detected_stream(torch, bfmod, orc):
     """End to end on the product path: a source whose voltage burst arrives later at lower frequencies (the sample
     delays of DM 120) goes through the fused kernel; the DM ladder's matched trial collects the whole burst in one
