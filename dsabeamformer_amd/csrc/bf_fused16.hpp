@@ -350,11 +350,15 @@ __global__ __launch_bounds__(kThreads16, ant_two_ksteps<AIN>() ? 2 : DSABF_OCC16
     // lane consecutive beams: vector stores.
     auto store_slots = [&](float* row, const float (&x)[NS]) {
         if (a.interleave) {
+            // Nontemporal: the powers are written once and read by nobody on this GPU before the D2H / gather.  Every
+            // store instruction covers whole 128-byte lines (16 lanes x 16 B, or 16 x 8 B), so streaming them past L2
+            // costs nothing at C3 / C5 (+0.3 %) and lifts the store-bound DEBUG geometry from 0.60 to 0.73 of 8 TB/s
+            // (profiles/r02_variants_log.txt).  The scalar stores of non-interleaved tiles cover partial lines: plain.
             if constexpr (PAIRED) {   // slots 0, 2 = base beams bb, bb + 1; slots 1, 3 = their mirrors B-1-bb, B-2-bb
-                *reinterpret_cast<v2f*>(row + slot_beam[0]) = v2f{x[0], x[2]};
-                *reinterpret_cast<v2f*>(row + slot_beam[3]) = v2f{x[3], x[1]};
+                __builtin_nontemporal_store(v2f{x[0], x[2]}, reinterpret_cast<v2f*>(row + slot_beam[0]));
+                __builtin_nontemporal_store(v2f{x[3], x[1]}, reinterpret_cast<v2f*>(row + slot_beam[3]));
             } else {
-                *reinterpret_cast<v4f*>(row + slot_beam[0]) = v4f{x[0], x[1], x[2], x[3]};
+                __builtin_nontemporal_store(v4f{x[0], x[1], x[2], x[3]}, reinterpret_cast<v4f*>(row + slot_beam[0]));
             }
         } else {
 #pragma unroll

@@ -49,35 +49,39 @@ namespace {
 
 // ---------------------------------------------------------------------------------------------------------
 // a1 alone (API parity with expand_input): byte b -> (int8)(b >> 4), (int8)((int8)(b << 4) >> 4), order kept.
-// HBM-bound: 16 B in, 32 B out per thread-iteration, fully coalesced.
+// HBM-bound, 1 B in / 2 B out.  One lane = 8 packed bytes -> 16 expanded bytes, so that every wave instruction moves ONE
+// contiguous run (512 B loaded, 1 KiB stored): the round-1 mapping (16 B in -> two 16-byte stores 32 B apart per lane) left
+// each nontemporal store instruction covering every other 16 bytes of its lines and ran at 4.1-4.4 TB/s; this one runs at
+// 6.3 TB/s algorithmic = 0.79 of 8 TB/s, the float4-copy rate of the chip (tools/ubench_expand.hip, profiles/r02_ubench_expand.txt).
 __device__ __forceinline__ unsigned sext4x4(unsigned nib)  // four 4-bit values in the low nibbles of 4 bytes
 {
     return ((nib ^ 0x88888888u) - 0x08080808u) ^ 0x80808080u;
 }
 
-__global__ void expand_kernel(const v4i* __restrict__ in, v4i* __restrict__ out, size_t n_vec)
+typedef int v2i_t __attribute__((ext_vector_type(2)));
+
+__global__ __launch_bounds__(256) void expand_kernel(const v2i_t* __restrict__ in, v4i* __restrict__ out, size_t n_half)
 {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_vec; i += (size_t)gridDim.x * blockDim.x) {
-        const v4i v = __builtin_nontemporal_load(in + i);
-        v4i o0, o1;
+    // a wave takes 128 consecutive 8-byte pieces per iteration, as two passes of 64
+    const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / 64, n_waves = (size_t)gridDim.x * blockDim.x / 64;
+    const int lane = threadIdx.x & 63;
+    for (size_t base = wave * 128; base < n_half; base += n_waves * 128) {
 #pragma unroll
-        for (int d = 0; d < 4; d++) {
-            const unsigned w = (unsigned)v[d];
-            const unsigned hi = sext4x4((w >> 4) & 0x0F0F0F0Fu);
-            const unsigned lo = sext4x4(w & 0x0F0F0F0Fu);
-            // bytes (hi0, lo0, hi1, lo1) and (hi2, lo2, hi3, lo3)
-            const unsigned e0 = __builtin_amdgcn_perm(lo, hi, 0x05010400u);
-            const unsigned e1 = __builtin_amdgcn_perm(lo, hi, 0x07030602u);
-            if (d < 2) {
-                o0[2 * d] = (int)e0;
-                o0[2 * d + 1] = (int)e1;
-            } else {
-                o1[2 * (d - 2)] = (int)e0;
-                o1[2 * (d - 2) + 1] = (int)e1;
+        for (int p = 0; p < 2; p++) {
+            const size_t i = base + p * 64 + lane;
+            if (i >= n_half) break;
+            const v2i_t v = __builtin_nontemporal_load(in + i);
+            v4i o;
+#pragma unroll
+            for (int d = 0; d < 2; d++) {
+                const unsigned w = (unsigned)v[d];
+                const unsigned hi = sext4x4((w >> 4) & 0x0F0F0F0Fu);
+                const unsigned lo = sext4x4(w & 0x0F0F0F0Fu);
+                o[2 * d] = (int)__builtin_amdgcn_perm(lo, hi, 0x05010400u);       // bytes (hi0, lo0, hi1, lo1)
+                o[2 * d + 1] = (int)__builtin_amdgcn_perm(lo, hi, 0x07030602u);   //       (hi2, lo2, hi3, lo3)
             }
+            __builtin_nontemporal_store(o, out + i);
         }
-        __builtin_nontemporal_store(o0, out + 2 * i);
-        __builtin_nontemporal_store(o1, out + 2 * i + 1);
     }
 }
 
@@ -528,12 +532,12 @@ hipError_t launch_weight_relayout(const Geometry& g, const int8_t* d_w, void* d_
 hipError_t launch_expand(const void* d_in, size_t nbytes, void* d_out, hipStream_t s)
 {
     clear_stale_error();
-    const size_t n_vec = nbytes / 16;
-    if (n_vec == 0) return hipSuccess;
-    size_t grid = (n_vec + 255) / 256;
-    if (grid > 65536) grid = 65536;  // measured best on MI355X (4.4 TB/s algorithmic vs 3.8 at 2048 blocks)
-    hipLaunchKernelGGL(expand_kernel, dim3((unsigned)grid), dim3(256), 0, s, static_cast<const v4i*>(d_in),
-                       static_cast<v4i*>(d_out), n_vec);
+    const size_t n_half = nbytes / 8;
+    if (n_half == 0) return hipSuccess;
+    size_t grid = (n_half + 511) / 512;   // one iteration per wave if the grid is not capped
+    if (grid > 65536) grid = 65536;
+    hipLaunchKernelGGL(expand_kernel, dim3((unsigned)grid), dim3(256), 0, s, static_cast<const v2i_t*>(d_in),
+                       static_cast<v4i*>(d_out), n_half);
     return hipGetLastError();
 }
 
