@@ -1,0 +1,73 @@
+"""bench.py's host logic without a GPU: defaults of the contract, the committed PMC summaries it quotes, the watchdog."""
+import json
+import os
+import subprocess
+import sys
+
+from conftest import ROOT
+
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def test_defaults_are_the_contract(monkeypatch):
+    """No flags = 1 GPU and a K / W that finish within minutes; --gpus N without a launcher refuses instead of hanging."""
+    monkeypatch.setattr(sys, "argv", ["bench.py"])
+    a = bench.parse()
+    assert (a.gpus, a.workload, a.detect, a.units) == (1, "c3", "canonical", 128)
+    assert a.steps * a.units * 16 >= 1000 and a.warmup == 25          # >= 1000 gemm-units after 25 warm-ups
+    assert bench.geometry("c3") == (16, 16) and bench.geometry("c2") == (1, 8) and bench.geometry("c5") == (16, 8)
+    pos, dirs = bench.grid_100()
+    assert pos.shape == (100, 3) and dirs.shape == (512, 2)
+
+
+def test_committed_pmc_summaries_give_the_quoted_traffic_and_mfma_busy():
+    """roofline.traffic / mfma_busy_frac come from profiles/r02_*_pmc_summary.txt: the files must parse, and the derived
+    numbers must be what DESIGN.md section 4 quotes (traffic within 1 % of the algorithmic bytes for C3 and C2)."""
+    c3 = bench.pmc_summary("r02_c3_paired_pmc_summary.txt")
+    gen = bench.pmc_summary("r02_c3_general_pmc_summary.txt")
+    c5 = bench.pmc_summary("r02_c5_pmc_summary.txt")
+    c2 = bench.pmc_summary("r02_c2_pmc_summary.txt")
+    assert c3 and gen and c5 and c2
+    alg_c3 = (64 * 32 * 256 + 4 * 256 * 256) * 128 * 16          # bytes per launch: SURVEY.md 8d x 2048 beam-blocks
+    assert abs(bench.pmc_traffic(c3) / alg_c3 - 1) < 0.01 and abs(bench.pmc_traffic(gen) / alg_c3 - 1) < 0.02
+    alg_c2 = (64 * 2 * 256 + 4 * 256 * 256) * 128 * 8
+    assert abs(bench.pmc_traffic(c2) / alg_c2 - 1) < 0.02
+    assert 0.25 < bench.pmc_mfma_busy(c3) < 0.32 and 0.47 < bench.pmc_mfma_busy(gen) < 0.55      # pair: half the MFMAs
+    assert 0.30 < bench.pmc_mfma_busy(c5) < 0.40 and bench.pmc_mfma_busy(c2) < 0.15
+    # the pair kernel executes half the algorithmic int8 ops: SQ_INSTS_VALU_MFMA_I8 x 16*16*64*2 ops
+    assert abs(c3["SQ_INSTS_VALU_MFMA_I8"] * 32768 / (8 * 256 * 64 * 32 * 256 * 2048 / 2) - 1) < 0.01
+    assert abs(gen["SQ_INSTS_VALU_MFMA_I8"] * 32768 / (8 * 256 * 64 * 32 * 256 * 2048) - 1) < 0.01
+    assert bench.pmc_summary("no_such_file.txt") == {} and bench.pmc_traffic({}) is None and bench.pmc_mfma_busy({}) is None
+
+
+def test_watchdog_prints_exactly_one_line(capsys):
+    out = {"metric": "m", "value": 1.0, "roofline": {"frac": 0.5}}
+    w = bench.Watchdog(out, 3600.0)
+    out["extra"] = {"a": 1}
+    w.finish()
+    w.finish()                      # a second call (or a late timer) prints nothing
+    lines = [l for l in capsys.readouterr().out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0])["extra"] == {"a": 1} and "truncated" not in lines[0]
+    w2 = bench.Watchdog(None, 3600.0)   # ranks other than 0 hold no record
+    w2.cancel()
+
+
+def test_watchdog_expiry_prints_the_partial_record_and_exits_zero():
+    code = ("import sys, time; sys.path.insert(0, %r); import bench\n"
+            "out = {'metric': 'm', 'value': 2.0, 'roofline': {'frac': 0.5}}\n"
+            "w = bench.Watchdog(out, 0.2)\n"
+            "out['half'] = object()      # a record the main thread has not finished: not serialisable\n"
+            "time.sleep(30)\n"
+            "print('never reached')\n" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and "never reached" not in r.stdout
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d["value"] == 2.0 and "truncated" in d and "half" not in d
+
+
+def test_multi_gpu_request_without_a_launcher_is_refused():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
+                       timeout=300, env=env)
+    assert r.returncode != 0 and "torch.distributed.run" in (r.stderr + r.stdout)
