@@ -168,7 +168,7 @@ __global__ __launch_bounds__(kDmThreads, 4) void dedisperse_dm_kernel(const floa
     // and by these latencies, and -- all workgroups being resident at once -- by its SLOWEST tile, so the ends of the
     // series must not be a slow path: rows past the end are dropped by the buffer descriptor's range check (they read as
     // +0, which is what the definition asks for), a partial trial block repeats its last trial (never stored).
-    extern __shared__ int trial_off[];   // [n_freq][kDmBlock]; only filled / used when the table fits (see the launcher)
+    extern __shared__ __attribute__((aligned(16))) int trial_off[];   // [n_freq][kDmBlock]; only filled / used when the table fits (see the launcher)
     const int* dlk[kDmBlock];
 #pragma unroll
     for (int k = 0; k < kDmBlock; k++) dlk[k] = delays + (size_t)min(dm0 + k, n_dm - 1) * n_freq;
