@@ -110,20 +110,22 @@ __global__ void dedisperse_kernel(const float* __restrict__ out_unit, float* __r
 // One thread = one beam x kDmTb consecutive output times x a block of kDmBlock consecutive DM trials.  Neighbouring
 // trials need almost the same input rows (their delays differ by a few samples per channel), so for each frequency the
 // thread loads ONE window of kDmTb + kDmSpan consecutive rows (first row = the delay of the block's first trial) and
-// every trial of the block adds its kDmTb values out of that window: 24 coalesced row loads instead of 64 per frequency.
+// every trial of the block adds its kDmTb values out of that window: 24 coalesced row loads instead of 64 per frequency
+// (round 1: 8 times x 8 trials; now 16 x 4).
 // The trial's offset into the window is only known at run time, and registers cannot be indexed dynamically, so the
 // window lives in LDS -- as a PRIVATE column per thread ([row][thread]: conflict-free, no barrier: a thread only ever
 // reads what it wrote).  The next frequency's rows are already in flight while the current window is consumed.
-// Round 2 (0.76 -> 0.46 ms for 64 trials x 901 samples x 256 x 256, profiles/r02_dm_*): the round-1 loop was bound by
+// Round 2 (0.76 -> 0.42 ms for 64 trials x 901 samples x 256 x 256, profiles/r02_dm_*): the round-1 loop was bound by
 // instruction issue -- 258 scalar + 257 vector instructions per (wave, frequency) around 64 useful adds: 64-bit flat
 // addresses per row, a range test per row, a scalar delay load + test per trial.  Now the loads are buffer loads (one
 // descriptor per frequency, the row in the 32-bit offset, the series' end enforced by the descriptor's range check),
 // the trials' window offsets are tabulated in LDS once per tile, and a tile whose trials all stay inside their windows
 // (any fine DM ladder) runs a loop without a data-dependent branch; tiles are ordered so that the ones sharing rows run
 // on one XCD (L2 hits 64 % -> 85 %, Infinity Cache / HBM fetches 2.0 -> 0.4 GB).  What binds now is LDS bandwidth
-// (24 rows written + 56 read per 64 adds).  Tiles with widely spaced / non-monotonic trials or negative delays take
+// (24 rows written + 48 read per 64 adds).  Tiles with widely spaced / non-monotonic trials or negative delays take
 // the general loop (direct loads for a trial outside the window).
-constexpr int kDmTb = 8, kDmBlock = 8, kDmSpan = 16, kDmWin = kDmTb + kDmSpan, kDmThreads = 256;
+// 16 times x 4 trials per thread: 24 window rows written + 48 read per 64 adds (8 x 8: 24 + 56, 9 % slower)
+constexpr int kDmTb = 16, kDmBlock = 4, kDmSpan = 8, kDmWin = kDmTb + kDmSpan, kDmThreads = 256;
 constexpr int kDmMaxTableFreq = 1024;   // the trials' window offsets of a tile ([f][trial] ints) live in LDS up to this many channels
 
 __global__ __launch_bounds__(kDmThreads, 4) void dedisperse_dm_kernel(const float* __restrict__ series,
@@ -187,7 +189,7 @@ __global__ __launch_bounds__(kDmThreads, 4) void dedisperse_dm_kernel(const floa
     irregular = __syncthreads_or(irregular);
 
     if (!irregular) {
-        static_assert(kDmBlock == 8, "two 16-byte table reads per frequency");
+        static_assert(kDmBlock == 4 || kDmBlock == 8, "one or two 16-byte table reads per frequency");
         const char* my_col = reinterpret_cast<const char*>(&win[0][tid]);
         const size_t series_floats = (size_t)n_t * row_stride;
         auto load_window = [&](int first, int f) {
@@ -210,9 +212,12 @@ __global__ __launch_bounds__(kDmThreads, 4) void dedisperse_dm_kernel(const floa
 #pragma unroll
             for (int i = 0; i < kDmTb; i++) acc[0][i] = acc[0][i] + nxt[i];   // trial 0 sits at offset 0: from registers
             load_window(first_next, fn);
-            const v4i o0 = *reinterpret_cast<const v4i*>(&trial_off[f * kDmBlock]);
-            const v4i o1 = *reinterpret_cast<const v4i*>(&trial_off[f * kDmBlock + 4]);
-            const int off[kDmBlock] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w};
+            int off[kDmBlock];
+#pragma unroll
+            for (int q = 0; q < kDmBlock / 4; q++) {
+                const v4i o = *reinterpret_cast<const v4i*>(&trial_off[f * kDmBlock + 4 * q]);
+                off[4 * q] = o.x, off[4 * q + 1] = o.y, off[4 * q + 2] = o.z, off[4 * q + 3] = o.w;
+            }
 #pragma unroll
             for (int k = 1; k < kDmBlock; k++) {
                 const float* w = reinterpret_cast<const float*>(my_col + off[k]);
