@@ -298,7 +298,7 @@ __global__ __launch_bounds__(kThreads16, ant_two_ksteps<AIN>() ? 2 : DSABF_OCC16
 #pragma unroll
             for (int k = 0; k < PPT; k++) {
                 stage[k] = stage_t{};
-                if (valid && piece_live(k)) stage[k] = *reinterpret_cast<const stage_t*>(base + lane_off(k));
+                if (valid && piece_live(k)) stage[k] = *reinterpret_cast<const stage_t*>(base + lane_off(k));   // (nontemporal: +-0.5 %, r02_variants_log)
             }
             return;
         }
