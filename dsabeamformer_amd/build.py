@@ -20,7 +20,7 @@ HIPCC = os.environ.get("HIPCC") or shutil.which("hipcc") or "/opt/rocm/bin/hipcc
 # -amdgpu-sched-strategy=max-ilp: the fused kernel's unrolled tile loop schedules 1-2 % faster than with the default
 #   occupancy-driven strategy (profiles/r01_variants_paired_log.txt); register counts stay inside every variant's budget.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize", "-Wall",
-         "-Wno-unused-function", "-mllvm", "-amdgpu-sched-strategy=max-ilp",
+         "-Wno-unused-function", "-mllvm", "-amdgpu-sched-strategy=" + os.environ.get("DSABF_SCHED", "max-ilp"),
          "-I" + os.path.join(ROOT, "include")] + os.environ.get("DSABF_EXTRA_FLAGS", "").split()
 
 
