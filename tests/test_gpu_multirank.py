@@ -32,9 +32,10 @@ def fake_rccl():
     return FAKE
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_gather_detected_with_several_ranks_on_one_gpu(orc, fake_rccl, tmp_path, world):
-    env = dict(os.environ, DSABF_RCCL_LIB=fake_rccl)
+    # 8 ranks = BASELINE configs[3]'s partition (one process per GPU there; here they time-share GPU 0)
+    env = dict(os.environ, DSABF_RCCL_LIB=fake_rccl, FAKERCCL_MAILBOX_MB="2" if world == 8 else "16")
     rng = np.random.default_rng(5)
     delays = np.sort(rng.integers(0, 3, size=(3, 8 * world)), axis=1)[:, ::-1].astype(np.int32).copy()   # [dm][F], falling with f
     delays[0] = 0
