@@ -108,25 +108,26 @@ def test_beam_sharded_over_two_ranks_gathers_the_whole_band(orc, fake_rccl, tmp_
             assert np.array_equal(raw[gemm][:, 128 * r:128 * (r + 1)], want), (gemm, r)
 
 
-@pytest.mark.parametrize("gather", ["alltoall", "root"])
-def test_bench_with_two_ranks_on_one_gpu(fake_rccl, gather):
+@pytest.mark.parametrize("gather,n", [("alltoall", 2), ("root", 2), ("alltoall", 8)])
+def test_bench_with_two_ranks_on_one_gpu(fake_rccl, gather, n):
     """bench.py as the driver launches it for N = 2 (torch.distributed.run, one process per rank) -- with both ranks on
     GPU 0, gloo for the barrier / max-over-ranks / id broadcast and the loopback stand-in under bf_gather_detected: the
     N > 1 control flow (sharded weights and inputs, double-buffered gather on the side stream, every gather mode side by
     side) runs end to end and rank 0 prints one well-formed line.  The numbers mean nothing (two ranks on one GPU)."""
     import json
 
-    env = dict(os.environ, DSABF_RCCL_LIB=fake_rccl, DSABF_BENCH_ONE_GPU="1", FAKERCCL_MAILBOX_MB="64")
+    # (n = 8: the driver's largest launch, 32 channels per rank; 64 rings of 4 MiB keep the shared memory small)
+    env = dict(os.environ, DSABF_RCCL_LIB=fake_rccl, DSABF_BENCH_ONE_GPU="1", FAKERCCL_MAILBOX_MB="64" if n == 2 else "4")
     port = str(29700 + os.getpid() % 200)
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-                        "127.0.0.1", "--master-port", port, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
-                        "--warmup", "1", "--units", "4", "--gather", gather, "--dist-backend", "gloo", "--min-warm-seconds", "0.1",
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
+                        "127.0.0.1", "--master-port", port, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "3",
+                        "--warmup", "1", "--units", "4" if n == 2 else "8", "--gather", gather, "--dist-backend", "gloo", "--min-warm-seconds", "0.1",
                         "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, (r.stdout + r.stderr)[-4000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1                                   # rank 0 only
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["config"]["freq_per_gpu"] == 128 and d["scaling"] == "strong"
+    assert d["n_gpus"] == n and d["config"]["freq_per_gpu"] == 256 // n and d["scaling"] == "strong"
     assert d["config"]["gather"].startswith(gather) and "C-ABI" in d["config"]["gather"] and "gather_note" not in d["config"]
     modes = d["gather_modes"]
     for k in ("none", "root_rank_major", "root_freq_major", "alltoall_rank_major", "alltoall_freq_major"):
