@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """A few launches of the DM-trial dedispersion on the stage bench's shape, for rocprofv3 (tools/dm_pmc.sh).
-DSABF_DM_V1=1 / DSABF_DM_CFG select the kernel."""
+(The experiment switches that selected other kernel versions are gone; the summaries of those runs are profiles/r02_dm_*.)"""
 import sys
 
 import torch
