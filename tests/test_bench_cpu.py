@@ -71,3 +71,26 @@ def test_multi_gpu_request_without_a_launcher_is_refused():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
                        timeout=300, env=env)
     assert r.returncode != 0 and "torch.distributed.run" in (r.stderr + r.stdout)
+
+
+def test_committed_bench_lines_agree_with_the_committed_rocprof_kernel_stats():
+    """profiles/: the HIP-event average of the dominant kernel in each committed bench line must agree with the AverageNs of
+    the same kernel in the rocprofv3 --kernel-trace --stats summary committed beside it (same command, another run and,
+    for rocprof, a profiled one: 5 %), and roofline.frac must follow from it."""
+    import csv
+
+    for wl, stats, units_blocks in (("c3", "r02_c3_paired_kernel_stats.csv", 2048), ("c5", "r02_c5_kernel_stats.csv", 128),
+                                    ("c2", "r02_c2_kernel_stats.csv", 1024)):
+        line = [l for l in open(os.path.join(ROOT, "profiles", "r02_%s_bench.json" % wl)) if l.startswith("{")][-1]
+        d = json.loads(line)
+        roof = d["roofline"]
+        rows = [r for r in csv.DictReader(open(os.path.join(ROOT, "profiles", stats))) if "fused16_kernel" in r["Name"]]
+        assert len(rows) == 1, (wl, rows)
+        rocprof_ms = float(rows[0]["AverageNs"]) * 1e-6
+        assert abs(rocprof_ms / roof["kernel_ms_avg"] - 1) < 0.05, (wl, rocprof_ms, roof["kernel_ms_avg"])
+        assert d["config"]["beam_blocks_per_step"] == units_blocks
+        per_launch = roof["algorithmic_ops_per_launch"] if roof["bound"] == "mfma" else roof["algorithmic_bytes_per_launch"]
+        scale = 1e12 if roof["bound"] == "mfma" else 1e9
+        assert abs(per_launch / (roof["kernel_ms_avg"] * 1e-3) / scale / roof["peak"] / roof["frac"] - 1) < 1e-6
+        assert roof["traffic"] is not None and roof["pmc_source"].startswith("profiles/r02_%s" % wl)
+        assert d["ms_per_step"] >= roof["kernel_ms_avg"] * 0.999          # the whole step cannot be shorter than its kernel
