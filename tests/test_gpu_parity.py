@@ -939,6 +939,36 @@ def test_grid_configuration_debug_flow_bit_identical(bfmod, orc, gpu):
         assert np.array_equal(ded[batch * 1024 + 1023], orc.dedisperse(g, out[1023]))
 
 
+@pytest.mark.parametrize("paired", ["default", "0"])
+def test_random_array_debug_flow_bit_identical(bfmod, orc, monkeypatch, paired):
+    """The reference's remaining fixtures end to end through the DEBUG flow: config/random_positions.txt (uniform +-250 m, an
+    array without any symmetry) with the 16x16 beam grid and the 61x61 source catalogue grid_source_directions_3721.txt --
+    3721 sources = 3 full generator batches + a partial fourth (sources beyond the catalogue are zero voltages,
+    src/test_data_generator.hh:77-90).  Symmetric beam SETS make the weights conjugate-symmetric whatever the array is, so
+    the default run takes the pair kernel; DSABF_PAIRED=0 sends the same observation through the general kernel.  Either way
+    the dedispersed table equals the oracle's row for row."""
+    from conftest import CFG
+    from dsabeamformer_amd import host
+
+    if paired == "0":
+        monkeypatch.setenv("DSABF_PAIRED", "0")
+    cfg = bfmod.debug_config()
+    pos_f, dir_f = os.path.join(CFG, "random_positions.txt"), os.path.join(CFG, "grid_beam_directions.txt")
+    src_f = os.path.join(CFG, "grid_source_directions_3721.txt")
+    ded, ms = host.run_debug_observation(cfg, gpu=3, positions=pos_f, directions=dir_f, sources=src_f, max_sources=3721)
+    assert ded.shape == (3721, 256) and ms > 0
+    g = orc.DEBUG_GEOM
+    pos, dirs, src = orc.read_positions(pos_f, 64), orc.read_directions(dir_f, 256), orc.read_directions(src_f)
+    assert src.shape == (3721, 2)
+    w = orc.make_weights(g, pos, dirs, 3)
+    for batch in range(4):
+        packed = orc.generate_test_data(g, pos, src, 3, batch_counter=batch)
+        out = orc.beamform(g, w, packed)                                   # [1024 units][8][256][256]
+        n_here = min(1024, 3721 - batch * 1024)
+        for u in list(range(0, n_here, 41)) + [n_here - 1]:
+            assert np.array_equal(ded[batch * 1024 + u], orc.dedisperse(g, out[u])), (batch, u)
+
+
 @pytest.mark.parametrize("mode", ["alltoall", "root"])
 @pytest.mark.parametrize("layout", ["rank", "freq"])
 def test_bench_rccl_gather_plumbing_on_one_gpu(mode, layout):
