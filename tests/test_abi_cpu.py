@@ -96,10 +96,11 @@ def test_headers_and_example_compile_as_plain_c(tmp_path):
 
     from conftest import ROOT
 
-    obj = tmp_path / "minimal.o"
-    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I" + os.path.join(ROOT, "include"),
-                        "-c", os.path.join(ROOT, "examples", "minimal.c"), "-o", str(obj)], capture_output=True, text=True)
-    assert r.returncode == 0, r.stderr
+    for name in ("minimal", "sharded"):     # single GPU; one rank of a frequency-sharded run (bf_comm_*, bf_gather_detected)
+        obj = tmp_path / (name + ".o")
+        r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I" + os.path.join(ROOT, "include"),
+                            "-c", os.path.join(ROOT, "examples", name + ".c"), "-o", str(obj)], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
 
 
 def test_product_library_ships_no_test_double_and_no_hard_runtime_dependencies():

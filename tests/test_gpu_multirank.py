@@ -132,3 +132,26 @@ def test_bench_with_two_ranks_on_one_gpu(fake_rccl, gather, n):
     modes = d["gather_modes"]
     for k in ("none", "root_rank_major", "root_freq_major", "alltoall_rank_major", "alltoall_freq_major"):
         assert "error" not in modes[k] and modes[k]["value"] > 0, (k, modes[k])
+
+
+@pytest.mark.parametrize("world", [1, 2, 4])
+def test_plain_c_sharded_example(fake_rccl, tmp_path, world):
+    """examples/sharded.c -- the multi-GPU half of the C-ABI from plain C99: `world` processes, each a frequency shard of the
+    DEBUG geometry, block launch, gather to rank 0 in the reference's [o][f][b] order (loopback stand-in for RCCL p2p when
+    world > 1, no RCCL at all for world 1), D2H of the gathered block; rank 0 checks the band it received."""
+    exe = str(tmp_path / "sharded")
+    pkg = os.path.join(ROOT, "dsabeamformer_amd")
+    b = subprocess.run(["/opt/rocm/bin/hipcc", "-x", "c", "-std=c99", "-I" + os.path.join(ROOT, "include"),
+                        os.path.join(ROOT, "examples", "sharded.c"), "-o", exe, "-L" + pkg, "-ldsabf",
+                        "-Wl,-rpath," + pkg], capture_output=True, text=True, timeout=300)
+    assert b.returncode == 0, b.stderr
+    env = dict(os.environ, DSABF_RCCL_LIB=fake_rccl)
+    idf = str(tmp_path / "id")
+    procs = [subprocess.Popen([exe, str(r), str(world), idf, "0"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in range(world)]
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    assert "gathered 32 rows x 256 channels x 256 beams" in outs[0] and all(("rank %d ok" % r) in outs[r] for r in range(world))
+    peaks = [l for l in outs[0].splitlines() if "peak beam" in l]
+    assert len(peaks) == 1
+    (tmp_path / ("peak%d.txt" % world)).write_text(peaks[0])
