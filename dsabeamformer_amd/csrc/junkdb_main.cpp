@@ -2,11 +2,12 @@
 // reference (makefile:28-33, README.md:151-175): create the ring, fill it with n blocks of pseudo-random 4-bit
 // voltages at an optional rate, write a short block (end of data), wait until the reader has drained it, delete it.
 //
-//   junkdb -k name [-n blocks] [-r ring_blocks] [-b block_bytes] [-s seed] [-d distinct] [-R MB/s] [-H header_file]
+//   junkdb -k name [-n blocks] [-r ring_blocks] [-b block_bytes] [-s seed] [-d distinct] [-R MB/s] [-H header_file] [-T copy_threads]
 //
 // Block i carries the bytes of block (i % distinct) of dsabf::junk_fill(seed), so a test can recompute every block.
 #include <unistd.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -28,9 +29,10 @@ int main(int argc, char* argv[])
     std::string name = "dsabf", header_file;
     long n_blocks = 8, ring_blocks = 4, distinct = 4;
     uint64_t seed = 0xD5A, block_bytes = 0;
+    int copy_threads = 4;  // threads that copy one block into the ring (1 = the single memcpy of dada_junkdb)
     double rate_mbs = 0;  // 0 = as fast as the reader takes them (the instrument: 4050 MB/s, makefile:29)
     int arg;
-    while ((arg = getopt(argc, argv, "k:n:r:b:s:d:R:H:a:h")) != -1) {
+    while ((arg = getopt(argc, argv, "k:n:r:b:s:d:R:H:T:a:h")) != -1) {
         switch (arg) {
             case 'k': name = optarg; break;
             case 'n': n_blocks = atol(optarg); break;
@@ -40,9 +42,10 @@ int main(int argc, char* argv[])
             case 'd': distinct = atol(optarg); break;
             case 'R': rate_mbs = atof(optarg); break;
             case 'H': header_file = optarg; break;
+            case 'T': copy_threads = atoi(optarg); break;
             default:
                 std::cout << "junkdb -k name [-n blocks] [-r ring_blocks] [-b block_bytes] [-s seed] [-d distinct] "
-                             "[-R MB/s] [-H header_file]\n";
+                             "[-R MB/s] [-H header_file] [-T copy_threads]\n";
                 return arg == 'h' ? 0 : 1;
         }
     }
@@ -86,7 +89,16 @@ int main(int argc, char* argv[])
     for (long i = 0; i < n_blocks; i++) {
         char* b = ring->open_block_write();
         if (!b) return 1;
-        std::memcpy(b, junk.data() + (size_t)(i % distinct) * block_bytes, block_bytes);
+        const char* src = junk.data() + (size_t)(i % distinct) * block_bytes;
+        if (copy_threads <= 1) {
+            std::memcpy(b, src, block_bytes);
+        } else {   // one core's memcpy (~30 GB/s) is slower than the reader's H2D (~55 GB/s): split the block
+            std::vector<std::thread> th;
+            const size_t slice = ((size_t)block_bytes / copy_threads + 4095) & ~(size_t)4095;
+            for (size_t off = 0; off < block_bytes; off += slice)
+                th.emplace_back([=] { std::memcpy(b + off, src + off, std::min(slice, (size_t)block_bytes - off)); });
+            for (auto& t : th) t.join();
+        }
         if (rate_mbs > 0) {
             const double due = (double)(i + 1) * block_bytes / (rate_mbs * 1e6);
             std::this_thread::sleep_until(t0 + std::chrono::duration_cast<std::chrono::steady_clock::duration>(
