@@ -21,8 +21,8 @@
 namespace dsabf {
 
 // ---- detected-stream sinks ------------------------------------------------------------------------------------------
-detected_sink::detected_sink(const bf_config& cfg, uint64_t slots)
-    : floats_per_gemm(bf_floats_per_detect(&cfg)), n_slots(slots ? slots : slots_for(cfg))
+detected_sink::detected_sink(const bf_config& cfg, uint64_t slots, bool asynchronous)
+    : floats_per_gemm(bf_floats_per_detect(&cfg)), n_slots(slots ? slots : slots_for(cfg)), async(asynchronous)
 {
     const size_t bytes = floats_per_gemm * n_slots * sizeof(float);
     void* p = nullptr;
@@ -31,10 +31,12 @@ detected_sink::detected_sink(const bf_config& cfg, uint64_t slots)
     else
         p = ::malloc(bytes);  // no device (CPU tests of the ring logic)
     ring = static_cast<float*>(p);
+    if (ring && async) worker = std::thread([this] { run(); });
 }
 
 detected_sink::~detected_sink()
 {
+    drain_and_stop();   // (a derived destructor has done this already; here it is a no-op)
     if (!ring) return;
     if (pinned)
         bf_free_pinned(ring);
@@ -42,22 +44,75 @@ detected_sink::~detected_sink()
         ::free(ring);
 }
 
+// The delivery thread: hands committed gemm-units to deliver() in index order, one at a time.
+void detected_sink::run()
+{
+    std::unique_lock<std::mutex> lk(m);
+    for (;;) {
+        work.wait(lk, [this] { return stop || delivered < next_commit; });
+        if (delivered == next_commit) return;   // stop requested and nothing left
+        const uint64_t g = delivered;
+        lk.unlock();
+        const bool ok_ = deliver(g, ring + (size_t)(g % n_slots) * floats_per_gemm, floats_per_gemm);
+        lk.lock();
+        if (!ok_) failed = true;
+        delivered++;
+        done.notify_all();
+    }
+}
+
+void detected_sink::drain_and_stop()
+{
+    if (!worker.joinable()) return;
+    {
+        std::lock_guard<std::mutex> lk(m);
+        stop = true;
+    }
+    work.notify_all();
+    worker.join();   // run() returns only when everything committed has been delivered
+}
+
+bool detected_sink::ok()
+{
+    std::lock_guard<std::mutex> lk(m);
+    return ring != nullptr && !failed;
+}
+
+uint64_t detected_sink::get_delivered()
+{
+    std::lock_guard<std::mutex> lk(m);
+    return delivered;
+}
+
 float* detected_sink::acquire(uint64_t gemm_index)
 {
+    std::unique_lock<std::mutex> lk(m);
     if (!ring || gemm_index < next_commit || gemm_index >= next_commit + n_slots) return nullptr;
+    // the slot's last occupant (gemm_index - n_slots) was committed; an asynchronous sink may still be delivering it
+    if (async) done.wait(lk, [&] { return gemm_index < delivered + n_slots; });
     return ring + (size_t)(gemm_index % n_slots) * floats_per_gemm;
 }
 
 bool detected_sink::commit(uint64_t gemm_index)
 {
+    std::unique_lock<std::mutex> lk(m);
     if (!ring || gemm_index != next_commit) return false;
-    if (!deliver(gemm_index, ring + (size_t)(gemm_index % n_slots) * floats_per_gemm, floats_per_gemm)) failed = true;
     next_commit++;
+    if (async) {
+        const bool was_ok = !failed;
+        lk.unlock();
+        work.notify_one();
+        return was_ok;
+    }
+    lk.unlock();   // synchronous: deliver here, on the caller's thread
+    const bool ok_ = deliver(gemm_index, ring + (size_t)(gemm_index % n_slots) * floats_per_gemm, floats_per_gemm);
+    lk.lock();
+    if (!ok_) failed = true;
     delivered++;
     return !failed;
 }
 
-file_sink::file_sink(const bf_config& cfg, const char* path, int gpu, uint64_t slots) : detected_sink(cfg, slots)
+file_sink::file_sink(const bf_config& cfg, const char* path, int gpu, uint64_t slots) : detected_sink(cfg, slots, true)
 {
     fp = ::fopen(path, "wb");
     if (!fp) return;
@@ -75,7 +130,11 @@ file_sink::file_sink(const bf_config& cfg, const char* path, int gpu, uint64_t s
     }
 }
 
-file_sink::~file_sink() { finish(); }
+file_sink::~file_sink()
+{
+    drain_and_stop();
+    finish();
+}
 
 bool file_sink::deliver(uint64_t, const float* data, size_t n_floats)
 {
@@ -89,7 +148,7 @@ void file_sink::finish()
 }
 
 ring_sink::ring_sink(const bf_config& cfg, const char* ring_name, uint64_t ring_blocks, int gpu, uint64_t slots)
-    : detected_sink(cfg, slots), name(ring_name ? ring_name : "")
+    : detected_sink(cfg, slots, true), name(ring_name ? ring_name : "")
 {
     char header[kRingHeaderBytes];
     ::snprintf(header, sizeof(header),
@@ -101,6 +160,7 @@ ring_sink::ring_sink(const bf_config& cfg, const char* ring_name, uint64_t ring_
 
 ring_sink::~ring_sink()
 {
+    drain_and_stop();
     finish();
 }
 

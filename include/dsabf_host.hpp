@@ -10,9 +10,12 @@
 // reference records on stream[7] only -- SURVEY.md section 5, latent race 2).
 #pragma once
 
+#include <condition_variable>
 #include <cstdint>
 #include <iosfwd>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "dsabf.h"
@@ -319,30 +322,44 @@ public:
 // gives the stream a consumer without changing the loop: the D2H copy of gemm-unit g lands in acquire(g) -- a pinned
 // slot of a ring -- and once the analysis event of g's block has been observed (src/observation_loop.hh:100-117) the
 // loop commits the block's gemm-units in index order; commit hands the slot to deliver() and frees it.
+// Asynchronous sinks (file, shared-memory ring) deliver on a thread of their own, in order: the loop's commit() only
+// marks the slot ready, so a slow consumer costs the loop nothing until the slot ring (five PSRDADA blocks of gemm-units)
+// is full -- then acquire() waits for the oldest slot, which is the back-pressure a PSRDADA writer applies.
 class detected_sink {
     size_t floats_per_gemm;
     uint64_t n_slots;
     float* ring = nullptr;
     bool pinned = false;
-    uint64_t next_commit = 0, delivered = 0;
-    bool failed = false;
+    bool async = false;
+    uint64_t next_commit = 0, delivered = 0;   // committed by the loop / handed to deliver(); guarded by `m` when async
+    bool failed = false, stop = false;
+    std::mutex m;
+    std::condition_variable work, done;
+    std::thread worker;
+    void run();
 
 protected:
     virtual bool deliver(uint64_t gemm_index, const float* data, size_t n_floats) = 0;  // in gemm order
     virtual void finish() {}
+    void drain_and_stop();   // every derived destructor calls this first: deliver() must not run on a half-destroyed object
 
 public:
     // slots: gemm-units that can be in flight; the loop needs (MAX_TOTAL_SEP + 1) * N_GEMMS_PER_BLOCK
-    detected_sink(const bf_config& cfg, uint64_t slots);
+    detected_sink(const bf_config& cfg, uint64_t slots, bool asynchronous = false);
     virtual ~detected_sink();
     detected_sink(const detected_sink&) = delete;
     detected_sink& operator=(const detected_sink&) = delete;
     static uint64_t slots_for(const bf_config& cfg) { return (uint64_t)(kMaxTotalSep + 1) * cfg.n_gemms_per_block; }
-    bool ok() const { return ring != nullptr && !failed; }
-    float* acquire(uint64_t gemm_index);   // nullptr if the slot still holds an uncommitted gemm-unit
+    bool ok();
+    float* acquire(uint64_t gemm_index);   // nullptr if the slot still holds an uncommitted gemm-unit (or was committed
+                                           // already); waits while an asynchronous delivery of its last occupant is pending
     bool commit(uint64_t gemm_index);      // gemm units must be committed in increasing order, each exactly once
-    void close() { finish(); }
-    uint64_t get_delivered() const { return delivered; }
+    void close()                           // everything committed has been delivered when this returns
+    {
+        drain_and_stop();
+        finish();
+    }
+    uint64_t get_delivered();
     size_t get_floats_per_gemm() const { return floats_per_gemm; }
 };
 
