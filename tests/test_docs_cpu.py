@@ -1,0 +1,50 @@
+"""The documents cite evidence by path: every profiles/, tools/, tests/, csrc/ ... file named in DESIGN.md, README.md,
+INTEGRATION.md, tools/README.md and oracle/README.md must exist in the tree."""
+import itertools
+import os
+import re
+
+from conftest import ROOT
+
+DOCS = ["DESIGN.md", "README.md", "INTEGRATION.md", os.path.join("tools", "README.md"), os.path.join("oracle", "README.md")]
+PREFIXES = ("profiles/", "tools/", "tests/", "include/", "examples/", "oracle/", "dsabeamformer_amd/", "csrc/")
+
+
+def expand(path):
+    """a{b,c}d -> abd, acd (one or several brace groups)."""
+    parts = re.split(r"\{([^{}]*)\}", path)
+    choices = [p.split(",") if i % 2 else [p] for i, p in enumerate(parts)]
+    return ["".join(c) for c in itertools.product(*choices)]
+
+
+def candidates(doc_dir, path):
+    if path.startswith("csrc/"):
+        path = "dsabeamformer_amd/" + path
+    yield os.path.join(ROOT, path)
+    yield os.path.join(ROOT, doc_dir, path)
+
+
+def test_every_cited_file_exists():
+    missing = []
+    names = set(os.listdir(os.path.join(ROOT, "profiles")))
+    for doc in DOCS:
+        text = open(os.path.join(ROOT, doc)).read()
+        for quoted in re.findall(r"`([^`\n]+)`", text):
+            token = quoted.split("::")[0].split(" ")[0].strip("().,;:")
+            if not token.startswith(PREFIXES) and not re.match(r"r0[12]_[\w{},.*-]+\.(txt|json|csv)$", token):
+                continue
+            if "*" in token or "<" in token or "…" in token or token.endswith("/"):
+                continue
+            if re.match(r"r0[12]_", token):                       # bare profile name: lives under profiles/
+                token = "profiles/" + token
+            for path in expand(token):
+                path = re.sub(r":[\w-]+$", "", path)                 # file:line and file:key citations
+                if path.rstrip("/") == "oracle/_ref":               # named only to say that it does not exist
+                    continue
+                if path.startswith("profiles/"):
+                    ok = os.path.basename(path) in names
+                else:
+                    ok = any(os.path.exists(c) for c in candidates(os.path.dirname(doc), path))
+                if not ok:
+                    missing.append((doc, quoted))
+    assert not missing, missing
