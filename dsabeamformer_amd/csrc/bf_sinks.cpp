@@ -13,6 +13,7 @@
 #include <memory>
 #include <sstream>
 #include <thread>
+#include <fcntl.h>
 #include <unistd.h>
 
 #include "../../include/dsabf_host.h"
@@ -52,13 +53,21 @@ void detected_sink::run()
         work.wait(lk, [this] { return stop || delivered < next_commit; });
         if (delivered == next_commit) return;   // stop requested and nothing left
         const uint64_t g = delivered;
+        const uint64_t k = std::min(next_commit - delivered, n_slots - g % n_slots);   // ready AND contiguous in the ring
         lk.unlock();
-        const bool ok_ = deliver(g, ring + (size_t)(g % n_slots) * floats_per_gemm, floats_per_gemm);
+        const bool ok_ = deliver_many(g, ring + (size_t)(g % n_slots) * floats_per_gemm, floats_per_gemm, k);
         lk.lock();
         if (!ok_) failed = true;
-        delivered++;
+        delivered += k;
         done.notify_all();
     }
+}
+
+bool detected_sink::deliver_many(uint64_t first_gemm, const float* data, size_t n_floats_each, uint64_t count)
+{
+    bool ok_ = true;
+    for (uint64_t i = 0; i < count; i++) ok_ = deliver(first_gemm + i, data + (size_t)i * n_floats_each, n_floats_each) && ok_;
+    return ok_;
 }
 
 void detected_sink::drain_and_stop()
@@ -114,8 +123,8 @@ bool detected_sink::commit(uint64_t gemm_index)
 
 file_sink::file_sink(const bf_config& cfg, const char* path, int gpu, uint64_t slots) : detected_sink(cfg, slots, true)
 {
-    fp = ::fopen(path, "wb");
-    if (!fp) return;
+    fd = ::open(path, O_CREAT | O_TRUNC | O_WRONLY, 0644);
+    if (fd < 0) return;
     char header[kHeaderBytes];
     ::memset(header, 0, sizeof(header));
     ::snprintf(header, sizeof(header),
@@ -124,10 +133,11 @@ file_sink::file_sink(const bf_config& cfg, const char* path, int gpu, uint64_t s
                "N_POL %d\nN_AVERAGING %d\nN_GEMMS_PER_BLOCK %d\nGPU %d\nFLOATS_PER_GEMM %zu\n",
                kHeaderBytes, cfg.n_beams, cfg.n_freq, cfg.n_out_per_gemm, cfg.n_ant, cfg.n_pol, cfg.n_avg,
                cfg.n_gemms_per_block, gpu, get_floats_per_gemm());
-    if (::fwrite(header, 1, sizeof(header), fp) != sizeof(header)) {
-        ::fclose(fp);
-        fp = nullptr;
+    if (::pwrite(fd, header, sizeof(header), 0) != (ssize_t)sizeof(header)) {
+        ::close(fd);
+        fd = -1;
     }
+    if (const char* e = getenv("DSABF_SINK_THREADS")) write_threads = std::max(1, atoi(e));
 }
 
 file_sink::~file_sink()
@@ -136,15 +146,46 @@ file_sink::~file_sink()
     finish();
 }
 
-bool file_sink::deliver(uint64_t, const float* data, size_t n_floats)
+// every gemm-unit has its place in the file (header + index * size): positional writes, in any order, from any thread
+static bool pwrite_all(int fd, const char* p, size_t n, off_t at)
 {
-    return fp && ::fwrite(data, sizeof(float), n_floats, fp) == n_floats;
+    while (n) {
+        const ssize_t w = ::pwrite(fd, p, n, at);
+        if (w <= 0) return false;
+        p += w;
+        n -= (size_t)w;
+        at += w;
+    }
+    return true;
+}
+
+bool file_sink::deliver(uint64_t gemm_index, const float* data, size_t n_floats)
+{
+    return deliver_many(gemm_index, data, n_floats, 1);
+}
+
+bool file_sink::deliver_many(uint64_t first_gemm, const float* data, size_t n_floats_each, uint64_t count)
+{
+    if (fd < 0) return false;
+    const size_t bytes = (size_t)count * n_floats_each * sizeof(float);
+    const off_t at = (off_t)kHeaderBytes + (off_t)first_gemm * (off_t)(n_floats_each * sizeof(float));
+    const char* p = reinterpret_cast<const char*>(data);
+    const int nt = (int)std::min<size_t>((size_t)write_threads, bytes >> 22);   // at least 4 MiB per thread
+    if (nt <= 1) return pwrite_all(fd, p, bytes, at);
+    const size_t slice = ((bytes / nt) + 4095) & ~(size_t)4095;
+    std::vector<std::thread> th;
+    std::vector<char> ok_((size_t)nt, 1);
+    int t = 0;
+    for (size_t off = 0; off < bytes; off += slice, t++)
+        th.emplace_back([=, &ok_] { ok_[(size_t)t] = pwrite_all(fd, p + off, std::min(slice, bytes - off), at + (off_t)off); });
+    for (auto& x : th) x.join();
+    return std::all_of(ok_.begin(), ok_.end(), [](char c) { return c != 0; });
 }
 
 void file_sink::finish()
 {
-    if (fp) ::fclose(fp);
-    fp = nullptr;
+    if (fd >= 0) ::close(fd);
+    fd = -1;
 }
 
 ring_sink::ring_sink(const bf_config& cfg, const char* ring_name, uint64_t ring_blocks, int gpu, uint64_t slots)

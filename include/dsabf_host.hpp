@@ -340,6 +340,9 @@ class detected_sink {
 
 protected:
     virtual bool deliver(uint64_t gemm_index, const float* data, size_t n_floats) = 0;  // in gemm order
+    // `count` consecutive gemm-units that are contiguous in the slot ring (an asynchronous sink that has fallen behind is
+    // handed everything that is ready at once); the default hands them to deliver() one by one
+    virtual bool deliver_many(uint64_t first_gemm, const float* data, size_t n_floats_each, uint64_t count);
     virtual void finish() {}
     void drain_and_stop();   // every derived destructor calls this first: deliver() must not run on a half-destroyed object
 
@@ -366,17 +369,19 @@ public:
 // Raw file: a 4096-byte ASCII header (PSRDADA style `KEY value` lines, NUL padded) followed by the gemm-units in
 // order, each [N_OUTPUTS_PER_GEMM][N_FREQUENCIES][N_BEAMS] little-endian float32 -- i.e. one long [o][f][b] series.
 class file_sink : public detected_sink {
-    FILE* fp = nullptr;
+    int fd = -1;
+    int write_threads = 4;   // a backlog of several gemm-units is written with positional writes from this many threads
 
 protected:
     bool deliver(uint64_t gemm_index, const float* data, size_t n_floats) override;
+    bool deliver_many(uint64_t first_gemm, const float* data, size_t n_floats_each, uint64_t count) override;
     void finish() override;
 
 public:
     static constexpr size_t kHeaderBytes = 4096;
     file_sink(const bf_config& cfg, const char* path, int gpu, uint64_t slots = 0);
     ~file_sink() override;
-    bool is_open() const { return fp != nullptr; }
+    bool is_open() const { return fd >= 0; }
 };
 
 // Hands every gemm-unit to another process through a shared-memory ring (one ring block per gemm-unit, then a short
