@@ -175,6 +175,22 @@ def cpu_baselines(n_avg, n_out, seconds):
     out = {"value": n * g.n_out_per_gemm / el, "unit": "beam-blocks/s", "cores": orc.get_threads(), "kind": "port",
            "sample": "%d gemm-unit(s) of the bench workload (%d beam-blocks), oracle/dsabf_oracle.c -O3 -mavx2 "
                      "-fopenmp, %.1f s" % (n, n * g.n_out_per_gemm, el)}
+    out["ms_per_beam_block"] = 1e3 * el / (n * g.n_out_per_gemm)
+    # the same port at the parity geometry (C1/C2: N_IPO 2, N_TIME 16), BASELINE.md section 4 item 2: a 3 s sample
+    g1 = orc.DEBUG_GEOM
+    w1 = orc.make_weights(g1, orc.default_positions(g1.n_ant), orc.default_directions(g1.n_beams), 0)
+    units1 = rng.integers(0, 256, size=(8, g1.n_freq, g1.n_time, g1.n_ant), dtype=np.uint8)
+    orc.beamform(g1, w1, units1)
+    n1, t1 = 0, time.perf_counter()
+    while True:
+        orc.beamform(g1, w1, units1)
+        n1 += units1.shape[0]
+        el1 = time.perf_counter() - t1
+        if el1 >= 3.0 or n1 >= 1 << 16:
+            break
+    out["debug_geometry"] = {"value": n1 * g1.n_out_per_gemm / el1, "unit": "beam-blocks/s", "cores": orc.get_threads(),
+                             "ms_per_beam_block": 1e3 * el1 / (n1 * g1.n_out_per_gemm),
+                             "sample": "%d gemm-units of the DEBUG geometry (N_IPO 2), %.1f s" % (n1, el1)}
     # (2) the generator
     dbg = debug_config()
     src = host.read_directions(os.path.join(ROOT, "tests", "golden", "config", "linear_source_directions_1024.txt"))
@@ -658,7 +674,7 @@ def main():
             guarded("debug_geometry", extras_geometries)
             guarded("streaming", extras_streaming)
         if world == 1 and not args.no_cpu_baseline:
-            print("bench.py: GPU part done; timing the CPU baselines on the host cores (~%.0f s) ..." % (args.cpu_seconds + 12),
+            print("bench.py: GPU part done; timing the CPU baselines on the host cores (~%.0f s) ..." % (args.cpu_seconds + 15),
                   file=sys.stderr, flush=True)
             guarded("cpu_baseline", lambda: out.__setitem__("cpu_baseline", cpu_baselines(n_avg, n_out, args.cpu_seconds)))
         watchdog.finish()
