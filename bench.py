@@ -176,6 +176,11 @@ def cpu_baselines(n_avg, n_out, seconds):
            "sample": "%d gemm-unit(s) of the bench workload (%d beam-blocks), oracle/dsabf_oracle.c -O3 -mavx2 "
                      "-fopenmp, %.1f s" % (n, n * g.n_out_per_gemm, el)}
     out["ms_per_beam_block"] = 1e3 * el / (n * g.n_out_per_gemm)
+    try:
+        out["cpu_model"] = next(l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name"))
+        out["nproc"] = os.cpu_count()
+    except Exception:   # pragma: no cover
+        pass
     # the same port at the parity geometry (C1/C2: N_IPO 2, N_TIME 16), BASELINE.md section 4 item 2: a 3 s sample
     g1 = orc.DEBUG_GEOM
     w1 = orc.make_weights(g1, orc.default_positions(g1.n_ant), orc.default_directions(g1.n_beams), 0)
