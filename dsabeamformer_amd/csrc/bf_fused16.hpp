@@ -6,6 +6,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <type_traits>
 
 #ifndef DSABF_PAIR_MFMA
@@ -586,10 +587,17 @@ template <int AIN, int NIPO, bool WRITE_C, int MODE, bool PAIRED>
 hipError_t launch_fused16_t(const FusedArgs& args, const LaunchShape& ls, hipStream_t s)
 {
     auto kern = fused16_kernel<AIN, NIPO, WRITE_C, MODE, PAIRED>;
-    if (ls.lds_bytes > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           ls.lds_bytes);
-        if (e != hipSuccess) return e;
+    if (ls.lds_bytes > 48 * 1024) {   // once per kernel and device, not per launch (the two-k-step image is always 64 KiB)
+        static std::atomic<unsigned> done_mask{0};
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        const unsigned bit = 1u << (dev & 31);
+        if (dev >= 32 || !(done_mask.load(std::memory_order_acquire) & bit)) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               ls.lds_bytes);
+            if (e != hipSuccess) return e;
+            done_mask.fetch_or(bit, std::memory_order_release);
+        }
     }
     (void)hipGetLastError();   // clear what earlier, unrelated calls left behind: return this launch's own status
     hipLaunchKernelGGL(kern, dim3(ls.grid), dim3(ls.block), ls.lds_bytes, s, args);
