@@ -17,7 +17,7 @@ pos100, dirs = bench.grid_100()
 stream = torch.cuda.current_stream()
 rows = {}
 handles = {}
-for n_ant in (96, 100, 112, 128):
+for n_ant in (68, 96, 100, 108, 112, 128):
     cfg = bfm.production_config(n_avg=n_avg, n_out_per_gemm=n_out, n_freq=1024, n_beams=512, n_ant=n_ant)
     from dsabeamformer_amd import host
 
