@@ -110,6 +110,22 @@ def product_weights(cfg, f0):
     return np.ascontiguousarray(w[f0:f0 + cfg.n_freq])
 
 
+def calibrated_weights(w, seed=7):
+    """What a real array uploads: the steering fan times a per-(frequency, antenna) complex calibration gain.  Here the
+    gains are unit-modulus with a seeded random phase; the product is re-quantised to int8 (clipped to +-127).  Any such
+    set breaks W[B-1-b] = conj(W[b]), so bf_set_weights selects the GENERAL kernel -- the production number."""
+    import numpy as np
+
+    rng = np.random.default_rng(seed)
+    phi = rng.uniform(0.0, 2.0 * np.pi, size=w.shape[:2])                     # [f][a]
+    g = np.exp(1j * phi)[:, :, None]
+    c = (w[..., 0].astype(np.float64) + 1j * w[..., 1].astype(np.float64)) * g
+    out = np.empty(w.shape, np.int8)
+    out[..., 0] = np.clip(np.rint(c.real), -127, 127)
+    out[..., 1] = np.clip(np.rint(c.imag), -127, 127)
+    return out
+
+
 def pmc_summary(name):
     """Counter means of one committed rocprofv3 PMC summary (tools/pmc.sh), {} if absent."""
     path = os.path.join(ROOT, "profiles", name)
@@ -330,16 +346,18 @@ def main():
 
     # ---- the gather (N > 1 or --force-dist): bf_comm / bf_gather_detected behind the C-ABI -------------------------------
     n_rows, row_floats = units * n_out, n_freq * cfg.n_beams
-    comm, comm_note = None, None
+    # There is ONE gather path.  If the communicator cannot be created the run ends non-zero: a scaling line must never
+    # come from a second code path.
+    comm, rccl_info = None, None
     if dist is not None:
-        try:
-            idt = torch.zeros(128, dtype=torch.uint8, device=dist_dev)
-            if rank == 0:
-                idt.copy_(torch.frombuffer(bytearray(api.comm_unique_id()), dtype=torch.uint8))
-            dist.broadcast(idt, 0)
-            comm = api.Comm(rank, world, bytes(idt.cpu().numpy().tobytes()), device=local)
-        except Exception as e:  # pragma: no cover -- keep a scaling run alive: fall back to the torch.distributed gather
-            comm_note = "C-ABI communicator failed (%s); gather runs through torch.distributed (dsabeamformer_amd/shard.py)" % e
+        idt = torch.zeros(128, dtype=torch.uint8, device=dist_dev)
+        if rank == 0:
+            idt.copy_(torch.frombuffer(bytearray(api.comm_unique_id()), dtype=torch.uint8))
+        dist.broadcast(idt, 0)
+        comm = api.Comm(rank, world, bytes(idt.cpu().numpy().tobytes()), device=local)
+        rccl_info = comm.info()      # ranks as the LIBRARY counts them, its version, the file it was loaded from
+        if rccl_info["ranks"] not in (world, -1):
+            sys.exit("bf_comm: the library reports %d ranks, the launcher %d" % (rccl_info["ranks"], world))
     side = torch.cuda.Stream() if dist is not None else None
 
     class GatherMode:
@@ -353,30 +371,19 @@ def main():
             self.kernel_done = [torch.cuda.Event() for _ in range(2)]
             self.gather_done = [None, None]
             self.full = [None, None]
-            self.torch_gather = None
             if mode == "none":
                 return
-            if comm is not None:
-                held = comm.rows_held(n_rows, self.root)
-                if held:
-                    self.full = [torch.empty(held * world * row_floats, dtype=torch.float32, device="cuda") for _ in range(2)]
-            else:
-                from dsabeamformer_amd.shard import DetectedGather
-
-                self.torch_gather = DetectedGather(torch, dist, mode, n_rows, n_freq, cfg.n_beams, torch.device("cuda", local))
+            held = comm.rows_held(n_rows, self.root)
+            if held:
+                self.full = [torch.empty(held * world * row_floats, dtype=torch.float32, device="cuda") for _ in range(2)]
 
         def before_kernel(self, slot):
-            if self.torch_gather is not None:
-                self.torch_gather.finish(slot)
-            elif self.gather_done[slot] is not None:
+            if self.gather_done[slot] is not None:
                 stream.wait_event(self.gather_done[slot])
                 self.gather_done[slot] = None
 
         def after_kernel(self, slot):
             if self.mode == "none":
-                return
-            if self.torch_gather is not None:
-                self.torch_gather.start(slot, d_out[slot])
                 return
             self.kernel_done[slot].record(stream)
             side.wait_event(self.kernel_done[slot])
@@ -442,7 +449,7 @@ def main():
     if args.force_dist and world == 1 and headline_mode.mode != "none":
         # one rank: the gathered tensor must be the kernel's output of that slot (both layouts are the identity)
         for slot in (0, 1):
-            got = headline_mode.full[slot] if headline_mode.torch_gather is None else headline_mode.torch_gather.full[slot]
+            got = headline_mode.full[slot]
             if got is not None and not torch.equal(got.reshape(-1), d_out[slot]):
                 sys.exit("gather plumbing check failed: slot %d differs from the kernel output" % slot)
 
@@ -504,15 +511,14 @@ def main():
                                           "unit is a 512-beam x 1024-freq block"}[args.workload],
                        "gemm_units_per_step": units, "beam_blocks_per_step": blocks_per_step,
                        "freq_per_gpu": n_freq,
-                       "gather": ("%s, %s-major layout, %s" % (args.gather, args.layout,
-                                                               "bf_gather_detected (RCCL p2p behind the C-ABI)" if comm is not None
-                                                               else "torch.distributed")) if dist is not None else "n/a",
+                       "gather": ("%s, %s-major layout, bf_gather_detected (RCCL p2p behind the C-ABI)"
+                                  % (args.gather, args.layout)) if dist is not None else "n/a",
                        "detect_mode": args.detect, "extra_warmup_steps": extra_warm,
                        "launch": info},
             "roofline": roof,
         }
-        if comm_note:
-            out["config"]["gather_note"] = comm_note
+        if rccl_info is not None:
+            out["rccl"] = rccl_info
 
     # ---- from here on nothing may cost the headline: a watchdog prints the line with what is there when the budget expires
     # (a collective that never returns cannot be caught as an exception) -------------------------------------------------

@@ -5,7 +5,8 @@ import ctypes as C
 import os
 
 PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG, "libdsabf.so")
+# DSABF_LIB_PATH: a measurement build made by tools/build_variant.py (A/B experiments only; never set by tests or bench.py)
+LIB_PATH = os.environ.get("DSABF_LIB_PATH") or os.path.join(PKG, "libdsabf.so")
 
 BF_OK = 0
 BF_NOT_READY = 1
@@ -68,6 +69,7 @@ SIGNATURES = {
     "bf_host_register": (C.c_int, [C.c_void_p, C.c_size_t]),
     "bf_host_unregister": (C.c_int, [C.c_void_p]),
     "bf_event_create": (C.c_int, [C.POINTER(C.c_void_p)]),
+    "bf_event_create_on": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "bf_event_destroy": (C.c_int, [C.c_void_p]),
     "bf_event_query": (C.c_int, [C.c_void_p]),
     "bf_event_synchronize": (C.c_int, [C.c_void_p]),
@@ -91,6 +93,7 @@ SIGNATURES = {
     "bf_comm_destroy": (C.c_int, [C.c_void_p]),
     "bf_comm_rank": (C.c_int, [C.c_void_p]),
     "bf_comm_world": (C.c_int, [C.c_void_p]),
+    "bf_comm_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, C.c_size_t]),
     "bf_gather_detected": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "bf_gather_offset": (C.c_size_t, [C.c_int, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_size_t]),
     "bf_gather_rows_held": (C.c_size_t, [C.c_size_t, C.c_int, C.c_int, C.c_int]),
@@ -210,7 +213,9 @@ def _preload_hip_runtime():
             global _rccl_path
             for r in ("librccl.so", "librccl.so.1"):
                 rp = os.path.join(os.path.dirname(c), r) if os.path.sep in c else r
-                if os.path.sep not in rp or os.path.exists(rp):
+                if os.path.sep in rp and os.path.exists(rp):
+                    # only a file that exists: a bare soname would turn bf_comm.cpp's soft resolution order (a copy
+                    # already in the process, librccl.so.1, librccl.so) into its hard-fail DSABF_RCCL_LIB branch
                     _rccl_path = rp
                     os.environ.setdefault("DSABF_RCCL_LIB", rp)
                     break

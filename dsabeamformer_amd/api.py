@@ -185,6 +185,12 @@ class Comm:
         check(self._lib.bf_comm_create(rank, world, idbuf, device, C.byref(self._c)))
         self.rank, self.world = rank, world
 
+    def info(self) -> dict:
+        """{"ranks": what the library reports (ncclCommCount), "version": ncclGetVersion, "lib": file it was loaded from}."""
+        n, v, path = C.c_int(), C.c_int(), C.create_string_buffer(512)
+        check(self._lib.bf_comm_info(self._c, C.byref(n), C.byref(v), path, 512))
+        return {"ranks": n.value, "version": v.value, "lib": path.value.decode(errors="replace")}
+
     def rows_held(self, n_rows: int, root: int) -> int:
         return self._lib.bf_gather_rows_held(n_rows, self.world, self.rank, root)
 
@@ -204,9 +210,13 @@ class Comm:
             pass
 
 
-def event_create() -> C.c_void_p:
+def event_create(bf=None) -> C.c_void_p:
+    """An event on the caller's current device, or -- given a Beamformer -- on that handle's device (bf_event_create_on)."""
     ev = C.c_void_p()
-    check(load().bf_event_create(C.byref(ev)))
+    if bf is not None:
+        check(load().bf_event_create_on(bf._h, C.byref(ev)))
+    else:
+        check(load().bf_event_create(C.byref(ev)))
     return ev
 
 

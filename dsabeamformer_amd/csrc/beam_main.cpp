@@ -16,6 +16,7 @@
 // streams them through the observation loop and writes bin/data.py (dedispersed beam responses, one row per source)
 // exactly like the reference's DEBUG build.  The PSRDADA observation mode (-c core, -k key) needs libpsrdada, which is
 // not part of this build; the options are accepted and reported.
+#include <fcntl.h>
 #include <unistd.h>
 
 #include <chrono>
@@ -102,9 +103,16 @@ int main(int argc, char* argv[])
                     fprintf(stderr, "GPUassert: %s\n", bf_last_error());
                     return EXIT_FAILURE;
                 }
+                // A stale id (a crashed run, a reused name) would make the other ranks join a communicator that no longer
+                // exists and hang: rank 0 removes whatever is there, writes a fresh file it alone created (O_EXCL |
+                // O_NOFOLLOW: no symlink is followed) and renames it into place -- readers see nothing or the whole id.
                 const std::string tmp = id_file + ".tmp";
-                std::ofstream(tmp, std::ios::binary).write(id, sizeof id);
-                if (rename(tmp.c_str(), id_file.c_str()) != 0) {
+                (void)unlink(id_file.c_str());
+                (void)unlink(tmp.c_str());
+                const int fd = open(tmp.c_str(), O_WRONLY | O_CREAT | O_EXCL | O_NOFOLLOW, 0600);
+                const bool ok = fd >= 0 && write(fd, id, sizeof id) == (ssize_t)sizeof id;
+                if (fd >= 0) close(fd);
+                if (!ok || rename(tmp.c_str(), id_file.c_str()) != 0) {
                     perror("beam: publishing the unique id");
                     return EXIT_FAILURE;
                 }

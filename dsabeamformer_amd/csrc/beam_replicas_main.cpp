@@ -43,9 +43,14 @@ int main(int argc, char* argv[])
         fprintf(stderr, "usage: beam_replicas -n N [-S] [-b path/to/beam] [--] [beam options; {i} = replica index]\n");
         return 2;
     }
-    char id_file[256];
-    snprintf(id_file, sizeof id_file, "/tmp/dsabf_comm_id_%d", (int)getpid());
-    unlink(id_file);
+    // the RCCL id travels through a file in a directory only this launcher's user can enter (mkdtemp: mode 0700, fresh name)
+    char id_dir[] = "/tmp/dsabf_comm_XXXXXX";
+    if (sharded && !mkdtemp(id_dir)) {
+        perror("beam_replicas: mkdtemp");
+        return 2;
+    }
+    const std::string id_file_s = std::string(id_dir) + "/id";
+    const char* id_file = id_file_s.c_str();
     std::vector<pid_t> kids;
     for (int i = 0; i < n; i++) {
         std::vector<std::string> args{beam};
@@ -83,6 +88,10 @@ int main(int argc, char* argv[])
         if (code) fprintf(stderr, "beam_replicas: replica %zu exited with %d\n", i, code);
         if (code > worst) worst = code;
     }
-    unlink(id_file);
+    if (sharded) {
+        unlink(id_file);
+        unlink((id_file_s + ".tmp").c_str());
+        rmdir(id_dir);
+    }
     return worst;
 }

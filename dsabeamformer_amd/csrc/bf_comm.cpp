@@ -43,6 +43,8 @@ struct rccl_api {
     int (*GroupEnd)() = nullptr;
     int (*Send)(const void*, size_t, int, int, rccl_comm_t, hipStream_t) = nullptr;
     int (*Recv)(void*, size_t, int, int, rccl_comm_t, hipStream_t) = nullptr;
+    int (*GetVersion)(int*) = nullptr;                 // optional (reports only)
+    int (*CommCount)(rccl_comm_t, int*) = nullptr;     // optional: how many ranks the LIBRARY says the communicator has
     std::string error;
 };
 
@@ -56,7 +58,8 @@ rccl_api& rccl()
     if (const char* e = getenv("DSABF_RCCL_LIB")) {
         if (e[0]) api.lib = dlopen(e, RTLD_NOW | RTLD_GLOBAL);
         if (e[0] && !api.lib) {
-            api.error = std::string("DSABF_RCCL_LIB=") + e + " could not be loaded: " + (dlerror() ? dlerror() : "?");
+            const char* why = dlerror();   // once: the call clears the error, a second one returns NULL
+            api.error = std::string("DSABF_RCCL_LIB=") + e + " could not be loaded: " + (why ? why : "?");
             return api;
         }
     }
@@ -67,7 +70,8 @@ rccl_api& rccl()
             if (api.lib) break;
         }
     if (!api.lib) {
-        api.error = std::string("librccl could not be loaded: ") + (dlerror() ? dlerror() : "not found");
+        const char* why = dlerror();
+        api.error = std::string("librccl could not be loaded: ") + (why ? why : "not found");
         return api;
     }
 #define BIND(field, sym)                                                            \
@@ -82,6 +86,8 @@ rccl_api& rccl()
     BIND(Send, "ncclSend")
     BIND(Recv, "ncclRecv")
 #undef BIND
+    *reinterpret_cast<void**>(&api.GetVersion) = dlsym(api.lib, "ncclGetVersion");
+    *reinterpret_cast<void**>(&api.CommCount) = dlsym(api.lib, "ncclCommCount");
     return api;
 }
 
@@ -208,6 +214,27 @@ int bf_comm_destroy(bf_comm* c)
     if (!c) return BF_OK;
     if (c->comm) (void)rccl().CommDestroy(c->comm);
     delete c;
+    return BF_OK;
+}
+
+// What a scaling record must be able to prove: which library carried the gather, its version, and how many ranks the
+// LIBRARY (not the caller) says the communicator spans.  lib_path = the file ncclSend was resolved from (dladdr).
+int bf_comm_info(const bf_comm* c, int* lib_ranks, int* version, char* lib_path, size_t n)
+{
+    if (!c) return comm_fail(BF_ERR_INVALID, "comm is NULL");
+    if (lib_ranks) *lib_ranks = c->comm ? -1 : 0;      // 0: no RCCL communicator behind this bf_comm (world 1 without an id)
+    if (version) *version = 0;
+    if (lib_path && n) lib_path[0] = 0;
+    if (!c->comm) return BF_OK;
+    rccl_api& r = rccl();
+    if (!r.error.empty()) return comm_fail(BF_ERR_DEVICE, r.error);
+    if (lib_ranks && r.CommCount) {
+        int cnt = -1;
+        if (r.CommCount(c->comm, &cnt) == 0) *lib_ranks = cnt;
+    }
+    if (version && r.GetVersion) (void)r.GetVersion(version);
+    Dl_info di{};
+    if (lib_path && n && dladdr(reinterpret_cast<void*>(r.Send), &di) && di.dli_fname) snprintf(lib_path, n, "%s", di.dli_fname);
     return BF_OK;
 }
 

@@ -18,6 +18,9 @@
 #ifndef DSABF_FASTADDR
 #define DSABF_FASTADDR 1  // scalar chunk addressing in fused16_kernel when gemm-units are a multiple of the chunk span
 #endif
+#ifndef DSABF_GEN3
+#define DSABF_GEN3 1      // general weight image holds 3 fragments per tile (Wr, -Wi, Wi) instead of 4 (Wr, -Wi, Wi, Wr again)
+#endif
 #ifndef DSABF_OCC16
 #define DSABF_OCC16 3     // register budget of the 64-antenna variants (168): the general kernel needs 153 VGPRs; the paired
                           // one (101) reaches 4 workgroups per CU by itself; capping at 128 spills for no gain
@@ -71,7 +74,7 @@ struct FusedArgs {
 // contiguous bytes per lane group, instead of four scattered 64-byte rows.  Otherwise: tile t = beams first + 16t + c.
 __host__ __device__ inline int beam_of_tile(int interleave, int paired, int tile, int c)
 {
-    const int per = paired ? 2 : 4;                    // column tiles per wave
+    const int per = paired ? DSABF_NS / 2 : DSABF_NS;  // MFMA column tiles per wave
     if (!interleave) return tile * 16 + c;
     return (tile / per) * (16 * per) + per * c + tile % per;
 }
@@ -134,9 +137,9 @@ __device__ __forceinline__ int swz16(int chunk, int row)  // 8 chunks of 16 B pe
     return chunk ^ ((((row >> 1) & 1) | (((row / LR) & 3) << 1)) ^ ((row & 1) << 2));
 }
 
-constexpr int kWaves16 = 4;                  // waves per workgroup of fused16_kernel
+constexpr int kWaves16 = DSABF_WAVES;        // waves per workgroup of fused16_kernel
 constexpr int kThreads16 = 64 * kWaves16;
-constexpr int kColTiles16 = 4;               // 16-beam column tiles per wave
+constexpr int kColTiles16 = DSABF_NS;        // 16-beam column tiles per wave
 
 // PAIRED: the steering weights of beam B-1-b are the complex conjugates of those of beam b for every (frequency,
 // antenna) -- true for any beam set that is symmetric about the boresight, e.g. the reference's linear fan and 16x16
@@ -153,7 +156,7 @@ template <int AIN>
 constexpr bool ant_two_ksteps() { return AIN > 64 || AIN == kAntK2P16 || AIN == kAntK2P4; }
 
 template <int AIN, int NIPO, bool WRITE_C, int MODE = kDetCanonical, bool PAIRED = false>
-__global__ __launch_bounds__(kThreads16, ant_two_ksteps<AIN>() ? 2 : DSABF_OCC16) void fused16_kernel(FusedArgs a)
+__global__ __launch_bounds__(kThreads16, DSABF_NS == 8 ? 2 : ant_two_ksteps<AIN>() ? 2 : DSABF_OCC16) void fused16_kernel(FusedArgs a)
 {
     constexpr bool FAST = MODE == kDetFast;
     constexpr bool CONTRACTED = MODE == kDetContracted;
@@ -198,7 +201,8 @@ __global__ __launch_bounds__(kThreads16, ant_two_ksteps<AIN>() ? 2 : DSABF_OCC16
     // ---- which beams this lane produces, and the weight fragments ------------------------------------------
     int slot_beam[NS];                                    // beam index of output slot s (>= n_beams: none)
     constexpr int NPC = DSABF_PAIR_MFMA >= 5 ? 3 : 2;     // paired fragments per tile: Wr, Wi (, -Wi)
-    v4i bw[NT][PAIRED ? NPC : 4][KS];                     // general: [ct][2*rho + s][k-step]; paired: [pct][Wr, Wi, -Wi][k-step]
+    constexpr int NGC = DSABF_GEN3 ? 3 : 4;               // general fragments per tile: Wr, -Wi, Wi (the im row's Wr IS comp 0)
+    v4i bw[NT][PAIRED ? NPC : NGC][KS];                   // general: [ct][Wr, -Wi, Wi][k-step]; paired: [pct][Wr, Wi, -Wi][k-step]
     bool wave_active;
     if constexpr (PAIRED) {
         const int n_pct = a.n_ptiles;                     // pair tiles of 16 base beams = n_beams / 32
@@ -226,11 +230,11 @@ __global__ __launch_bounds__(kThreads16, ant_two_ksteps<AIN>() ? 2 : DSABF_OCC16
             const bool ok = ct0 + t < n_ctiles;
             slot_beam[t] = ok ? beam_of_tile(a.interleave, 0, ct0 + t, c16) : a.n_beams;
 #pragma unroll
-            for (int k = 0; k < 4; k++)                    // k = 2*rho + s
+            for (int k = 0; k < NGC; k++)
 #pragma unroll
                 for (int h = 0; h < KS; h++)
                     bw[t][k][h] =
-                        ok ? a.wimg[((((size_t)f * n_ctiles + ct0 + t) * 4 + k) * KS + h) * 64 + lane] : v4i{0, 0, 0, 0};
+                        ok ? a.wimg[((((size_t)f * n_ctiles + ct0 + t) * NGC + k) * KS + h) * 64 + lane] : v4i{0, 0, 0, 0};
         }
     }
 
@@ -355,11 +359,16 @@ __global__ __launch_bounds__(kThreads16, ant_two_ksteps<AIN>() ? 2 : DSABF_OCC16
             // store instruction covers whole 128-byte lines (16 lanes x 16 B, or 16 x 8 B), so streaming them past L2
             // costs nothing at C3 / C5 (+0.3 %) and lifts the store-bound DEBUG geometry from 0.60 to 0.73 of 8 TB/s
             // (profiles/r02_variants_log.txt).  The scalar stores of non-interleaved tiles cover partial lines: plain.
-            if constexpr (PAIRED) {   // slots 0, 2 = base beams bb, bb + 1; slots 1, 3 = their mirrors B-1-bb, B-2-bb
+            if constexpr (PAIRED && NS == 4) {   // slots 0, 2 = base beams bb, bb + 1; slots 1, 3 = their mirrors B-1-bb, B-2-bb
                 __builtin_nontemporal_store(v2f{x[0], x[2]}, reinterpret_cast<v2f*>(row + slot_beam[0]));
                 __builtin_nontemporal_store(v2f{x[3], x[1]}, reinterpret_cast<v2f*>(row + slot_beam[3]));
+            } else if constexpr (PAIRED) {       // NS == 8: four base beams ascending, their four mirrors descending
+                __builtin_nontemporal_store(v4f{x[0], x[2], x[4], x[6]}, reinterpret_cast<v4f*>(row + slot_beam[0]));
+                __builtin_nontemporal_store(v4f{x[7], x[5], x[3], x[1]}, reinterpret_cast<v4f*>(row + slot_beam[7]));
             } else {
-                __builtin_nontemporal_store(v4f{x[0], x[1], x[2], x[3]}, reinterpret_cast<v4f*>(row + slot_beam[0]));
+#pragma unroll
+                for (int q = 0; q < NS; q += 4)
+                    __builtin_nontemporal_store(v4f{x[q], x[q + 1], x[q + 2], x[q + 3]}, reinterpret_cast<v4f*>(row + slot_beam[q]));
             }
         } else {
 #pragma unroll
@@ -539,8 +548,8 @@ __global__ __launch_bounds__(kThreads16, ant_two_ksteps<AIN>() ? 2 : DSABF_OCC16
                         im[1] = p3 - p4;
                     }
                 } else {
-                    re[0] = dot(a1, bw[t][1], dot(a0, bw[t][0], kc));
-                    im[0] = dot(a1, bw[t][3], dot(a0, bw[t][2], kc));
+                    re[0] = dot(a1, bw[t][1], dot(a0, bw[t][0], kc));              // Wr*Vr - Wi*Vi
+                    im[0] = dot(a1, bw[t][DSABF_GEN3 ? 0 : 3], dot(a0, bw[t][2], kc));   // Wi*Vr + Wr*Vi
                 }
             };
             auto consume = [&](const int t8, const int t, const v4i (&re)[SPS], const v4i (&im)[SPS]) {

@@ -140,17 +140,21 @@ void junk_fill(const bf_config& c, int ring_blocks, uint64_t seed, char* ring)
 {
     // every byte value (all 16 nibble codes in both halves), distinct blocks: 64-bit xorshift* per 8 bytes
     const size_t total = (size_t)bf_bytes_per_block(&c) * ring_blocks;
-    parallel_for((long)ring_blocks * 64, [&](long lo, long hi) {
+    const long parts = (long)ring_blocks * 64;
+    const size_t n8 = total / 8 / (size_t)parts;       // 8-byte words per part; the LAST part also takes the remainder
+    parallel_for(parts, [&](long lo, long hi) {
         for (long part = lo; part < hi; part++) {
-            const size_t n8 = total / 8 / ((size_t)ring_blocks * 64);
             uint64_t x = seed * 0x9E3779B97F4A7C15ULL + (uint64_t)(part + 1) * 0xBF58476D1CE4E5B9ULL;
-            uint64_t* q = reinterpret_cast<uint64_t*>(ring) + (size_t)part * n8;
-            for (size_t i = 0; i < n8; i++) {
+            const size_t first = (size_t)part * n8, words = part == parts - 1 ? total / 8 - first : n8;
+            uint64_t* q = reinterpret_cast<uint64_t*>(ring) + first;
+            for (size_t i = 0; i < words; i++) {
                 x ^= x >> 12;
                 x ^= x << 25;
                 x ^= x >> 27;
                 q[i] = x * 0x2545F4914F6CDD1DULL;
             }
+            if (part == parts - 1)                      // and the < 8 trailing bytes of a block size that is no multiple of 8
+                for (size_t b = total / 8 * 8; b < total; b++) ring[b] = (char)(x >> (8 * (b & 7)));
         }
     });
 }

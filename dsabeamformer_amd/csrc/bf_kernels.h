@@ -9,7 +9,13 @@
 namespace dsabf {
 
 constexpr int kRowsPerChunk = 128;   // time samples per LDS buffer
-constexpr int kBeamsPerWg = 256;     // 4 waves x 4 column tiles x 16 beams
+#ifndef DSABF_WAVES
+#define DSABF_WAVES 4    // waves per workgroup of fused16_kernel
+#endif
+#ifndef DSABF_NS
+#define DSABF_NS 4       // 16-beam output slots per wave
+#endif
+constexpr int kBeamsPerWg = DSABF_WAVES * DSABF_NS * 16;   // waves x column tiles x 16 beams
 
 struct Geometry {
     int n_beams, n_ant, n_freq, n_ipo, n_out, n_time;  // n_time = n_out * n_ipo (per gemm-unit)

@@ -314,23 +314,22 @@ __global__ void weight_relayout16p_kernel(const int8_t* __restrict__ w, v4i* __r
     }
 }
 
-// 16x16x64 weight image: image[f][ct16][rho][s][h][lane] (16 bytes): lane = 16*kb + c; byte i multiplies LDS chunk
-// 4*s + kb of the A row of k-step h = component s (0 = re, 1 = im) of antenna 64*h + 16*kb + i (zero behind the last
-// antenna), for output row rho of beam beam_of_tile(ct16, c).
+// 16x16x64 weight image: image[f][ct16][comp][h][lane] (16 bytes): lane = 16*kb + c; byte i = Wr (comp 0), -Wi (comp 1) or
+// Wi (comp 2) of antenna 64*h + 16*kb + i (zero behind the last antenna) for beam beam_of_tile(ct16, c).  The real row of
+// the embedding multiplies (Vr | Vi) by (Wr | -Wi), the imaginary row by (Wi | Wr): Wr serves both.
 __global__ void weight_relayout16_kernel(const int8_t* __restrict__ w, v4i* __restrict__ image, int n_freq, int n_ant,
                                          int n_beams, int ks, int interleave, int* __restrict__ bad)
 {
     const int n_ct = (n_beams + 15) / 16;   // the last tile may be partly filled: zero weights behind the last beam
-    const size_t total = (size_t)n_freq * n_ct * 2 * 2 * ks * 64;
+    constexpr int NGC = DSABF_GEN3 ? 3 : 4;
+    const size_t total = (size_t)n_freq * n_ct * NGC * ks * 64;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
         const int lane = (int)(idx & 63);
         size_t r = idx >> 6;
         const int h = (int)(r % ks);
         r /= ks;
-        const int sk = (int)(r & 1);
-        r >>= 1;
-        const int rho = (int)(r & 1);
-        r >>= 1;
+        const int comp = (int)(r % NGC);
+        r /= NGC;
         const int ct = (int)(r % n_ct);
         const int f = (int)(r / n_ct);
         const int kb = lane >> 4, b = beam_of_tile(interleave, 0, ct, lane & 15);
@@ -342,7 +341,7 @@ __global__ void weight_relayout16_kernel(const int8_t* __restrict__ w, v4i* __re
                 const int8_t* e = w + 2 * (((size_t)f * n_ant + ant) * n_beams + b);
                 const int wr = e[0], wi = e[1];
                 if (wi == -128) *bad = 1;
-                v = (rho == 0) ? (sk == 0 ? wr : -wi) : (sk == 0 ? wi : wr);
+                v = (comp == 1) ? -wi : (comp == 2) ? wi : wr;
             }
             d[i >> 2] |= ((unsigned)v & 0xFFu) << (8 * (i & 3));
         }
@@ -353,7 +352,7 @@ __global__ void weight_relayout16_kernel(const int8_t* __restrict__ w, v4i* __re
 
 // ---- which instantiation a geometry runs ---------------------------------------------------------------------------------
 int ksteps16(const Geometry& g) { return g.n_ant > 64 ? 2 : 1; }
-int interleaved(const Geometry& g) { return DSABF_INTERLEAVE && g.n_beams % 64 == 0; }  // every wave owns 64 whole beams
+int interleaved(const Geometry& g) { return DSABF_INTERLEAVE && g.n_beams % (16 * kColTiles16) == 0; }  // every wave owns whole beams
 bool nipo_supported(int n_ipo) { return n_ipo == 2 || n_ipo == 4 || n_ipo == 8 || n_ipo == 16 || n_ipo == 32 || n_ipo == 64; }
 int detect_mode_of(const Geometry& g) { return g.fast_detect ? kDetFast : g.contracted_detect ? kDetContracted : kDetCanonical; }
 
@@ -395,7 +394,7 @@ hipError_t dispatch_fused(const Geometry& g, bool write_c, const FusedArgs& args
 
 size_t weight_image_bytes(const Geometry& g)
 {
-    return (size_t)g.n_freq * g.n_ctiles * 4 * ksteps16(g) * 64 * 16;  // [f][ct16][rho][s][k-step][lane] x 16 B
+    return (size_t)g.n_freq * g.n_ctiles * (DSABF_GEN3 ? 3 : 4) * ksteps16(g) * 64 * 16;  // [f][ct16][Wr, -Wi, Wi][k-step][lane] x 16 B
 }
 
 // the conjugate-pair kernel works on tiles of 16 base beams + their 16 mirror images

@@ -353,7 +353,20 @@ int bf_host_unregister(void* ptr)
     return BF_OK;
 }
 
-int bf_event_create(bf_event** ev)
+static int event_create_here(bf_event** ev);
+
+// HIP binds an event to the device that is current when it is created, and it can only be recorded on that device's
+// streams: events a handle's queues will record are created under the HANDLE's device, whatever the caller's is.
+int bf_event_create_on(bf_handle* h, bf_event** ev)
+{
+    if (!h) return fail(BF_ERR_INVALID, "handle is NULL");
+    ON_DEVICE(h);
+    return event_create_here(ev);
+}
+
+int bf_event_create(bf_event** ev) { return event_create_here(ev); }
+
+static int event_create_here(bf_event** ev)
 {
     if (!ev) return fail(BF_ERR_INVALID, "ev is NULL");
     *ev = nullptr;
@@ -565,6 +578,7 @@ int bf_timer_stop(bf_handle* h, float* ms)
 {
     if (!h || !ms) return fail(BF_ERR_INVALID, "NULL argument");
     if (!h->t0) return fail(BF_ERR_STATE, "bf_timer_start has not been called");
+    ON_DEVICE(h);   // t1 goes onto the handle's device's null stream, where t0 is
     HIP_TRY(hipEventRecord(h->t1, nullptr));
     HIP_TRY(hipEventSynchronize(h->t1));
     HIP_TRY(hipEventElapsedTime(ms, h->t0, h->t1));

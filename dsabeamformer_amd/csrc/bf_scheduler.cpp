@@ -30,7 +30,7 @@ struct hip_backend : event_backend {
     void* create() override
     {
         bf_event* e = nullptr;
-        if (bf_event_create(&e) != BF_OK) return nullptr;
+        if (bf_event_create_on(h, &e) != BF_OK) return nullptr;   // on the handle's device, not the caller's current one
         return e;
     }
     void destroy(void* ev) override { bf_event_destroy(static_cast<bf_event*>(ev)); }

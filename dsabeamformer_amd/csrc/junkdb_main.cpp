@@ -94,7 +94,9 @@ int main(int argc, char* argv[])
             std::memcpy(b, src, block_bytes);
         } else {   // one core's memcpy (~30 GB/s) is slower than the reader's H2D (~55 GB/s): split the block
             std::vector<std::thread> th;
-            const size_t slice = ((size_t)block_bytes / copy_threads + 4095) & ~(size_t)4095;
+            const int nth = copy_threads > 64 ? 64 : copy_threads;      // -T is clamped to [1, 64]
+            size_t slice = ((size_t)block_bytes / nth + 4095) & ~(size_t)4095;
+            if (slice < 4096) slice = 4096;                              // never 0: tiny blocks are one slice
             for (size_t off = 0; off < block_bytes; off += slice)
                 th.emplace_back([=] { std::memcpy(b + off, src + off, std::min(slice, (size_t)block_bytes - off)); });
             for (auto& t : th) t.join();

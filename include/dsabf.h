@@ -123,7 +123,10 @@ int bf_host_unregister(void *ptr);
 
 /* Events.  Replace the cudaEvent ring of observation_loop_state (src/observation_loop.hh:58-61,65-68,73,
  * 79,86,95-96,105,112-113).  bf_event_query returns BF_OK (done), BF_NOT_READY, or a negative error. */
-int bf_event_create(bf_event **ev);
+int bf_event_create(bf_event **ev);                    /* on the caller's current device (as cudaEventCreate) */
+int bf_event_create_on(bf_handle *h, bf_event **ev);   /* on the handle's device: use this for events that bf_submit_block /
+                                                        * bf_record_*_event of `h` will record when h's device may not be
+                                                        * the caller's current one (`beam -D i`, one thread driving several GPUs) */
 int bf_event_destroy(bf_event *ev);
 int bf_event_query(bf_event *ev);
 int bf_event_synchronize(bf_event *ev);
@@ -228,6 +231,10 @@ int bf_comm_create(int rank, int world, const void *id128, int device, bf_comm *
 int bf_comm_destroy(bf_comm *c);
 int bf_comm_rank(const bf_comm *c);
 int bf_comm_world(const bf_comm *c);
+/* Evidence for a scaling record: how many ranks the LIBRARY reports for the communicator (ncclCommCount; 0 = this bf_comm
+ * has no RCCL communicator, -1 = the library cannot say), its version (ncclGetVersion, e.g. 22203; 0 = unknown) and the
+ * file the point-to-point calls were resolved from.  Any pointer may be NULL. */
+int bf_comm_info(const bf_comm *c, int *lib_ranks, int *version, char *lib_path, size_t n);
 int bf_gather_detected(bf_comm *c, const float *d_local, size_t n_rows, size_t row_floats, int root, int layout,
                        float *d_full, void *hip_stream);
 /* The layout arithmetic as plain host functions (no device, no RCCL): float offset of (rank, row) in the gathered array,

@@ -205,6 +205,21 @@ int ncclCommInitRank(void** comm, int nranks, fake_id id, int rank)
     return 0;
 }
 
+// reports only (bf_comm_info): the ranks that actually JOINED the segment, and version 0 = "not RCCL"
+int ncclCommCount(void* comm, int* count)
+{
+    fake_comm* c = static_cast<fake_comm*>(comm);
+    if (!c || !count) return 4;
+    *count = (int)c->hdr()->joined.load();
+    return 0;
+}
+
+int ncclGetVersion(int* v)
+{
+    if (v) *v = 0;
+    return 0;
+}
+
 int ncclCommDestroy(void* comm)
 {
     fake_comm* c = static_cast<fake_comm*>(comm);

@@ -1,4 +1,8 @@
-"""Frequency sharding across the GPUs of one node and the ONE collective of the path: the detected-power gather.
+"""TEST INFRASTRUCTURE (tests/test_shard_gloo.py): the gloo-testable statement of the frequency partition and of the two
+gathered layouts.  The product's gather is bf_comm_create / bf_gather_detected behind the C-ABI (csrc/bf_comm.cpp); nothing
+in dsabeamformer_amd/ or bench.py imports this file.
+
+Frequency sharding across the GPUs of one node and the ONE collective of the path: the detected-power gather.
 
 The reference scales by running one process per GPU on a different 256-channel slice (`-g`, README.md:168,
 src/beamformer.cu:233) and has no communication at all.  Here rank r of R owns frequencies

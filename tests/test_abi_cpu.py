@@ -115,3 +115,31 @@ def test_product_library_ships_no_test_double_and_no_hard_runtime_dependencies()
     assert exported_c == set(_declared_symbols())
     needed = subprocess.run(["readelf", "-d", lib], capture_output=True, text=True).stdout
     assert "amdhip" not in needed and "rccl" not in needed
+
+
+def test_unloadable_rccl_is_an_error_code_not_a_crash():
+    """ADVICE r02: `dlerror() ? dlerror() : ...` called dlerror twice -- the second call returns NULL and std::string + NULL
+    segfaults -- so a librccl that cannot be loaded killed the process instead of returning BF_ERR_DEVICE."""
+    import subprocess
+    import sys
+
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import dsabeamformer_amd as bfm\nfrom dsabeamformer_amd import api\n"
+            "try:\n"
+            "    api.comm_unique_id()\n"
+            "except bfm.DsabfError as e:\n"
+            "    print('DsabfError:', e)\n"
+            "    sys.exit(0)\n"
+            "sys.exit(3)\n" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, DSABF_RCCL_LIB="/nonexistent/librccl.so"),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+    assert "DSABF_RCCL_LIB=/nonexistent/librccl.so could not be loaded" in r.stdout
+
+
+def test_bench_has_one_gather_path():
+    """a scaling line must never come from a second code path -- bench.py imports no torch.distributed
+    gather, and the gloo statement of the layouts lives under tests/ only."""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "shard_layouts" not in src and "DetectedGather" not in src and "import shard" not in src
+    assert not os.path.exists(os.path.join(ROOT, "dsabeamformer_amd", "shard.py"))

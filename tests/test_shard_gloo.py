@@ -13,9 +13,10 @@ from conftest import ROOT
 WORKER = r'''
 import os, sys
 sys.path.insert(0, os.environ["REPO_ROOT"])
+sys.path.insert(0, os.path.join(os.environ["REPO_ROOT"], "tests"))
 import numpy as np, torch, torch.distributed as dist
 import oracle as orc
-from dsabeamformer_amd import shard
+from support import shard_layouts as shard
 dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
 g = orc.Geom(n_beams=32, n_ant=16, n_freq=8, n_avg=16, n_out_per_gemm=2)
@@ -92,7 +93,7 @@ def test_frequency_shard_and_gather(tmp_path, world):
 
 
 def test_freq_range_rules():
-    from dsabeamformer_amd import shard
+    from support import shard_layouts as shard
 
     assert [shard.freq_range(r, 8, 256) for r in (0, 3, 7)] == [(0, 32), (96, 128), (224, 256)]
     with pytest.raises(ValueError):
