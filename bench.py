@@ -490,6 +490,9 @@ def main():
                      "executed_frac": (executed / (kern_avg_ms * 1e-3) / 1e12 / INT8_DENSE_PEAK_TOPS) if mfma_bound else None,
                      "mfma_busy_frac": pmc_mfma_busy(pmc),
                      "pmc_source": ("profiles/" + pmc_name) if pmc else None,
+                     # traffic and mfma_busy_frac are read from the committed rocprofv3 summary named above -- measured
+                     # on an earlier box with the same kernel, NOT observed in this run (everything else in this object is)
+                     "from_committed_profile": ["traffic", "mfma_busy_frac"] if pmc else [],
                      "note": "int8 ops: 1 complex MAC = 8 ops.  frac = ALGORITHMIC ops / kernel time / peak; executed_frac = "
                              "the int8 ops the MFMA pipe really executes / time / peak (the conjugate-pair kernel forms two "
                              "beams from shared products: half the algorithmic ops, same bits); mfma_busy_frac = "
@@ -513,7 +516,20 @@ def main():
                        "freq_per_gpu": n_freq,
                        "gather": ("%s, %s-major layout, bf_gather_detected (RCCL p2p behind the C-ABI)"
                                   % (args.gather, args.layout)) if dist is not None else "n/a",
-                       "detect_mode": args.detect, "extra_warmup_steps": extra_warm,
+                       "detect_mode": args.detect,
+                       "detect_reading": {"canonical": "x*x + y*y as two multiplies and an add: what g++ makes of "
+                                                       "src/beamformer.cuh:151 and what the CPU oracle computes (bit-exact "
+                                                       "parity); the reference's production build is nvcc -O3 "
+                                                       "-use_fast_math (makefile:13-16), which most likely contracts it: "
+                                                       "see contracted_detect_mode for that reading's rate",
+                                          "contracted": "acc + fma(x, x, y*y): nvcc's default -fmad=true reading of "
+                                                        "src/beamformer.cuh:151 (makefile:13-16), most likely what the "
+                                                        "reference's GPU build computes; bit-exact vs the oracle's "
+                                                        "ORC_CONTRACT_NVCC",
+                                          "fast": "opt-in tolerance mode (include/dsabf.h)"}[args.detect],
+                       "weights": "the reference's linear fan (conjugate-symmetric: the pair kernel); a calibrated "
+                                  "instrument's weights run the general kernel: see calibrated_weights",
+                       "extra_warmup_steps": extra_warm,
                        "launch": info},
             "roofline": roof,
         }
@@ -549,7 +565,7 @@ def main():
                                            "per sender, freq-major = the reference's [o][f][b], one message per (row, sender); "
                                            "root = everything to rank 0, alltoall = rank j owns rows j*n/N.. of the whole band")
 
-        def variant(detect_mode, paired_env=None, wl=None, n_units=None, reps=None):
+        def variant(detect_mode, paired_env=None, wl=None, n_units=None, reps=None, calibrated=False):
             """Kernel-time record of another variant / workload on this GPU (HIP events around every launch)."""
             old = os.environ.get("DSABF_PAIRED")
             if paired_env is not None:
@@ -560,7 +576,8 @@ def main():
                 if wl == "c5":
                     c2.n_ant, c2.n_beams, c2.n_freq = 100, 512, 128
                 b2 = bfm.Beamformer(c2, device=local)
-                b2.set_weights(product_weights(c2, 0))
+                w2 = product_weights(c2, 0)
+                b2.set_weights(calibrated_weights(w2) if calibrated else w2)
             finally:
                 if paired_env is not None:
                     if old is None:
@@ -621,6 +638,16 @@ def main():
             out["contracted_detect_mode"] = c
             if paired:
                 out["contracted_detect_mode_general_kernel"] = variant(2, "0")
+            # what a real array uploads: the fan times per-(frequency, antenna) complex gains -> no conjugate symmetry ->
+            # bf_set_weights selects the general kernel by itself (no environment switch): the PRODUCTION number
+            for key, dm in (("calibrated_weights", 0), ("calibrated_weights_contracted", 2)):
+                cw = variant(dm, calibrated=True)
+                assert "PAIRED" not in cw["kernel"]
+                cw["note"] = ("steering fan x seeded random unit-modulus per-(frequency, antenna) gains, re-quantised to int8 "
+                              "(bench.calibrated_weights): the weight set of a calibrated instrument; bf_set_weights finds no "
+                              "conjugate symmetry and runs the general kernel; bit-exact vs the oracle in "
+                              "tests/test_gpu_round3.py")
+                out[key] = cw
             f = variant(1)
             f["tolerance"] = "(n_ipo+1)*2^-23 relative to the exact value (include/dsabf.h); canonical: (n_ipo+4)*2^-24"
             f["note"] = "opt-in bf_config.detect_mode = BF_DETECT_FAST; not the headline"
@@ -648,6 +675,39 @@ def main():
                 r = variant(0, n_units=nu, reps=60)
                 ls["%d_units" % nu] = {"kernel_us_per_beam_block": r["kernel_ms_avg"] * 1e3 / (nu * n_out), "grid": r["grid"],
                                        "kernel_ms_avg": r["kernel_ms_avg"], "frac": r["frac"]}
+            # what the reference's loop really issues: N_STREAMS = 8 one-unit launches in flight at once, one per queue
+            qs = [torch.cuda.Stream() for _ in range(8)]
+            per_in, per_out = n_freq * n_time * cfg.n_ant, n_out * n_freq * cfg.n_beams
+            done = [torch.cuda.Event() for _ in qs]
+
+            N_EACH = 16                                   # one-unit launches per queue between the fork and the join
+
+            def eight(i):
+                fork = torch.cuda.Event()
+                fork.record(stream)
+                for q, sq in enumerate(qs):
+                    sq.wait_event(fork)
+                for k in range(N_EACH):
+                    for q, sq in enumerate(qs):
+                        u = (q * N_EACH + k) % units
+                        bf.beamform(d_in[i % len(d_in)][u * per_in:(u + 1) * per_in], 1,
+                                    d_out[i & 1][u * per_out:(u + 1) * per_out], sq.cuda_stream)
+                for q, sq in enumerate(qs):
+                    done[q].record(sq)
+                    stream.wait_event(done[q])
+
+            for i in range(5):
+                eight(i)
+            torch.cuda.synchronize()
+            avg8, _, _ = time_launches(torch, eight, 30, stream)
+            ops1 = 8 * cfg.n_beams * cfg.n_ant * n_ipo * n_freq * n_out
+            n_l = 8 * N_EACH
+            ls["8x1_units_concurrent"] = {"kernel_us_per_beam_block": avg8 * 1e3 / (n_l * n_out), "ms_for_%d_units" % n_l: avg8,
+                                          "frac": n_l * ops1 / (avg8 * 1e-3) / 1e12 / INT8_DENSE_PEAK_TOPS,
+                                          "note": "%d one-unit launches, %d on each of 8 queues, between one fork and one "
+                                                  "join event: the aggregate rate of the reference's launch pattern "
+                                                  "(N_STREAMS = 8 queues of one-unit launches, src/beamformer.cu:454-519); "
+                                                  "1_units above is ONE such launch alone on the chip" % (n_l, N_EACH)}
             ls["note"] = ("bf_enqueue_gemm_unit launches 1 unit (the reference's pattern, src/beamformer.cu:454-519), "
                           "bf_enqueue_block 32 (one PSRDADA block), the headline step 128")
             out["launch_size"] = ls

@@ -77,6 +77,7 @@ SIGNATURES = {
     "bf_record_transfer_event": (C.c_int, [C.c_void_p, C.c_void_p]),
     "bf_enqueue_gemm_unit": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "bf_enqueue_block": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "bf_enqueue_block_dedisperse": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "bf_enqueue_dedisperse": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "bf_record_analysis_event": (C.c_int, [C.c_void_p, C.c_void_p]),
     "bf_stream_sync": (C.c_int, [C.c_void_p, C.c_int]),
@@ -178,7 +179,7 @@ SIGNATURES = {
     "bfh_run_observation_shm": (C.c_int, [C.POINTER(BfConfig), C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p,
                                           C.POINTER(C.c_float), C.POINTER(C.c_uint64), C.POINTER(C.c_int)]),
     "bfh_run_debug_observation": (C.c_int, [C.POINTER(BfConfig), C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p,
-                                            C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_int),
+                                            C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_int),
                                             C.POINTER(C.c_float)]),
 }
 

@@ -120,6 +120,9 @@ class Beamformer:
             arr = (C.c_void_p * n_units)(*[_ptr(p).value for p in host_outs])
         check(self._lib.bf_enqueue_block(self._h, stream_idx, slot, first_unit, n_units, arr))
 
+    def enqueue_block_dedisperse(self, stream_idx: int, first_unit: int, n_units: int, host_rows=None) -> None:
+        check(self._lib.bf_enqueue_block_dedisperse(self._h, stream_idx, first_unit, n_units, _ptr(host_rows)))
+
     def enqueue_dedisperse(self, stream_idx: int, host_out_row=None) -> None:
         check(self._lib.bf_enqueue_dedisperse(self._h, stream_idx, _ptr(host_out_row)))
 

@@ -1,7 +1,8 @@
 // beam_main.cpp -- the `beam` driver: command line and lifecycle of the reference's main() (src/beamformer.cu:12-157,
 // 539-571; usage() src/beamformer.hh:222-243) on top of libdsabf.so.
 //
-//   beam [-g gpu] [-p position_file] [-d direction_file] [-s source_file] [-o data.py] [-D device] [-a n_avg] [-v] [-h]
+//   beam [-g gpu] [-p position_file] [-d direction_file] [-s source_file] [-o data.py] [-D device] [-a n_avg] [-u] [-v] [-h]
+//        (-u: the reference's launch pattern, one launch + copy per gemm-unit, instead of one per block; same data.py)
 //   beam -j n_blocks [-g gpu] [-p ...] [-d ...]     production geometry, observation loop fed by the in-memory
 //                                                   dada_junkdb stand-in (soak / data-rate run, makefile:28-29)
 //   beam -j n_blocks -R world -r rank -I idfile     one frequency SHARD of a sub-band: this process beamforms channels
@@ -38,6 +39,7 @@ int main(int argc, char* argv[])
     bf_config cfg;
     bf_config_default(&cfg, /*debug=*/1);
     debug_run_options opt;
+    bool per_unit = false;
     std::string positions, directions, sources, output = "bin/data.py", detected_path, out_ring;
     std::string ring_key;
     int core = -1;
@@ -46,7 +48,7 @@ int main(int argc, char* argv[])
     std::string id_file;
 
     int arg = 0;
-    while ((arg = getopt(argc, argv, "s:g:p:d:o:D:a:c:k:K:j:w:R:r:I:vh")) != -1) {  // src/beamformer.cu:41-43 (+ -o -D -a -v)
+    while ((arg = getopt(argc, argv, "s:g:p:d:o:D:a:c:k:K:j:w:R:r:I:uvh")) != -1) {  // src/beamformer.cu:41-43 (+ -o -D -a -v)
         switch (arg) {
             case 's': sources = optarg; break;                 // :77-89
             case 'g': opt.gpu = atoi(optarg); break;           // :92-100
@@ -61,6 +63,7 @@ int main(int argc, char* argv[])
             case 'R': world = atoi(optarg); break;
             case 'r': rank = atoi(optarg); break;
             case 'I': id_file = optarg; break;
+            case 'u': per_unit = true; break;                   // the reference's launch pattern: one launch per gemm-unit
             case 'v': opt.verbose = true; cfg.verbose = 1; break;
             case 'c': core = atoi(optarg); break;              // :59-65
             case 'k': ring_key = optarg; break;                // :66-75 (a shared-memory ring name instead of a hex key)
@@ -72,6 +75,7 @@ int main(int argc, char* argv[])
     opt.directions = directions.empty() ? nullptr : directions.c_str();
     opt.sources = sources.empty() ? nullptr : sources.c_str();
     opt.output = output.c_str();
+    opt.block_launch = !per_unit;
 
     int n_dev = 0;
     if (bf_device_count(&n_dev) != BF_OK || n_dev == 0) {

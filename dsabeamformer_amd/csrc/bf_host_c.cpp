@@ -255,11 +255,12 @@ int bfh_obs_describe(bfh_obs* o, char* buf, size_t buflen)
     return BF_OK;
 }
 int bfh_run_debug_observation(const bf_config* cfg, int gpu, const char* positions, const char* directions,
-                              const char* sources, const char* output, int device, int verbose, float* ded_out,
-                              size_t ded_capacity, int* n_pt_sources, float* observation_ms)
+                              const char* sources, const char* output, int device, int verbose, int per_unit_launches,
+                              float* ded_out, size_t ded_capacity, int* n_pt_sources, float* observation_ms)
 {
     if (!cfg) return BF_ERR_INVALID;
     debug_run_options opt;
+    opt.block_launch = per_unit_launches == 0;
     opt.gpu = gpu;
     opt.positions = positions;
     opt.directions = directions;

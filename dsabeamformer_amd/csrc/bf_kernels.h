@@ -58,6 +58,9 @@ hipError_t launch_gemm_only(const Geometry& g, const void* d_image, const void* 
 
 hipError_t launch_expand(const void* d_in, size_t nbytes, void* d_out, hipStream_t s);
 hipError_t launch_dedisperse(const Geometry& g, const float* d_out_unit, float* d_ded, hipStream_t s);
+// ded[u][b] = ascending-f fp32 sum of output 0 of unit u, units `unit_stride` floats apart: one launch for a whole block
+hipError_t launch_dedisperse_units(const Geometry& g, const float* d_out_units, size_t unit_stride, int n_units, float* d_ded,
+                                   hipStream_t s);
 // out[dm][t][b] = sum_f series[t + delays[dm][f]][f][b]  (series: n_t beam-blocks [f][b]; t < n_t_out)
 hipError_t launch_dedisperse_dm(const Geometry& g, const float* d_series, int n_t, const int* d_delays, int n_dm,
                                 int n_t_out, float* d_out, hipStream_t s);

@@ -103,6 +103,30 @@ __global__ void dedisperse_kernel(const float* __restrict__ out_unit, float* __r
     ded[b] = acc;
 }
 
+// a8 for every gemm-unit of a block in ONE launch (bf_enqueue_block_dedisperse): ded[u][b] = the same ascending-f fp32 sum
+// over output 0 of unit u.  The order forbids splitting one beam's sum over threads, so the parallelism is units x beams:
+// 32 units x 256 beams = 128 waves in one launch instead of 32 launches of 4 waves (7 us each, more than half the 12 us
+// one-unit fused launch they follow in the reference's DEBUG loop).
+__global__ void dedisperse_units_kernel(const float* __restrict__ out_units, size_t unit_stride, float* __restrict__ ded,
+                                        int n_freq, int n_beams, int n_units)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    const int u = blockIdx.y;
+    if (b >= n_beams || u >= n_units) return;
+    const float* out_unit = out_units + (size_t)u * unit_stride;
+    float acc = 0.0f;
+    int f = 0;
+    for (; f + 16 <= n_freq; f += 16) {
+        float v[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) v[i] = out_unit[(size_t)(f + i) * n_beams + b];
+#pragma unroll
+        for (int i = 0; i < 16; i++) acc = acc + v[i] * 1.0f;
+    }
+    for (; f < n_freq; f++) acc = acc + out_unit[(size_t)f * n_beams + b] * 1.0f;
+    ded[(size_t)u * n_beams + b] = acc;
+}
+
 // 8f-4: incoherent dedispersion of a detected series: out[dm][t][b] = sum over f (ascending, fp32) of
 // series[t + delay[dm][f]][f][b]; rows past the end of the series contribute nothing (adding +0 is the same thing: a
 // running sum that starts at +0 never becomes -0).
@@ -550,6 +574,16 @@ hipError_t launch_dedisperse(const Geometry& g, const float* d_out_unit, float* 
     clear_stale_error();
     hipLaunchKernelGGL(dedisperse_kernel, dim3((g.n_beams + 63) / 64), dim3(64), 0, s, d_out_unit, d_ded, g.n_freq,
                        g.n_beams);
+    return hipGetLastError();
+}
+
+hipError_t launch_dedisperse_units(const Geometry& g, const float* d_out_units, size_t unit_stride, int n_units, float* d_ded,
+                                   hipStream_t s)
+{
+    if (n_units <= 0) return hipSuccess;
+    clear_stale_error();
+    hipLaunchKernelGGL(dedisperse_units_kernel, dim3((g.n_beams + 63) / 64, n_units), dim3(64), 0, s, d_out_units, unit_stride,
+                       d_ded, g.n_freq, g.n_beams, n_units);
     return hipGetLastError();
 }
 

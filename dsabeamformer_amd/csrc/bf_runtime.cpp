@@ -37,6 +37,7 @@ struct bf_handle {
     float* d_out = nullptr;       // n_streams x floats_per_detect
     float* d_ded = nullptr;       // n_streams x n_beams
     std::vector<float*> d_out_blk;  // per compute queue, n_gemms_per_block x floats_per_detect: bf_enqueue_block (lazy)
+    std::vector<float*> d_ded_blk;  // per compute queue, n_gemms_per_block x n_beams: bf_enqueue_block_dedisperse (lazy)
     std::vector<float*> d_full_blk; // per compute queue, the gathered block (world x as large): bf_block_gather_device (lazy)
     int full_world = 0;
     hipStream_t h2d = nullptr;
@@ -269,6 +270,7 @@ int bf_destroy(bf_handle* h)
     (void)hipFree(h->d_ded);
     for (float* p : h->d_out_blk) (void)hipFree(p);
     for (float* p : h->d_full_blk) (void)hipFree(p);
+    for (float* p : h->d_ded_blk) (void)hipFree(p);
     delete h;
     return BF_OK;
 }
@@ -470,9 +472,39 @@ int bf_enqueue_block(bf_handle* h, int stream_idx, int slot, int first_unit, int
     hipStream_t s = h->streams[stream_idx];
     HIP_TRY(dsabf::launch_fused(h->geom, h->d_wimage, h->d_wimage_p, in, n_units, out, h->n_cus, s));
     if (host_out)
-        for (int u = 0; u < n_units; u++)
-            if (host_out[u])
-                HIP_TRY(hipMemcpyAsync(host_out[u], out + per_det * (size_t)u, per_det * sizeof(float), hipMemcpyDeviceToHost, s));
+        for (int u = 0; u < n_units;) {   // destinations that follow each other in host memory travel as ONE copy
+            if (!host_out[u]) {
+                u++;
+                continue;
+            }
+            int run = 1;
+            while (u + run < n_units && host_out[u + run] == host_out[u] + per_det * (size_t)run) run++;
+            HIP_TRY(hipMemcpyAsync(host_out[u], out + per_det * (size_t)u, per_det * sizeof(float) * (size_t)run,
+                                   hipMemcpyDeviceToHost, s));
+            u += run;
+        }
+    return BF_OK;
+}
+
+int bf_enqueue_block_dedisperse(bf_handle* h, int stream_idx, int first_unit, int n_units, float* host_rows)
+{
+    if (!h) return fail(BF_ERR_INVALID, "handle is NULL");
+    if (stream_idx < 0 || stream_idx >= h->cfg.n_streams) return fail(BF_ERR_INVALID, "stream %d out of range", stream_idx);
+    if (first_unit < 0 || n_units <= 0 || first_unit + n_units > h->cfg.n_gemms_per_block)
+        return fail(BF_ERR_INVALID, "gemm-units [%d, %d) are not inside a block of %d", first_unit, first_unit + n_units,
+                    h->cfg.n_gemms_per_block);
+    if (h->d_out_blk.empty() || !h->d_out_blk[stream_idx])
+        return fail(BF_ERR_STATE, "bf_enqueue_block has not run on queue %d", stream_idx);
+    ON_DEVICE(h);
+    const size_t per_det = bf_floats_per_detect(&h->cfg);
+    if (h->d_ded_blk.empty()) h->d_ded_blk.assign((size_t)h->cfg.n_streams, nullptr);
+    if (!h->d_ded_blk[stream_idx])
+        HIP_TRY(hipMalloc((void**)&h->d_ded_blk[stream_idx], (size_t)h->cfg.n_beams * sizeof(float) * (size_t)h->cfg.n_gemms_per_block));
+    hipStream_t s = h->streams[stream_idx];
+    float* ded = h->d_ded_blk[stream_idx] + (size_t)h->cfg.n_beams * first_unit;
+    HIP_TRY(dsabf::launch_dedisperse_units(h->geom, h->d_out_blk[stream_idx] + per_det * (size_t)first_unit, per_det, n_units, ded, s));
+    if (host_rows)
+        HIP_TRY(hipMemcpyAsync(host_rows, ded, (size_t)h->cfg.n_beams * sizeof(float) * (size_t)n_units, hipMemcpyDeviceToHost, s));
     return BF_OK;
 }
 

@@ -261,6 +261,14 @@ int run_debug_observation(const bf_config& cfg, const debug_run_options& opt, de
 
     std::vector<int> timeSlice((size_t)n_streams);
     for (int i = 0; i < n_streams; i++) timeSlice[i] = i;  // :319
+    float* beam_out_blk[2] = {nullptr, nullptr};   // block_launch: a block's detected powers on the host, per alternating queue
+    uint64_t block_launches = 0;
+    for (int q = 0; q < 2 && opt.block_launch; q++) {   // (page-locking 2 x N_GEMMS_PER_BLOCK x 2 MiB is setup, like beam_out)
+        void* pb = nullptr;
+        if ((rc = bf_alloc_pinned(&pb, n_f_per_detect * (size_t)cfg.n_gemms_per_block * sizeof(float))) != BF_OK) return rc;
+        g.pinned.push_back(pb);
+        beam_out_blk[q] = static_cast<float*>(pb);
+    }
 
     hip_backend backend(h);
     observation_loop_state obs_state(kMaxTransferSep, kMaxTotalSep, cfg, &backend, /*debug_mode=*/true);  // :322
@@ -306,7 +314,26 @@ int run_debug_observation(const bf_config& cfg, const debug_run_options& opt, de
         }
         obs_state.check_transfer_events();  // :446
 
-        if (obs_state.check_ready_for_analysis()) {  // :452
+        if (obs_state.check_ready_for_analysis() && opt.block_launch) {
+            // Block-granular analysis: one fused launch over the block's gemm-units, their detected powers to the host in
+            // ONE copy (a4: every unit still travels, as src/beamformer.cu:485-488 has it), one DM-0 launch for all of
+            // them (a8).  Two queues alternate so that block i+1's kernel overlaps block i's copy.
+            const int q = (int)(block_launches++ % 2) % n_streams;
+            const int first_gemm = (int)obs_state.get_current_analysis_gemm(0);
+            if (opt.verbose) log << "Queueing Beamforming. Start Dir = " << first_gemm << std::endl;
+            std::vector<float*> dst((size_t)cfg.n_gemms_per_block);
+            for (int u = 0; u < cfg.n_gemms_per_block; u++) dst[(size_t)u] = beam_out_blk[q] + n_f_per_detect * (size_t)u;
+            rc = bf_enqueue_block(h, q, (int)obs_state.get_next_gpu_analysis_block(), 0, cfg.n_gemms_per_block, dst.data());
+            const int n_valid = std::min(cfg.n_gemms_per_block, n_src - first_gemm);   // check_ready_for_dh2_transfer, :492
+            if (rc == BF_OK && n_valid > 0)
+                rc = bf_enqueue_block_dedisperse(h, q, 0, n_valid, &dedispersed_out[(size_t)first_gemm * cfg.n_beams]);
+            if (rc != BF_OK) {
+                log << "GPUassert: " << bf_last_error() << std::endl;
+                return rc;
+            }
+            (void)obs_state.get_current_analysis_gemm(cfg.n_gemms_per_block - 1);   // most_recent_gemm = the block's last unit
+            obs_state.generate_analysis_event();  // :525
+        } else if (obs_state.check_ready_for_analysis()) {  // :452
             for (int part = 0; part < cfg.n_gemms_per_block / n_streams; part++) {
                 if (opt.verbose)
                     log << "Queueing Beamforming. Start Dir = " << obs_state.get_current_analysis_gemm(timeSlice[0])

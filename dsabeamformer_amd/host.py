@@ -204,14 +204,16 @@ class ObservationLoopState:
 
 def run_debug_observation(cfg: BfConfig, gpu: int = 0, positions: str | None = None, directions: str | None = None,
                           sources: str | None = None, output: str | None = None, device: int = 0,
-                          verbose: bool = False, max_sources: int = 4096):
-    """The reference's `make debug` main() end to end; returns (dedispersed [n_src][n_beams], observation_ms)."""
+                          verbose: bool = False, max_sources: int = 4096, per_unit_launches: bool = False):
+    """The reference's `make debug` main() end to end; returns (dedispersed [n_src][n_beams], observation_ms).
+    per_unit_launches: the reference's own launch pattern instead of one launch / copy / DM-0 launch per block."""
     ded = np.zeros((max_sources, cfg.n_beams), np.float32)
     n = C.c_int()
     ms = C.c_float()
     enc = lambda s: s.encode() if s else None  # noqa: E731
     check(load().bfh_run_debug_observation(C.byref(cfg), gpu, enc(positions), enc(directions), enc(sources), enc(output),
-                                           device, 1 if verbose else 0, _p(ded), ded.size, C.byref(n), C.byref(ms)))
+                                           device, 1 if verbose else 0, 1 if per_unit_launches else 0, _p(ded), ded.size,
+                                           C.byref(n), C.byref(ms)))
     return ded[:n.value].copy(), ms.value
 
 

@@ -159,6 +159,10 @@ int bf_enqueue_block(bf_handle *h, int stream_idx, int slot, int first_unit, int
 /* Replaces K5, the DEBUG dedisperse, src/beamformer.cu:498-510: sums output 0 of the unit last enqueued on
  * `stream_idx` over frequency (ascending f, fp32) and copies the n_beams floats to host_out_row. */
 int bf_enqueue_dedisperse(bf_handle *h, int stream_idx, float *host_out_row);
+/* The same K5 for the gemm-units [first_unit, first_unit + n_units) of the block bf_enqueue_block last put on
+ * `stream_idx`, in ONE launch (units x beams threads; every beam's sum still runs over ascending f in one thread, so the
+ * bits are those of n_units bf_enqueue_dedisperse calls).  host_rows, if not NULL, receives [n_units][n_beams] floats. */
+int bf_enqueue_block_dedisperse(bf_handle *h, int stream_idx, int first_unit, int n_units, float *host_rows);
 
 /* Replaces generate_analysis_event, src/beamformer.cu:525 / src/observation_loop.hh:77-81.  The reference
  * records on stream[N_STREAMS-1] only (a latent race); this records `ev` behind ALL

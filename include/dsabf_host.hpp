@@ -194,6 +194,11 @@ struct debug_run_options {
     const char* output = "bin/data.py";
     int device = 0;
     bool verbose = false;
+    // launch granularity (as observation_options::block_launch): true = one fused launch, ONE D2H copy of the block's
+    // detected powers and one dedisperse launch (bf_enqueue_block + bf_enqueue_block_dedisperse) per block of
+    // N_GEMMS_PER_BLOCK sources, alternating between two compute queues; false = the reference's own pattern, per
+    // gemm-unit launches + copies round-robin over the N_STREAMS queues (src/beamformer.cu:454-519).  Same data.py.
+    bool block_launch = true;
 };
 struct debug_run_result {
     float observation_time_ms = 0;

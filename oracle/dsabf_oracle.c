@@ -357,7 +357,7 @@ void orc_dedisperse(const orc_geom *g, const float *out_unit, float *ded)
     }
 }
 
-/* 8f-4 -- sandbox/Dispersion Theory.ipynb cells 1-2 (parity unpinned: no reference implementation, see the header). */
+/* 8f-4 -- sandbox/Dispersion Theory.ipynb cells 1-2 (pinned by executing the cells: tests/golden/make_dispersion_golden.py). */
 int orc_dm_trials(double dm0, double dm_max, int nchan, double epsilon, double nu_ghz, double chan_bw_mhz, double ti_us,
                   double tscat_us, double tsamp_us, double *out, int cap)
 {

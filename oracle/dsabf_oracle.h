@@ -125,8 +125,10 @@ void orc_beamform(const orc_geom *g, const int8_t *w, const uint8_t *packed, int
 void orc_dedisperse(const orc_geom *g, const float *out_unit, float *ded);
 
 /* ---- incoherent dedispersion beyond DM 0 -------------------------------------------------
- * PARITY UNPINNED: the reference has no implementation of this stage (only the DM-0 column sum above, a8); these
- * restate the formulas of its design notebook, sandbox/Dispersion Theory.ipynb, in the a8 summation order.
+ * The reference has no implementation of this stage (only the DM-0 column sum above, a8) -- these restate the formulas of
+ * its design notebook, sandbox/Dispersion Theory.ipynb.  orc_dm_trials / orc_dm_delays are PINNED BY EXECUTING cells 1, 2, 5
+ * (tests/golden/make_dispersion_golden.py -> dispersion_notebook.npz: the whole ladder and the 2048 delays of the cell's
+ * DM-2000 pulse).  The SUMMATION (orc_dedisperse_dm) has no reference counterpart: a8's order extended by the delays.
  * orc_dm_trials: the trial ladder of cells 1-2 (all double, as numpy): dm_{k+1} = N^2 a dm_k +
  *   4 sqrt(a (eps^2 - N^2 a) dm_k^2 + a beta (eps^2 - 1) (nu^3 / (8.3 B))^2), a = 1/(16 + N^2), beta = ti^2+tscat^2+tsamp^2;
  *   stops after the first trial >= dm_max; returns the count (<= cap).

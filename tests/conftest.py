@@ -35,3 +35,34 @@ def linear_inputs(orc):
 def linear_weights(orc, linear_inputs):
     pos, dirs, _ = linear_inputs
     return orc.make_weights(orc.DEBUG_GEOM, pos, dirs, 0)
+
+
+@pytest.fixture(scope="session")
+def notebook_integers(orc, linear_inputs, linear_weights):
+    """The integers the reference's notebook itself used (tests/golden/make_notebook_golden.py, round 3): its A * 127 for all
+    256 frequencies and its quantised signal for every (source, frequency, antenna), rebuilt from the committed differences
+    to the oracle's a5 / a6 output and CHECKED against the SHA-256 of the notebook's full arrays.
+    Returns (weights int8 [f][a][b][2], packed uint8 [source][f][a], notebook out float64 [beam][source], diff counts)."""
+    import hashlib
+
+    import numpy as np
+
+    nb = np.load(os.path.join(GOLDEN, "notebook_linear.npz"))
+    pos, _, src = linear_inputs
+    w = linear_weights.copy()
+    w.reshape(-1)[nb["nb2d_A127_diff_index"]] = nb["nb2d_A127_diff_value"]
+    assert hashlib.sha256(w.tobytes()).digest() == nb["nb2d_A127_sha256"].tobytes(), "not the notebook's A * 127"
+    g = orc.DEBUG_GEOM
+    batch = orc.generate_test_data(g, pos, src, 0, 0, 1024)            # [source][f][t][a]; every t column is the same
+    col = np.ascontiguousarray(batch[:, :, 0, :])
+    col.reshape(-1)[nb["nb2d_packed_diff_index"]] = nb["nb2d_packed_diff_value"]
+    assert hashlib.sha256(col.tobytes()).digest() == nb["nb2d_packed_sha256"].tobytes(), "not the notebook's signals"
+    # the 16 raw sample sources say the same without the oracle
+    assert np.array_equal(col[nb["nb2d_packed_sample_sources"]], nb["nb2d_packed_sample"])
+    return w, col, nb["nb2d_out"], (len(nb["nb2d_A127_diff_index"]), len(nb["nb2d_packed_diff_index"]))
+
+
+# a2 / a3 / a8 against the executed notebook ON IDENTICAL INTEGERS: what is left is fp32 rounding only.  Per frequency
+# term at most (n_ipo + 4) * 2^-24 relative (include/dsabf.h: 4 roundings per sample term + n_ipo - 1 accumulate
+# roundings), plus 255 roundings of the ascending-f sum of 256 non-negative terms.  Measured: 1.5e-6.
+NOTEBOOK_INTEGER_TOL = (255 + 2 + 4) * 2.0 ** -24

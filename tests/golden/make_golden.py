@@ -81,37 +81,10 @@ def main():
         small[tag + "_geom"] = np.array([geom.n_beams, geom.n_ant, geom.n_freq, geom.n_pol, geom.n_avg,
                                          geom.n_out_per_gemm])
     np.savez_compressed(os.path.join(HERE, "random_small.npz"), **small)
-    meta["dispersion"] = dispersion_values()
     with open(os.path.join(HERE, "golden.json"), "w") as fp:
         json.dump(meta, fp, indent=1, sort_keys=True)
         fp.write("\n")
     print(json.dumps(meta, indent=1))
-
-
-def dispersion_values():
-    """The values the formulas of the reference's design notebook give (sandbox/Dispersion Theory.ipynb cells 1, 2 and
-    5), written out here with numpy exactly as the notebook writes them: the DM trial ladder and the sample delays of a
-    DM-2000 pulse over 2048 channels (the channel frequencies rounded to float32, the type of the product's table)."""
-    dm0 = 0
-    Nchan = 2048
-    epsilon = 1.25
-    alpha = 1.0 / (16 + Nchan ** 2)
-    nu = (1.28 + 1.53) / 2
-    B = (1.53 - 1.28) / Nchan * 1000
-    ti, tscat, tsamp = 40.0, 0, 131
-    beta = ti ** 2 + tscat ** 2 + tsamp ** 2
-    dm_prev = dm0
-    dms = [dm0]
-    while dm_prev < 2000:
-        dm_prev = Nchan ** 2 * alpha * dm_prev + 4 * np.sqrt(
-            alpha * (epsilon ** 2 - Nchan ** 2 * alpha) * dm_prev ** 2 + alpha * beta * (epsilon ** 2 - 1) * ((nu ** 3) / (8.3 * B)) ** 2)
-        dms.append(dm_prev)
-    d = 4.15 * 2000
-    f1 = 1.53
-    delays = [int(d * (-f1 ** (-2) + float(np.float32(1.28 + (1.53 - 1.28) / Nchan * i)) ** (-2)) / (0.131 * 16))
-              for i in range(Nchan)]
-    return {"n_trials": len(dms), "dm1": float(dms[1]), "dm_last": float(dms[-1]), "delay_dm2000_chan0": delays[0],
-            "delay_dm2000_sum": int(sum(delays))}
 
 
 if __name__ == "__main__":

@@ -27,7 +27,20 @@ removed-alias fix, none touches a formula):
      a cached .npy instead -- so cell 8 takes the notebook's own serial branch, selected by the notebook's own flag.
   8. Theory notebook cell 0 (``sys.path.append(os.chdir(...))``, imports) is replaced by the equivalent imports.
 
-Run from the repo root:  python tests/golden/make_notebook_golden.py      (about 3 minutes, 8 processes for cell 5)
+Round 3 -- the notebook's own INTEGERS.  The comparison above is statistical (the notebook is all-double, its weights
+are quantised from a double wavelength): it cannot see a 1e-4 scale error.  To pin a2 / a3 / a8 to fp32 rounding, the
+integers the notebook itself used are captured while its cells run, with no formula touched:
+  * ``A * 127`` for all 256 frequencies (exactly integer: asserted) -> ``nb2d_A127`` int8 [freq][beam][ant][re,im];
+  * every ``np.round(7 * exp(...))`` of cell 8 -- the quantised signal of every (frequency, source, antenna) -- through a
+    recording proxy for the name ``np`` in the cell namespace (``np.round`` is the only numpy call of cell 8 that it
+    intercepts; everything else is forwarded) -> packed 4-bit bytes [source][freq][ant].
+They are stored as: the full A127 (xz-compressed inside the .npz would not pay: stored as the difference to the oracle's
+``make_weights`` -- a handful of entries -- plus the SHA-256 of the full array, which the test re-checks after
+reconstruction), the full signal catalogue the same way (difference to ``generate_test_data`` + SHA-256), and the raw
+signals of 16 sources so that a reader can check the reconstruction without the oracle.  ``nb2d_out`` (already stored) is
+the matching output.  tests/test_oracle.py / tests/test_gpu_round3.py feed THESE integers to the oracle and to the HIP path.
+
+Run from the repo root:  python tests/golden/make_notebook_golden.py      (about 5 minutes, 8 processes for cell 5)
 """
 import json
 import os
@@ -79,6 +92,27 @@ def run_cells(mod, nb_name, indices):
         exec(compile(src, "%s[cell %d]" % (nb_name, idx), "exec"), mod.__dict__)
 
 
+class RoundRecorder:
+    """Stands in for the name `np` in cell 8's namespace: forwards everything to numpy, and records the result of every
+    np.round call (cell 8 calls it once per (frequency, source, antenna), in that loop order) as a complex integer."""
+
+    def __init__(self, n):
+        self.re = np.zeros(n, np.int8)
+        self.im = np.zeros(n, np.int8)
+        self.n = 0
+
+    def __getattr__(self, name):
+        return getattr(np, name)
+
+    def round(self, x):
+        r = np.round(x)
+        assert r.real == int(r.real) and r.imag == int(r.imag) and abs(r.real) <= 7 and abs(r.imag) <= 7
+        self.re[self.n] = int(r.real)
+        self.im[self.n] = int(r.imag)
+        self.n += 1
+        return r
+
+
 def main():
     os.environ["MPLBACKEND"] = "Agg"                                # 6
     import matplotlib
@@ -96,14 +130,22 @@ def main():
     assert m2.multiproc == 1 and m2.A.dtype == np.complex128 and m2.A.shape == (256, 256, 64)
     sum_a = complex(np.sum(m2.A))                                   # cell 6 is the bare expression np.sum(A)
     m2.multiproc = 0                                                # 7
+    rec = RoundRecorder(256 * 1024 * 64)
+    m2.np = rec                                                     # cell 8 sees numpy through the recorder
     devnull = open(os.devnull, "w")
     stdout, sys.stdout = sys.stdout, devnull                        # cell 8 prints one line per (freq, source)
     try:
         run_cells(m2, nb, [8])
     finally:
         sys.stdout = stdout
+    m2.np = np
     out2d = np.array(m2.out, dtype=np.float64)
     assert out2d.shape == (256, 1024) and m2.N_AVERAGING == 1 and m2.Antenna_positions == "Linear"
+    assert rec.n == 256 * 1024 * 64, rec.n                          # one np.round per (frequency k, source jj, antenna i)
+    sig_re = rec.re.reshape(256, 1024, 64).transpose(1, 0, 2)       # -> [source][freq][ant]
+    sig_im = rec.im.reshape(256, 1024, 64).transpose(1, 0, 2)
+    nb_packed = ((sig_re.astype(np.uint8) << 4) | (sig_im.astype(np.uint8) & 0x0F)).astype(np.uint8)   # (re << 4) | (im & 15)
+    nb_packed = np.ascontiguousarray(nb_packed)
     last_signal = np.array(m2.signal)                               # source 1023 at frequency 255 (last loop iteration)
     a127 = np.round(m2.A * 127.0)                                   # the integers the notebook divided by 127
     assert np.abs(a127 / 127.0 - m2.A).max() < 1e-15
@@ -119,6 +161,28 @@ def main():
     def cplx_i8(x):   # complex integers -> int8 [..., 2]
         return np.stack([x.real, x.imag], axis=-1).astype(np.int8)
 
+    # ---- the notebook's integers against the C++ path's (the oracle's restatement of a5 / a6), whole catalogue ----------
+    import hashlib
+
+    sys.path.insert(0, os.path.join(HERE, "..", ".."))
+    import oracle as orc
+
+    cfg_dir = os.path.join(HERE, "config")
+    pos = orc.read_positions(os.path.join(cfg_dir, "linear_positions.txt"), 64)
+    dirs = orc.read_directions(os.path.join(cfg_dir, "linear_directions.txt"), 256)
+    src = orc.read_directions(os.path.join(cfg_dir, "linear_source_directions_1024.txt"))
+    g = orc.DEBUG_GEOM
+    nb_w = np.ascontiguousarray(cplx_i8(a127).transpose(0, 2, 1, 3))             # [freq][beam][ant][2] -> [f][a][b][2]
+    orc_w = orc.make_weights(g, pos, dirs, 0)
+    w_idx = np.flatnonzero(nb_w.reshape(-1) != orc_w.reshape(-1)).astype(np.int64)
+    batch = orc.generate_test_data(g, pos, src, 0, 0, 1024)                      # [1024][f][t][a], all t columns identical
+    orc_packed = np.ascontiguousarray(batch[:, :, 0, :])                         # [source][freq][ant]
+    assert all(np.array_equal(batch[:, :, t, :], orc_packed) for t in range(1, g.n_time))
+    s_idx = np.flatnonzero(nb_packed.reshape(-1) != orc_packed.reshape(-1)).astype(np.int64)
+    sample_src = np.array([0, 1, 100, 255, 256, 333, 400, 511, 512, 513, 640, 700, 767, 768, 1000, 1023])
+    print("A*127: %d of %d int8 entries differ from the C++ weights; signals: %d of %d bytes differ from generate_test_data"
+          % (len(w_idx), nb_w.size, len(s_idx), nb_packed.size))
+
     np.savez_compressed(
         os.path.join(HERE, "notebook_linear.npz"),
         nb2d_out=out2d,                                             # out[beam, source], float64, sum over 256 freqs
@@ -128,6 +192,12 @@ def main():
         nb2d_pos=np.array(m2.pos, dtype=np.float64), nb2d_theta=np.array(m2.theta, dtype=np.float64),
         nb2d_source_angles=np.array(m2.T_angles, dtype=np.float64),
         nb2d_signal_src1023_f255=cplx_i8(last_signal),
+        # round 3: the notebook's integers over the whole catalogue, as differences to the oracle + SHA-256 of the full arrays
+        nb2d_A127_sha256=np.frombuffer(hashlib.sha256(nb_w.tobytes()).digest(), np.uint8),          # of [f][a][b][re,im] int8
+        nb2d_A127_diff_index=w_idx, nb2d_A127_diff_value=nb_w.reshape(-1)[w_idx],
+        nb2d_packed_sha256=np.frombuffer(hashlib.sha256(nb_packed.tobytes()).digest(), np.uint8),  # of [source][f][a] uint8
+        nb2d_packed_diff_index=s_idx, nb2d_packed_diff_value=nb_packed.reshape(-1)[s_idx],
+        nb2d_packed_sample_sources=sample_src, nb2d_packed_sample=nb_packed[sample_src],            # raw, 16 sources
         theory_out=out_theory.astype(np.float32),                   # float32 is 1e-4 of the tolerance it is used at
         theory_sum_A=np.array([complex(np.sum(mt.A)).real, complex(np.sum(mt.A)).imag]),
     )

@@ -389,18 +389,36 @@ def test_shm_ring_in_process_backpressure(host):
         ring.unlink()
 
 
-def test_dm_trials_and_delays_match_oracle_and_notebook_values(host, orc):
-    """8f-4: host mirror == oracle, and both == the values the notebook's own formulas give (fixture generated by
-    tests/golden/make_golden.py restating sandbox/Dispersion Theory.ipynb cells 1, 2, 5 in numpy)."""
-    gold = json.load(open(os.path.join(GOLDEN, "golden.json")))["dispersion"]
+def test_dm_trials_and_delays_match_the_executed_dispersion_notebook(host, orc):
+    """8f-4, pinned by EXECUTION: tests/golden/make_dispersion_golden.py runs cells 1, 2 and 5 of the
+    reference's sandbox/Dispersion Theory.ipynb as they stand and stores what they produced -- the whole 1627-trial DM ladder
+    and the 2048 per-channel sample delays of the cell's DM-2000 pulse (read out twice: from the cell's int() calls and
+    from the pulse positions left in its array C).  Host mirror == oracle == the notebook."""
+    nb = np.load(os.path.join(GOLDEN, "dispersion_notebook.npz"))
     dms = host.dm_trials()
     assert np.array_equal(dms, orc.dm_trials())
-    assert len(dms) == gold["n_trials"] and dms[1] == gold["dm1"] and dms[-1] == gold["dm_last"]
-    freq = np.array([1.28 + (1.53 - 1.28) / 2048 * i for i in range(2048)], np.float32)
-    d = host.dm_delays([2000.0, 56.5], freq, 1.53, 0.131 * 16)
-    assert np.array_equal(d, orc.dm_delays(np.array([2000.0, 56.5]), freq, 1.53, 0.131 * 16))
-    assert d[0, 0] == gold["delay_dm2000_chan0"] and int(d[0].sum()) == gold["delay_dm2000_sum"]
+    assert len(dms) == len(nb["dms"]) == 1627                          # "Number of trials = 1627" in the committed notebook
+    # the ladder is a 1626-step recurrence in double; C and numpy group two products differently (x*d*d vs x*d**2):
+    # agreement to a few units in the last place at every step, identical trial count
+    assert np.abs(dms[1:] / nb["dms"][1:] - 1).max() <= 1e-13 and dms[0] == nb["dms"][0] == 0.0
+    n_chan, _eps, _nu, _b, _ti, _tscat, _tsamp = nb["constants"]
+    assert (n_chan, _eps, _ti, _tscat, _tsamp) == (2048, 1.25, 40.0, 0.0, 131.0)      # the defaults of dm_trials are cell 1
+    # cell 5: channel i sits at 1.28 + 0.25/2048*i GHz, reference 1.53 GHz, 0.131*16 ms samples, DM 2000
+    freq64 = np.array([1.28 + (1.53 - 1.28) / 2048 * i for i in range(2048)])
+    assert float(nb["f_ref_ghz"][0]) == 1.53 and abs(float(nb["d_over_dm"][0]) - 4.15) < 1e-15
+    # the delay law itself, in double on the notebook's own real numbers: exact
+    law = 4.15 * 2000.0 * (-1.53 ** -2 + freq64 ** -2) / float(nb["tsamp_ms"][0])
+    assert np.abs(law - nb["delay_args_dm2000"]).max() <= 1e-9 and np.array_equal(law.astype(np.int32), nb["delays_dm2000"])
+    # the product's / oracle's table type is float32 (src/beamformer.hh: `float` frequencies): a channel whose real delay
+    # lies within float32 rounding of an integer may truncate the other way -- never by more than one sample
+    d = host.dm_delays([2000.0, 56.5], freq64.astype(np.float32), 1.53, float(nb["tsamp_ms"][0]))
+    assert np.array_equal(d, orc.dm_delays(np.array([2000.0, 56.5]), freq64.astype(np.float32), 1.53, float(nb["tsamp_ms"][0])))
+    diff = d[0] - nb["delays_dm2000"]
+    assert np.abs(diff).max() <= 1 and np.count_nonzero(diff) <= 4, np.count_nonzero(diff)
+    frac = nb["delay_args_dm2000"] - np.floor(nb["delay_args_dm2000"])
+    assert all(min(frac[i], 1 - frac[i]) < 1e-4 for i in np.flatnonzero(diff))      # only where the real number is at an edge
     assert d[:, -1].tolist() == [0, 0] and (np.diff(d[0]) <= 0).all()
+    assert int(nb["delays_dm2000"][0]) == 725 and int(nb["delays_dm2000"].sum()) == 675987
     # a different ladder (coarser channels, shorter span)
     assert np.array_equal(host.dm_trials(5.0, 300.0, 256, 1.5, 1.4, 0.9765625, 20.0, 5.0, 65.5),
                           orc.dm_trials(5.0, 300.0, 256, 1.5, 1.4, 0.9765625, 20.0, 5.0, 65.5))
