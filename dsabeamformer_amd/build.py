@@ -22,6 +22,12 @@ HIPCC = os.environ.get("HIPCC") or shutil.which("hipcc") or "/opt/rocm/bin/hipcc
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize", "-Wall",
          "-Wno-unused-function", "-mllvm", "-amdgpu-sched-strategy=" + os.environ.get("DSABF_SCHED", "max-ilp"),
          "-I" + os.path.join(ROOT, "include")] + os.environ.get("DSABF_EXTRA_FLAGS", "").split()
+# Optional: the real PSRDADA input adapter (csrc/bf_dada.cpp).  libpsrdada is not in this image, so it is off
+# by default; DSABF_WITH_PSRDADA=1 [PSRDADA_INCLUDE=dir PSRDADA_LIB=dir] builds it and links -lpsrdada (makefile:5-6,13).
+WITH_PSRDADA = os.environ.get("DSABF_WITH_PSRDADA") == "1"
+if WITH_PSRDADA:
+    FLAGS += ["-DDSABF_WITH_PSRDADA"] + (["-I" + os.environ["PSRDADA_INCLUDE"]] if os.environ.get("PSRDADA_INCLUDE") else [])
+PSRDADA_LINK = ((["-L" + os.environ["PSRDADA_LIB"]] if os.environ.get("PSRDADA_LIB") else []) + ["-lpsrdada"]) if WITH_PSRDADA else []
 
 
 BEAM = os.path.join(PKG, "beam")                      # the `beam` CLI driver (reference: bin/beam)
@@ -91,7 +97,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     cxx = os.path.join(os.path.dirname(os.path.realpath(HIPCC)), "..", "lib", "llvm", "bin", "clang++")
     if not os.path.exists(cxx):
         cxx = shutil.which("g++") or "g++"
-    cmd = [cxx, "-shared", "-fPIC", "-o", LIB] + objs + ["-lpthread", "-lrt"]
+    cmd = [cxx, "-shared", "-fPIC", "-o", LIB] + objs + ["-lpthread", "-lrt"] + PSRDADA_LINK
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
@@ -103,7 +109,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
             cmd = [shutil.which("g++") or "g++", "-O2", "-std=c++17", src, "-o", exe]
         else:
             cmd = [HIPCC, "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "include"), src, "-o", exe, "-L" + PKG, "-ldsabf",
-                   "-Wl,-rpath,$ORIGIN"]
+                   "-Wl,-rpath,$ORIGIN"] + (["-DDSABF_WITH_PSRDADA"] if WITH_PSRDADA else [])
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

@@ -147,6 +147,18 @@ int main(int argc, char* argv[])
             default_directions(pcfg.n_beams, dir.data());
         std::unique_ptr<block_source> src;
         observation_options oopt;
+#ifdef DSABF_WITH_PSRDADA
+        unsigned in_key = 0;
+        char trailing = 0;
+        if (!ring_key.empty() && sscanf(ring_key.c_str(), "%x%c", &in_key, &trailing) == 1) {   // -k baab: src/beamformer.cu:66-75
+            char name[] = "beam";
+            dada_block_source* s = new dada_block_source(name, core, in_key, std::cout);        // :132
+            src.reset(s);
+            if (!s->ok()) return EXIT_FAILURE;
+            s->expect_block_bytes(bf_bytes_per_block(&pcfg));
+            oopt.burn_in = kBurnIn;                                                              // BURNIN reads, :348-355
+        } else
+#endif
         if (!ring_key.empty()) {  // -k: blocks from the shared-memory ring (the PSRDADA stand-in), no burn-in reads
             shm_block_source* s = new shm_block_source(ring_key.c_str(), core, /*pin=*/true, std::cout);
             src.reset(s);

@@ -1,0 +1,263 @@
+// bf_dm_wide.hip -- DM-trial dedispersion, round-3 kernel: one workgroup = 32 trials x 16 output times x
+// 128 beams, the window of input rows SHARED by all 32 trials through LDS.
+//
+//   out[dm][t][b] = sum over f (ascending, fp32, from +0) of series[t + delay[dm][f]][f][b]
+//
+// Why a second kernel.  dedisperse_dm_kernel (bf_kernels.hip: 4 trials x 16 times per THREAD, a private LDS column per
+// thread) re-loads every input row once per block of 4 trials through the vector-memory path (64 B/clk/CU) and reads one
+// LDS dword per add (ds_read_b32: 128 B/clk/CU): 0.42-0.44 ms for 64 trials x 901 samples x 256 x 256, 0.094 of the HBM
+// roofline of its algorithmic bytes, LDS-bound (profiles/r02_dm_pmc_summary.txt).  Every add needs one 4-byte operand, so
+// what matters is where it comes from: global 16 adds/clk/CU, LDS b32 32, LDS b64/b128 64, registers 128 (the VALU).
+// Here
+//   * a row is fetched from global memory ONCE per workgroup and serves all 32 trials of the tile (reuse 32 x 16 /
+//     (16 + spread) instead of 4 x 16 / 24): the vector-memory path drops out of the picture;
+//   * a wave owns TWO trials, one per half-wave, x 4 beams per lane: one ds_read_b128 (256 B/clk/CU, against 128 for the
+//     b32 reads of the per-thread-window kernel) fetches row d_A + i for lanes 0-31 and row d_B + i for lanes 32-63 -- the
+//     trial's offset into the window is just part of the lane's LDS address, so there is no dynamic register index and no
+//     specialised code: 16 reads + 64 adds per channel and wave;
+//   * what binds is the LDS read rate: 16 waves x 16 reads x 4 cycles = 1024 cycles per channel and tile, twice the VALU
+//     time of the adds (4 waves per SIMD x 64 x 2 cycles).  (Letting the two trials of a pair SHARE the rows they have in
+//     common -- 16 + delta reads for both -- would halve that, but needs one unrolled body per delta; the compiler merges
+//     the bodies' common parts back together and spills: profiles/r03_variants_log.txt.)
+// The sum of one (trial, time, beam) still runs over ascending f in ONE register, one add per channel: the same bits as
+// dedisperse_dm_kernel and as the oracle (orc_dedisperse_dm).
+//
+// A trial group "fits" when, at every channel, the delays of its <= 32 trials span no more than the window holds
+// (dm_fit_kernel decides per group, on the device: the delays are device data).  Groups that
+// do not fit -- coarse or non-monotonic ladders, negative-going delays -- are left to dedisperse_dm_kernel, which skips the
+// groups this kernel took.
+#include "bf_kernels.h"
+
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+
+namespace dsabf {
+
+namespace {
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef int v2i __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+constexpr int kDwTb = 16;            // output times per tile
+constexpr int kDwWaves = 16;         // waves per workgroup, two trials each
+constexpr int kDwThreads = 64 * kDwWaves;
+constexpr int kDwBeams = 128;        // beams per tile: 4 per lane of a half-wave
+constexpr int kDwRowBytes = kDwBeams * 4;
+constexpr int kDwMaxRows = 128;      // rows per window buffer at most (the offset table holds bytes)
+#ifndef DSABF_DW_BATCH
+#define DSABF_DW_BATCH 4
+#endif
+constexpr int kDwBatch = DSABF_DW_BATCH;   // LDS reads per register set (x 4 registers); two sets alternate
+constexpr int kDwNbuf = 3;           // window buffers in LDS: channel f is consumed while f + 1 and f + 2 are landing
+constexpr int kDwPairsPerWave = kDwMaxRows / 2 / kDwWaves;   // LDS-DMA instructions (2 rows each) a wave issues per window at most
+constexpr int kDwLdsBytes = 160 * 1024;
+
+// LDS carve-up for n_freq channels: [offs: kDwTrials x n_freq bytes][{base, rows}: n_freq x 2 int][kDwNbuf window buffers]
+__host__ __device__ inline int dw_table_bytes(int n_freq) { return (n_freq * (kDwTrials + 8) + 511) & ~511; }
+__host__ __device__ inline int dw_rows_cap(int n_freq)
+{
+    const int r = ((kDwLdsBytes - dw_table_bytes(n_freq)) / (kDwNbuf * kDwRowBytes)) & ~1;   // even: a DMA moves two rows
+    return r > kDwMaxRows ? kDwMaxRows : r;
+}
+
+// flags[g] = 1 iff trial group g (trials [32 g, 32 g + 32)) can run dedisperse_dm_wide_kernel
+__global__ void dm_fit_kernel(const int* __restrict__ delays, int n_dm, int n_freq, int rows_cap, int* __restrict__ flags)
+{
+    const int dm0 = blockIdx.x * kDwTrials, nk = min(kDwTrials, n_dm - dm0);
+    int ok = 1;
+    for (int f = threadIdx.x; f < n_freq; f += blockDim.x) {
+        int lo = 0x7fffffff, hi = -0x7fffffff - 1;
+        for (int k = 0; k < nk; k++) {
+            const int d = delays[(size_t)(dm0 + k) * n_freq + f];
+            lo = min(lo, d);
+            hi = max(hi, d);
+        }
+        ok &= (long long)hi - lo + kDwTb <= rows_cap;
+    }
+    ok = __syncthreads_and(ok);
+    if (threadIdx.x == 0) flags[blockIdx.x] = ok;
+}
+
+__global__ __launch_bounds__(kDwThreads) void dedisperse_dm_wide_kernel(const float* __restrict__ series,
+                                                                        const int* __restrict__ delays,
+                                                                        const int* __restrict__ flags,
+                                                                        const float* __restrict__ zero_row, float* __restrict__ out,
+                                                                        int n_t, int n_freq, int n_beams, int n_t_out, int n_dm,
+                                                                        int rows_cap)
+{
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    unsigned char* offs = reinterpret_cast<unsigned char*>(lds);                         // [trial][f]: delay - base[f] (< 128)
+    v2i* tab = reinterpret_cast<v2i*>(lds + kDwTrials * n_freq);                          // [f] {smallest delay of the group, rows of the window}
+    char* win = lds + dw_table_bytes(n_freq);                                             // kDwNbuf x rows_cap x 512 B
+
+    // tile order: beam half fastest, then trial group, then time block; consecutive tiles on one XCD (they share rows)
+    const int n_g = (n_dm + kDwTrials - 1) / kDwTrials, n_y = (n_t_out + kDwTb - 1) / kDwTb;
+    const int n_bg = (n_beams + kDwBeams - 1) / kDwBeams;
+    const int per_xcd = gridDim.x / 8;
+    const int v = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+    if (v >= n_g * n_y * n_bg) return;
+    const int bg = v % n_bg, g = (v / n_bg) % n_g, ty = v / (n_bg * n_g);
+    if (!flags[g]) return;                               // dedisperse_dm_kernel takes this group
+    const int dm0 = g * kDwTrials, nk = min(kDwTrials, n_dm - dm0), t0 = ty * kDwTb;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // ---- tables: per channel the group's smallest delay and window height, per trial its offset into the window ----------
+    for (int f = tid; f < n_freq; f += kDwThreads) {
+        int lo = 0x7fffffff, hi = -0x7fffffff - 1;
+        for (int k = 0; k < nk; k++) {
+            const int d = delays[(size_t)(dm0 + k) * n_freq + f];
+            lo = min(lo, d);
+            hi = max(hi, d);
+        }
+        tab[f] = v2i{lo, hi - lo + kDwTb};
+        for (int k = 0; k < kDwTrials; k++)               // a missing trial repeats the last one (computed, never stored)
+            offs[k * n_freq + f] = (unsigned char)(delays[(size_t)(dm0 + min(k, nk - 1)) * n_freq + f] - lo);
+    }
+    __syncthreads();
+
+    // ---- staging by LDS-DMA (global_load_lds_dwordx4: 16 B per lane, 1 KiB = TWO window rows per wave instruction, no
+    // register on the way): wave w moves row pairs w, w + 16, ... of a window.  Rows outside the series -- and the beams
+    // behind the last one -- are fetched from a 512-byte row of zeros (they contribute +0).
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    const int bq = bg * kDwBeams + 4 * (lane & 31);       // this lane's four beams (n_beams % 4 == 0: all live or none)
+    const size_t row_stride = (size_t)n_freq * n_beams;
+    const int win_bytes = rows_cap * kDwRowBytes;
+    auto pairs_of = [&](v2i t) {                          // DMA instructions THIS wave issues for a window of t.y rows
+        const int np = (__builtin_amdgcn_readfirstlane(t.y) + 1) >> 1;
+        return np > wave ? (np - wave + kDwWaves - 1) / kDwWaves : 0;
+    };
+    const float* lane_src = series + bq;                  // + (row * n_freq + f) * n_beams
+    const float* lane_zero = zero_row + 4 * (lane & 31);
+    const bool beams_ok = bq < n_beams;
+    auto dma_window = [&](int f, v2i t) {                 // t = tab[f], already in registers
+        const int nr = __builtin_amdgcn_readfirstlane(t.y);
+        const int first = t0 + __builtin_amdgcn_readfirstlane(t.x);
+        const float* col = lane_src + (size_t)f * n_beams;
+        char* buf = win + (f % kDwNbuf) * win_bytes;
+#pragma unroll
+        for (int j = 0; j < kDwPairsPerWave; j++) {
+            const int pr = wave + kDwWaves * j;           // wave-uniform
+            if (2 * pr < nr) {
+                const int row = first + 2 * pr + (lane >> 5);
+                const bool ok = row >= 0 && row < n_t && beams_ok;
+                const float* src = ok ? col + (size_t)row * row_stride : lane_zero;
+                __builtin_amdgcn_global_load_lds(src, (lds_ptr)(buf + 2 * pr * kDwRowBytes), 16, 0, 0);
+            }
+        }
+    };
+    // The compiler must neither drain the DMA queue at a barrier (a fence would: vmcnt(0)) nor move LDS reads across one:
+    // raw s_barrier between compiler-level memory barriers, the waits written out.
+    auto wait_dma_but = [&](int newest) {                 // until at most `newest` of this wave's DMA instructions are in flight
+        switch (newest) {
+            case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+            case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+            case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        }
+    };
+    static_assert(kDwPairsPerWave <= 4, "wait_dma_but covers up to 4 instructions per window");
+    auto block_barrier = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's reads of the buffer about to be refilled are done
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+
+    // ---- the adds: half-wave h of wave w owns trial 2 w + h, 4 beams per lane, 16 output times -----------------------------
+    const int k_mine = 2 * wave + (lane >> 5);
+    const unsigned char* my_offs = offs + k_mine * n_freq;
+    const int lane_col = (lane & 31) * 16;
+    v4f acc[kDwTb];   // (float4 adds = 2 v_pk_add_f32: measured 5 % FASTER here than 4 scalar v_add_f32, profiles/r03_variants_log.txt)
+#pragma unroll
+    for (int i = 0; i < kDwTb; i++) acc[i] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
+
+    dma_window(0, tab[0]);
+    if (n_freq > 1) dma_window(1, tab[1]);
+    int off = my_offs[0];
+    v2i tnext = tab[min(2, n_freq - 1)];                  // the window the first iteration will fetch
+    wait_dma_but(0);
+    block_barrier();
+    static_assert(kDwTb == 4 * kDwBatch, "four batches of reads over two register sets");
+    for (int f = 0; f < n_freq; f++) {
+        const char* p = win + (f % kDwNbuf) * win_bytes + off * kDwRowBytes + lane_col;
+        v4f ra[kDwBatch], rb[kDwBatch];
+        auto rd = [&](v4f (&r)[kDwBatch], int h) {
+#pragma unroll
+            for (int i = 0; i < kDwBatch; i++) r[i] = *reinterpret_cast<const v4f*>(p + (h + i) * kDwRowBytes);
+        };
+        // `pin` fixes the order of the batches -- left alone the scheduler issues all 16 reads first (64 registers), spills,
+        // and the spill reloads drain the DMA queue (vmcnt(0)).
+        auto add_pin = [&](const v4f (&r)[kDwBatch], int h) {
+#pragma unroll
+            for (int i = 0; i < kDwBatch; i++) acc[h + i] = acc[h + i] + r[i];
+#pragma unroll
+            for (int i = 0; i < kDwBatch; i++) asm volatile("" : "+v"(acc[h + i]) : : "memory");
+        };
+        // The 16 waves leave the barrier together, so whatever a wave does before its first LDS data arrives is dead time for
+        // the whole CU: the data reads go first, the bookkeeping reads (next offset, the window after next) queue behind
+        // them, and the DMA of window f + 2 -- address arithmetic on values fetched one iteration ago -- is issued in their
+        // shadow.  Two register sets of kDwBatch rows then take turns.
+        rd(ra, 0);
+        rd(rb, kDwBatch);
+        const int off_next = my_offs[min(f + 1, n_freq - 1)];
+        const v2i tafter = tab[min(f + 3, n_freq - 1)];
+        // buffer (f+2) % 3 was last read in iteration f-1: every wave is past that iteration's barrier
+        const int newest = f + 2 < n_freq ? pairs_of(tnext) : 0;
+        if (f + 2 < n_freq) dma_window(f + 2, tnext);
+        add_pin(ra, 0);
+        rd(ra, 2 * kDwBatch);
+        add_pin(rb, kDwBatch);
+        rd(rb, 3 * kDwBatch);
+        add_pin(ra, 2 * kDwBatch);
+        add_pin(rb, 3 * kDwBatch);
+        off = off_next;
+        tnext = tafter;
+        wait_dma_but(newest);                             // this wave's pieces of window f + 1 have landed ...
+        block_barrier();                                  // ... and so have everybody else's
+    }
+
+    if (bq >= n_beams || k_mine >= nk) return;
+    float* o = out + ((size_t)(dm0 + k_mine) * n_t_out + t0) * n_beams + bq;
+#pragma unroll
+    for (int i = 0; i < kDwTb; i++)
+        if (t0 + i < n_t_out) *reinterpret_cast<v4f*>(o + (size_t)i * n_beams) = acc[i];
+}
+
+}  // namespace
+
+bool dm_wide_supported(const Geometry& g, int n_dm)
+{
+    return g.n_freq <= kDwMaxFreq && n_dm > 0 && (n_dm + kDwTrials - 1) / kDwTrials <= kDwMaxGroups;
+}
+
+// Decides per trial group (d_flags[g], kDwMaxGroups ints owned by the handle) and runs the wide kernel on the groups that fit.
+hipError_t launch_dedisperse_dm_wide(const Geometry& g, const float* d_series, int n_t, const int* d_delays, int n_dm,
+                                     int n_t_out, float* d_out, int* d_flags, hipStream_t s)
+{
+    const int n_g = (n_dm + kDwTrials - 1) / kDwTrials;
+    const int rows_cap = dw_rows_cap(g.n_freq);
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(dm_fit_kernel, dim3(n_g), dim3(256), 0, s, d_delays, n_dm, g.n_freq, rows_cap, d_flags);
+    const size_t tiles = (size_t)n_g * (size_t)((n_t_out + kDwTb - 1) / kDwTb) * (size_t)((g.n_beams + kDwBeams - 1) / kDwBeams);
+    if (tiles > (size_t)1 << 30) return hipErrorInvalidValue;
+    const int lds = dw_table_bytes(g.n_freq) + kDwNbuf * rows_cap * kDwRowBytes;
+    const float* zero_row = reinterpret_cast<const float*>(d_flags + kDwMaxGroups);   // 512 B of zeros behind the flags
+    static std::atomic<unsigned> done_mask{0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned bit = 1u << (dev & 31);
+    if (dev >= 32 || !(done_mask.load(std::memory_order_acquire) & bit)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(dedisperse_dm_wide_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, kDwLdsBytes);
+        if (e != hipSuccess) return e;
+        done_mask.fetch_or(bit, std::memory_order_release);
+    }
+    hipLaunchKernelGGL(dedisperse_dm_wide_kernel, dim3((unsigned)((tiles + 7) / 8 * 8)), dim3(kDwThreads), lds, s, d_series,
+                       d_delays, d_flags, zero_row, d_out, n_t, g.n_freq, g.n_beams, n_t_out, n_dm, rows_cap);
+    return hipGetLastError();
+}
+
+}  // namespace dsabf

@@ -62,8 +62,17 @@ hipError_t launch_dedisperse(const Geometry& g, const float* d_out_unit, float* 
 hipError_t launch_dedisperse_units(const Geometry& g, const float* d_out_units, size_t unit_stride, int n_units, float* d_ded,
                                    hipStream_t s);
 // out[dm][t][b] = sum_f series[t + delays[dm][f]][f][b]  (series: n_t beam-blocks [f][b]; t < n_t_out)
+// d_flags: kDmScratchBytes of scratch owned by the caller, its last 512 bytes zero (one per group of kDwTrials trials; NULL: the per-thread-window
+// kernel alone).  Groups whose delays fit run dedisperse_dm_wide_kernel (bf_dm_wide.hip), the rest dedisperse_dm_kernel.
 hipError_t launch_dedisperse_dm(const Geometry& g, const float* d_series, int n_t, const int* d_delays, int n_dm,
-                                int n_t_out, float* d_out, hipStream_t s);
+                                int n_t_out, float* d_out, int* d_flags, hipStream_t s);
+constexpr int kDwTrials = 32;        // trials per tile of the wide kernel (two per wave)
+constexpr int kDwMaxGroups = 4096;   // flag ints a caller provides ...
+constexpr size_t kDmScratchBytes = kDwMaxGroups * sizeof(int) + 512;   // ... followed by a 512-byte row of zeros (zero-filled by the caller)
+constexpr int kDwMaxFreq = 1024;     // channels the wide kernel's LDS tables hold
+bool dm_wide_supported(const Geometry& g, int n_dm);
+hipError_t launch_dedisperse_dm_wide(const Geometry& g, const float* d_series, int n_t, const int* d_delays, int n_dm,
+                                     int n_t_out, float* d_out, int* d_flags, hipStream_t s);
 
 int fused_vgprs(const Geometry& g);  // from hipFuncGetAttributes, for reports
 const char* fused_kernel_name(const Geometry& g, char* buf, size_t n);

@@ -154,7 +154,8 @@ constexpr int kDmMaxTableFreq = 1024;   // the trials' window offsets of a tile 
 
 __global__ __launch_bounds__(kDmThreads, 4) void dedisperse_dm_kernel(const float* __restrict__ series,
                                                                    const int* __restrict__ delays, float* __restrict__ out,
-                                                                   int n_t, int n_freq, int n_beams, int n_t_out, int n_dm)
+                                                                   int n_t, int n_freq, int n_beams, int n_t_out, int n_dm,
+                                                                   const int* __restrict__ taken)
 {
     __shared__ float win[kDmWin][kDmThreads];
     // XCD-aware tile order: workgroup L runs on XCD L % 8 (round-robin dispatch), and each XCD has its own L2.  The trial
@@ -166,6 +167,8 @@ __global__ __launch_bounds__(kDmThreads, 4) void dedisperse_dm_kernel(const floa
     const int v = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
     if (v >= n_x * n_y * ((n_beams + kDmThreads - 1) / kDmThreads)) return;
     const int dm0 = (v % n_x) * kDmBlock;
+    static_assert(kDwTrials % kDmBlock == 0, "a trial block lies inside one group of the wide kernel");
+    if (taken && taken[dm0 / kDwTrials]) return;   // dedisperse_dm_wide_kernel (bf_dm_wide.hip) has this trial group
     const int t0 = ((v / n_x) % n_y) * kDmTb;
     const int tid = threadIdx.x;
     const int b_raw = (v / (n_x * n_y)) * kDmThreads + tid;
@@ -588,9 +591,16 @@ hipError_t launch_dedisperse_units(const Geometry& g, const float* d_out_units, 
 }
 
 hipError_t launch_dedisperse_dm(const Geometry& g, const float* d_series, int n_t, const int* d_delays, int n_dm,
-                                int n_t_out, float* d_out, hipStream_t s)
+                                int n_t_out, float* d_out, int* d_flags, hipStream_t s)
 {
     if (n_dm <= 0 || n_t_out <= 0) return hipSuccess;
+    const char* env = getenv("DSABF_DM_WIDE");      // measurement / test switch: 0 = the per-thread-window kernel alone
+    const bool wide = d_flags && dm_wide_supported(g, n_dm) && !(env && env[0] == '0') &&
+                      !((uintptr_t)d_series & 7) && !((uintptr_t)d_out & 15);   // its 8-byte row loads / 16-byte stores
+    if (wide) {
+        hipError_t e = launch_dedisperse_dm_wide(g, d_series, n_t, d_delays, n_dm, n_t_out, d_out, d_flags, s);
+        if (e != hipSuccess) return e;
+    }
     clear_stale_error();
     if ((size_t)kDmWin * g.n_freq * g.n_beams * 4 >= ((size_t)1 << 32)) return hipErrorInvalidValue;   // SGPR row offsets are 32-bit
     const size_t tiles = (size_t)((n_dm + kDmBlock - 1) / kDmBlock) * (size_t)((n_t_out + kDmTb - 1) / kDmTb) *
@@ -599,7 +609,7 @@ hipError_t launch_dedisperse_dm(const Geometry& g, const float* d_series, int n_
     const dim3 grid((unsigned)((tiles + 7) / 8 * 8));    // a multiple of the 8 XCDs (see the kernel's tile order)
     const size_t table = g.n_freq <= kDmMaxTableFreq ? (size_t)g.n_freq * kDmBlock * sizeof(int) : 0;
     hipLaunchKernelGGL(dedisperse_dm_kernel, grid, dim3(kDmThreads), table, s, d_series, d_delays, d_out, n_t, g.n_freq,
-                       g.n_beams, n_t_out, n_dm);
+                       g.n_beams, n_t_out, n_dm, wide ? (const int*)d_flags : nullptr);
     return hipGetLastError();
 }
 

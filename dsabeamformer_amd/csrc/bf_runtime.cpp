@@ -36,6 +36,7 @@ struct bf_handle {
     uint8_t* d_data = nullptr;    // ring: n_blocks_on_gpu x bytes_per_block
     float* d_out = nullptr;       // n_streams x floats_per_detect
     float* d_ded = nullptr;       // n_streams x n_beams
+    int* d_dm_flags = nullptr;    // kDwMaxGroups ints: which trial groups the wide DM kernel takes (bf_dedisperse_dm_device)
     std::vector<float*> d_out_blk;  // per compute queue, n_gemms_per_block x floats_per_detect: bf_enqueue_block (lazy)
     std::vector<float*> d_ded_blk;  // per compute queue, n_gemms_per_block x n_beams: bf_enqueue_block_dedisperse (lazy)
     std::vector<float*> d_full_blk; // per compute queue, the gathered block (world x as large): bf_block_gather_device (lazy)
@@ -268,6 +269,7 @@ int bf_destroy(bf_handle* h)
     (void)hipFree(h->d_data);
     (void)hipFree(h->d_out);
     (void)hipFree(h->d_ded);
+    (void)hipFree(h->d_dm_flags);
     for (float* p : h->d_out_blk) (void)hipFree(p);
     for (float* p : h->d_full_blk) (void)hipFree(p);
     for (float* p : h->d_ded_blk) (void)hipFree(p);
@@ -657,13 +659,23 @@ int bf_dedisperse_device(bf_handle* h, const float* d_out_unit, float* d_ded, vo
     return BF_OK;
 }
 
+// scratch of the DM-trial dedispersion: kDwMaxGroups flag ints + one 512-byte row of zeros (dsabf::kDmScratchBytes)
+static hipError_t dm_scratch(bf_handle* h)
+{
+    if (h->d_dm_flags) return hipSuccess;
+    hipError_t e = hipMalloc((void**)&h->d_dm_flags, dsabf::kDmScratchBytes);
+    if (e == hipSuccess) e = hipMemset(h->d_dm_flags, 0, dsabf::kDmScratchBytes);
+    return e;
+}
+
 int bf_dedisperse_dm_device(bf_handle* h, const float* d_series, int n_t, const int32_t* d_delays, int n_dm, int n_t_out,
                             float* d_out, void* hip_stream)
 {
     if (!h || !d_series || !d_delays || !d_out) return fail(BF_ERR_INVALID, "NULL argument");
     if (n_t <= 0 || n_dm < 0 || n_t_out < 0 || n_t_out > n_t) return fail(BF_ERR_INVALID, "need 0 <= n_t_out <= n_t, n_dm >= 0");
     ON_DEVICE(h);
-    HIP_TRY(dsabf::launch_dedisperse_dm(h->geom, d_series, n_t, d_delays, n_dm, n_t_out, d_out, as_stream(hip_stream)));
+    HIP_TRY(dm_scratch(h));
+    HIP_TRY(dsabf::launch_dedisperse_dm(h->geom, d_series, n_t, d_delays, n_dm, n_t_out, d_out, h->d_dm_flags, as_stream(hip_stream)));
     return BF_OK;
 }
 
@@ -687,7 +699,8 @@ int bf_dedisperse_dm_band_device(bf_handle* h, const float* d_series, int n_t, i
     ON_DEVICE(h);
     dsabf::Geometry g = h->geom;
     g.n_freq = n_freq_total;
-    HIP_TRY(dsabf::launch_dedisperse_dm(g, d_series, n_t, d_delays, n_dm, n_t_out, d_out, as_stream(hip_stream)));
+    HIP_TRY(dm_scratch(h));
+    HIP_TRY(dsabf::launch_dedisperse_dm(g, d_series, n_t, d_delays, n_dm, n_t_out, d_out, h->d_dm_flags, as_stream(hip_stream)));
     return BF_OK;
 }
 

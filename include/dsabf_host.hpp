@@ -321,6 +321,39 @@ public:
     const char* get_header() const { return ring ? ring->get_header() : ""; }
 };
 
+#ifdef DSABF_WITH_PSRDADA
+// dada_handler itself (src/dada_handler.hh:1-177) on a real PSRDADA ring -- only in builds made with -DDSABF_WITH_PSRDADA
+// against libpsrdada (csrc/bf_dada.cpp).  Same constructor arguments as the reference (name, core, hex key), same
+// messages; errors that make the reference exit(-1) make ok() false / the loop's source fail instead.  No psrdada type
+// appears here: the hdu and the multilog are kept as opaque pointers.
+class dada_block_source : public block_source {
+    void* log = nullptr;      // multilog_t*
+    void* hdu_in = nullptr;   // dada_hdu_t*
+    std::ostream& out;
+    uint64_t header_size = 0, block_size = 0, bytes_read = 0, block_id = 0, expected_bytes = 0;
+    bool registered = false, failed = false;
+    void cleanup();           // dsaX_dbgpu_cleanup, :118-124
+    int dbregister();         // dada_cuda_dbregister, :127-158
+    int dbunregister();       // dada_cuda_dbunregister, :160-177
+
+public:
+    dada_block_source(const char* name, int core, unsigned in_key, std::ostream& log);   // :25-60
+    ~dada_block_source() override;                                                        // :62-64
+    dada_block_source(const dada_block_source&) = delete;
+    dada_block_source& operator=(const dada_block_source&) = delete;
+    bool ok() const { return hdu_in != nullptr && !failed; }
+    bool is_pinned() const { return registered; }
+    void expect_block_bytes(uint64_t n) { expected_bytes = n; }   // N_BYTES_PRE_EXPANSION_PER_BLOCK check, :101-103
+    bool close_releases_block() const override { return true; }   // ipcio_close_block_read hands the block back to the writer
+    void read_headers() override;                                  // :66-90
+    char* read() override;                                         // :92-94
+    void close() override;                                         // :96-98
+    bool check_transfers_complete() override;                      // :100-116
+    uint64_t get_block_size() const override { return block_size; }
+    uint64_t get_bytes_read() const override { return bytes_read; }
+};
+#endif
+
 // ---- detected-stream sink ---------------------------------------------------------------
 // The reference copies each gemm-unit's detected powers into beam_out[stream] and the next gemm-unit of that stream
 // overwrites them (src/beamformer.cu:485-488); "writing out ... has not yet been implemented" (README.md:149).  A sink

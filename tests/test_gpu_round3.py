@@ -184,3 +184,36 @@ def test_debug_flow_block_and_reference_launch_patterns_write_the_same_table(bfm
     assert np.array_equal(blk, golden) and np.array_equal(ref, golden)
     assert open(tmp_path / "a.py").read() == open(tmp_path / "b.py").read()
     print("DEBUG flow: block launches %.1f ms, reference pattern %.1f ms" % (ms_blk, ms_ref))
+
+
+def test_pulse_dispersed_with_the_notebooks_own_delays_is_recovered(torch, bfmod, orc):
+    """8f-4 end to end on what the reference's notebook produced: a pulse drawn with the 2048 per-channel delays that
+    sandbox/Dispersion Theory.ipynb cell 5 used for DM 2000 (tests/golden/dispersion_notebook.npz, captured by executing the
+    cell) into a [1000 sample][2048 channel] series, dedispersed over the last trials of the notebook's own ladder (cell 2)
+    plus the cell's DM-2000 delays themselves: the DM-2000 trial collects all 2048 channels at the pulse's start sample,
+    every ladder trial a step away collects fewer; the device result is the oracle's, bit for bit."""
+    from conftest import GOLDEN
+    from dsabeamformer_amd import host
+
+    nb = np.load(os.path.join(GOLDEN, "dispersion_notebook.npz"))
+    nb_delays = nb["delays_dm2000"].astype(np.int32)                      # channel i at 1.28 + 0.25/2048 i GHz
+    n_t, n_f, n_b, start = 1000, 2048, 16, 100                             # the cell's max_time, Nchan, start_index
+    freq = np.array([1.28 + (1.53 - 1.28) / 2048 * i for i in range(n_f)], np.float32)
+    ladder = nb["dms"][-6:]                                                # ... 1990.6, 1993.1, 1995.6, 1998.0, 2000.5
+    delays = np.concatenate([host.dm_delays(ladder, freq, 1.53, float(nb["tsamp_ms"][0])), nb_delays[None]]).astype(np.int32)
+    series = np.zeros((n_t, n_f, n_b), np.float32)
+    series[start + nb_delays, np.arange(n_f), :] = 1.0                     # what cell 5 draws (its += 2.0 without the noise)
+    cfg = bfmod.debug_config(n_beams=n_b, n_freq=n_f)
+    bf = bfmod.Beamformer(cfg)
+    n_t_out = n_t - int(delays.max())
+    d_out = torch.full((len(delays), n_t_out, n_b), float("nan"), dtype=torch.float32, device="cuda")
+    bf.dedisperse_dm(torch.from_numpy(series).cuda(), n_t, torch.from_numpy(delays).cuda(), len(delays), n_t_out, d_out,
+                     torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    got = d_out.cpu().numpy()
+    bf.close()
+    assert np.array_equal(got, orc.dedisperse_dm(series, delays, n_t_out))
+    assert got[-1, start, 0] == n_f and got[-1].max() == n_f               # every channel lands on the start sample
+    peaks = got[:-1].max(axis=(1, 2))
+    assert (peaks < n_f).all() and peaks.argmax() >= len(ladder) - 2        # the closest ladder trials come closest
+    assert np.array_equal(got[:-1].argmax(axis=1)[:, 0] >= start - 2, np.ones(len(ladder), bool))

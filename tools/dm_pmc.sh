@@ -19,7 +19,7 @@ for f in glob.glob(out + "/pass*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
         if "dedisperse_dm" not in k: continue
-        agg[k.split("(")[0][-70:]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        agg[k.replace("(anonymous namespace)::", "").split("(")[0][-70:]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 with open(out + "/summary.txt", "w") as fp:
     for k, d in agg.items():
         fp.write(k + "\n")
