@@ -739,11 +739,55 @@ def main():
                           "PCIe-bound either way; interleaved sweep over the launch granularities: profiles/r02_streaming.txt")
             out["streaming"] = st
 
+        def extras_dm():
+            # DM-trial dedispersion of a detected series -- an HBM-roofline kernel of its own (algorithmic
+            # bytes = the series once + the output once); 64 trials of the reference notebook's ladder to DM 250 over 1024
+            # beam-blocks of 256 x 256, the shape of tools/bench_stages.py / profiles/r0N_stage_kernels.json
+            from dsabeamformer_amd import host
+
+            n_t, n_dm = 1024, 64
+            freq = [host.channel_frequency(0, c) for c in range(256)]
+            ladder = host.dm_trials(dm_max=250.0)
+            dms = ladder[:: max(1, len(ladder) // n_dm)][:n_dm]
+            delays = host.dm_delays(dms, freq, freq[0], 0.131)
+            n_t_out = n_t - int(delays.max())
+            b2 = bfm.Beamformer(bfm.production_config(), device=local)
+            d_series = torch.rand(n_t * 256 * 256, device="cuda")
+            d_delays = torch.from_numpy(delays).cuda()
+            d_dd = torch.empty(len(dms) * n_t_out * 256, device="cuda")
+            rec = {}
+            for label, env in (("shared_window", None), ("per_thread_window_alone", "0")):
+                if env is not None:
+                    os.environ["DSABF_DM_WIDE"] = env
+                try:
+                    fn = lambda i: b2.dedisperse_dm(d_series, n_t, d_delays, len(dms), n_t_out, d_dd, sptr)  # noqa: E731
+                    for i in range(5):
+                        fn(i)
+                    avg, med, mn = time_launches(torch, fn, 30, stream)
+                finally:
+                    os.environ.pop("DSABF_DM_WIDE", None)
+                rec[label] = {"ms_avg": avg, "ms_median": med}
+            b2.close()
+            alg = 4 * (n_t * 256 * 256 + len(dms) * n_t_out * 256)
+            ms = rec["shared_window"]["ms_avg"]
+            rec.update({"workload": "%d DM trials (notebook ladder to DM 250) x %d output samples x 256 freq x 256 beams, series of %d "
+                                    "beam-blocks" % (len(dms), n_t_out, n_t),
+                        "roofline": {"bound": "hbm", "achieved": alg / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                     "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                                     "algorithmic_bytes_per_launch": alg,
+                                     "kernel": "dsabf::dedisperse_dm_wide_kernel (+ dm_fit_kernel; dedisperse_dm_kernel for "
+                                               "trial groups whose delays do not fit a window)"},
+                        "note": "not the headline; ascending-f fp32 sum per (trial, time, beam), bit-exact vs the oracle in both "
+                                "kernels; the delay law and the ladder are pinned by executing the reference's notebook "
+                                "(tests/golden/make_dispersion_golden.py)"})
+            out["dedisperse_dm"] = rec
+
         if world == 1 and args.detect == "canonical" and args.workload in ("c3", "prod") and not args.no_extras:
             guarded("general_kernel", extras_variants)
         if world == 1 and args.workload == "c3" and not args.no_extras:
             guarded("debug_geometry", extras_geometries)
             guarded("streaming", extras_streaming)
+            guarded("dedisperse_dm", extras_dm)
         if world == 1 and not args.no_cpu_baseline:
             print("bench.py: GPU part done; timing the CPU baselines on the host cores (~%.0f s) ..." % (args.cpu_seconds + 15),
                   file=sys.stderr, flush=True)

@@ -40,25 +40,32 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 typedef int v2i __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 
-constexpr int kDwTb = 16;            // output times per tile
-constexpr int kDwWaves = 16;         // waves per workgroup, two trials each
+#ifndef DSABF_DW_TB
+#define DSABF_DW_TB 16
+#endif
+constexpr int kDwTb = DSABF_DW_TB;   // output times per tile; x beams per lane = 64 accumulator registers
+constexpr int kDwBpl = 64 / kDwTb;   // beams per lane: 4 (ds_read_b128) or 2 (ds_read_b64), both 256 B/clk/CU
+static_assert(kDwTb == 16 || kDwTb == 32, "16 times x 4 beams or 32 times x 2 beams per lane");
+constexpr int kDwWaves = DSABF_DW_WAVES;   // waves per workgroup, two trials each
 constexpr int kDwThreads = 64 * kDwWaves;
-constexpr int kDwBeams = 128;        // beams per tile: 4 per lane of a half-wave
+constexpr int kDwBeams = 32 * kDwBpl; // beams per tile: a half-wave across
 constexpr int kDwRowBytes = kDwBeams * 4;
-constexpr int kDwMaxRows = 128;      // rows per window buffer at most (the offset table holds bytes)
+constexpr int kDwRowsPerDma = 1024 / kDwRowBytes;   // window rows one LDS-DMA instruction moves (16 B per lane, 1 KiB): 2 or 4
+typedef float vbf __attribute__((ext_vector_type(kDwBpl)));   // a lane's beams
+constexpr int kDwMaxRows = 4 * kDwRowsPerDma * kDwWaves < 224 ? 4 * kDwRowsPerDma * kDwWaves : 224;   // rows per window buffer at most (byte offsets; <= 4 DMAs per wave)
 #ifndef DSABF_DW_BATCH
 #define DSABF_DW_BATCH 4
 #endif
 constexpr int kDwBatch = DSABF_DW_BATCH;   // LDS reads per register set (x 4 registers); two sets alternate
 constexpr int kDwNbuf = 3;           // window buffers in LDS: channel f is consumed while f + 1 and f + 2 are landing
-constexpr int kDwPairsPerWave = kDwMaxRows / 2 / kDwWaves;   // LDS-DMA instructions (2 rows each) a wave issues per window at most
-constexpr int kDwLdsBytes = 160 * 1024;
+constexpr int kDwPairsPerWave = (kDwMaxRows / kDwRowsPerDma + kDwWaves - 1) / kDwWaves;   // LDS-DMA instructions a wave issues per window at most
+constexpr int kDwLdsBytes = 160 * 1024 / (16 / kDwWaves);   // the CU's LDS over the workgroups its 16 wave slots hold
 
 // LDS carve-up for n_freq channels: [offs: kDwTrials x n_freq bytes][{base, rows}: n_freq x 2 int][kDwNbuf window buffers]
 __host__ __device__ inline int dw_table_bytes(int n_freq) { return (n_freq * (kDwTrials + 8) + 511) & ~511; }
 __host__ __device__ inline int dw_rows_cap(int n_freq)
 {
-    const int r = ((kDwLdsBytes - dw_table_bytes(n_freq)) / (kDwNbuf * kDwRowBytes)) & ~1;   // even: a DMA moves two rows
+    const int r = ((kDwLdsBytes - dw_table_bytes(n_freq)) / (kDwNbuf * kDwRowBytes)) & ~(kDwRowsPerDma - 1);   // whole DMAs
     return r > kDwMaxRows ? kDwMaxRows : r;
 }
 
@@ -78,6 +85,29 @@ __global__ void dm_fit_kernel(const int* __restrict__ delays, int n_dm, int n_fr
     }
     ok = __syncthreads_and(ok);
     if (threadIdx.x == 0) flags[blockIdx.x] = ok;
+}
+
+// One lane's beams of one window row, as an explicit ds_read_b64 / ds_read_b128.  Left to itself the compiler fuses two
+// 8-byte reads of neighbouring rows into ds_read2_b64, which runs at HALF the LDS rate of ds_read_b64 (128 instead of
+// 256 B/clk/CU, MI355X_MICROARCH.md section LDS) -- and the LDS read rate is what this kernel's adds live on.  The compiler
+// does not see these reads in lgkmcnt: dw_wait<N>() below is the matching s_waitcnt, tied to the registers it releases.
+__device__ __forceinline__ void lds_row(vbf& v, const char* p)
+{
+    const unsigned a = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)p;
+    if constexpr (kDwBpl == 2)
+        asm volatile("ds_read_b64 %0, %1" : "=v"(v) : "v"(a) : "memory");
+    else
+        asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(a) : "memory");
+}
+// wait until at most N LDS operations issued AFTER the batch `r` are outstanding (LDS returns in order): r is then valid
+template <int N, int B>
+__device__ __forceinline__ void dw_wait(vbf (&r)[B])
+{
+    static_assert(B == 4 || B == 8, "batch");
+    if constexpr (B == 8)
+        asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]) : "n"(N) : "memory");
+    else
+        asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]) : "n"(N) : "memory");
 }
 
 __global__ __launch_bounds__(kDwThreads) void dedisperse_dm_wide_kernel(const float* __restrict__ series,
@@ -122,16 +152,18 @@ __global__ __launch_bounds__(kDwThreads) void dedisperse_dm_wide_kernel(const fl
     // register on the way): wave w moves row pairs w, w + 16, ... of a window.  Rows outside the series -- and the beams
     // behind the last one -- are fetched from a 512-byte row of zeros (they contribute +0).
     typedef __attribute__((address_space(3))) void* lds_ptr;
-    const int bq = bg * kDwBeams + 4 * (lane & 31);       // this lane's four beams (n_beams % 4 == 0: all live or none)
+    // staging lane: 16 B (4 beams) of row (lane / lanes-per-row) of the DMA's rows; n_beams % 4 == 0: all four live or none
+    constexpr int kLpr = kDwRowBytes / 16;                // lanes per row
+    const int bs = bg * kDwBeams + 4 * (lane % kLpr);
     const size_t row_stride = (size_t)n_freq * n_beams;
     const int win_bytes = rows_cap * kDwRowBytes;
     auto pairs_of = [&](v2i t) {                          // DMA instructions THIS wave issues for a window of t.y rows
-        const int np = (__builtin_amdgcn_readfirstlane(t.y) + 1) >> 1;
+        const int np = (__builtin_amdgcn_readfirstlane(t.y) + kDwRowsPerDma - 1) / kDwRowsPerDma;
         return np > wave ? (np - wave + kDwWaves - 1) / kDwWaves : 0;
     };
-    const float* lane_src = series + bq;                  // + (row * n_freq + f) * n_beams
-    const float* lane_zero = zero_row + 4 * (lane & 31);
-    const bool beams_ok = bq < n_beams;
+    const float* lane_src = series + bs;                  // + (row * n_freq + f) * n_beams
+    const float* lane_zero = zero_row + 4 * (lane % kLpr);
+    const bool beams_ok = bs < n_beams;
     auto dma_window = [&](int f, v2i t) {                 // t = tab[f], already in registers
         const int nr = __builtin_amdgcn_readfirstlane(t.y);
         const int first = t0 + __builtin_amdgcn_readfirstlane(t.x);
@@ -140,11 +172,11 @@ __global__ __launch_bounds__(kDwThreads) void dedisperse_dm_wide_kernel(const fl
 #pragma unroll
         for (int j = 0; j < kDwPairsPerWave; j++) {
             const int pr = wave + kDwWaves * j;           // wave-uniform
-            if (2 * pr < nr) {
-                const int row = first + 2 * pr + (lane >> 5);
+            if (kDwRowsPerDma * pr < nr) {
+                const int row = first + kDwRowsPerDma * pr + lane / kLpr;
                 const bool ok = row >= 0 && row < n_t && beams_ok;
                 const float* src = ok ? col + (size_t)row * row_stride : lane_zero;
-                __builtin_amdgcn_global_load_lds(src, (lds_ptr)(buf + 2 * pr * kDwRowBytes), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds(src, (lds_ptr)(buf + kDwRowsPerDma * pr * kDwRowBytes), 16, 0, 0);
             }
         }
     };
@@ -169,10 +201,11 @@ __global__ __launch_bounds__(kDwThreads) void dedisperse_dm_wide_kernel(const fl
     // ---- the adds: half-wave h of wave w owns trial 2 w + h, 4 beams per lane, 16 output times -----------------------------
     const int k_mine = 2 * wave + (lane >> 5);
     const unsigned char* my_offs = offs + k_mine * n_freq;
-    const int lane_col = (lane & 31) * 16;
-    v4f acc[kDwTb];   // (float4 adds = 2 v_pk_add_f32: measured 5 % FASTER here than 4 scalar v_add_f32, profiles/r03_variants_log.txt)
+    const int bq = bg * kDwBeams + kDwBpl * (lane & 31);  // this lane's beams in the adds (n_beams % 4 == 0 ...: all live or none
+    const int lane_col = (lane & 31) * 4 * kDwBpl;        //  -- for 2 per lane because bq is even and n_beams a multiple of 4)
+    vbf acc[kDwTb];   // (vector adds = v_pk_add_f32: measured 5 % FASTER here than scalar v_add_f32, profiles/r03_variants_log.txt)
 #pragma unroll
-    for (int i = 0; i < kDwTb; i++) acc[i] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
+    for (int i = 0; i < kDwTb; i++) acc[i] = vbf{};
 
     dma_window(0, tab[0]);
     if (n_freq > 1) dma_window(1, tab[1]);
@@ -180,17 +213,17 @@ __global__ __launch_bounds__(kDwThreads) void dedisperse_dm_wide_kernel(const fl
     v2i tnext = tab[min(2, n_freq - 1)];                  // the window the first iteration will fetch
     wait_dma_but(0);
     block_barrier();
-    static_assert(kDwTb == 4 * kDwBatch, "four batches of reads over two register sets");
+    static_assert(kDwTb % (2 * kDwBatch) == 0, "batches of reads alternate over two register sets");
     for (int f = 0; f < n_freq; f++) {
         const char* p = win + (f % kDwNbuf) * win_bytes + off * kDwRowBytes + lane_col;
-        v4f ra[kDwBatch], rb[kDwBatch];
-        auto rd = [&](v4f (&r)[kDwBatch], int h) {
+        vbf ra[kDwBatch], rb[kDwBatch];
+        auto rd = [&](vbf (&r)[kDwBatch], int h) {
 #pragma unroll
-            for (int i = 0; i < kDwBatch; i++) r[i] = *reinterpret_cast<const v4f*>(p + (h + i) * kDwRowBytes);
+            for (int i = 0; i < kDwBatch; i++) lds_row(r[i], p + (h + i) * kDwRowBytes);
         };
         // `pin` fixes the order of the batches -- left alone the scheduler issues all 16 reads first (64 registers), spills,
         // and the spill reloads drain the DMA queue (vmcnt(0)).
-        auto add_pin = [&](const v4f (&r)[kDwBatch], int h) {
+        auto add_pin = [&](const vbf (&r)[kDwBatch], int h) {
 #pragma unroll
             for (int i = 0; i < kDwBatch; i++) acc[h + i] = acc[h + i] + r[i];
 #pragma unroll
@@ -200,19 +233,29 @@ __global__ __launch_bounds__(kDwThreads) void dedisperse_dm_wide_kernel(const fl
         // the whole CU: the data reads go first, the bookkeeping reads (next offset, the window after next) queue behind
         // them, and the DMA of window f + 2 -- address arithmetic on values fetched one iteration ago -- is issued in their
         // shadow.  Two register sets of kDwBatch rows then take turns.
-        rd(ra, 0);
-        rd(rb, kDwBatch);
+        // (the bookkeeping reads are the compiler's own and come FIRST, so that every LDS operation after them is one of the
+        //  explicit row reads dw_wait counts)
         const int off_next = my_offs[min(f + 1, n_freq - 1)];
         const v2i tafter = tab[min(f + 3, n_freq - 1)];
+        asm volatile("" ::: "memory");
+        rd(ra, 0);
+        rd(rb, kDwBatch);
         // buffer (f+2) % 3 was last read in iteration f-1: every wave is past that iteration's barrier
         const int newest = f + 2 < n_freq ? pairs_of(tnext) : 0;
         if (f + 2 < n_freq) dma_window(f + 2, tnext);
-        add_pin(ra, 0);
-        rd(ra, 2 * kDwBatch);
-        add_pin(rb, kDwBatch);
-        rd(rb, 3 * kDwBatch);
-        add_pin(ra, 2 * kDwBatch);
-        add_pin(rb, 3 * kDwBatch);
+#pragma unroll
+        for (int h = 0; h < kDwTb; h += 2 * kDwBatch) {
+            dw_wait<kDwBatch>(ra);                        // rb's reads may still be in flight
+            add_pin(ra, h);
+            if (h + 2 * kDwBatch < kDwTb) {
+                rd(ra, h + 2 * kDwBatch);
+                dw_wait<kDwBatch>(rb);
+            } else {
+                dw_wait<0>(rb);
+            }
+            add_pin(rb, h + kDwBatch);
+            if (h + 3 * kDwBatch < kDwTb) rd(rb, h + 3 * kDwBatch);
+        }
         off = off_next;
         tnext = tafter;
         wait_dma_but(newest);                             // this wave's pieces of window f + 1 have landed ...
@@ -223,7 +266,7 @@ __global__ __launch_bounds__(kDwThreads) void dedisperse_dm_wide_kernel(const fl
     float* o = out + ((size_t)(dm0 + k_mine) * n_t_out + t0) * n_beams + bq;
 #pragma unroll
     for (int i = 0; i < kDwTb; i++)
-        if (t0 + i < n_t_out) *reinterpret_cast<v4f*>(o + (size_t)i * n_beams) = acc[i];
+        if (t0 + i < n_t_out) *reinterpret_cast<vbf*>(o + (size_t)i * n_beams) = acc[i];
 }
 
 }  // namespace

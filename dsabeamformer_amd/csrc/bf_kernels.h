@@ -66,7 +66,10 @@ hipError_t launch_dedisperse_units(const Geometry& g, const float* d_out_units, 
 // kernel alone).  Groups whose delays fit run dedisperse_dm_wide_kernel (bf_dm_wide.hip), the rest dedisperse_dm_kernel.
 hipError_t launch_dedisperse_dm(const Geometry& g, const float* d_series, int n_t, const int* d_delays, int n_dm,
                                 int n_t_out, float* d_out, int* d_flags, hipStream_t s);
-constexpr int kDwTrials = 32;        // trials per tile of the wide kernel (two per wave)
+#ifndef DSABF_DW_WAVES
+#define DSABF_DW_WAVES 16   // waves per workgroup of the shared-window DM kernel (8: two workgroups per CU)
+#endif
+constexpr int kDwTrials = 2 * DSABF_DW_WAVES;   // trials per tile of the wide kernel (two per wave)
 constexpr int kDwMaxGroups = 4096;   // flag ints a caller provides ...
 constexpr size_t kDmScratchBytes = kDwMaxGroups * sizeof(int) + 512;   // ... followed by a 512-byte row of zeros (zero-filled by the caller)
 constexpr int kDwMaxFreq = 1024;     // channels the wide kernel's LDS tables hold

@@ -217,3 +217,51 @@ def test_pulse_dispersed_with_the_notebooks_own_delays_is_recovered(torch, bfmod
     peaks = got[:-1].max(axis=(1, 2))
     assert (peaks < n_f).all() and peaks.argmax() >= len(ladder) - 2        # the closest ladder trials come closest
     assert np.array_equal(got[:-1].argmax(axis=1)[:, 0] >= start - 2, np.ones(len(ladder), bool))
+
+
+@pytest.mark.parametrize("case", ["fine_64", "ragged_beams_trials", "mixed_groups", "negative_and_tail", "tiny"])
+def test_shared_window_dm_kernel_bit_exact(torch, bfmod, orc, case, monkeypatch):
+    """The round-3 DM-trial kernel (csrc/bf_dm_wide.hip: 32 trials x 16 times x 128 beams per workgroup, windows staged by
+    LDS-DMA and shared by all trials) against the oracle and against the per-thread-window kernel alone (DSABF_DM_WIDE=0):
+    the same bits.  Cases: a fine ladder (every group fits); beams that do not fill the last 128-beam tile with a trial count
+    that does not fill the last pair / group; groups that fit next to groups that do not (the two kernels share one launch);
+    delays that start negative (rows before the series read +0) with outputs running past its end; a tiny problem."""
+    rng = np.random.default_rng(hash(case) % 1000)
+    if case == "fine_64":
+        n_t, n_f, n_b, n_dm = 300, 64, 256, 64
+        delays = np.sort(rng.integers(0, 40, size=(n_dm, n_f)), axis=0)
+        delays = np.sort(delays, axis=1)[:, ::-1].copy()
+    elif case == "ragged_beams_trials":
+        n_t, n_f, n_b, n_dm = 200, 48, 132, 37
+        delays = (np.arange(n_dm)[:, None] * np.linspace(1.5, 0, n_f)[None, :]).astype(np.int64)
+    elif case == "mixed_groups":
+        n_t, n_f, n_b, n_dm = 400, 32, 64, 96      # group 0 fine, group 1 far too coarse, group 2 fine
+        step = np.concatenate([np.full(32, 0.5), np.full(32, 9.0), np.full(32, 0.5)])
+        delays = (np.cumsum(step)[:, None] * np.linspace(1.0, 0.1, n_f)[None, :]).astype(np.int64)
+    elif case == "negative_and_tail":
+        n_t, n_f, n_b, n_dm = 150, 40, 128, 33
+        delays = (np.arange(n_dm)[:, None] * np.linspace(1.0, -0.5, n_f)[None, :]).astype(np.int64) - 7
+    else:
+        n_t, n_f, n_b, n_dm = 20, 4, 4, 3
+        delays = np.array([[0, 0, 0, 0], [2, 1, 1, 0], [5, 3, 2, 0]])
+    delays = np.ascontiguousarray(delays.astype(np.int32))
+    series = (rng.random((n_t, n_f, n_b), dtype=np.float32) * 1e4).astype(np.float32)
+    bf = bfmod.Beamformer(bfmod.debug_config(n_beams=n_b, n_freq=n_f))
+    d_series, d_delays = torch.from_numpy(series).cuda(), torch.from_numpy(delays).cuda()
+    s = torch.cuda.current_stream().cuda_stream
+    for n_t_out in sorted({max(1, n_t - int(delays.max())), n_t}):
+        want = orc.dedisperse_dm(series, delays, n_t_out)
+        got = {}
+        for mode in ("shared", "thread"):
+            if mode == "thread":
+                monkeypatch.setenv("DSABF_DM_WIDE", "0")
+            else:
+                monkeypatch.delenv("DSABF_DM_WIDE", raising=False)
+            d_out = torch.full((n_dm, n_t_out, n_b), float("nan"), dtype=torch.float32, device="cuda")
+            bf.dedisperse_dm(d_series, n_t, d_delays, n_dm, n_t_out, d_out, s)
+            torch.cuda.synchronize()
+            got[mode] = d_out.cpu().numpy()
+        monkeypatch.delenv("DSABF_DM_WIDE", raising=False)
+        assert np.array_equal(got["shared"], want), (case, n_t_out)
+        assert np.array_equal(got["thread"], want), (case, n_t_out)
+    bf.close()
