@@ -23,7 +23,7 @@
 // dedisperse_dm_kernel and as the oracle (orc_dedisperse_dm).
 //
 // A trial group "fits" when, at every channel, the delays of its <= 32 trials span no more than the window holds
-// (dm_fit_kernel decides per group, on the device: the delays are device data).  Groups that
+// (every tile decides for its group, on the device: the delays are device data).  Groups that
 // do not fit -- coarse or non-monotonic ladders, negative-going delays -- are left to dedisperse_dm_kernel, which skips the
 // groups this kernel took.
 #include "bf_kernels.h"
@@ -59,7 +59,8 @@ constexpr int kDwMaxRows = 4 * kDwRowsPerDma * kDwWaves < 224 ? 4 * kDwRowsPerDm
 constexpr int kDwBatch = DSABF_DW_BATCH;   // LDS reads per register set (x 4 registers); two sets alternate
 constexpr int kDwNbuf = 3;           // window buffers in LDS: channel f is consumed while f + 1 and f + 2 are landing
 constexpr int kDwPairsPerWave = (kDwMaxRows / kDwRowsPerDma + kDwWaves - 1) / kDwWaves;   // LDS-DMA instructions a wave issues per window at most
-constexpr int kDwLdsBytes = 160 * 1024 / (16 / kDwWaves);   // the CU's LDS over the workgroups its 16 wave slots hold
+constexpr int kDwLdsBytes = 160 * 1024 / (16 / kDwWaves) - 1024;   // the CU's LDS over the workgroups its 16 wave slots hold,
+                                                                   // less the static words of __syncthreads_and (256 B)
 
 // LDS carve-up for n_freq channels: [offs: kDwTrials x n_freq bytes][{base, rows}: n_freq x 2 int][kDwNbuf window buffers]
 __host__ __device__ inline int dw_table_bytes(int n_freq) { return (n_freq * (kDwTrials + 8) + 511) & ~511; }
@@ -67,24 +68,6 @@ __host__ __device__ inline int dw_rows_cap(int n_freq)
 {
     const int r = ((kDwLdsBytes - dw_table_bytes(n_freq)) / (kDwNbuf * kDwRowBytes)) & ~(kDwRowsPerDma - 1);   // whole DMAs
     return r > kDwMaxRows ? kDwMaxRows : r;
-}
-
-// flags[g] = 1 iff trial group g (trials [32 g, 32 g + 32)) can run dedisperse_dm_wide_kernel
-__global__ void dm_fit_kernel(const int* __restrict__ delays, int n_dm, int n_freq, int rows_cap, int* __restrict__ flags)
-{
-    const int dm0 = blockIdx.x * kDwTrials, nk = min(kDwTrials, n_dm - dm0);
-    int ok = 1;
-    for (int f = threadIdx.x; f < n_freq; f += blockDim.x) {
-        int lo = 0x7fffffff, hi = -0x7fffffff - 1;
-        for (int k = 0; k < nk; k++) {
-            const int d = delays[(size_t)(dm0 + k) * n_freq + f];
-            lo = min(lo, d);
-            hi = max(hi, d);
-        }
-        ok &= (long long)hi - lo + kDwTb <= rows_cap;
-    }
-    ok = __syncthreads_and(ok);
-    if (threadIdx.x == 0) flags[blockIdx.x] = ok;
 }
 
 // One lane's beams of one window row, as an explicit ds_read_b64 / ds_read_b128.  Left to itself the compiler fuses two
@@ -112,7 +95,7 @@ __device__ __forceinline__ void dw_wait(vbf (&r)[B])
 
 __global__ __launch_bounds__(kDwThreads) void dedisperse_dm_wide_kernel(const float* __restrict__ series,
                                                                         const int* __restrict__ delays,
-                                                                        const int* __restrict__ flags,
+                                                                        int* __restrict__ flags,
                                                                         const float* __restrict__ zero_row, float* __restrict__ out,
                                                                         int n_t, int n_freq, int n_beams, int n_t_out, int n_dm,
                                                                         int rows_cap)
@@ -129,12 +112,12 @@ __global__ __launch_bounds__(kDwThreads) void dedisperse_dm_wide_kernel(const fl
     const int v = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
     if (v >= n_g * n_y * n_bg) return;
     const int bg = v % n_bg, g = (v / n_bg) % n_g, ty = v / (n_bg * n_g);
-    if (!flags[g]) return;                               // dedisperse_dm_kernel takes this group
     const int dm0 = g * kDwTrials, nk = min(kDwTrials, n_dm - dm0), t0 = ty * kDwTb;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
     // ---- tables: per channel the group's smallest delay and window height, per trial its offset into the window ----------
+    int fits = 1;
     for (int f = tid; f < n_freq; f += kDwThreads) {
         int lo = 0x7fffffff, hi = -0x7fffffff - 1;
         for (int k = 0; k < nk; k++) {
@@ -143,10 +126,16 @@ __global__ __launch_bounds__(kDwThreads) void dedisperse_dm_wide_kernel(const fl
             hi = max(hi, d);
         }
         tab[f] = v2i{lo, hi - lo + kDwTb};
+        fits &= (long long)hi - lo + kDwTb <= rows_cap;
         for (int k = 0; k < kDwTrials; k++)               // a missing trial repeats the last one (computed, never stored)
             offs[k * n_freq + f] = (unsigned char)(delays[(size_t)(dm0 + min(k, nk - 1)) * n_freq + f] - lo);
     }
-    __syncthreads();
+    // Does the group fit -- at every channel, do the delays of its trials span no more than a window holds?  Every tile of
+    // the group reaches the same verdict from the same delays; one of them records it for dedisperse_dm_kernel, which runs
+    // behind this kernel on the same stream and takes the groups that do not fit.
+    fits = __syncthreads_and(fits);
+    if (ty == 0 && bg == 0 && tid == 0) flags[g] = fits;
+    if (!fits) return;
 
     // ---- staging by LDS-DMA (global_load_lds_dwordx4: 16 B per lane, 1 KiB = TWO window rows per wave instruction, no
     // register on the way): wave w moves row pairs w, w + 16, ... of a window.  Rows outside the series -- and the beams
@@ -276,14 +265,14 @@ bool dm_wide_supported(const Geometry& g, int n_dm)
     return g.n_freq <= kDwMaxFreq && n_dm > 0 && (n_dm + kDwTrials - 1) / kDwTrials <= kDwMaxGroups;
 }
 
-// Decides per trial group (d_flags[g], kDwMaxGroups ints owned by the handle) and runs the wide kernel on the groups that fit.
+// Runs the wide kernel on the trial groups that fit a window and records which did (d_flags[g], kDwMaxGroups ints owned by
+// the handle) for dedisperse_dm_kernel.
 hipError_t launch_dedisperse_dm_wide(const Geometry& g, const float* d_series, int n_t, const int* d_delays, int n_dm,
                                      int n_t_out, float* d_out, int* d_flags, hipStream_t s)
 {
     const int n_g = (n_dm + kDwTrials - 1) / kDwTrials;
     const int rows_cap = dw_rows_cap(g.n_freq);
     (void)hipGetLastError();
-    hipLaunchKernelGGL(dm_fit_kernel, dim3(n_g), dim3(256), 0, s, d_delays, n_dm, g.n_freq, rows_cap, d_flags);
     const size_t tiles = (size_t)n_g * (size_t)((n_t_out + kDwTb - 1) / kDwTb) * (size_t)((g.n_beams + kDwBeams - 1) / kDwBeams);
     if (tiles > (size_t)1 << 30) return hipErrorInvalidValue;
     const int lds = dw_table_bytes(g.n_freq) + kDwNbuf * rows_cap * kDwRowBytes;

@@ -488,6 +488,7 @@ LaunchShape fused_launch_shape(const Geometry& g, int n_units, int n_cus)
     ls.grid = base * ls.n_tsplit;
     ls.block = kThreads16;
     ls.lds_bytes = 2 * ksteps16(g) * kRowsPerChunk * 128;  // double buffer x k-step planes x 128 rows x (64 re | 64 im)
+    if (const char* e = getenv("DSABF_LDS_PAD")) ls.lds_bytes += atoi(e);   // measurement switch: fewer resident workgroups per CU
     return ls;
 }
 

@@ -32,7 +32,7 @@ rm -rf $O/prof_c5g
 unset DSABF_PAIRED
 # the DM-trial dedispersion: kernel trace + counters
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_dm -- python3 $R/tools/dm_one.py > $O/prof_dm.log 2>&1
-find $O/prof_dm -name "*kernel_stats.csv" | head -1 | xargs -I{} sh -c "grep -E 'Name|dedisperse|dm_fit' {} > $O/r03_dm_kernel_stats.csv"
+find $O/prof_dm -name "*kernel_stats.csv" | head -1 | xargs -I{} sh -c "grep -E 'Name|dedisperse' {} > $O/r03_dm_kernel_stats.csv"
 rm -rf $O/prof_dm
 (cd $R && bash tools/dm_pmc.sh r03p/pmc_dm > /dev/null 2>&1 && cp $O/pmc_dm/summary.txt $O/r03_dm_pmc_summary.txt; rm -rf $O/pmc_dm)
 cd $R; rm -f $O/*.log; ls -la $O
