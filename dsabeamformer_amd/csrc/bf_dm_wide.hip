@@ -150,21 +150,29 @@ __global__ __launch_bounds__(kDwThreads) void dedisperse_dm_wide_kernel(const fl
         const int np = (__builtin_amdgcn_readfirstlane(t.y) + kDwRowsPerDma - 1) / kDwRowsPerDma;
         return np > wave ? (np - wave + kDwWaves - 1) / kDwWaves : 0;
     };
-    const float* lane_src = series + bs;                  // + (row * n_freq + f) * n_beams
+    // Addressing is split so that the per-lane part is loop-invariant: lane_src already holds the lane's row inside a DMA
+    // (lane / lanes-per-row) and its beams; what changes per DMA -- first row of the piece, channel -- is wave-uniform and
+    // stays on the scalar unit (a per-lane row * stride would be two quarter-rate 64-bit multiplies per instruction).  The
+    // common case -- every row of the piece inside the series, every beam live -- needs no per-lane test either.
+    const float* lane_src = series + (size_t)(lane / kLpr) * row_stride + bs;
     const float* lane_zero = zero_row + 4 * (lane % kLpr);
     const bool beams_ok = bs < n_beams;
-    auto dma_window = [&](int f, v2i t) {                 // t = tab[f], already in registers
+    const bool all_beams_ok = __builtin_amdgcn_readfirstlane((int)__all(beams_ok ? 1 : 0)) != 0;   // wave-uniform
+    auto dma_window = [&](int f, int slot, v2i t) {       // t = tab[f], already in registers; slot = f % kDwNbuf
         const int nr = __builtin_amdgcn_readfirstlane(t.y);
         const int first = t0 + __builtin_amdgcn_readfirstlane(t.x);
-        const float* col = lane_src + (size_t)f * n_beams;
-        char* buf = win + (f % kDwNbuf) * win_bytes;
+        const size_t col = (size_t)f * n_beams;           // uniform
+        char* buf = win + slot * win_bytes;
 #pragma unroll
         for (int j = 0; j < kDwPairsPerWave; j++) {
             const int pr = wave + kDwWaves * j;           // wave-uniform
             if (kDwRowsPerDma * pr < nr) {
-                const int row = first + kDwRowsPerDma * pr + lane / kLpr;
-                const bool ok = row >= 0 && row < n_t && beams_ok;
-                const float* src = ok ? col + (size_t)row * row_stride : lane_zero;
+                const int row0 = first + kDwRowsPerDma * pr;                       // uniform: first row of this piece
+                const float* src = lane_src + ((long long)row0 * (long long)row_stride + (long long)col);
+                if (!(all_beams_ok && row0 >= 0 && row0 + kDwRowsPerDma <= n_t)) {   // an end of the series / of the beams
+                    const int row = row0 + lane / kLpr;
+                    if (!(row >= 0 && row < n_t && beams_ok)) src = lane_zero;
+                }
                 __builtin_amdgcn_global_load_lds(src, (lds_ptr)(buf + kDwRowsPerDma * pr * kDwRowBytes), 16, 0, 0);
             }
         }
@@ -196,15 +204,16 @@ __global__ __launch_bounds__(kDwThreads) void dedisperse_dm_wide_kernel(const fl
 #pragma unroll
     for (int i = 0; i < kDwTb; i++) acc[i] = vbf{};
 
-    dma_window(0, tab[0]);
-    if (n_freq > 1) dma_window(1, tab[1]);
+    dma_window(0, 0, tab[0]);
+    if (n_freq > 1) dma_window(1, 1 % kDwNbuf, tab[1]);
     int off = my_offs[0];
     v2i tnext = tab[min(2, n_freq - 1)];                  // the window the first iteration will fetch
     wait_dma_but(0);
     block_barrier();
     static_assert(kDwTb % (2 * kDwBatch) == 0, "batches of reads alternate over two register sets");
+    int slot = 0, slot2 = 2 % kDwNbuf;                    // ring positions of channel f and of channel f + 2
     for (int f = 0; f < n_freq; f++) {
-        const char* p = win + (f % kDwNbuf) * win_bytes + off * kDwRowBytes + lane_col;
+        const char* p = win + slot * win_bytes + off * kDwRowBytes + lane_col;
         vbf ra[kDwBatch], rb[kDwBatch];
         auto rd = [&](vbf (&r)[kDwBatch], int h) {
 #pragma unroll
@@ -219,19 +228,18 @@ __global__ __launch_bounds__(kDwThreads) void dedisperse_dm_wide_kernel(const fl
             for (int i = 0; i < kDwBatch; i++) asm volatile("" : "+v"(acc[h + i]) : : "memory");
         };
         // The 16 waves leave the barrier together, so whatever a wave does before its first LDS data arrives is dead time for
-        // the whole CU: the data reads go first, the bookkeeping reads (next offset, the window after next) queue behind
-        // them, and the DMA of window f + 2 -- address arithmetic on values fetched one iteration ago -- is issued in their
-        // shadow.  Two register sets of kDwBatch rows then take turns.
-        // (the bookkeeping reads are the compiler's own and come FIRST, so that every LDS operation after them is one of the
-        //  explicit row reads dw_wait counts)
+        // the whole CU: the bookkeeping reads (next offset, the window after next: the compiler's own, so they come FIRST and
+        // every LDS operation after them is one of the explicit row reads dw_wait counts) and the data reads go out at once,
+        // and the DMA of window f + 2 -- address arithmetic on values fetched one iteration ago -- is issued in their shadow.
+        // Two register sets of kDwBatch rows then take turns.
         const int off_next = my_offs[min(f + 1, n_freq - 1)];
         const v2i tafter = tab[min(f + 3, n_freq - 1)];
         asm volatile("" ::: "memory");
         rd(ra, 0);
         rd(rb, kDwBatch);
-        // buffer (f+2) % 3 was last read in iteration f-1: every wave is past that iteration's barrier
+        // ring slot of f + 2 was last read in iteration f - 1: every wave is past that iteration's barrier
         const int newest = f + 2 < n_freq ? pairs_of(tnext) : 0;
-        if (f + 2 < n_freq) dma_window(f + 2, tnext);
+        if (f + 2 < n_freq) dma_window(f + 2, slot2, tnext);
 #pragma unroll
         for (int h = 0; h < kDwTb; h += 2 * kDwBatch) {
             dw_wait<kDwBatch>(ra);                        // rb's reads may still be in flight
@@ -247,6 +255,8 @@ __global__ __launch_bounds__(kDwThreads) void dedisperse_dm_wide_kernel(const fl
         }
         off = off_next;
         tnext = tafter;
+        slot = slot + 1 == kDwNbuf ? 0 : slot + 1;
+        slot2 = slot2 + 1 == kDwNbuf ? 0 : slot2 + 1;
         wait_dma_but(newest);                             // this wave's pieces of window f + 1 have landed ...
         block_barrier();                                  // ... and so have everybody else's
     }
