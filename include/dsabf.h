@@ -200,8 +200,12 @@ int bf_dedisperse_device(bf_handle *h, const float *d_out_unit, float *d_ded, vo
 /* Incoherent dedispersion beyond DM 0 (the reference stops at the DM-0 sum above and sketches
  * the delay law in sandbox/Dispersion Theory.ipynb).  d_series: n_t consecutive beam-blocks [t][freq][beam] (the
  * detected stream is exactly that); d_delays: int32 [n_dm][freq] sample delays (dsabf::dm_delays / bfh_dm_delays);
- * d_out [n_dm][n_t_out][beam] = sum over freq, ascending, fp32, of d_series[t + delay][freq][beam]; rows >= n_t
- * contribute nothing, so size n_t_out = n_t - (largest delay) for complete sums. */
+ * d_out [n_dm][n_t_out][beam] = sum over freq, ascending, fp32, of d_series[t + delay][freq][beam]; rows outside [0, n_t)
+ * contribute nothing, so size n_t_out = n_t - (largest delay) for complete sums.  Groups of 32 consecutive trials whose
+ * delays, at every channel, span no more than ~100 samples (any fine DM ladder) run a kernel that fetches each window of
+ * input rows once for the whole group (csrc/bf_dm_wide.hip); other groups -- coarse or non-monotonic ladders -- a kernel with
+ * a window per thread; the result does not depend on which (one thread, one ascending-f sum either way).  Delays are read
+ * on the device: nothing about them has to be known to the host. */
 int bf_dedisperse_dm_device(bf_handle *h, const float *d_series, int n_t, const int32_t *d_delays, int n_dm, int n_t_out,
                             float *d_out, void *hip_stream);
 

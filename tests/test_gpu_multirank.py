@@ -165,9 +165,25 @@ def test_bench_with_two_ranks_on_one_gpu(fake_rccl, gather, n):
     d = json.loads(lines[0])
     assert d["n_gpus"] == n and d["config"]["freq_per_gpu"] == 256 // n and d["scaling"] == "strong"
     assert d["config"]["gather"].startswith(gather) and "C-ABI" in d["config"]["gather"] and "gather_note" not in d["config"]
+    # what the LIBRARY says about the communicator (bf_comm_info): as many ranks as the launcher started, and which file
+    assert d["rccl"]["ranks"] == n and d["rccl"]["lib"].endswith("libfakerccl.so") and d["rccl"]["version"] == 0
     modes = d["gather_modes"]
     for k in ("none", "root_rank_major", "root_freq_major", "alltoall_rank_major", "alltoall_freq_major"):
         assert "error" not in modes[k] and modes[k]["value"] > 0, (k, modes[k])
+
+
+def test_bench_exits_nonzero_when_the_communicator_cannot_be_created():
+    """a scaling line must never come from a second code path.  With an RCCL that cannot be loaded the
+    two-rank bench must FAIL (round 2 fell back to a torch.distributed gather and noted it in config.gather_note)."""
+    env = dict(os.environ, DSABF_RCCL_LIB="/nonexistent/librccl.so", DSABF_BENCH_ONE_GPU="1")
+    port = str(29900 + os.getpid() % 90)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", port, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
+                        "--warmup", "1", "--units", "4", "--dist-backend", "gloo", "--min-warm-seconds", "0.1",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode != 0
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]           # no line at all
+    assert "could not be loaded" in (r.stdout + r.stderr)
 
 
 @pytest.mark.parametrize("world", [1, 2, 4])
