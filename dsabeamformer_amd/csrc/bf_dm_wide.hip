@@ -126,7 +126,7 @@ __global__ __launch_bounds__(kDwThreads) void dedisperse_dm_wide_kernel(const fl
             hi = max(hi, d);
         }
         tab[f] = v2i{lo, hi - lo + kDwTb};
-        fits &= (long long)hi - lo + kDwTb <= rows_cap;
+        fits &= (long long)hi - lo + kDwTb <= rows_cap && lo > -(1 << 30) && hi < (1 << 30);   // (and row arithmetic stays in int)
         for (int k = 0; k < kDwTrials; k++)               // a missing trial repeats the last one (computed, never stored)
             offs[k * n_freq + f] = (unsigned char)(delays[(size_t)(dm0 + min(k, nk - 1)) * n_freq + f] - lo);
     }
