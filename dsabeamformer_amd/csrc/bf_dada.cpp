@@ -108,39 +108,49 @@ bool dada_block_source::check_transfers_complete()                 // :100-116
     return bytes_read < block_size;                                // short block: the observation ends
 }
 
-// dada_cuda_dbregister, :127-158: page-lock every data block of the ring (bf_host_register = hipHostRegister)
+// Page-locking of the ring's data blocks for DMA (the reference's dada_cuda_dbregister / dada_cuda_dbunregister,
+// src/dada_handler.hh:127-177, with hipHostRegister behind bf_host_register): one walk over the blocks serves both directions.
+// A ring whose blocks already live in device memory (ipcbuf_get_device >= 0) is left alone, as in the reference.
+static int for_each_ring_block(void* hdu_void, bool pin, uint64_t* done)
+{
+    ipcbuf_t* ring = reinterpret_cast<ipcbuf_t*>(static_cast<dada_hdu_t*>(hdu_void)->data_block);
+    if (ipcbuf_get_device(ring) >= 0) return 0;
+    const uint64_t n_blocks = ring->sync->nbufs;
+    const size_t block_bytes = ring->sync->bufsz;
+    for (uint64_t b = 0; b < n_blocks; b++) {
+        void* block = ring->buffer[b];
+        const int rc = pin ? bf_host_register(block, block_bytes) : bf_host_unregister(block);
+        if (rc != BF_OK) return -1;
+        if (done) *done = b + 1;
+    }
+    return 0;
+}
+
 int dada_block_source::dbregister()
 {
-    ipcbuf_t* db = (ipcbuf_t*)static_cast<dada_hdu_t*>(hdu_in)->data_block;
-    if (ipcbuf_lock(db) < 0) {                                     // ensure that the data blocks are SHM locked
+    ipcbuf_t* ring = reinterpret_cast<ipcbuf_t*>(static_cast<dada_hdu_t*>(hdu_in)->data_block);
+    if (ipcbuf_lock(ring) < 0) {                                   // the blocks must be locked in shared memory first (:131-134)
         perror("dada_dbregister: ipcbuf_lock failed\n");
         return -1;
     }
-    if (ipcbuf_get_device(db) >= 0) return 0;                      // dont register buffers if they reside on the device
-    const size_t bufsz = db->sync->bufsz;
-    for (uint64_t ibuf = 0; ibuf < db->sync->nbufs; ibuf++) {
-        if (bf_host_register((void*)db->buffer[ibuf], bufsz) != BF_OK) {
-            perror("dada_dbregister:  hipHostRegister failed\n");
-            for (uint64_t j = 0; j < ibuf; j++) bf_host_unregister((void*)db->buffer[j]);
-            return -1;
-        }
+    uint64_t pinned = 0;
+    if (for_each_ring_block(hdu_in, /*pin=*/true, &pinned) != 0) {
+        fprintf(stderr, "dada_dbregister: hipHostRegister failed: %s\n", bf_last_error());
+        for (uint64_t b = 0; b < pinned; b++) bf_host_unregister(ring->buffer[b]);   // leave nothing half-registered
+        return -1;
     }
     registered = true;
     return 0;
 }
 
-// dada_cuda_dbunregister, :160-177
 int dada_block_source::dbunregister()
 {
-    ipcbuf_t* db = (ipcbuf_t*)static_cast<dada_hdu_t*>(hdu_in)->data_block;
-    if (!registered || ipcbuf_get_device(db) >= 0) return 0;
-    for (uint64_t ibuf = 0; ibuf < db->sync->nbufs; ibuf++) {
-        if (bf_host_unregister((void*)db->buffer[ibuf]) != BF_OK) {
-            fprintf(stderr, "dada_dbunregister: hipHostUnregister failed: %s\n", bf_last_error());
-            return -1;
-        }
-    }
+    if (!registered) return 0;
     registered = false;
+    if (for_each_ring_block(hdu_in, /*pin=*/false, nullptr) != 0) {
+        fprintf(stderr, "dada_dbunregister: hipHostUnregister failed: %s\n", bf_last_error());
+        return -1;
+    }
     return 0;
 }
 

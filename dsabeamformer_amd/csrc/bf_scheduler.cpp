@@ -268,6 +268,8 @@ int run_debug_observation(const bf_config& cfg, const debug_run_options& opt, de
         if ((rc = bf_alloc_pinned(&pb, n_f_per_detect * (size_t)cfg.n_gemms_per_block * sizeof(float))) != BF_OK) return rc;
         g.pinned.push_back(pb);
         beam_out_blk[q] = static_cast<float*>(pb);
+        float* d_blk = nullptr;                        // and the queue's device-side block buffer (allocated at first use otherwise)
+        if ((rc = bf_block_output_device(h, q % n_streams, &d_blk)) != BF_OK) return rc;
     }
 
     hip_backend backend(h);
