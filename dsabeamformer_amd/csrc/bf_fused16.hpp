@@ -22,7 +22,7 @@
 #define DSABF_GEN3 1      // general weight image holds 3 fragments per tile (Wr, -Wi, Wi) instead of 4 (Wr, -Wi, Wi, Wr again)
 #endif
 #ifndef DSABF_OCC16
-#define DSABF_OCC16 3     // register budget of the 64-antenna variants (168): the general kernel needs 153 VGPRs; the paired
+#define DSABF_OCC16 3     // register budget of the 64-antenna variants (168): the general kernel needs 147 VGPRs; the paired
                           // one (101) reaches 4 workgroups per CU by itself; capping at 128 spills for no gain
 #endif
 
