@@ -22,8 +22,8 @@
 #define DSABF_GEN3 1      // general weight image holds 3 fragments per tile (Wr, -Wi, Wi) instead of 4 (Wr, -Wi, Wi, Wr again)
 #endif
 #ifndef DSABF_OCC16
-#define DSABF_OCC16 3     // register budget of the 64-antenna variants (168): the general kernel needs 147 VGPRs; the paired
-                          // one (101) reaches 4 workgroups per CU by itself; capping at 128 spills for no gain
+#define DSABF_OCC16 3     // default register budget of the one-k-step variants (168 VGPRs: 3 waves per SIMD); fused_min_waves()
+                          // raises it to 4 where 128 registers suffice
 #endif
 
 namespace dsabf {
@@ -155,8 +155,21 @@ constexpr int kColTiles16 = DSABF_NS;        // 16-beam column tiles per wave
 template <int AIN>
 constexpr bool ant_two_ksteps() { return AIN > 64 || AIN == kAntK2P16 || AIN == kAntK2P4; }
 
+// Waves per SIMD the register allocation is held to (= resident workgroups per CU).  Two k-steps: 2 (their 64 KiB of LDS
+// allow no more).  One k-step: 3 -- except where 4 fit without a spill: since round 3's 3-fragment weight image the general
+// kernel of the 16-byte-staged classes needs 124 VGPRs for n_ipo 8 / 16 / 32 (the conjugate-pair kernel always did), and the
+// fourth resident workgroup is worth 2 % (canonical) to 3 % (contracted) on C3 (profiles/r03_ab_c3_general_occ4.txt).  The
+// other window lengths and the dword-staged class would spill at 128 and stay at 3.
+template <int AIN, int NIPO, bool WRITE_C>
+constexpr int fused_min_waves()
+{
+    if (DSABF_NS == 8 || ant_two_ksteps<AIN>()) return 2;
+    if (DSABF_OCC16 == 3 && (AIN == 64 || AIN == kAntK1P16) && (NIPO == 8 || NIPO == 16 || NIPO == 32) && !WRITE_C) return 4;
+    return DSABF_OCC16;
+}
+
 template <int AIN, int NIPO, bool WRITE_C, int MODE = kDetCanonical, bool PAIRED = false>
-__global__ __launch_bounds__(kThreads16, DSABF_NS == 8 ? 2 : ant_two_ksteps<AIN>() ? 2 : DSABF_OCC16) void fused16_kernel(FusedArgs a)
+__global__ __launch_bounds__(kThreads16, (fused_min_waves<AIN, NIPO, WRITE_C>())) void fused16_kernel(FusedArgs a)
 {
     constexpr bool FAST = MODE == kDetFast;
     constexpr bool CONTRACTED = MODE == kDetContracted;
