@@ -139,6 +139,7 @@ __device__ __forceinline__ int swz16(int chunk, int row)  // 8 chunks of 16 B pe
 
 constexpr int kWaves16 = DSABF_WAVES;        // waves per workgroup of fused16_kernel
 constexpr int kThreads16 = 64 * kWaves16;
+constexpr int kWavesWide16 = 8;              // ... of the two-k-step classes where the beam count allows (fused_wg_waves)
 constexpr int kColTiles16 = DSABF_NS;        // 16-beam column tiles per wave
 
 // PAIRED: the steering weights of beam B-1-b are the complex conjugates of those of beam b for every (frequency,
@@ -168,9 +169,13 @@ constexpr int fused_min_waves()
     return DSABF_OCC16;
 }
 
-template <int AIN, int NIPO, bool WRITE_C, int MODE = kDetCanonical, bool PAIRED = false>
-__global__ __launch_bounds__(kThreads16, (fused_min_waves<AIN, NIPO, WRITE_C>())) void fused16_kernel(FusedArgs a)
+//
+// WAVES = waves per workgroup (4, or 8 where fused_wg_waves() in bf_kernels.hip says so): a workgroup stages one frequency's
+// voltages for 64 * WAVES beams.
+template <int AIN, int NIPO, bool WRITE_C, int MODE = kDetCanonical, bool PAIRED = false, int WAVES = kWaves16>
+__global__ __launch_bounds__(64 * WAVES, (fused_min_waves<AIN, NIPO, WRITE_C>())) void fused16_kernel(FusedArgs a)
 {
+    constexpr int THREADS = 64 * WAVES;
     constexpr bool FAST = MODE == kDetFast;
     constexpr bool CONTRACTED = MODE == kDetContracted;
     static_assert(!FAST || (NIPO >= 16 && !WRITE_C), "the fast detect exists for n_ipo >= 16 only");
@@ -194,7 +199,7 @@ __global__ __launch_bounds__(kThreads16, (fused_min_waves<AIN, NIPO, WRITE_C>())
     constexpr int L = LONG ? NIPO : 16;                  // samples per stream
     constexpr int LR = NIPO >= 32 ? 32 : 16;             // stream rows held by one chunk
     constexpr int CPG = L > 32 ? L / 32 : 1;             // chunks per group of 4 streams
-    constexpr int PPT = (TOTALP_MAX + kThreads16 - 1) / kThreads16;  // pieces per thread per chunk (2; 4; 13 for 100 antennas)
+    constexpr int PPT = (TOTALP_MAX + THREADS - 1) / THREADS;  // pieces per thread per chunk (2; 4; 13 for 100 antennas)
     using stage_t = std::conditional_t<DW, int, v4i>;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 buffers x KS planes x 128 rows x 128 B
@@ -219,7 +224,7 @@ __global__ __launch_bounds__(kThreads16, (fused_min_waves<AIN, NIPO, WRITE_C>())
     bool wave_active;
     if constexpr (PAIRED) {
         const int n_pct = a.n_ptiles;                     // pair tiles of 16 base beams = n_beams / 32
-        const int pct0 = (bg * kWaves16 + wave) * NT;
+        const int pct0 = (bg * WAVES + wave) * NT;
         wave_active = pct0 < n_pct;
 #pragma unroll
         for (int t = 0; t < NT; t++) {
@@ -236,7 +241,7 @@ __global__ __launch_bounds__(kThreads16, (fused_min_waves<AIN, NIPO, WRITE_C>())
         }
     } else {
         const int n_ctiles = a.n_ctiles;
-        const int ct0 = (bg * kWaves16 + wave) * NT;      // first 16-beam column tile of this wave
+        const int ct0 = (bg * WAVES + wave) * NT;      // first 16-beam column tile of this wave
         wave_active = ct0 < n_ctiles;
 #pragma unroll
         for (int t = 0; t < NT; t++) {
@@ -277,7 +282,7 @@ __global__ __launch_bounds__(kThreads16, (fused_min_waves<AIN, NIPO, WRITE_C>())
     int lds_re[PPT];                      // LDS byte offset (inside one buffer) of the piece's 16*re image
 #pragma unroll
     for (int k = 0; k < PPT; k++) {
-        const int pc = tid + k * kThreads16;
+        const int pc = tid + k * THREADS;
         const int row = (pc / PPR) % kRowsPerChunk, pi = pc % PPR;   // (% keeps the unused tail pieces in range)
         if constexpr (NIPO == 64) lane_off64[k] = (unsigned)((row / LR) * L + (row % LR)) * A + pi * PB;
         const int blk = DW ? pi / 4 : pi;                            // 16-antenna block of the piece
@@ -288,9 +293,9 @@ __global__ __launch_bounds__(kThreads16, (fused_min_waves<AIN, NIPO, WRITE_C>())
         if constexpr (NIPO == 64)
             return lane_off64[k];
         else
-            return (unsigned)PB * (unsigned)(tid + k * kThreads16);
+            return (unsigned)PB * (unsigned)(tid + k * THREADS);
     };
-    auto piece_live = [&](int k) { return (!RT && TOTALP_MAX % kThreads16 == 0) || (tid + k * kThreads16 < TOTALP); };
+    auto piece_live = [&](int k) { return (!RT && TOTALP_MAX % THREADS == 0) || (tid + k * THREADS < TOTALP); };
     int ld_span = -1;                 // span the scalar state below describes
     unsigned ld_u = 0, ld_t0 = 0;     // its gemm-unit and first sample inside the unit
     auto load_chunk = [&](int c) {
@@ -322,7 +327,7 @@ __global__ __launch_bounds__(kThreads16, (fused_min_waves<AIN, NIPO, WRITE_C>())
         }
 #pragma unroll
         for (int k = 0; k < PPT; k++) {
-            const int pc = tid + k * kThreads16;       // (run-time antenna classes: a real division per piece, but this is
+            const int pc = tid + k * THREADS;       // (run-time antenna classes: a real division per piece, but this is
             const int row = (pc / PPR) % kRowsPerChunk, pi = pc % PPR;   //  the path of small DEBUG-style gemm-units only)
             const unsigned s0 = run_sample0(c, row / LR) + (unsigned)(row % LR);
             stage[k] = stage_t{};
@@ -605,10 +610,11 @@ __global__ __launch_bounds__(kThreads16, (fused_min_waves<AIN, NIPO, WRITE_C>())
 #endif
 }
 
-template <int AIN, int NIPO, bool WRITE_C, int MODE, bool PAIRED>
+template <int AIN, int NIPO, bool WRITE_C, int MODE, bool PAIRED, int WAVES>
 hipError_t launch_fused16_t(const FusedArgs& args, const LaunchShape& ls, hipStream_t s)
 {
-    auto kern = fused16_kernel<AIN, NIPO, WRITE_C, MODE, PAIRED>;
+    auto kern = fused16_kernel<AIN, NIPO, WRITE_C, MODE, PAIRED, WAVES>;
+    if (ls.block != 64 * WAVES) return hipErrorInvalidValue;
     if (ls.lds_bytes > 48 * 1024) {   // once per kernel and device, not per launch (the two-k-step image is always 64 KiB)
         static std::atomic<unsigned> done_mask{0};
         int dev = 0;
@@ -634,23 +640,28 @@ struct FusedVariant {
     fused_launch_fn launch = nullptr;
 };
 
-template <int AIN, int NIPO, bool WRITE_C, int MODE, bool PAIRED>
+template <int AIN, int NIPO, bool WRITE_C, int MODE, bool PAIRED, int WAVES>
 FusedVariant make_variant()
 {
-    return FusedVariant{reinterpret_cast<const void*>(fused16_kernel<AIN, NIPO, WRITE_C, MODE, PAIRED>),
-                        launch_fused16_t<AIN, NIPO, WRITE_C, MODE, PAIRED>};
+    return FusedVariant{reinterpret_cast<const void*>(fused16_kernel<AIN, NIPO, WRITE_C, MODE, PAIRED, WAVES>),
+                        launch_fused16_t<AIN, NIPO, WRITE_C, MODE, PAIRED, WAVES>};
 }
 
-template <int AIN, int NIPO>
+template <int AIN, int NIPO, int WAVES>
 FusedVariant fused16_variant_nipo(bool write_c, int mode, bool paired)
 {
-    if (write_c) return make_variant<AIN, NIPO, true, kDetCanonical, false>();   // stage parity: general kernel, canonical scale
+    if (write_c) {   // stage parity: general kernel, canonical scale, 4 waves
+        if constexpr (WAVES == kWaves16) return make_variant<AIN, NIPO, true, kDetCanonical, false, WAVES>();
+        return FusedVariant{};
+    }
     if constexpr (NIPO >= 16) {
-        if (mode == kDetFast) return paired ? make_variant<AIN, NIPO, false, kDetFast, true>() : make_variant<AIN, NIPO, false, kDetFast, false>();
+        if (mode == kDetFast)
+            return paired ? make_variant<AIN, NIPO, false, kDetFast, true, WAVES>() : make_variant<AIN, NIPO, false, kDetFast, false, WAVES>();
     }
     if (mode == kDetContracted)
-        return paired ? make_variant<AIN, NIPO, false, kDetContracted, true>() : make_variant<AIN, NIPO, false, kDetContracted, false>();
-    return paired ? make_variant<AIN, NIPO, false, kDetCanonical, true>() : make_variant<AIN, NIPO, false, kDetCanonical, false>();
+        return paired ? make_variant<AIN, NIPO, false, kDetContracted, true, WAVES>()
+                      : make_variant<AIN, NIPO, false, kDetContracted, false, WAVES>();
+    return paired ? make_variant<AIN, NIPO, false, kDetCanonical, true, WAVES>() : make_variant<AIN, NIPO, false, kDetCanonical, false, WAVES>();
 }
 
 // Every instantiation of one antenna class (n_ipo 2 ... 64, general / conjugate-pair, three detect modes, stage parity).
@@ -659,12 +670,25 @@ template <int AIN>
 FusedVariant fused16_variant(int n_ipo, bool write_c, int mode, bool paired)
 {
     switch (n_ipo) {
-        case 2: return fused16_variant_nipo<AIN, 2>(write_c, mode, paired);
-        case 4: return fused16_variant_nipo<AIN, 4>(write_c, mode, paired);
-        case 8: return fused16_variant_nipo<AIN, 8>(write_c, mode, paired);
-        case 16: return fused16_variant_nipo<AIN, 16>(write_c, mode, paired);
-        case 32: return fused16_variant_nipo<AIN, 32>(write_c, mode, paired);
-        case 64: return fused16_variant_nipo<AIN, 64>(write_c, mode, paired);
+        case 2: return fused16_variant_nipo<AIN, 2, kWaves16>(write_c, mode, paired);
+        case 4: return fused16_variant_nipo<AIN, 4, kWaves16>(write_c, mode, paired);
+        case 8: return fused16_variant_nipo<AIN, 8, kWaves16>(write_c, mode, paired);
+        case 16: return fused16_variant_nipo<AIN, 16, kWaves16>(write_c, mode, paired);
+        case 32: return fused16_variant_nipo<AIN, 32, kWaves16>(write_c, mode, paired);
+        case 64: return fused16_variant_nipo<AIN, 64, kWaves16>(write_c, mode, paired);
+        default: return FusedVariant{};
+    }
+}
+
+// The 8-wave workgroups of the two-k-step classes (n_ipo >= 16; see fused_wg_waves() in bf_kernels.hip).
+template <int AIN>
+FusedVariant fused16_variant_w8(int n_ipo, int mode, bool paired)
+{
+    static_assert(ant_two_ksteps<AIN>(), "8-wave workgroups exist for the two-k-step classes only");
+    switch (n_ipo) {
+        case 16: return fused16_variant_nipo<AIN, 16, kWavesWide16>(false, mode, paired);
+        case 32: return fused16_variant_nipo<AIN, 32, kWavesWide16>(false, mode, paired);
+        case 64: return fused16_variant_nipo<AIN, 64, kWavesWide16>(false, mode, paired);
         default: return FusedVariant{};
     }
 }
@@ -677,5 +701,10 @@ FusedVariant fused16_variant_k1p16(int n_ipo, bool write_c, int mode, bool paire
 FusedVariant fused16_variant_k1p4(int n_ipo, bool write_c, int mode, bool paired);
 FusedVariant fused16_variant_k2p16(int n_ipo, bool write_c, int mode, bool paired);
 FusedVariant fused16_variant_k2p4(int n_ipo, bool write_c, int mode, bool paired);
+// ... and one per two-k-step class for its 8-wave workgroups (bf_fused16_*_w8.hip)
+FusedVariant fused16_variant_a100_w8(int n_ipo, int mode, bool paired);
+FusedVariant fused16_variant_a128_w8(int n_ipo, int mode, bool paired);
+FusedVariant fused16_variant_k2p16_w8(int n_ipo, int mode, bool paired);
+FusedVariant fused16_variant_k2p4_w8(int n_ipo, int mode, bool paired);
 
 }  // namespace dsabf

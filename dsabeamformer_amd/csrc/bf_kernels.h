@@ -15,12 +15,11 @@ constexpr int kRowsPerChunk = 128;   // time samples per LDS buffer
 #ifndef DSABF_NS
 #define DSABF_NS 4       // 16-beam output slots per wave
 #endif
-constexpr int kBeamsPerWg = DSABF_WAVES * DSABF_NS * 16;   // waves x column tiles x 16 beams
+constexpr int kBeamsPerWave = DSABF_NS * 16;   // column tiles x 16 beams
 
 struct Geometry {
     int n_beams, n_ant, n_freq, n_ipo, n_out, n_time;  // n_time = n_out * n_ipo (per gemm-unit)
     int n_ctiles;                                       // 16-beam column tiles: ceil(n_beams / 16)
-    int n_bgroups;                                      // workgroups along the beam axis: ceil(n_beams / 256)
     bool fast_detect;                                   // BF_DETECT_FAST requested (honoured by fused16_kernel, n_ipo >= 16)
     bool contracted_detect = false;                     // BF_DETECT_CONTRACTED requested
     bool paired = false;                                // weights verified conjugate-symmetric: beam B-1-b = conj(beam b)
@@ -39,8 +38,12 @@ bool fused_supported(const Geometry& g, const char** why);
 
 struct LaunchShape {
     int grid, block, lds_bytes, n_tsplit, chunks_total;
+    int n_bgroups;   // workgroups along the beam axis: ceil(n_beams / (64 * waves per workgroup))
 };
-LaunchShape fused_launch_shape(const Geometry& g, int n_units, int n_cus);
+// Waves per workgroup of the fused kernel for this geometry: 4, or 8 (two k-steps, n_ipo >= 16, an even number of 256-beam
+// groups).  write_c: the stage-parity launch (always 4).
+int fused_wg_waves(const Geometry& g, bool write_c = false);
+LaunchShape fused_launch_shape(const Geometry& g, int n_units, int n_cus, bool write_c = false);
 
 // Reference-layout weights [f][a][b]{re,im} (device) -> fragment image (device).  Sets *d_bad to non-zero if
 // any imaginary part is -128 (its negation does not fit int8).  With d_pair_image (pairing_supported geometries) also

@@ -392,6 +392,11 @@ FusedVariant select_variant(const Geometry& g, bool write_c)
     const int mode = detect_mode_of(g);
     const char* force_rt = getenv("DSABF_RUNTIME_ANT");   // test / measurement switch: run the run-time classes everywhere
     const bool rt = force_rt && force_rt[0] == '1';
+    if (fused_wg_waves(g, write_c) == kWavesWide16) {
+        if (!rt && g.n_ant == 100) return fused16_variant_a100_w8(g.n_ipo, mode, paired);
+        if (!rt && g.n_ant == 128) return fused16_variant_a128_w8(g.n_ipo, mode, paired);
+        return g.n_ant % 16 == 0 ? fused16_variant_k2p16_w8(g.n_ipo, mode, paired) : fused16_variant_k2p4_w8(g.n_ipo, mode, paired);
+    }
     if (!rt) {
         if (g.n_ant == 64) return fused16_variant_a64(g.n_ipo, write_c, mode, paired);
         if (g.n_ant == 100) return fused16_variant_a100(g.n_ipo, write_c, mode, paired);
@@ -443,9 +448,25 @@ bool fused_supported(const Geometry& g, const char** why)
     return true;
 }
 
-LaunchShape fused_launch_shape(const Geometry& g, int n_units, int n_cus)
+// A workgroup stages one frequency's voltages for all of its waves.  The two-k-step classes hold 2 waves per SIMD whatever
+// the workgroup size (their registers), so where the beams fill them, 8-wave workgroups -- one per CU instead of two -- stage
+// and read every voltage once per 512 beams instead of once per 256: BASELINE config 5 runs 2 % faster (pair and general
+// kernel, profiles/r03_ab_c5_w8.txt).  The one-k-step classes keep 4 (their 3-4 resident workgroups overlap each other's
+// barriers); so do the store-bound short windows and the stage-parity launch.
+int fused_wg_waves(const Geometry& g, bool write_c)
+{
+    const char* e = getenv("DSABF_WG_WAVES");   // test / measurement switch: 4 = the 4-wave workgroups everywhere
+    const int forced = e ? atoi(e) : 0;
+    const bool can = !write_c && ksteps16(g) == 2 && g.n_ipo >= 16 && kWaves16 == 4 && ((g.n_beams + 255) / 256) % 2 == 0;
+    if (forced == kWaves16 || !can) return kWaves16;
+    return kWavesWide16;
+}
+
+LaunchShape fused_launch_shape(const Geometry& g, int n_units, int n_cus, bool write_c)
 {
     LaunchShape ls{};
+    const int wg_waves = fused_wg_waves(g, write_c);
+    ls.n_bgroups = (g.n_beams + wg_waves * kBeamsPerWave - 1) / (wg_waves * kBeamsPerWave);
     const long long S = (long long)n_units * g.n_time;
     long long rows;
     int cpg = 1;  // chunks per output group: a workgroup's chunk range must cover whole groups
@@ -458,7 +479,7 @@ LaunchShape fused_launch_shape(const Geometry& g, int n_units, int n_cus)
     }
     ls.chunks_total = (int)((rows + kRowsPerChunk - 1) / kRowsPerChunk);
     ls.chunks_total = (ls.chunks_total + cpg - 1) / cpg * cpg;
-    const int base = g.n_freq * g.n_bgroups;
+    const int base = g.n_freq * ls.n_bgroups;
     // Time splits per frequency.  Measured (profiles/r01_variants_log.txt): the kernel is fastest with ~16-32 chunks
     // per workgroup (long enough to amortise the weight-fragment load and the prologue, short enough that the tail
     // of the launch is fine-grained); small launches still get ~2 workgroups per resident slot, but never fewer
@@ -468,16 +489,22 @@ LaunchShape fused_launch_shape(const Geometry& g, int n_units, int n_cus)
     // k-steps = twice the fragments: at least 4) -- unless that leaves fewer than 4 (2) workgroups per CU: a single
     // gemm-unit is 4 chunks per frequency, 1 chunk each is then 6 % faster (profiles/r02_launch_size.txt).
     const bool two_k = ksteps16(g) == 2;
+    const bool wide = wg_waves == kWavesWide16;   // one resident workgroup per CU
     const int min_groups = two_k ? 4 : 2;
     int max_split = groups_avail >= min_groups ? groups_avail / min_groups : 1;
-    if ((long long)base * max_split < (two_k ? 2LL : 4LL) * n_cus) max_split = groups_avail >= 1 ? groups_avail : 1;
-    int want = (groups_avail + 10) / 20;                                       // ~20 chunk-groups per workgroup
+    if ((long long)base * max_split < (wide ? 1LL : two_k ? 2LL : 4LL) * n_cus) max_split = groups_avail >= 1 ? groups_avail : 1;
+    // ~20 chunk-groups per workgroup; the 8-wave workgroups (one resident per CU) the longer the better: BASELINE config 5 on
+    // 1024 workgroups of 32 chunks -2.0 % (general kernel -3.1 %) against 4-wave workgroups, on 2048 of 16 -1.3 % (-2.1 %),
+    // on 4096 of 8 +1.3 % (profiles/r03_ab_c5_w8.txt)
+    int want = wide ? (groups_avail + 20) / 40 : (groups_avail + 10) / 20;
     // Short windows (n_ipo < 16) are store-bound: fewer, longer workgroups measured better (C2: 2 per CU 0.54 of the
     // HBM peak, 8 per CU 0.49).  The MFMA-bound one-k-step shapes want ~4 resident sets of 4: a 32-unit block (one
     // PSRDADA block, bf_enqueue_block) runs 4 % faster on 4096 workgroups than on 2048 (profiles/r02_launch_size.txt);
     // two-k-step shapes (2 resident per CU, 128 KiB of weight fragments each) want 2 sets of 2: a 16-unit launch of a
     // BASELINE-config-5 rank shard is 14 % faster on 1024 workgroups than on 4096 (profiles/r02_launch_size_c5shard.txt).
-    const int target_wgs_per_cu = g.n_ipo < 16 ? 2 : (two_k ? 4 : 4 * (16 / kWaves16));
+    // Their 8-wave workgroups, one resident per CU, want one set: the same shard 256 workgroups -7.0 %, 512 -4.9 %, 1024 -1.2 %
+    // against the 4-wave launch (profiles/r03_ab_c5_w8.txt).
+    const int target_wgs_per_cu = g.n_ipo < 16 ? 2 : wide ? 1 : (two_k ? 4 : 4 * (16 / kWaves16));
     int want_fill = (target_wgs_per_cu * n_cus + base - 1) / base;            // enough workgroups to fill the chip
     if (want_fill > max_split) want_fill = max_split;
     if (want < want_fill) want = want_fill;
@@ -486,7 +513,7 @@ LaunchShape fused_launch_shape(const Geometry& g, int n_units, int n_cus)
     if (want > ls.chunks_total / cpg) want = ls.chunks_total / cpg;
     ls.n_tsplit = want;
     ls.grid = base * ls.n_tsplit;
-    ls.block = kThreads16;
+    ls.block = 64 * wg_waves;
     ls.lds_bytes = 2 * ksteps16(g) * kRowsPerChunk * 128;  // double buffer x k-step planes x 128 rows x (64 re | 64 im)
     if (const char* e = getenv("DSABF_LDS_PAD")) ls.lds_bytes += atoi(e);   // measurement switch: fewer resident workgroups per CU
     return ls;
@@ -504,7 +531,7 @@ static FusedArgs make_args(const Geometry& g, const void* d_image, const void* d
     a.n_ctiles = g.n_ctiles;
     a.n_ptiles = g.n_beams / 32;
     a.n_ant = g.n_ant;
-    a.n_bgroups = g.n_bgroups;
+    a.n_bgroups = ls.n_bgroups;
     a.T = g.n_time;
     a.t_shift = ilog2_exact(g.n_time);
     a.S = (unsigned)((long long)n_units * g.n_time);
@@ -530,7 +557,7 @@ hipError_t launch_gemm_only(const Geometry& g, const void* d_image, const void* 
 {
     Geometry gg = g;
     gg.paired = false;  // the stage-parity path always runs the general kernel on the general image
-    const LaunchShape ls = fused_launch_shape(gg, 1, n_cus);
+    const LaunchShape ls = fused_launch_shape(gg, 1, n_cus, true);
     const FusedArgs a = make_args(gg, d_image, d_packed, 1, d_c, ls);
     return dispatch_fused(gg, true, a, ls, s);
 }

@@ -92,7 +92,6 @@ dsabf::Geometry make_geom(const bf_config& c)
     g.n_out = c.n_out_per_gemm;
     g.n_time = g.n_out * g.n_ipo;
     g.n_ctiles = (c.n_beams + 15) / 16;
-    g.n_bgroups = (c.n_beams + dsabf::kBeamsPerWg - 1) / dsabf::kBeamsPerWg;
     g.fast_detect = c.detect_mode == BF_DETECT_FAST;
     g.contracted_detect = c.detect_mode == BF_DETECT_CONTRACTED;
     return g;

@@ -265,3 +265,52 @@ def test_shared_window_dm_kernel_bit_exact(torch, bfmod, orc, case, monkeypatch)
         assert np.array_equal(got["shared"], want), (case, n_t_out)
         assert np.array_equal(got["thread"], want), (case, n_t_out)
     bf.close()
+
+
+def _conj_symmetric(w):
+    out = w.copy()
+    b = w.shape[2]
+    out[:, :, b // 2:, 0] = w[:, :, :b // 2, 0][:, :, ::-1]
+    out[:, :, b // 2:, 1] = -w[:, :, :b // 2, 1][:, :, ::-1]
+    return out
+
+
+@pytest.mark.parametrize("n_ant,n_beams,n_avg", [(100, 512, 8), (100, 512, 16), (100, 480, 32), (128, 512, 16), (128, 1024, 8),
+                                                 (112, 512, 8), (108, 512, 16), (68, 288, 8), (124, 992, 32)])
+@pytest.mark.parametrize("paired", [False, True])
+@pytest.mark.parametrize("mode", [0, 2])
+def test_eight_wave_workgroups_of_the_two_kstep_classes_bit_exact(torch, bfmod, orc, monkeypatch, n_ant, n_beams, n_avg, paired, mode):
+    """Two-k-step classes with an even number of 256-beam groups run 8-wave workgroups (512 threads, one frequency's voltages
+    staged once for 512 beams; fused_wg_waves, bf_kernels.hip): both compile-time classes and both run-time ones, full and
+    ragged last groups (480, 288, 992 beams), canonical and contracted detect, general and conjugate-pair kernel -- bit-exact
+    against the oracle, and bit-identical to the same geometry forced onto 4-wave workgroups."""
+    g = orc.Geom(n_beams=n_beams, n_ant=n_ant, n_freq=3, n_avg=n_avg, n_out_per_gemm=6)
+    n_units = max(2, -(-500 // g.n_time))
+    rng = np.random.default_rng(n_ant * 7 + n_beams + n_avg + 17 * paired)
+    w = rng.integers(-127, 128, size=(g.n_freq, g.n_ant, g.n_beams, 2), dtype=np.int8)
+    w[0, :, 5] = 127
+    if paired:
+        w = _conj_symmetric(w)
+    packed = rng.integers(0, 256, size=(n_units, g.n_freq, g.n_time, g.n_ant), dtype=np.uint8)
+    packed[0, 0, :4] = 0x88
+    cfg = bfmod.production_config(n_beams=g.n_beams, n_ant=g.n_ant, n_freq=g.n_freq, n_avg=g.n_avg, n_out_per_gemm=g.n_out_per_gemm,
+                                  detect_mode=mode)
+    with orc.detect_contract(orc.CONTRACT_NVCC if mode == 2 else orc.CONTRACT_NONE):
+        want = orc.beamform(g, w, packed)
+    s = torch.cuda.current_stream().cuda_stream
+    d_in = torch.from_numpy(packed).cuda()
+    got = {}
+    for forced in (None, "4"):
+        if forced:
+            monkeypatch.setenv("DSABF_WG_WAVES", forced)
+        bf = bfmod.Beamformer(cfg)
+        bf.set_weights(w)
+        info = bf.kernel_info(n_units)
+        assert ("PAIRED" in info["kernel"]) == paired
+        d_out = torch.full((want.size,), float("nan"), dtype=torch.float32, device="cuda")
+        bf.beamform(d_in, n_units, d_out, s)
+        torch.cuda.synchronize()
+        got[forced] = (info["block"], d_out.cpu().numpy().reshape(want.shape))
+        bf.close()
+    assert got[None][0] == 512 and np.array_equal(got[None][1], want)
+    assert np.array_equal(got["4"][1], want)
