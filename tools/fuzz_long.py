@@ -3,7 +3,7 @@
 128, any n_beams % 4, n_ipo 2..64), random launch shapes, conjugate-pair or general weights, canonical or contracted
 detect, through bf_beamform_device, each compared bit for bit with the CPU oracle in the same reading.  Not part of the
 test suite (the suite runs seeded subsets).  Round 1: 3 seeds x 150 cases on the then whitelist, 0 mismatches.
-usage: SEED=1 CASES=150 python tools/fuzz_long.py"""
+usage: SEED=1 CASES=150 [FUZZ_WIDE=1] python tools/fuzz_long.py"""
 import os
 import sys
 
@@ -24,7 +24,13 @@ for case in range(N):
     n_ipo = 2 * n_avg
     n_out = int(rng.integers(1, 7)) * max(1, 16 // n_ipo)
     n_beams = 32 * int(rng.integers(1, 13)) if rng.integers(2) else 4 * int(rng.integers(1, 100))
-    g = orc.Geom(n_beams=n_beams, n_ant=n_ant, n_freq=int(rng.integers(1, 18)), n_avg=n_avg, n_out_per_gemm=n_out)
+    if os.environ.get("FUZZ_WIDE") == "1":   # bias towards the 8-wave workgroups of the two-k-step classes (fused_wg_waves)
+        n_ant = int(rng.choice([100, 128])) if rng.integers(3) == 0 else 4 * int(rng.integers(17, 33))
+        n_avg = int(rng.choice([8, 16, 32]))
+        n_ipo = 2 * n_avg
+        n_out = int(rng.integers(1, 7))
+        n_beams = 32 * int(rng.integers(9, 36)) if rng.integers(2) else 4 * int(rng.integers(65, 280))
+    g = orc.Geom(n_beams=n_beams, n_ant=n_ant, n_freq=int(rng.integers(1, 18 if n_beams <= 400 else 6)), n_avg=n_avg, n_out_per_gemm=n_out)
     n_units = int(rng.integers(1, 1 + max(1, 900 // g.n_time)))
     w = rng.integers(-127, 128, size=(g.n_freq, g.n_ant, g.n_beams, 2), dtype=np.int8)
     paired = bool(rng.integers(2)) and n_beams % 32 == 0
@@ -38,9 +44,10 @@ for case in range(N):
     bf = bfm.Beamformer(bfm.debug_config(n_beams=g.n_beams, n_ant=g.n_ant, n_freq=g.n_freq, n_avg=g.n_avg,
                                           n_out_per_gemm=g.n_out_per_gemm, detect_mode=mode))
     bf.set_weights(w)
-    name = bf.kernel_info(n_units)["kernel"]
+    info = bf.kernel_info(n_units)
+    name = info["kernel"]
     assert ("PAIRED" in name) == paired, (name, paired)
-    key = ("rt" if "(run-time)" in name else str(n_ant), n_ipo, paired, mode)
+    key = ("rt" if "(run-time)" in name else str(n_ant), n_ipo, paired, mode, info["block"])
     classes[key] = classes.get(key, 0) + 1
     d_in = torch.from_numpy(packed).cuda()
     with orc.detect_contract(orc.CONTRACT_NVCC if mode == 2 else orc.CONTRACT_NONE):
@@ -53,4 +60,5 @@ for case in range(N):
         bad += 1
         print("MISMATCH", case, g, n_units, paired, mode, os.environ["DSABF_TSPLIT"])
     bf.close()
-print("seed", os.environ.get("SEED", "1"), "cases", N, "mismatches", bad, "distinct (antenna class, n_ipo, paired, mode) combinations", len(classes))
+print("seed", os.environ.get("SEED", "1"), "cases", N, "mismatches", bad, "distinct (antenna class, n_ipo, paired, mode, block) combinations", len(classes),
+      "cases on 8-wave workgroups", sum(v for k, v in classes.items() if k[4] == 512))
