@@ -65,17 +65,17 @@ struct FusedArgs {
     unsigned S;                      // total time samples per frequency in this launch (n_units * T)
     int chunks_total;                // 128-sample chunks per frequency in this launch
     int n_tsplit;                    // workgroups along time
-    int interleave;                  // beams are dealt to the column tiles of a wave 4 (pairs: 2) at a time: see beam_of_tile
+    int interleave;                  // MFMA column tiles per wave if beams are dealt to them round-robin (beam_of_tile), else 0
 };
 
-// Which beam MFMA column c of a wave's column tile t computes.  A wave owns 64 consecutive beams (paired: 32 base
-// beams and their mirror images).  Interleaved (n_beams % 64 == 0): beam = first + 4c + t (paired: 2c + t), so a lane's
-// four results of one output are 4 (2 + 2) consecutive floats -> one 16-byte (two 8-byte) stores per lane, 256 (128)
-// contiguous bytes per lane group, instead of four scattered 64-byte rows.  Otherwise: tile t = beams first + 16t + c.
-__host__ __device__ inline int beam_of_tile(int interleave, int paired, int tile, int c)
+// Which beam MFMA column c of MFMA column tile `tile` computes.  A wave owns 16 * NS consecutive beams (paired: 8 * NS base
+// beams and their mirror images) in `per` MFMA column tiles (per = NS, paired NS / 2).  Interleaved (per > 0; n_beams a multiple
+// of 16 * NS): beam = first + per * c + t, so a lane's results of one output are `per` consecutive floats (paired: per + per)
+// -> 16-byte (8-byte for 2) stores, whole 128-byte lines per store instruction, instead of scattered 64-byte rows.
+// per = 0: tile t = beams first + 16 t + c.
+__host__ __device__ inline int beam_of_tile(int per, int tile, int c)
 {
-    const int per = paired ? DSABF_NS / 2 : DSABF_NS;  // MFMA column tiles per wave
-    if (!interleave) return tile * 16 + c;
+    if (!per) return tile * 16 + c;
     return (tile / per) * (16 * per) + per * c + tile % per;
 }
 
@@ -140,7 +140,8 @@ __device__ __forceinline__ int swz16(int chunk, int row)  // 8 chunks of 16 B pe
 constexpr int kWaves16 = DSABF_WAVES;        // waves per workgroup of fused16_kernel
 constexpr int kThreads16 = 64 * kWaves16;
 constexpr int kWavesWide16 = 8;              // ... of the two-k-step classes where the beam count allows (fused_wg_waves)
-constexpr int kColTiles16 = DSABF_NS;        // 16-beam column tiles per wave
+constexpr int kColTiles16 = DSABF_NS;        // 16-beam column tiles (output slots) per wave
+constexpr int kColTilesWide16 = 8;           // ... of the two-k-step conjugate-pair kernels where the beams allow (fused_col_tiles)
 
 // PAIRED: the steering weights of beam B-1-b are the complex conjugates of those of beam b for every (frequency,
 // antenna) -- true for any beam set that is symmetric about the boresight, e.g. the reference's linear fan and 16x16
@@ -161,10 +162,10 @@ constexpr bool ant_two_ksteps() { return AIN > 64 || AIN == kAntK2P16 || AIN == 
 // kernel of the 16-byte-staged classes needs 124 VGPRs for n_ipo 8 / 16 / 32 (the conjugate-pair kernel always did), and the
 // fourth resident workgroup is worth 2 % (canonical) to 3 % (contracted) on C3 (profiles/r03_ab_c3_general_occ4.txt).  The
 // other window lengths and the dword-staged class would spill at 128 and stay at 3.
-template <int AIN, int NIPO, bool WRITE_C>
+template <int AIN, int NIPO, bool WRITE_C, int NS = kColTiles16>
 constexpr int fused_min_waves()
 {
-    if (DSABF_NS == 8 || ant_two_ksteps<AIN>()) return 2;
+    if (NS == 8 || ant_two_ksteps<AIN>()) return 2;
     if (DSABF_OCC16 == 3 && (AIN == 64 || AIN == kAntK1P16) && (NIPO == 8 || NIPO == 16 || NIPO == 32) && !WRITE_C) return 4;
     return DSABF_OCC16;
 }
@@ -172,8 +173,10 @@ constexpr int fused_min_waves()
 //
 // WAVES = waves per workgroup (4, or 8 where fused_wg_waves() in bf_kernels.hip says so): a workgroup stages one frequency's
 // voltages for 64 * WAVES beams.
-template <int AIN, int NIPO, bool WRITE_C, int MODE = kDetCanonical, bool PAIRED = false, int WAVES = kWaves16>
-__global__ __launch_bounds__(64 * WAVES, (fused_min_waves<AIN, NIPO, WRITE_C>())) void fused16_kernel(FusedArgs a)
+// NS = 16-beam output slots per wave (4, or 8 where fused_col_tiles() says so): a wave's LDS fragment reads feed NS (paired: NS / 2)
+// MFMA column tiles.
+template <int AIN, int NIPO, bool WRITE_C, int MODE = kDetCanonical, bool PAIRED = false, int WAVES = kWaves16, int NS = kColTiles16>
+__global__ __launch_bounds__(64 * WAVES, (fused_min_waves<AIN, NIPO, WRITE_C, NS>())) void fused16_kernel(FusedArgs a)
 {
     constexpr int THREADS = 64 * WAVES;
     constexpr bool FAST = MODE == kDetFast;
@@ -193,7 +196,6 @@ __global__ __launch_bounds__(64 * WAVES, (fused_min_waves<AIN, NIPO, WRITE_C>())
     const int PPR = A / PB;                              // pieces per time sample
     const int TOTALP = kRowsPerChunk * PPR;              // pieces per chunk
     constexpr int TOTALP_MAX = kRowsPerChunk * (AMAX / PB);
-    constexpr int NS = kColTiles16;                      // 16-beam output slots per lane (beams per wave = 16 * NS)
     constexpr int NT = PAIRED ? NS / 2 : NS;             // MFMA column tiles per wave (a paired tile feeds 2 slots)
     constexpr bool LONG = NIPO >= 16;
     constexpr int L = LONG ? NIPO : 16;                  // samples per stream
@@ -228,7 +230,7 @@ __global__ __launch_bounds__(64 * WAVES, (fused_min_waves<AIN, NIPO, WRITE_C>())
         wave_active = pct0 < n_pct;
 #pragma unroll
         for (int t = 0; t < NT; t++) {
-            const int bb = beam_of_tile(a.interleave, 1, pct0 + t, c16);  // base beam (< n_beams / 2)
+            const int bb = beam_of_tile(a.interleave ? NT : 0, pct0 + t, c16);  // base beam (< n_beams / 2)
             const bool ok = pct0 + t < n_pct;
             slot_beam[2 * t] = ok ? bb : a.n_beams;
             slot_beam[2 * t + 1] = ok ? a.n_beams - 1 - bb : a.n_beams;
@@ -246,7 +248,7 @@ __global__ __launch_bounds__(64 * WAVES, (fused_min_waves<AIN, NIPO, WRITE_C>())
 #pragma unroll
         for (int t = 0; t < NT; t++) {
             const bool ok = ct0 + t < n_ctiles;
-            slot_beam[t] = ok ? beam_of_tile(a.interleave, 0, ct0 + t, c16) : a.n_beams;
+            slot_beam[t] = ok ? beam_of_tile(a.interleave ? NT : 0, ct0 + t, c16) : a.n_beams;
 #pragma unroll
             for (int k = 0; k < NGC; k++)
 #pragma unroll
@@ -610,11 +612,11 @@ __global__ __launch_bounds__(64 * WAVES, (fused_min_waves<AIN, NIPO, WRITE_C>())
 #endif
 }
 
-template <int AIN, int NIPO, bool WRITE_C, int MODE, bool PAIRED, int WAVES>
+template <int AIN, int NIPO, bool WRITE_C, int MODE, bool PAIRED, int WAVES, int NS>
 hipError_t launch_fused16_t(const FusedArgs& args, const LaunchShape& ls, hipStream_t s)
 {
-    auto kern = fused16_kernel<AIN, NIPO, WRITE_C, MODE, PAIRED, WAVES>;
-    if (ls.block != 64 * WAVES) return hipErrorInvalidValue;
+    auto kern = fused16_kernel<AIN, NIPO, WRITE_C, MODE, PAIRED, WAVES, NS>;
+    if (ls.block != 64 * WAVES || (args.interleave && args.interleave != (PAIRED ? NS / 2 : NS))) return hipErrorInvalidValue;
     if (ls.lds_bytes > 48 * 1024) {   // once per kernel and device, not per launch (the two-k-step image is always 64 KiB)
         static std::atomic<unsigned> done_mask{0};
         int dev = 0;
@@ -640,11 +642,11 @@ struct FusedVariant {
     fused_launch_fn launch = nullptr;
 };
 
-template <int AIN, int NIPO, bool WRITE_C, int MODE, bool PAIRED, int WAVES>
+template <int AIN, int NIPO, bool WRITE_C, int MODE, bool PAIRED, int WAVES, int NS = kColTiles16>
 FusedVariant make_variant()
 {
-    return FusedVariant{reinterpret_cast<const void*>(fused16_kernel<AIN, NIPO, WRITE_C, MODE, PAIRED, WAVES>),
-                        launch_fused16_t<AIN, NIPO, WRITE_C, MODE, PAIRED, WAVES>};
+    return FusedVariant{reinterpret_cast<const void*>(fused16_kernel<AIN, NIPO, WRITE_C, MODE, PAIRED, WAVES, NS>),
+                        launch_fused16_t<AIN, NIPO, WRITE_C, MODE, PAIRED, WAVES, NS>};
 }
 
 template <int AIN, int NIPO, int WAVES>
@@ -680,15 +682,34 @@ FusedVariant fused16_variant(int n_ipo, bool write_c, int mode, bool paired)
     }
 }
 
-// The 8-wave workgroups of the two-k-step classes (n_ipo >= 16; see fused_wg_waves() in bf_kernels.hip).
-template <int AIN>
-FusedVariant fused16_variant_w8(int n_ipo, int mode, bool paired)
+// The conjugate-pair kernel with 8 output slots per wave (two-k-step classes, n_ipo >= 16; fused_col_tiles() in bf_kernels.hip).
+// ... where its 236-256 registers hold without a spill: not the run-time dword-staged class (13 staging pieces per thread:
+// 60-412 bytes of scratch per lane) and not 100 antennas at n_ipo 64 (140); those keep 4 slots on 8-wave workgroups.
+template <int AIN, int NIPO>
+constexpr bool ns8_fits() { return AIN == 128 || AIN == kAntK2P16 || (AIN == 100 && NIPO < 64); }
+
+template <int AIN, int NIPO>
+FusedVariant fused16_variant_ns8_nipo(int mode)
 {
-    static_assert(ant_two_ksteps<AIN>(), "8-wave workgroups exist for the two-k-step classes only");
+    if constexpr (!ns8_fits<AIN, NIPO>()) return FusedVariant{};
+    else {
+    if (mode == kDetFast) return make_variant<AIN, NIPO, false, kDetFast, true, kWaves16, kColTilesWide16>();
+    if (mode == kDetContracted) return make_variant<AIN, NIPO, false, kDetContracted, true, kWaves16, kColTilesWide16>();
+    return make_variant<AIN, NIPO, false, kDetCanonical, true, kWaves16, kColTilesWide16>();
+    }
+}
+
+// The wide launches of the two-k-step classes (n_ipo >= 16): 8-wave workgroups (fused_wg_waves() in bf_kernels.hip), or -- ns8,
+// conjugate-pair kernel only -- 4-wave workgroups whose waves own 8 output slots.
+template <int AIN>
+FusedVariant fused16_variant_wide(int n_ipo, int mode, bool paired, bool ns8)
+{
+    static_assert(ant_two_ksteps<AIN>(), "the wide launches exist for the two-k-step classes only");
+    if (ns8 && !paired) return FusedVariant{};
     switch (n_ipo) {
-        case 16: return fused16_variant_nipo<AIN, 16, kWavesWide16>(false, mode, paired);
-        case 32: return fused16_variant_nipo<AIN, 32, kWavesWide16>(false, mode, paired);
-        case 64: return fused16_variant_nipo<AIN, 64, kWavesWide16>(false, mode, paired);
+        case 16: return ns8 ? fused16_variant_ns8_nipo<AIN, 16>(mode) : fused16_variant_nipo<AIN, 16, kWavesWide16>(false, mode, paired);
+        case 32: return ns8 ? fused16_variant_ns8_nipo<AIN, 32>(mode) : fused16_variant_nipo<AIN, 32, kWavesWide16>(false, mode, paired);
+        case 64: return ns8 ? fused16_variant_ns8_nipo<AIN, 64>(mode) : fused16_variant_nipo<AIN, 64, kWavesWide16>(false, mode, paired);
         default: return FusedVariant{};
     }
 }
@@ -701,10 +722,10 @@ FusedVariant fused16_variant_k1p16(int n_ipo, bool write_c, int mode, bool paire
 FusedVariant fused16_variant_k1p4(int n_ipo, bool write_c, int mode, bool paired);
 FusedVariant fused16_variant_k2p16(int n_ipo, bool write_c, int mode, bool paired);
 FusedVariant fused16_variant_k2p4(int n_ipo, bool write_c, int mode, bool paired);
-// ... and one per two-k-step class for its 8-wave workgroups (bf_fused16_*_w8.hip)
-FusedVariant fused16_variant_a100_w8(int n_ipo, int mode, bool paired);
-FusedVariant fused16_variant_a128_w8(int n_ipo, int mode, bool paired);
-FusedVariant fused16_variant_k2p16_w8(int n_ipo, int mode, bool paired);
-FusedVariant fused16_variant_k2p4_w8(int n_ipo, int mode, bool paired);
+// ... and one per two-k-step class for its wide launches (bf_fused16_*_wide.hip)
+FusedVariant fused16_variant_a100_wide(int n_ipo, int mode, bool paired, bool ns8);
+FusedVariant fused16_variant_a128_wide(int n_ipo, int mode, bool paired, bool ns8);
+FusedVariant fused16_variant_k2p16_wide(int n_ipo, int mode, bool paired, bool ns8);
+FusedVariant fused16_variant_k2p4_wide(int n_ipo, int mode, bool paired, bool ns8);
 
 }  // namespace dsabf

@@ -15,7 +15,6 @@ constexpr int kRowsPerChunk = 128;   // time samples per LDS buffer
 #ifndef DSABF_NS
 #define DSABF_NS 4       // 16-beam output slots per wave
 #endif
-constexpr int kBeamsPerWave = DSABF_NS * 16;   // column tiles x 16 beams
 
 struct Geometry {
     int n_beams, n_ant, n_freq, n_ipo, n_out, n_time;  // n_time = n_out * n_ipo (per gemm-unit)
@@ -43,6 +42,8 @@ struct LaunchShape {
 // Waves per workgroup of the fused kernel for this geometry: 4, or 8 (two k-steps, n_ipo >= 16, an even number of 256-beam
 // groups).  write_c: the stage-parity launch (always 4).
 int fused_wg_waves(const Geometry& g, bool write_c = false);
+// 16-beam output slots per wave: 4, or 8 (conjugate-pair kernel, two k-steps, n_ipo >= 16, n_beams a multiple of 512).
+int fused_col_tiles(const Geometry& g, bool paired);
 LaunchShape fused_launch_shape(const Geometry& g, int n_units, int n_cus, bool write_c = false);
 
 // Reference-layout weights [f][a][b]{re,im} (device) -> fragment image (device).  Sets *d_bad to non-zero if

@@ -328,7 +328,7 @@ __global__ void weight_relayout16p_kernel(const int8_t* __restrict__ w, v4i* __r
         r /= 3;
         const int pct = (int)(r % n_pct);
         const int f = (int)(r / n_pct);
-        const int kb = lane >> 4, b = beam_of_tile(interleave, 1, pct, lane & 15);
+        const int kb = lane >> 4, b = beam_of_tile(interleave, pct, lane & 15);
         unsigned d[4] = {0, 0, 0, 0};
         for (int i = 0; i < 16; i++) {
             const int ant = 64 * h + kb * 16 + i;
@@ -359,7 +359,7 @@ __global__ void weight_relayout16_kernel(const int8_t* __restrict__ w, v4i* __re
         r /= NGC;
         const int ct = (int)(r % n_ct);
         const int f = (int)(r / n_ct);
-        const int kb = lane >> 4, b = beam_of_tile(interleave, 0, ct, lane & 15);
+        const int kb = lane >> 4, b = beam_of_tile(interleave, ct, lane & 15);
         unsigned d[4] = {0, 0, 0, 0};
         for (int i = 0; i < 16; i++) {
             const int ant = 64 * h + kb * 16 + i;
@@ -379,7 +379,14 @@ __global__ void weight_relayout16_kernel(const int8_t* __restrict__ w, v4i* __re
 
 // ---- which instantiation a geometry runs ---------------------------------------------------------------------------------
 int ksteps16(const Geometry& g) { return g.n_ant > 64 ? 2 : 1; }
-int interleaved(const Geometry& g) { return DSABF_INTERLEAVE && g.n_beams % (16 * kColTiles16) == 0; }  // every wave owns whole beams
+// MFMA column tiles per wave the beams are dealt to round-robin (beam_of_tile), 0 = tile t is beams 16 t ...: interleaved when every
+// wave owns whole groups of 16 * NS beams.  paired: the layout of the conjugate-pair image / kernel (NS / 2 pair tiles per wave).
+int interleaved(const Geometry& g, bool paired)
+{
+    const int ns = fused_col_tiles(g, paired);
+    if (!DSABF_INTERLEAVE || g.n_beams % (16 * ns)) return 0;
+    return paired ? ns / 2 : ns;
+}
 bool nipo_supported(int n_ipo) { return n_ipo == 2 || n_ipo == 4 || n_ipo == 8 || n_ipo == 16 || n_ipo == 32 || n_ipo == 64; }
 int detect_mode_of(const Geometry& g) { return g.fast_detect ? kDetFast : g.contracted_detect ? kDetContracted : kDetCanonical; }
 
@@ -392,10 +399,11 @@ FusedVariant select_variant(const Geometry& g, bool write_c)
     const int mode = detect_mode_of(g);
     const char* force_rt = getenv("DSABF_RUNTIME_ANT");   // test / measurement switch: run the run-time classes everywhere
     const bool rt = force_rt && force_rt[0] == '1';
-    if (fused_wg_waves(g, write_c) == kWavesWide16) {
-        if (!rt && g.n_ant == 100) return fused16_variant_a100_w8(g.n_ipo, mode, paired);
-        if (!rt && g.n_ant == 128) return fused16_variant_a128_w8(g.n_ipo, mode, paired);
-        return g.n_ant % 16 == 0 ? fused16_variant_k2p16_w8(g.n_ipo, mode, paired) : fused16_variant_k2p4_w8(g.n_ipo, mode, paired);
+    const bool ns8 = fused_col_tiles(g, paired) == kColTilesWide16;
+    if (ns8 || fused_wg_waves(g, write_c) == kWavesWide16) {
+        if (!rt && g.n_ant == 100) return fused16_variant_a100_wide(g.n_ipo, mode, paired, ns8);
+        if (!rt && g.n_ant == 128) return fused16_variant_a128_wide(g.n_ipo, mode, paired, ns8);
+        return g.n_ant % 16 == 0 ? fused16_variant_k2p16_wide(g.n_ipo, mode, paired, ns8) : fused16_variant_k2p4_wide(g.n_ipo, mode, paired, ns8);
     }
     if (!rt) {
         if (g.n_ant == 64) return fused16_variant_a64(g.n_ipo, write_c, mode, paired);
@@ -448,16 +456,35 @@ bool fused_supported(const Geometry& g, const char** why)
     return true;
 }
 
+// Output slots (16 beams each) per wave.  The two-k-step conjugate-pair kernels hold 2 waves per SIMD whatever they do (64 KiB of
+// LDS per workgroup), and with 8 slots instead of 4 a wave's LDS fragment reads feed twice the MFMAs (32 between two reads) at 241
+// of its 256 registers: BASELINE config 5 runs 6.4-7.0 % faster than on 8-wave workgroups, 8.5 % faster than on the 4-slot
+// 4-wave launch (profiles/r03_ab_c5_ns8.txt).  Needs whole workgroups of 4 x 128 beams; the general kernel would spill (192
+// registers of weight fragments alone) and keeps 4; so do the run-time dword-staged class and 100 antennas at n_ipo 64 (they would
+// spill, ns8_fits) and the one-k-step classes, where 8 slots cost two of the four resident waves per SIMD (+6 % time,
+// profiles/r03_variants_log.txt).
+int fused_col_tiles(const Geometry& g, bool paired)
+{
+    const char* e = getenv("DSABF_COL_TILES");   // test / measurement switch: 4 = four slots per wave everywhere
+    const char* force_rt = getenv("DSABF_RUNTIME_ANT");
+    const bool rt = force_rt && force_rt[0] == '1';
+    // the instantiations that fit their registers (ns8_fits, bf_fused16.hpp): 16-byte-staged rows, or the compile-time 100 antennas
+    const bool fits = g.n_ant % 16 == 0 || (!rt && g.n_ant == 100 && g.n_ipo < 64);
+    const bool can = paired && fits && kColTiles16 == 4 && kWaves16 == 4 && ksteps16(g) == 2 && g.n_ipo >= 16 && g.n_beams % 512 == 0;
+    return (can && !(e && atoi(e) == kColTiles16)) ? kColTilesWide16 : kColTiles16;
+}
+
 // A workgroup stages one frequency's voltages for all of its waves.  The two-k-step classes hold 2 waves per SIMD whatever
 // the workgroup size (their registers), so where the beams fill them, 8-wave workgroups -- one per CU instead of two -- stage
 // and read every voltage once per 512 beams instead of once per 256: BASELINE config 5 runs 2 % faster (pair and general
 // kernel, profiles/r03_ab_c5_w8.txt).  The one-k-step classes keep 4 (their 3-4 resident workgroups overlap each other's
-// barriers); so do the store-bound short windows and the stage-parity launch.
+// barriers); so do the store-bound short windows, the stage-parity launch and the 8-slot pair kernel above.
 int fused_wg_waves(const Geometry& g, bool write_c)
 {
     const char* e = getenv("DSABF_WG_WAVES");   // test / measurement switch: 4 = the 4-wave workgroups everywhere
     const int forced = e ? atoi(e) : 0;
-    const bool can = !write_c && ksteps16(g) == 2 && g.n_ipo >= 16 && kWaves16 == 4 && ((g.n_beams + 255) / 256) % 2 == 0;
+    const bool can = !write_c && ksteps16(g) == 2 && g.n_ipo >= 16 && kWaves16 == 4 && kColTiles16 == 4 &&
+                     ((g.n_beams + 255) / 256) % 2 == 0 && fused_col_tiles(g, g.paired) == kColTiles16;
     if (forced == kWaves16 || !can) return kWaves16;
     return kWavesWide16;
 }
@@ -466,7 +493,8 @@ LaunchShape fused_launch_shape(const Geometry& g, int n_units, int n_cus, bool w
 {
     LaunchShape ls{};
     const int wg_waves = fused_wg_waves(g, write_c);
-    ls.n_bgroups = (g.n_beams + wg_waves * kBeamsPerWave - 1) / (wg_waves * kBeamsPerWave);
+    const int beams_per_wg = wg_waves * 16 * fused_col_tiles(g, g.paired && !write_c);
+    ls.n_bgroups = (g.n_beams + beams_per_wg - 1) / beams_per_wg;
     const long long S = (long long)n_units * g.n_time;
     long long rows;
     int cpg = 1;  // chunks per output group: a workgroup's chunk range must cover whole groups
@@ -490,13 +518,14 @@ LaunchShape fused_launch_shape(const Geometry& g, int n_units, int n_cus, bool w
     // gemm-unit is 4 chunks per frequency, 1 chunk each is then 6 % faster (profiles/r02_launch_size.txt).
     const bool two_k = ksteps16(g) == 2;
     const bool wide = wg_waves == kWavesWide16;   // one resident workgroup per CU
+    const bool ns8 = fused_col_tiles(g, g.paired && !write_c) == kColTilesWide16;   // two resident, long like the wide ones
     const int min_groups = two_k ? 4 : 2;
     int max_split = groups_avail >= min_groups ? groups_avail / min_groups : 1;
     if ((long long)base * max_split < (wide ? 1LL : two_k ? 2LL : 4LL) * n_cus) max_split = groups_avail >= 1 ? groups_avail : 1;
     // ~20 chunk-groups per workgroup; the 8-wave workgroups (one resident per CU) the longer the better: BASELINE config 5 on
     // 1024 workgroups of 32 chunks -2.0 % (general kernel -3.1 %) against 4-wave workgroups, on 2048 of 16 -1.3 % (-2.1 %),
     // on 4096 of 8 +1.3 % (profiles/r03_ab_c5_w8.txt)
-    int want = wide ? (groups_avail + 20) / 40 : (groups_avail + 10) / 20;
+    int want = (wide || ns8) ? (groups_avail + 20) / 40 : (groups_avail + 10) / 20;
     // Short windows (n_ipo < 16) are store-bound: fewer, longer workgroups measured better (C2: 2 per CU 0.54 of the
     // HBM peak, 8 per CU 0.49).  The MFMA-bound one-k-step shapes want ~4 resident sets of 4: a 32-unit block (one
     // PSRDADA block, bf_enqueue_block) runs 4 % faster on 4096 workgroups than on 2048 (profiles/r02_launch_size.txt);
@@ -504,7 +533,7 @@ LaunchShape fused_launch_shape(const Geometry& g, int n_units, int n_cus, bool w
     // BASELINE-config-5 rank shard is 14 % faster on 1024 workgroups than on 4096 (profiles/r02_launch_size_c5shard.txt).
     // Their 8-wave workgroups, one resident per CU, want one set: the same shard 256 workgroups -7.0 %, 512 -4.9 %, 1024 -1.2 %
     // against the 4-wave launch (profiles/r03_ab_c5_w8.txt).
-    const int target_wgs_per_cu = g.n_ipo < 16 ? 2 : wide ? 1 : (two_k ? 4 : 4 * (16 / kWaves16));
+    const int target_wgs_per_cu = g.n_ipo < 16 ? 2 : wide ? 1 : ns8 ? 2 : (two_k ? 4 : 4 * (16 / kWaves16));
     int want_fill = (target_wgs_per_cu * n_cus + base - 1) / base;            // enough workgroups to fill the chip
     if (want_fill > max_split) want_fill = max_split;
     if (want < want_fill) want = want_fill;
@@ -537,7 +566,7 @@ static FusedArgs make_args(const Geometry& g, const void* d_image, const void* d
     a.S = (unsigned)((long long)n_units * g.n_time);
     a.chunks_total = ls.chunks_total;
     a.n_tsplit = ls.n_tsplit;
-    a.interleave = interleaved(g);
+    a.interleave = interleaved(g, g.paired);
     return a;
 }
 
@@ -581,10 +610,10 @@ hipError_t launch_weight_relayout(const Geometry& g, const int8_t* d_w, void* d_
         int rgrid = (int)((weight_pair_image_bytes(g) / 16 + 255) / 256);
         if (rgrid > 4096) rgrid = 4096;
         hipLaunchKernelGGL(weight_relayout16p_kernel, dim3(rgrid), dim3(256), 0, s, d_w, static_cast<v4i*>(d_pair_image),
-                           g.n_freq, g.n_ant, g.n_beams, ksteps16(g), interleaved(g));
+                           g.n_freq, g.n_ant, g.n_beams, ksteps16(g), interleaved(g, true));
     }
     hipLaunchKernelGGL(weight_relayout16_kernel, dim3(grid), dim3(256), 0, s, d_w, static_cast<v4i*>(d_image), g.n_freq,
-                       g.n_ant, g.n_beams, ksteps16(g), interleaved(g), d_bad);
+                       g.n_ant, g.n_beams, ksteps16(g), interleaved(g, false), d_bad);
     return hipGetLastError();
 }
 
@@ -644,9 +673,10 @@ hipError_t launch_dedisperse_dm(const Geometry& g, const float* d_series, int n_
 const char* fused_kernel_name(const Geometry& g, char* buf, size_t n)
 {
     const bool rt = !(g.n_ant == 64 || g.n_ant == 100 || g.n_ant == 128);
-    snprintf(buf, n, "dsabf::fused16_kernel<ANT=%d%s,NIPO=%d%s%s> (v_mfma_i32_16x16x64_i8)", g.n_ant, rt ? "(run-time)" : "",
+    snprintf(buf, n, "dsabf::fused16_kernel<ANT=%d%s,NIPO=%d%s%s%s> (v_mfma_i32_16x16x64_i8)", g.n_ant, rt ? "(run-time)" : "",
              g.n_ipo, (g.fast_detect && g.n_ipo >= 16) ? ",FAST" : g.contracted_detect ? ",CONTRACTED" : "",
-             g.paired ? ",PAIRED" : "");
+             g.paired ? ",PAIRED" : "",
+             fused_col_tiles(g, g.paired) == kColTilesWide16 ? ",SLOTS=8" : fused_wg_waves(g) == kWavesWide16 ? ",WAVES=8" : "");
     return buf;
 }
 

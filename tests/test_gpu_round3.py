@@ -275,15 +275,18 @@ def _conj_symmetric(w):
     return out
 
 
-@pytest.mark.parametrize("n_ant,n_beams,n_avg", [(100, 512, 8), (100, 512, 16), (100, 480, 32), (128, 512, 16), (128, 1024, 8),
-                                                 (112, 512, 8), (108, 512, 16), (68, 288, 8), (124, 992, 32)])
+@pytest.mark.parametrize("n_ant,n_beams,n_avg", [(100, 512, 8), (100, 512, 16), (100, 480, 32), (100, 512, 32), (128, 512, 16),
+                                                 (128, 1024, 8), (128, 512, 32), (112, 512, 8), (112, 1024, 16), (108, 512, 16),
+                                                 (68, 288, 8), (124, 992, 32)])
 @pytest.mark.parametrize("paired", [False, True])
-@pytest.mark.parametrize("mode", [0, 2])
-def test_eight_wave_workgroups_of_the_two_kstep_classes_bit_exact(torch, bfmod, orc, monkeypatch, n_ant, n_beams, n_avg, paired, mode):
-    """Two-k-step classes with an even number of 256-beam groups run 8-wave workgroups (512 threads, one frequency's voltages
-    staged once for 512 beams; fused_wg_waves, bf_kernels.hip): both compile-time classes and both run-time ones, full and
-    ragged last groups (480, 288, 992 beams), canonical and contracted detect, general and conjugate-pair kernel -- bit-exact
-    against the oracle, and bit-identical to the same geometry forced onto 4-wave workgroups."""
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_wide_launches_of_the_two_kstep_classes_bit_exact(torch, bfmod, orc, monkeypatch, n_ant, n_beams, n_avg, paired, mode):
+    """The two-k-step classes at n_ipo >= 16 (bf_kernels.hip): the conjugate-pair kernel runs 8 output slots per wave where the
+    beams come in whole groups of 512 and the instantiation fits its registers (fused_col_tiles: not the run-time dword class, not
+    100 antennas at n_ipo 64); otherwise, with an even number of 256-beam groups, 8-wave workgroups (fused_wg_waves).  Both
+    compile-time classes and both run-time ones, full and ragged last groups (480, 288, 992 beams), canonical / contracted /
+    fast detect, general and conjugate-pair kernel: bit-exact against the oracle (fast: within its tolerance), and bit-identical
+    to the same geometry forced onto the plain 4-wave, 4-slot launch."""
     g = orc.Geom(n_beams=n_beams, n_ant=n_ant, n_freq=3, n_avg=n_avg, n_out_per_gemm=6)
     n_units = max(2, -(-500 // g.n_time))
     rng = np.random.default_rng(n_ant * 7 + n_beams + n_avg + 17 * paired)
@@ -303,6 +306,7 @@ def test_eight_wave_workgroups_of_the_two_kstep_classes_bit_exact(torch, bfmod, 
     for forced in (None, "4"):
         if forced:
             monkeypatch.setenv("DSABF_WG_WAVES", forced)
+            monkeypatch.setenv("DSABF_COL_TILES", forced)
         bf = bfmod.Beamformer(cfg)
         bf.set_weights(w)
         info = bf.kernel_info(n_units)
@@ -310,7 +314,16 @@ def test_eight_wave_workgroups_of_the_two_kstep_classes_bit_exact(torch, bfmod, 
         d_out = torch.full((want.size,), float("nan"), dtype=torch.float32, device="cuda")
         bf.beamform(d_in, n_units, d_out, s)
         torch.cuda.synchronize()
-        got[forced] = (info["block"], d_out.cpu().numpy().reshape(want.shape))
+        got[forced] = (info, d_out.cpu().numpy().reshape(want.shape))
         bf.close()
-    assert got[None][0] == 512 and np.array_equal(got[None][1], want)
-    assert np.array_equal(got["4"][1], want)
+    info, out = got[None]
+    slots8 = paired and n_beams % 512 == 0 and (n_ant % 16 == 0 or (n_ant == 100 and n_avg < 32))
+    assert ("SLOTS=8" in info["kernel"]) == slots8 and ("WAVES=8" in info["kernel"]) == (not slots8)
+    assert info["block"] == (256 if slots8 else 512)
+    assert got["4"][0]["block"] == 256 and "=8" not in got["4"][0]["kernel"]
+    assert np.array_equal(out, got["4"][1])
+    if mode == 1:
+        rel = np.abs(out.astype(np.float64) - want) / np.maximum(want.astype(np.float64), 1e-30)
+        assert rel.max() <= 4 * g.n_ipo * 2.0 ** -24
+    else:
+        assert np.array_equal(out, want)

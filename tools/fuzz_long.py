@@ -30,6 +30,8 @@ for case in range(N):
         n_ipo = 2 * n_avg
         n_out = int(rng.integers(1, 7))
         n_beams = 32 * int(rng.integers(9, 36)) if rng.integers(2) else 4 * int(rng.integers(65, 280))
+        if rng.integers(3) == 0:
+            n_beams = 512 * int(rng.integers(1, 3))
     g = orc.Geom(n_beams=n_beams, n_ant=n_ant, n_freq=int(rng.integers(1, 18 if n_beams <= 400 else 6)), n_avg=n_avg, n_out_per_gemm=n_out)
     n_units = int(rng.integers(1, 1 + max(1, 900 // g.n_time)))
     w = rng.integers(-127, 128, size=(g.n_freq, g.n_ant, g.n_beams, 2), dtype=np.int8)
@@ -47,7 +49,7 @@ for case in range(N):
     info = bf.kernel_info(n_units)
     name = info["kernel"]
     assert ("PAIRED" in name) == paired, (name, paired)
-    key = ("rt" if "(run-time)" in name else str(n_ant), n_ipo, paired, mode, info["block"])
+    key = ("rt" if "(run-time)" in name else str(n_ant), n_ipo, paired, mode, "slots8" if "SLOTS=8" in name else "waves8" if "WAVES=8" in name else "plain")
     classes[key] = classes.get(key, 0) + 1
     d_in = torch.from_numpy(packed).cuda()
     with orc.detect_contract(orc.CONTRACT_NVCC if mode == 2 else orc.CONTRACT_NONE):
@@ -60,5 +62,6 @@ for case in range(N):
         bad += 1
         print("MISMATCH", case, g, n_units, paired, mode, os.environ["DSABF_TSPLIT"])
     bf.close()
-print("seed", os.environ.get("SEED", "1"), "cases", N, "mismatches", bad, "distinct (antenna class, n_ipo, paired, mode, block) combinations", len(classes),
-      "cases on 8-wave workgroups", sum(v for k, v in classes.items() if k[4] == 512))
+print("seed", os.environ.get("SEED", "1"), "cases", N, "mismatches", bad, "distinct (antenna class, n_ipo, paired, mode, launch) combinations", len(classes),
+      "cases on 8-wave workgroups", sum(v for k, v in classes.items() if k[4] == "waves8"),
+      "on 8 slots per wave", sum(v for k, v in classes.items() if k[4] == "slots8"))
