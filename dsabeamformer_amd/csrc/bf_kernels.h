@@ -22,7 +22,13 @@ struct Geometry {
     bool fast_detect;                                   // BF_DETECT_FAST requested (honoured by fused16_kernel, n_ipo >= 16)
     bool contracted_detect = false;                     // BF_DETECT_CONTRACTED requested
     bool paired = false;                                // weights verified conjugate-symmetric: beam B-1-b = conj(beam b)
+    // Test / measurement switches, read from the environment ONCE per handle (read_env_switches, at bf_create) -- they decide
+    // the layout of the weight images as well as the kernel, so a handle must not see them change between two calls:
+    bool plain_wg_waves = false;                        // DSABF_WG_WAVES=4: 4-wave workgroups everywhere
+    bool plain_col_tiles = false;                       // DSABF_COL_TILES=4: 4 output slots per wave everywhere
+    bool runtime_ant = false;                           // DSABF_RUNTIME_ANT=1: the run-time antenna classes everywhere
 };
+void read_env_switches(Geometry& g);
 
 // Bytes of the MFMA-fragment weight image: [freq][16-beam tile][re|im row][re|im operand][k-step][lane] x 16 B.
 size_t weight_image_bytes(const Geometry& g);

@@ -397,8 +397,7 @@ FusedVariant select_variant(const Geometry& g, bool write_c)
     if (!nipo_supported(g.n_ipo) || g.n_ant <= 0 || g.n_ant > 128 || g.n_ant % 4) return FusedVariant{};
     const bool paired = g.paired && !write_c;
     const int mode = detect_mode_of(g);
-    const char* force_rt = getenv("DSABF_RUNTIME_ANT");   // test / measurement switch: run the run-time classes everywhere
-    const bool rt = force_rt && force_rt[0] == '1';
+    const bool rt = g.runtime_ant;
     const bool ns8 = fused_col_tiles(g, paired) == kColTilesWide16;
     if (ns8 || fused_wg_waves(g, write_c) == kWavesWide16) {
         if (!rt && g.n_ant == 100) return fused16_variant_a100_wide(g.n_ipo, mode, paired, ns8);
@@ -456,6 +455,16 @@ bool fused_supported(const Geometry& g, const char** why)
     return true;
 }
 
+void read_env_switches(Geometry& g)
+{
+    const char* w = getenv("DSABF_WG_WAVES");
+    const char* t = getenv("DSABF_COL_TILES");
+    const char* r = getenv("DSABF_RUNTIME_ANT");
+    g.plain_wg_waves = w && atoi(w) == kWaves16;
+    g.plain_col_tiles = t && atoi(t) == kColTiles16;
+    g.runtime_ant = r && r[0] == '1';
+}
+
 // Output slots (16 beams each) per wave.  The two-k-step conjugate-pair kernels hold 2 waves per SIMD whatever they do (64 KiB of
 // LDS per workgroup), and with 8 slots instead of 4 a wave's LDS fragment reads feed twice the MFMAs (32 between two reads) at 241
 // of its 256 registers: BASELINE config 5 runs 6.4-7.0 % faster than on 8-wave workgroups, 8.5 % faster than on the 4-slot
@@ -465,13 +474,11 @@ bool fused_supported(const Geometry& g, const char** why)
 // profiles/r03_variants_log.txt).
 int fused_col_tiles(const Geometry& g, bool paired)
 {
-    const char* e = getenv("DSABF_COL_TILES");   // test / measurement switch: 4 = four slots per wave everywhere
-    const char* force_rt = getenv("DSABF_RUNTIME_ANT");
-    const bool rt = force_rt && force_rt[0] == '1';
+    const bool rt = g.runtime_ant;
     // the instantiations that fit their registers (ns8_fits, bf_fused16.hpp): 16-byte-staged rows, or the compile-time 100 antennas
     const bool fits = g.n_ant % 16 == 0 || (!rt && g.n_ant == 100 && g.n_ipo < 64);
     const bool can = paired && fits && kColTiles16 == 4 && kWaves16 == 4 && ksteps16(g) == 2 && g.n_ipo >= 16 && g.n_beams % 512 == 0;
-    return (can && !(e && atoi(e) == kColTiles16)) ? kColTilesWide16 : kColTiles16;
+    return (can && !g.plain_col_tiles) ? kColTilesWide16 : kColTiles16;
 }
 
 // A workgroup stages one frequency's voltages for all of its waves.  The two-k-step classes hold 2 waves per SIMD whatever
@@ -481,12 +488,9 @@ int fused_col_tiles(const Geometry& g, bool paired)
 // barriers); so do the store-bound short windows, the stage-parity launch and the 8-slot pair kernel above.
 int fused_wg_waves(const Geometry& g, bool write_c)
 {
-    const char* e = getenv("DSABF_WG_WAVES");   // test / measurement switch: 4 = the 4-wave workgroups everywhere
-    const int forced = e ? atoi(e) : 0;
     const bool can = !write_c && ksteps16(g) == 2 && g.n_ipo >= 16 && kWaves16 == 4 && kColTiles16 == 4 &&
                      ((g.n_beams + 255) / 256) % 2 == 0 && fused_col_tiles(g, g.paired) == kColTiles16;
-    if (forced == kWaves16 || !can) return kWaves16;
-    return kWavesWide16;
+    return (can && !g.plain_wg_waves) ? kWavesWide16 : kWaves16;
 }
 
 LaunchShape fused_launch_shape(const Geometry& g, int n_units, int n_cus, bool write_c)
@@ -672,7 +676,7 @@ hipError_t launch_dedisperse_dm(const Geometry& g, const float* d_series, int n_
 
 const char* fused_kernel_name(const Geometry& g, char* buf, size_t n)
 {
-    const bool rt = !(g.n_ant == 64 || g.n_ant == 100 || g.n_ant == 128);
+    const bool rt = !(g.n_ant == 64 || g.n_ant == 100 || g.n_ant == 128);   // (the geometry's class; DSABF_RUNTIME_ANT is not shown)
     snprintf(buf, n, "dsabf::fused16_kernel<ANT=%d%s,NIPO=%d%s%s%s> (v_mfma_i32_16x16x64_i8)", g.n_ant, rt ? "(run-time)" : "",
              g.n_ipo, (g.fast_detect && g.n_ipo >= 16) ? ",FAST" : g.contracted_detect ? ",CONTRACTED" : "",
              g.paired ? ",PAIRED" : "",

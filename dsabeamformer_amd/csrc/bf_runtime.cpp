@@ -94,6 +94,7 @@ dsabf::Geometry make_geom(const bf_config& c)
     g.n_ctiles = (c.n_beams + 15) / 16;
     g.fast_detect = c.detect_mode == BF_DETECT_FAST;
     g.contracted_detect = c.detect_mode == BF_DETECT_CONTRACTED;
+    dsabf::read_env_switches(g);
     return g;
 }
 
