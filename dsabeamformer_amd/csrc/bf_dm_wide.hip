@@ -154,26 +154,33 @@ __global__ __launch_bounds__(kDwThreads) void dedisperse_dm_wide_kernel(const fl
     // (lane / lanes-per-row) and its beams; what changes per DMA -- first row of the piece, channel -- is wave-uniform and
     // stays on the scalar unit (a per-lane row * stride would be two quarter-rate 64-bit multiplies per instruction).  The
     // common case -- every row of the piece inside the series, every beam live -- needs no per-lane test either.
-    const float* lane_src = series + (size_t)(lane / kLpr) * row_stride + bs;
+    // (byte offsets in 32 bits: the launcher sends series of 4 GiB and more to dedisperse_dm_kernel)
+    const unsigned lane_off = (unsigned)(((size_t)(lane / kLpr) * row_stride + bs) * sizeof(float));
     const float* lane_zero = zero_row + 4 * (lane % kLpr);
     const bool beams_ok = bs < n_beams;
     const bool all_beams_ok = __builtin_amdgcn_readfirstlane((int)__all(beams_ok ? 1 : 0)) != 0;   // wave-uniform
+    const unsigned row_stride_b = (unsigned)(row_stride * sizeof(float));   // uniform
     auto dma_window = [&](int f, int slot, v2i t) {       // t = tab[f], already in registers; slot = f % kDwNbuf
         const int nr = __builtin_amdgcn_readfirstlane(t.y);
         const int first = t0 + __builtin_amdgcn_readfirstlane(t.x);
-        const size_t col = (size_t)f * n_beams;           // uniform
+        const unsigned col_b = (unsigned)f * (unsigned)n_beams * (unsigned)sizeof(float);   // uniform
         char* buf = win + slot * win_bytes;
 #pragma unroll
         for (int j = 0; j < kDwPairsPerWave; j++) {
             const int pr = wave + kDwWaves * j;           // wave-uniform
             if (kDwRowsPerDma * pr < nr) {
                 const int row0 = first + kDwRowsPerDma * pr;                       // uniform: first row of this piece
-                const float* src = lane_src + ((long long)row0 * (long long)row_stride + (long long)col);
-                if (!(all_beams_ok && row0 >= 0 && row0 + kDwRowsPerDma <= n_t)) {   // an end of the series / of the beams
+                const char* src;
+                if (all_beams_ok && row0 >= 0 && row0 + kDwRowsPerDma <= n_t) {    // the common case: scalar base + the lane's constant offset
+                    const char* sbase = reinterpret_cast<const char*>(series) + ((unsigned)row0 * row_stride_b + col_b);
+                    src = sbase + lane_off;
+                } else {                                                            // an end of the series / of the beams
                     const int row = row0 + lane / kLpr;
-                    if (!(row >= 0 && row < n_t && beams_ok)) src = lane_zero;
+                    src = (row >= 0 && row < n_t && beams_ok)
+                              ? reinterpret_cast<const char*>(series + ((size_t)row * row_stride + (size_t)f * n_beams + bs))
+                              : reinterpret_cast<const char*>(lane_zero);
                 }
-                __builtin_amdgcn_global_load_lds(src, (lds_ptr)(buf + kDwRowsPerDma * pr * kDwRowBytes), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(src), (lds_ptr)(buf + kDwRowsPerDma * pr * kDwRowBytes), 16, 0, 0);
             }
         }
     };

@@ -657,7 +657,8 @@ hipError_t launch_dedisperse_dm(const Geometry& g, const float* d_series, int n_
     if (n_dm <= 0 || n_t_out <= 0) return hipSuccess;
     const char* env = getenv("DSABF_DM_WIDE");      // measurement / test switch: 0 = the per-thread-window kernel alone
     const bool wide = d_flags && dm_wide_supported(g, n_dm) && !(env && env[0] == '0') &&
-                      !((uintptr_t)d_series & 15) && !((uintptr_t)d_out & 15);   // its 16-byte LDS-DMA pieces / 16-byte stores
+                      !((uintptr_t)d_series & 15) && !((uintptr_t)d_out & 15) &&   // its 16-byte LDS-DMA pieces / 16-byte stores
+                      (size_t)n_t * g.n_freq * g.n_beams * sizeof(float) < ((size_t)1 << 32);   // ... and 32-bit byte offsets into the series
     if (wide) {
         hipError_t e = launch_dedisperse_dm_wide(g, d_series, n_t, d_delays, n_dm, n_t_out, d_out, d_flags, s);
         if (e != hipSuccess) return e;
