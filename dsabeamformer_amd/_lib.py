@@ -110,6 +110,8 @@ SIGNATURES = {
     "bf_kernel_info": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
                                  C.POINTER(C.c_int)]),
     "bf_kernel_name": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t]),
+    "bf_launch_plan": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
+                               C.c_char_p, C.c_size_t]),
     # ---- include/dsabf_host.h ----
     "bfh_default_positions": (C.c_int, [C.c_int, C.c_void_p]),
     "bfh_default_directions": (C.c_int, [C.c_int, C.c_void_p]),

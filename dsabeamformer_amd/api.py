@@ -29,6 +29,14 @@ def production_config(**over) -> BfConfig:
     return cfg
 
 
+def launch_plan(cfg: BfConfig, paired: bool, n_units: int = 1, n_cus: int = 256) -> dict:
+    """Which fused kernel and launch shape ``cfg`` would run (bf_launch_plan: host arithmetic, no device needed)."""
+    g, b, l = C.c_int(), C.c_int(), C.c_int()
+    name = C.create_string_buffer(200)
+    check(load().bf_launch_plan(C.byref(cfg), int(paired), n_units, n_cus, C.byref(g), C.byref(b), C.byref(l), name, 200))
+    return {"kernel": name.value.decode(), "grid": g.value, "block": b.value, "lds_bytes": l.value}
+
+
 def _ptr(x) -> C.c_void_p:
     """Accept ints, ctypes pointers, numpy arrays (host) and torch tensors (device or host)."""
     if x is None:

@@ -715,6 +715,23 @@ int bf_kernel_info(const bf_handle* h, int n_units, int* grid, int* block, int* 
     return BF_OK;
 }
 
+int bf_launch_plan(const bf_config* cfg, int paired, int n_units, int n_cus, int* grid, int* block, int* lds_bytes, char* name,
+                   size_t name_len)
+{
+    if (int rc = check_cfg(cfg)) return rc;
+    dsabf::Geometry g = make_geom(*cfg);
+    const char* why = nullptr;
+    if (!dsabf::fused_supported(g, &why)) return fail(BF_ERR_INVALID, "unsupported geometry: %s", why);
+    if (n_units <= 0 || n_cus <= 0) return fail(BF_ERR_INVALID, "need n_units > 0 and n_cus > 0");
+    g.paired = paired && dsabf::pairing_supported(g);   // what bf_set_weights decides for a conjugate-symmetric weight set
+    const dsabf::LaunchShape ls = dsabf::fused_launch_shape(g, n_units, n_cus);
+    if (grid) *grid = ls.grid;
+    if (block) *block = ls.block;
+    if (lds_bytes) *lds_bytes = ls.lds_bytes;
+    if (name && name_len) dsabf::fused_kernel_name(g, name, name_len);
+    return BF_OK;
+}
+
 int bf_kernel_name(const bf_handle* h, char* buf, size_t buflen)
 {
     if (!h || !buf || !buflen) return fail(BF_ERR_INVALID, "NULL argument");

@@ -281,6 +281,11 @@ int bf_dedisperse_dm_band_device(bf_handle *h, const float *d_series, int n_t, i
 /* Introspection for benchmarks/roofline reports. */
 int bf_kernel_info(const bf_handle *h, int n_units, int *grid, int *block, int *lds_bytes, int *vgprs);
 int bf_kernel_name(const bf_handle *h, char *buf, size_t buflen); /* which fused kernel this geometry runs */
+/* The same answers WITHOUT a handle or a device: which kernel and launch shape a configuration would run for n_units gemm-units
+ * on a chip of n_cus compute units (MI355X: 256); paired != 0: as for a conjugate-symmetric weight set (honoured where a
+ * conjugate-pair kernel exists).  Pure host arithmetic -- for planning, and so that the launch logic is testable anywhere. */
+int bf_launch_plan(const bf_config *cfg, int paired, int n_units, int n_cus, int *grid, int *block, int *lds_bytes, char *name,
+                   size_t name_len);
 
 #ifdef __cplusplus
 }

@@ -143,3 +143,51 @@ def test_bench_has_one_gather_path():
     src = open(os.path.join(ROOT, "bench.py")).read()
     assert "shard_layouts" not in src and "DetectedGather" not in src and "import shard" not in src
     assert not os.path.exists(os.path.join(ROOT, "dsabeamformer_amd", "shard.py"))
+
+
+def test_launch_plan_picks_the_launch_of_every_class_without_a_device(monkeypatch):
+    """bf_launch_plan: the host arithmetic behind fused_launch_shape / fused_wg_waves / fused_col_tiles (csrc/bf_kernels.hip) --
+    which kernel, workgroup size and grid a configuration runs -- needs no GPU.  BASELINE configs[1] (C3), configs[4] (C5) and
+    its rank shard, and the geometries on either side of every rule."""
+    import dsabeamformer_amd as bfm
+
+    def plan(paired, n_units, **kw):
+        return bfm.launch_plan(bfm.production_config(**kw), paired, n_units)
+
+    c3 = plan(True, 128, n_out_per_gemm=16)
+    assert c3 == {"kernel": "dsabf::fused16_kernel<ANT=64,NIPO=32,PAIRED> (v_mfma_i32_16x16x64_i8)", "grid": 6656, "block": 256,
+                  "lds_bytes": 32768}
+    assert plan(False, 128, n_out_per_gemm=16)["grid"] == 6656
+    c5 = dict(n_ant=100, n_beams=512, n_freq=1024, n_out_per_gemm=8)
+    # conjugate-pair kernel, two k-steps, beams in whole groups of 512: 8 output slots per wave, one set of long workgroups
+    p = plan(True, 16, **c5)
+    assert "PAIRED,SLOTS=8" in p["kernel"] and (p["grid"], p["block"], p["lds_bytes"]) == (1024, 256, 65536)
+    # the general kernel (calibrated weights) cannot hold 8 slots: 8-wave workgroups, one per CU
+    g = plan(False, 16, **c5)
+    assert g["kernel"].endswith("NIPO=32,WAVES=8> (v_mfma_i32_16x16x64_i8)") and (g["grid"], g["block"]) == (1024, 512)
+    # one rank's shard of C5 (128 channels): two resident 8-slot workgroups per CU -> 512; one 8-wave workgroup per CU -> 256
+    assert plan(True, 16, **dict(c5, n_freq=128))["grid"] == 512 and plan(False, 16, **dict(c5, n_freq=128))["grid"] == 256
+    # 8 slots need whole groups of 512 beams and an instantiation that fits its registers; otherwise 8 waves, or the plain launch
+    assert "WAVES=8" in plan(True, 16, **dict(c5, n_beams=480))["kernel"]            # ragged: 8-wave workgroups
+    assert "WAVES=8" in plan(True, 16, **dict(c5, n_ant=108))["kernel"]              # run-time dword-staged class
+    assert "SLOTS=8" in plan(True, 16, **dict(c5, n_ant=112))["kernel"]              # run-time 16-byte-staged class
+    assert "SLOTS=8" in plan(True, 16, **dict(c5, n_ant=128))["kernel"]
+    assert "WAVES=8" in plan(True, 16, **dict(c5, n_avg=32))["kernel"]               # 100 antennas at n_ipo 64 would spill
+    assert "SLOTS=8" in plan(True, 16, **dict(c5, n_ant=128, n_avg=32))["kernel"]
+    for kw in (dict(c5, n_beams=256), dict(c5, n_beams=768), dict(c5, n_avg=4, n_out_per_gemm=32), dict(c5, n_ant=64)):
+        q = plan(True, 16, **kw)                                                     # odd group count / short window / one k-step
+        assert "S=8" not in q["kernel"] and q["block"] == 256, kw
+    # the test switches give the plain launch back (read once per handle: here per call)
+    monkeypatch.setenv("DSABF_COL_TILES", "4")
+    assert "WAVES=8" in plan(True, 16, **c5)["kernel"]
+    monkeypatch.setenv("DSABF_WG_WAVES", "4")
+    q = plan(True, 16, **c5)
+    assert "S=8" not in q["kernel"] and (q["grid"], q["block"]) == (4096, 256)
+    monkeypatch.delenv("DSABF_COL_TILES")
+    monkeypatch.delenv("DSABF_WG_WAVES")
+    # errors: a geometry outside the reference's contract, a non-positive unit count
+    import ctypes as C
+    lib = bfm.load()
+    bad = bfm.production_config(n_beams=6)
+    assert lib.bf_launch_plan(C.byref(bad), 0, 1, 256, None, None, None, None, 0) != 0 and b"N_BEAMS" in lib.bf_last_error()
+    assert lib.bf_launch_plan(C.byref(bfm.production_config()), 0, 0, 256, None, None, None, None, 0) != 0
