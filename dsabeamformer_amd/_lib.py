@@ -110,6 +110,8 @@ SIGNATURES = {
     "bf_kernel_info": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
                                  C.POINTER(C.c_int)]),
     "bf_kernel_name": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t]),
+    "bf_mfma_peak_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_double),
+                                    C.c_void_p]),
     "bf_launch_plan": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
                                C.c_char_p, C.c_size_t]),
     # ---- include/dsabf_host.h ----

@@ -148,6 +148,13 @@ class Beamformer:
         check(self._lib.bf_timer_stop(self._h, C.byref(ms)))
         return ms.value
 
+    def mfma_peak(self, d_operands, operand_bytes: int, d_scratch, scratch_bytes: int, iters: int, stream) -> float:
+        """One launch of back-to-back v_mfma_i32_16x16x64_i8 on the caller's operand bytes; returns the int8 ops it executes."""
+        ops = C.c_double()
+        check(self._lib.bf_mfma_peak_device(self._h, _ptr(d_operands), operand_bytes, _ptr(d_scratch), scratch_bytes, iters,
+                                            C.byref(ops), C.c_void_p(stream)))
+        return ops.value
+
     def kernel_info(self, n_units: int = 1) -> dict:
         g, b, l, v = C.c_int(), C.c_int(), C.c_int(), C.c_int()
         check(self._lib.bf_kernel_info(self._h, n_units, C.byref(g), C.byref(b), C.byref(l), C.byref(v)))

@@ -633,6 +633,49 @@ hipError_t launch_expand(const void* d_in, size_t nbytes, void* d_out, hipStream
     return hipGetLastError();
 }
 
+// ---- the matrix pipe by itself ("a back-to-back v_mfma micro-benchmark; report utilisation against both nominal
+// and measured peak") -------------------------------------------------------------------------------------------------------------
+// 4 waves per SIMD, 16 independent accumulator chains of v_mfma_i32_16x16x64_i8 per wave and nothing else in the loop; the operands
+// are the caller's bytes -- A as the fused kernel sees voltages (16 * nibble), B as it sees weights (any int8) -- because the
+// clock the chip holds under this load depends on the operand bits (tools/ubench_shape.hip: constant operands 4.6 POP/s, random
+// ones 3.6-4.1).  The sums are stored so that nothing is optimised away.
+__global__ __launch_bounds__(256, 4) void mfma_peak_kernel(const v4i* __restrict__ src, int* __restrict__ sink, int iters)
+{
+    v4i a[4], b[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) b[i] = src[((blockIdx.x & 63) * 8 + i) * 256 + threadIdx.x];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const v4i r = src[(512 + (blockIdx.x & 63) * 4 + i) * 256 + threadIdx.x];
+        a[i] = v4i{r[0] & (int)0xF0F0F0F0u, r[1] & (int)0xF0F0F0F0u, r[2] & (int)0xF0F0F0F0u, r[3] & (int)0xF0F0F0F0u};
+    }
+    int acc = 0;
+    for (int it = 0; it < iters; it++) {
+        v4i c[8];
+#pragma unroll
+        for (int t = 0; t < 8; t++) c[t] = v4i{0, 0, 0, 0};
+#pragma unroll
+        for (int m = 0; m < 2; m++)
+#pragma unroll
+            for (int t = 0; t < 8; t++) c[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[(t + m) & 3], b[(t + 2 * m) & 7], c[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 8; t++) acc += c[t][0] + c[t][3];
+        asm volatile("" : "+v"(acc));
+    }
+    sink[blockIdx.x * 256 + threadIdx.x] = acc;
+}
+
+// src: kMfmaPeakSrcBytes of caller data; sink: kMfmaPeakSinkBytes of scratch.  *ops = int8 ops (2 per MAC) the launch executes.
+hipError_t launch_mfma_peak(const void* d_src, void* d_sink, int iters, int n_cus, double* ops, hipStream_t s)
+{
+    clear_stale_error();
+    const int grid = n_cus * 4;   // 4 workgroups of 4 waves per CU = 4 waves per SIMD, one set
+    if ((size_t)grid * 256 * sizeof(int) > kMfmaPeakSinkBytes || iters <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(mfma_peak_kernel, dim3(grid), dim3(256), 0, s, static_cast<const v4i*>(d_src), static_cast<int*>(d_sink), iters);
+    if (ops) *ops = (double)grid * 4.0 * iters * 16.0 * 2.0 * 16 * 16 * 64;
+    return hipGetLastError();
+}
+
 hipError_t launch_dedisperse(const Geometry& g, const float* d_out_unit, float* d_ded, hipStream_t s)
 {
     clear_stale_error();

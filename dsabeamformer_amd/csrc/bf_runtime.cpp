@@ -642,6 +642,18 @@ int bf_expand_device(bf_handle* h, const void* d_in, size_t nbytes, void* d_out,
     return BF_OK;
 }
 
+int bf_mfma_peak_device(bf_handle* h, const void* d_operands, size_t operand_bytes, void* d_scratch, size_t scratch_bytes, int iters,
+                        double* ops, void* hip_stream)
+{
+    if (!h || !d_operands || !d_scratch) return fail(BF_ERR_INVALID, "NULL argument");
+    if (operand_bytes < dsabf::kMfmaPeakSrcBytes || scratch_bytes < dsabf::kMfmaPeakSinkBytes || ((uintptr_t)d_operands & 15) || iters <= 0)
+        return fail(BF_ERR_INVALID, "need >= %zu operand bytes (16-byte aligned), >= %zu scratch bytes, iters > 0",
+                    dsabf::kMfmaPeakSrcBytes, dsabf::kMfmaPeakSinkBytes);
+    ON_DEVICE(h);
+    HIP_TRY(dsabf::launch_mfma_peak(d_operands, d_scratch, iters, h->n_cus, ops, as_stream(hip_stream)));
+    return BF_OK;
+}
+
 int bf_gemm_device(bf_handle* h, const void* d_packed_unit, float* d_c, void* hip_stream)
 {
     if (!h || !d_packed_unit || !d_c) return fail(BF_ERR_INVALID, "NULL argument");

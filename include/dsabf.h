@@ -278,6 +278,14 @@ int bf_dedisperse_band_device(bf_handle *h, const float *d_out_unit, int n_freq_
 int bf_dedisperse_dm_band_device(bf_handle *h, const float *d_series, int n_t, int n_freq_total, const int32_t *d_delays,
                                  int n_dm, int n_t_out, float *d_out, void *hip_stream);
 
+/* The matrix pipe by itself, for roofline reports ("a back-to-back v_mfma micro-benchmark; report utilisation
+ * against both nominal and measured peak"): one launch of `iters` x 16 independent v_mfma_i32_16x16x64_i8 per wave, 4 waves per
+ * SIMD, nothing else in the loop.  Operands are read from the caller's buffer (>= 3 MiB; A = bytes & 0xF0 as the fused kernel
+ * sees voltages, B = bytes as it sees weights): the clock the chip holds depends on the operand bits.  d_scratch: >= 4 MiB.
+ * *ops = int8 ops the launch executes; the caller times it (HIP events on hip_stream). */
+int bf_mfma_peak_device(bf_handle *h, const void *d_operands, size_t operand_bytes, void *d_scratch, size_t scratch_bytes,
+                        int iters, double *ops, void *hip_stream);
+
 /* Introspection for benchmarks/roofline reports. */
 int bf_kernel_info(const bf_handle *h, int n_units, int *grid, int *block, int *lds_bytes, int *vgprs);
 int bf_kernel_name(const bf_handle *h, char *buf, size_t buflen); /* which fused kernel this geometry runs */

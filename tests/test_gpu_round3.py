@@ -327,3 +327,26 @@ def test_wide_launches_of_the_two_kstep_classes_bit_exact(torch, bfmod, orc, mon
         assert rel.max() <= 4 * g.n_ipo * 2.0 ** -24
     else:
         assert np.array_equal(out, want)
+
+
+def test_mfma_peak_microbenchmark_runs_and_counts_its_ops(torch, bfmod):
+    """bf_mfma_peak_device (the measured peak beside the nominal one): the launch executes the ops it reports --
+    n_cus x 4 workgroups x 4 waves x iters x 16 MFMAs x 32,768 int8 ops -- lasts in proportion to iters, lands between 40 % and
+    100 % of the nominal 5 POP/s on random operands, and refuses short buffers."""
+    bf = bfmod.Beamformer(bfmod.production_config())
+    s = torch.cuda.current_stream()
+    src = torch.randint(0, 256, (4 << 20,), dtype=torch.uint8, device="cuda")
+    sink = torch.zeros(4 << 20, dtype=torch.uint8, device="cuda")
+    ms = {}
+    for iters in (500, 2000):
+        for _ in range(5):
+            ops = bf.mfma_peak(src, src.numel(), sink, sink.numel(), iters, s.cuda_stream)
+        assert ops == 256 * 4 * 4 * iters * 16 * 32768
+        ms[iters] = bench.time_launches(torch, lambda i: bf.mfma_peak(src, src.numel(), sink, sink.numel(), iters, s.cuda_stream), 20, s)[1]
+    assert 3.0 < ms[2000] / ms[500] < 4.6
+    tops = 256 * 4 * 4 * 2000 * 16 * 32768 / (ms[2000] * 1e-3) / 1e12
+    assert 2000 < tops <= 5000 * 1.02, tops
+    assert sink.view(torch.int32)[: 1024 * 256].abs().sum().item() > 0          # the accumulators were stored
+    with pytest.raises(bfmod.DsabfError):
+        bf.mfma_peak(src, 1 << 20, sink, sink.numel(), 100, s.cuda_stream)
+    bf.close()
