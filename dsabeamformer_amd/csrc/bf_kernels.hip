@@ -537,6 +537,8 @@ LaunchShape fused_launch_shape(const Geometry& g, int n_units, int n_cus, bool w
     // BASELINE-config-5 rank shard is 14 % faster on 1024 workgroups than on 4096 (profiles/r02_launch_size_c5shard.txt).
     // Their 8-wave workgroups, one resident per CU, want one set: the same shard 256 workgroups -7.0 %, 512 -4.9 %, 1024 -1.2 %
     // against the 4-wave launch (profiles/r03_ab_c5_w8.txt).
+    // The 8-slot pair kernel (two resident per CU) wants one set of two: the shard on 512 workgroups -12.1 %, on 1024 -10.6 %, on
+    // 256 (half the chip's slots empty) +35 % (profiles/r03_ab_c5_ns8.txt).
     const int target_wgs_per_cu = g.n_ipo < 16 ? 2 : wide ? 1 : ns8 ? 2 : (two_k ? 4 : 4 * (16 / kWaves16));
     int want_fill = (target_wgs_per_cu * n_cus + base - 1) / base;            // enough workgroups to fill the chip
     if (want_fill > max_split) want_fill = max_split;
