@@ -505,6 +505,27 @@ def main():
             achieved = launch_bytes / (kern_avg_ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(pmc)}
+            # the measured counterpart of the nominal 8 TB/s: a pure streaming kernel on this box, after the timed region --
+            # bf_expand_device (a1 alone: 1 byte in, 2 out per packed byte, whole 128-byte lines, nontemporal both ways)
+            try:
+                n_exp = 256 << 20      # 256 MiB in, 512 MiB out: well past the 256 MiB Infinity Cache
+                d_exp_in = torch.randint(0, 256, (n_exp,), dtype=torch.uint8, device="cuda")
+                d_exp = torch.empty(2 * n_exp, dtype=torch.uint8, device="cuda")
+
+                def exp_fn(i):
+                    bf.expand(d_exp_in, n_exp, d_exp, sptr)
+                for i in range(10):
+                    exp_fn(i)
+                torch.cuda.synchronize()
+                e_avg, _, _ = time_launches(torch, exp_fn, 30, stream)
+                peak_measured = 3 * n_exp / (e_avg * 1e-3) / 1e9
+                roof.update({"peak_measured": peak_measured, "frac_of_measured_peak": achieved / peak_measured,
+                             "peak_measured_note": "bf_expand_device streaming %d MiB in / %d MiB out: %.3f ms per launch, "
+                                                   "measured after the timed region" % (n_exp >> 20, n_exp >> 19, e_avg)})
+                del d_exp, d_exp_in
+            except Exception as e:
+                roof["peak_measured"] = None
+                roof["peak_measured_note"] = "streaming micro-benchmark failed: %s" % e
         executed = launch_ops / 2 if paired else launch_ops
         roof.update({"kernel": info["kernel"],
                      "kernel_ms_avg": kern_avg_ms, "kernel_ms_median": kern_ms[len(kern_ms) // 2],

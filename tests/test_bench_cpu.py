@@ -100,7 +100,7 @@ def test_committed_bench_lines_agree_with_the_committed_rocprof_kernel_stats():
         assert roof["traffic"] is not None and roof["pmc_source"].startswith("profiles/r0")
         assert set(roof["from_committed_profile"]) == {"traffic", "mfma_busy_frac"}     # labelled: not observed in that run
         assert d["ms_per_step"] >= roof["kernel_ms_avg"] * 0.999          # the whole step cannot be shorter than its kernel
-        if roof["bound"] == "mfma":      # the measured peak beside the nominal one, from the same run
-            assert 0.6 * roof["peak"] < roof["peak_measured"] <= roof["peak"] * 1.02
-            assert abs(roof["achieved"] / roof["peak_measured"] / roof["frac_of_measured_peak"] - 1) < 1e-9
-            assert roof["frac"] < roof["frac_of_measured_peak"] < 1.0
+        # the measured peak beside the nominal one, from the same run (a pure MFMA loop / a pure streaming kernel)
+        assert 0.6 * roof["peak"] < roof["peak_measured"] <= roof["peak"] * 1.02
+        assert abs(roof["achieved"] / roof["peak_measured"] / roof["frac_of_measured_peak"] - 1) < 1e-9
+        assert roof["frac"] < roof["frac_of_measured_peak"] < 1.05
