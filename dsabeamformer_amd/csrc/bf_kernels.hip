@@ -398,7 +398,7 @@ FusedVariant select_variant(const Geometry& g, bool write_c)
     const bool paired = g.paired && !write_c;
     const int mode = detect_mode_of(g);
     const bool rt = g.runtime_ant;
-    const bool ns8 = fused_col_tiles(g, paired) == kColTilesWide16;
+    const bool ns8 = kColTiles16 != kColTilesWide16 && fused_col_tiles(g, paired) == kColTilesWide16;   // (a -DDSABF_NS=8 build: every kernel)
     if (ns8 || fused_wg_waves(g, write_c) == kWavesWide16) {
         if (!rt && g.n_ant == 100) return fused16_variant_a100_wide(g.n_ipo, mode, paired, ns8);
         if (!rt && g.n_ant == 128) return fused16_variant_a128_wide(g.n_ipo, mode, paired, ns8);

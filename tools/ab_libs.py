@@ -2,7 +2,7 @@
 """Interleaved A/B timing of the fused kernel across BUILDS and environment switches, one subprocess per measurement.
 
   python tools/ab_libs.py [--workload c3|c5|c2] [--paired 0|1] [--detect canonical|contracted|fast] [--weights fan|calibrated]
-                          [--units N] [--n-freq F] [--rounds R] [--launches L]  NAME=LIB[,ENV=VAL...] ...
+                          [--units N] [--n-freq F] [--n-beams B] [--rounds R] [--launches L]  NAME=LIB[,ENV=VAL...] ...
 
 LIB is a library made by tools/build_variant.py (or `product` for the in-tree one); ENV=VAL pairs are set for that variant's
 process (e.g. DSABF_TSPLIT=24).  Every round measures every variant once, back to back, so clock drift cancels; the table
@@ -31,6 +31,8 @@ def child(a):
         cfg.n_ant, cfg.n_beams = 100, 512
     if a.n_freq:
         cfg.n_freq = a.n_freq          # e.g. 128: one rank's shard of BASELINE configs[4]
+    if a.n_beams:
+        cfg.n_beams = a.n_beams
     if not a.paired:
         os.environ["DSABF_PAIRED"] = "0"
     bf = bfm.Beamformer(cfg)
@@ -70,6 +72,7 @@ def main():
     ap.add_argument("--weights", default="fan")
     ap.add_argument("--units", type=int, default=0)
     ap.add_argument("--n-freq", type=int, default=0)
+    ap.add_argument("--n-beams", type=int, default=0)
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--launches", type=int, default=150)
     ap.add_argument("--warm", type=float, default=1.0)
@@ -91,7 +94,7 @@ def main():
     for r in range(a.rounds):
         for name, env in variants:
             cmd = [sys.executable, os.path.abspath(__file__), "--child", "--workload", a.workload, "--paired", str(a.paired),
-                   "--detect", a.detect, "--weights", a.weights, "--units", str(a.units), "--n-freq", str(a.n_freq), "--launches", str(a.launches),
+                   "--detect", a.detect, "--weights", a.weights, "--units", str(a.units), "--n-freq", str(a.n_freq), "--n-beams", str(a.n_beams), "--launches", str(a.launches),
                    "--warm", str(a.warm)]
             p = subprocess.run(cmd, env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
             try:
