@@ -22,6 +22,22 @@ HIPCC = os.environ.get("HIPCC") or shutil.which("hipcc") or "/opt/rocm/bin/hipcc
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize", "-Wall",
          "-Wno-unused-function", "-mllvm", "-amdgpu-sched-strategy=" + os.environ.get("DSABF_SCHED", "max-ilp"),
          "-I" + os.path.join(ROOT, "include")] + os.environ.get("DSABF_EXTRA_FLAGS", "").split()
+# The 8-wave-workgroup kernels of the two-k-step classes (csrc/bf_fused16_*_w8.hip) schedule better with iterative-ilp: C5
+# general kernel -2.0...-2.6 %, its rank shard -3.6 %, the 8-wave pair kernel -3.6 % (profiles/r03_ab_sched.txt); every other
+# kernel is neutral or slightly worse with it (C3 +-0.5 %, the 8-slot pair kernel +0.4 %) and keeps max-ilp.
+SCHED_BY_SUFFIX = {"_w8.hip": "iterative-ilp"}
+
+
+def flags_for(src: str) -> list[str]:
+    """FLAGS with the scheduling strategy of this source (an explicit DSABF_SCHED in the environment wins everywhere)."""
+    if "DSABF_SCHED" in os.environ:
+        return list(FLAGS)
+    for suffix, sched in SCHED_BY_SUFFIX.items():
+        if src.endswith(suffix):
+            return [("-amdgpu-sched-strategy=" + sched) if f.startswith("-amdgpu-sched-strategy=") else f for f in FLAGS]
+    return list(FLAGS)
+
+
 # Optional: the real PSRDADA input adapter (csrc/bf_dada.cpp, SURVEY.md 8f-3).  libpsrdada is not in this image, so it is off
 # by default; DSABF_WITH_PSRDADA=1 [PSRDADA_INCLUDE=dir PSRDADA_LIB=dir] builds it and links -lpsrdada (makefile:5-6,13).
 WITH_PSRDADA = os.environ.get("DSABF_WITH_PSRDADA") == "1"
@@ -48,12 +64,16 @@ def sources() -> list[str]:
 STAMP = os.path.join(PKG, "build", "flags.stamp")   # the flag set the in-tree library was built with
 
 
+def _stamp() -> str:
+    return " ".join(FLAGS) + " | " + repr(sorted(SCHED_BY_SUFFIX.items()))
+
+
 def _stale() -> bool:
     if not os.path.exists(LIB):
         return True
     # a library built with other flags (an experiment's DSABF_EXTRA_FLAGS, tools/variants.sh) is stale even if it is newer
     # than every source: never let tests / bench / profiles silently run a variant build
-    if not os.path.exists(STAMP) or open(STAMP).read() != " ".join(FLAGS):
+    if not os.path.exists(STAMP) or open(STAMP).read() != _stamp():
         return True
     t = os.path.getmtime(LIB)
     if not all(os.path.exists(b) for b in MAINS):
@@ -74,16 +94,19 @@ def build(force: bool = False, verbose: bool = False) -> str:
     for src in sources():
         obj = os.path.join(objdir, os.path.basename(src) + ".o")
         objs.append(obj)
-        flags_same = os.path.exists(STAMP) and open(STAMP).read() == " ".join(FLAGS)
+        flags_same = os.path.exists(STAMP) and open(STAMP).read() == _stamp()
         if not force and flags_same and os.path.exists(obj) and os.path.getmtime(obj) > max(
                 [os.path.getmtime(src)] + [os.path.getmtime(p) for p in glob.glob(os.path.join(CSRC, "*.h*"))] +
                 [os.path.getmtime(p) for p in glob.glob(os.path.join(ROOT, "include", "*.h*"))]):
             continue
         # .hip: device + host; .cpp: plain host C++ (HIP host API only), also through hipcc for the include paths
-        cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
+        cmd = [HIPCC] + flags_for(src) + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    for stale in glob.glob(os.path.join(objdir, "*.o")):   # objects of sources that no longer exist (tools link build/*.o by glob)
+        if stale not in objs:
+            os.remove(stale)
     for cmd, p in procs:
         out, _ = p.communicate()
         if p.returncode != 0:
@@ -102,7 +125,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
     with open(STAMP, "w") as fp:
-        fp.write(" ".join(FLAGS))
+        fp.write(_stamp())
     # the CLI programs are ordinary HIP applications: they link libdsabf.so AND the HIP runtime
     for exe, src in MAINS.items():
         if src == REPLICAS_SRC:   # a plain launcher: no HIP, no libdsabf (it must not initialise a GPU before exec)

@@ -701,17 +701,29 @@ FusedVariant fused16_variant_ns8_nipo(int mode)
     }
 }
 
-// The wide launches of the two-k-step classes (n_ipo >= 16): 8-wave workgroups (fused_wg_waves() in bf_kernels.hip), or -- ns8,
-// conjugate-pair kernel only -- 4-wave workgroups whose waves own 8 output slots.
+// The wide launches of the two-k-step classes (n_ipo >= 16), each in translation units of its own because they want different
+// instruction scheduling (dsabeamformer_amd/build.py): 8-wave workgroups (fused_wg_waves() in bf_kernels.hip) ...
 template <int AIN>
-FusedVariant fused16_variant_wide(int n_ipo, int mode, bool paired, bool ns8)
+FusedVariant fused16_variant_w8(int n_ipo, int mode, bool paired)
 {
     static_assert(ant_two_ksteps<AIN>(), "the wide launches exist for the two-k-step classes only");
-    if (ns8 && !paired) return FusedVariant{};
     switch (n_ipo) {
-        case 16: return ns8 ? fused16_variant_ns8_nipo<AIN, 16>(mode) : fused16_variant_nipo<AIN, 16, kWavesWide16>(false, mode, paired);
-        case 32: return ns8 ? fused16_variant_ns8_nipo<AIN, 32>(mode) : fused16_variant_nipo<AIN, 32, kWavesWide16>(false, mode, paired);
-        case 64: return ns8 ? fused16_variant_ns8_nipo<AIN, 64>(mode) : fused16_variant_nipo<AIN, 64, kWavesWide16>(false, mode, paired);
+        case 16: return fused16_variant_nipo<AIN, 16, kWavesWide16>(false, mode, paired);
+        case 32: return fused16_variant_nipo<AIN, 32, kWavesWide16>(false, mode, paired);
+        case 64: return fused16_variant_nipo<AIN, 64, kWavesWide16>(false, mode, paired);
+        default: return FusedVariant{};
+    }
+}
+
+// ... and the conjugate-pair kernel on 4-wave workgroups whose waves own 8 output slots (fused_col_tiles()).
+template <int AIN>
+FusedVariant fused16_variant_s8(int n_ipo, int mode)
+{
+    static_assert(ant_two_ksteps<AIN>(), "the wide launches exist for the two-k-step classes only");
+    switch (n_ipo) {
+        case 16: return fused16_variant_ns8_nipo<AIN, 16>(mode);
+        case 32: return fused16_variant_ns8_nipo<AIN, 32>(mode);
+        case 64: return fused16_variant_ns8_nipo<AIN, 64>(mode);
         default: return FusedVariant{};
     }
 }
@@ -724,10 +736,14 @@ FusedVariant fused16_variant_k1p16(int n_ipo, bool write_c, int mode, bool paire
 FusedVariant fused16_variant_k1p4(int n_ipo, bool write_c, int mode, bool paired);
 FusedVariant fused16_variant_k2p16(int n_ipo, bool write_c, int mode, bool paired);
 FusedVariant fused16_variant_k2p4(int n_ipo, bool write_c, int mode, bool paired);
-// ... and one per two-k-step class for its wide launches (bf_fused16_*_wide.hip)
-FusedVariant fused16_variant_a100_wide(int n_ipo, int mode, bool paired, bool ns8);
-FusedVariant fused16_variant_a128_wide(int n_ipo, int mode, bool paired, bool ns8);
-FusedVariant fused16_variant_k2p16_wide(int n_ipo, int mode, bool paired, bool ns8);
-FusedVariant fused16_variant_k2p4_wide(int n_ipo, int mode, bool paired, bool ns8);
+// ... and two per two-k-step class for its wide launches (bf_fused16_*_w8.hip, bf_fused16_*_s8.hip)
+FusedVariant fused16_variant_a100_w8(int n_ipo, int mode, bool paired);
+FusedVariant fused16_variant_a128_w8(int n_ipo, int mode, bool paired);
+FusedVariant fused16_variant_k2p16_w8(int n_ipo, int mode, bool paired);
+FusedVariant fused16_variant_k2p4_w8(int n_ipo, int mode, bool paired);
+FusedVariant fused16_variant_a100_s8(int n_ipo, int mode);
+FusedVariant fused16_variant_a128_s8(int n_ipo, int mode);
+FusedVariant fused16_variant_k2p16_s8(int n_ipo, int mode);
+FusedVariant fused16_variant_k2p4_s8(int n_ipo, int mode);
 
 }  // namespace dsabf

@@ -399,10 +399,15 @@ FusedVariant select_variant(const Geometry& g, bool write_c)
     const int mode = detect_mode_of(g);
     const bool rt = g.runtime_ant;
     const bool ns8 = kColTiles16 != kColTilesWide16 && fused_col_tiles(g, paired) == kColTilesWide16;   // (a -DDSABF_NS=8 build: every kernel)
-    if (ns8 || fused_wg_waves(g, write_c) == kWavesWide16) {
-        if (!rt && g.n_ant == 100) return fused16_variant_a100_wide(g.n_ipo, mode, paired, ns8);
-        if (!rt && g.n_ant == 128) return fused16_variant_a128_wide(g.n_ipo, mode, paired, ns8);
-        return g.n_ant % 16 == 0 ? fused16_variant_k2p16_wide(g.n_ipo, mode, paired, ns8) : fused16_variant_k2p4_wide(g.n_ipo, mode, paired, ns8);
+    if (ns8) {
+        if (!rt && g.n_ant == 100) return fused16_variant_a100_s8(g.n_ipo, mode);
+        if (!rt && g.n_ant == 128) return fused16_variant_a128_s8(g.n_ipo, mode);
+        return g.n_ant % 16 == 0 ? fused16_variant_k2p16_s8(g.n_ipo, mode) : fused16_variant_k2p4_s8(g.n_ipo, mode);
+    }
+    if (fused_wg_waves(g, write_c) == kWavesWide16) {
+        if (!rt && g.n_ant == 100) return fused16_variant_a100_w8(g.n_ipo, mode, paired);
+        if (!rt && g.n_ant == 128) return fused16_variant_a128_w8(g.n_ipo, mode, paired);
+        return g.n_ant % 16 == 0 ? fused16_variant_k2p16_w8(g.n_ipo, mode, paired) : fused16_variant_k2p4_w8(g.n_ipo, mode, paired);
     }
     if (!rt) {
         if (g.n_ant == 64) return fused16_variant_a64(g.n_ipo, write_c, mode, paired);

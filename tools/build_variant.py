@@ -25,7 +25,7 @@ def main():
             continue
         obj = os.path.join(out, base + ".o")
         objs.append(obj)
-        procs.append(subprocess.Popen([b.HIPCC] + b.FLAGS + extra + ["-c", src, "-o", obj]))
+        procs.append(subprocess.Popen([b.HIPCC] + b.flags_for(src) + extra + ["-c", src, "-o", obj]))
     if any(p.wait() for p in procs):
         sys.exit("compile failed")
     cxx = os.path.join(os.path.dirname(os.path.realpath(b.HIPCC)), "..", "lib", "llvm", "bin", "clang++")
