@@ -22,10 +22,12 @@ HIPCC = os.environ.get("HIPCC") or shutil.which("hipcc") or "/opt/rocm/bin/hipcc
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize", "-Wall",
          "-Wno-unused-function", "-mllvm", "-amdgpu-sched-strategy=" + os.environ.get("DSABF_SCHED", "max-ilp"),
          "-I" + os.path.join(ROOT, "include")] + os.environ.get("DSABF_EXTRA_FLAGS", "").split()
-# The 8-wave-workgroup kernels of the two-k-step classes (csrc/bf_fused16_*_w8.hip) schedule better with iterative-ilp: C5
-# general kernel -2.0...-2.6 %, its rank shard -3.6 %, the 8-wave pair kernel -3.6 % (profiles/r03_ab_sched.txt); every other
-# kernel is neutral or slightly worse with it (C3 +-0.5 %, the 8-slot pair kernel +0.4 %) and keeps max-ilp.
-SCHED_BY_SUFFIX = {"_w8.hip": "iterative-ilp"}
+# The 8-wave-workgroup kernels of the two-k-step classes schedule better with other LLVM strategies than max-ilp, so they live in
+# translation units of their own (profiles/r03_ab_sched.txt, one box, interleaved): the general kernel (csrc/bf_fused16_*_w8.hip)
+# with iterative-maxocc -4.3 % (C5), -5.0 % contracted, -6.3 % on a C5 rank shard (iterative-ilp: -2.5 / -2.2 / -3.6 %); the
+# conjugate-pair kernel (bf_fused16_*_w8p.hip) with iterative-ilp -4.2 % (iterative-maxocc: -1.8 %).  Every other kernel is
+# neutral or worse with either (C3 +-0.5 ... +1.1 %, the 8-slot pair kernel +0.2 ... +0.5 %) and keeps max-ilp.
+SCHED_BY_SUFFIX = {"_w8.hip": "iterative-maxocc", "_w8p.hip": "iterative-ilp"}
 
 
 def flags_for(src: str) -> list[str]:

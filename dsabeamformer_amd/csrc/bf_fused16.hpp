@@ -701,16 +701,26 @@ FusedVariant fused16_variant_ns8_nipo(int mode)
     }
 }
 
-// The wide launches of the two-k-step classes (n_ipo >= 16), each in translation units of its own because they want different
-// instruction scheduling (dsabeamformer_amd/build.py): 8-wave workgroups (fused_wg_waves() in bf_kernels.hip) ...
-template <int AIN>
-FusedVariant fused16_variant_w8(int n_ipo, int mode, bool paired)
+// The wide launches of the two-k-step classes (n_ipo >= 16), each kind in translation units of its own because each wants a
+// different instruction scheduling strategy (dsabeamformer_amd/build.py): 8-wave workgroups (fused_wg_waves() in
+// bf_kernels.hip), general kernel ...
+template <int AIN, int NIPO, bool PAIRED>
+FusedVariant fused16_variant_w8_nipo(int mode)
+{
+    if (mode == kDetFast) return make_variant<AIN, NIPO, false, kDetFast, PAIRED, kWavesWide16>();
+    if (mode == kDetContracted) return make_variant<AIN, NIPO, false, kDetContracted, PAIRED, kWavesWide16>();
+    return make_variant<AIN, NIPO, false, kDetCanonical, PAIRED, kWavesWide16>();
+}
+
+// (PAIRED = false: bf_fused16_*_w8.hip; true, the conjugate-pair kernel on 8-wave workgroups: bf_fused16_*_w8p.hip)
+template <int AIN, bool PAIRED>
+FusedVariant fused16_variant_w8(int n_ipo, int mode)
 {
     static_assert(ant_two_ksteps<AIN>(), "the wide launches exist for the two-k-step classes only");
     switch (n_ipo) {
-        case 16: return fused16_variant_nipo<AIN, 16, kWavesWide16>(false, mode, paired);
-        case 32: return fused16_variant_nipo<AIN, 32, kWavesWide16>(false, mode, paired);
-        case 64: return fused16_variant_nipo<AIN, 64, kWavesWide16>(false, mode, paired);
+        case 16: return fused16_variant_w8_nipo<AIN, 16, PAIRED>(mode);
+        case 32: return fused16_variant_w8_nipo<AIN, 32, PAIRED>(mode);
+        case 64: return fused16_variant_w8_nipo<AIN, 64, PAIRED>(mode);
         default: return FusedVariant{};
     }
 }
@@ -736,11 +746,15 @@ FusedVariant fused16_variant_k1p16(int n_ipo, bool write_c, int mode, bool paire
 FusedVariant fused16_variant_k1p4(int n_ipo, bool write_c, int mode, bool paired);
 FusedVariant fused16_variant_k2p16(int n_ipo, bool write_c, int mode, bool paired);
 FusedVariant fused16_variant_k2p4(int n_ipo, bool write_c, int mode, bool paired);
-// ... and two per two-k-step class for its wide launches (bf_fused16_*_w8.hip, bf_fused16_*_s8.hip)
-FusedVariant fused16_variant_a100_w8(int n_ipo, int mode, bool paired);
-FusedVariant fused16_variant_a128_w8(int n_ipo, int mode, bool paired);
-FusedVariant fused16_variant_k2p16_w8(int n_ipo, int mode, bool paired);
-FusedVariant fused16_variant_k2p4_w8(int n_ipo, int mode, bool paired);
+// ... and three per two-k-step class for its wide launches (bf_fused16_*_w8.hip, bf_fused16_*_w8p.hip, bf_fused16_*_s8.hip)
+FusedVariant fused16_variant_a100_w8(int n_ipo, int mode);
+FusedVariant fused16_variant_a128_w8(int n_ipo, int mode);
+FusedVariant fused16_variant_k2p16_w8(int n_ipo, int mode);
+FusedVariant fused16_variant_k2p4_w8(int n_ipo, int mode);
+FusedVariant fused16_variant_a100_w8p(int n_ipo, int mode);
+FusedVariant fused16_variant_a128_w8p(int n_ipo, int mode);
+FusedVariant fused16_variant_k2p16_w8p(int n_ipo, int mode);
+FusedVariant fused16_variant_k2p4_w8p(int n_ipo, int mode);
 FusedVariant fused16_variant_a100_s8(int n_ipo, int mode);
 FusedVariant fused16_variant_a128_s8(int n_ipo, int mode);
 FusedVariant fused16_variant_k2p16_s8(int n_ipo, int mode);

@@ -1,7 +1,7 @@
-// bf_fused16_a100_w8.hip -- the 8-wave-workgroup instantiations of antenna class a100 (bf_fused16.hpp).  Their own translation
-// unit: they are compiled with the iterative-ilp scheduling strategy (build.py; -2...-3.6 % against max-ilp, which the others keep).
+// bf_fused16_a100_w8.hip -- the GENERAL kernel on 8-wave workgroups for antenna class a100 (bf_fused16.hpp).  Its own translation
+// unit: it is compiled with the iterative-maxocc scheduling strategy (build.py; -4...-6 % against max-ilp, which the others keep).
 #include "bf_fused16.hpp"
 
 namespace dsabf {
-FusedVariant fused16_variant_a100_w8(int n_ipo, int mode, bool paired) { return fused16_variant_w8<100>(n_ipo, mode, paired); }
+FusedVariant fused16_variant_a100_w8(int n_ipo, int mode) { return fused16_variant_w8<100, false>(n_ipo, mode); }
 }  // namespace dsabf

@@ -405,9 +405,14 @@ FusedVariant select_variant(const Geometry& g, bool write_c)
         return g.n_ant % 16 == 0 ? fused16_variant_k2p16_s8(g.n_ipo, mode) : fused16_variant_k2p4_s8(g.n_ipo, mode);
     }
     if (fused_wg_waves(g, write_c) == kWavesWide16) {
-        if (!rt && g.n_ant == 100) return fused16_variant_a100_w8(g.n_ipo, mode, paired);
-        if (!rt && g.n_ant == 128) return fused16_variant_a128_w8(g.n_ipo, mode, paired);
-        return g.n_ant % 16 == 0 ? fused16_variant_k2p16_w8(g.n_ipo, mode, paired) : fused16_variant_k2p4_w8(g.n_ipo, mode, paired);
+        if (paired) {
+            if (!rt && g.n_ant == 100) return fused16_variant_a100_w8p(g.n_ipo, mode);
+            if (!rt && g.n_ant == 128) return fused16_variant_a128_w8p(g.n_ipo, mode);
+            return g.n_ant % 16 == 0 ? fused16_variant_k2p16_w8p(g.n_ipo, mode) : fused16_variant_k2p4_w8p(g.n_ipo, mode);
+        }
+        if (!rt && g.n_ant == 100) return fused16_variant_a100_w8(g.n_ipo, mode);
+        if (!rt && g.n_ant == 128) return fused16_variant_a128_w8(g.n_ipo, mode);
+        return g.n_ant % 16 == 0 ? fused16_variant_k2p16_w8(g.n_ipo, mode) : fused16_variant_k2p4_w8(g.n_ipo, mode);
     }
     if (!rt) {
         if (g.n_ant == 64) return fused16_variant_a64(g.n_ipo, write_c, mode, paired);
