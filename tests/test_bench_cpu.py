@@ -31,8 +31,8 @@ def test_committed_pmc_summaries_give_the_quoted_traffic_and_mfma_busy():
     c2 = bench.pmc_summary("r03_c2_pmc_summary.txt")
     assert c3 and gen and c5 and c5g and c2
     # the general kernel of the 100-antenna geometry keeps the matrix pipe busy more than half the time (22 % of that on the
-    # zero weights behind antenna 99); round 3's 3-fragment image fits its 255 registers without the spills of round 2
-    assert 0.55 < bench.pmc_mfma_busy(c5g) < 0.62 and abs(c5g["SQ_INSTS_VALU_MFMA_I8"] / (2 * c5["SQ_INSTS_VALU_MFMA_I8"]) - 1) < 1e-4
+    # zero weights behind antenna 99); round 3: 3-fragment image, 8-wave workgroups, iterative-maxocc scheduling: 58 -> 63 %
+    assert 0.55 < bench.pmc_mfma_busy(c5g) < 0.68 and abs(c5g["SQ_INSTS_VALU_MFMA_I8"] / (2 * c5["SQ_INSTS_VALU_MFMA_I8"]) - 1) < 1e-4
     alg_c3 = (64 * 32 * 256 + 4 * 256 * 256) * 128 * 16          # bytes per launch: SURVEY.md 8d x 2048 beam-blocks
     assert abs(bench.pmc_traffic(c3) / alg_c3 - 1) < 0.01 and abs(bench.pmc_traffic(gen) / alg_c3 - 1) < 0.02
     alg_c2 = (64 * 2 * 256 + 4 * 256 * 256) * 128 * 8
