@@ -3,6 +3,8 @@
 
 Contract (driver):  python bench.py --gpus N --steps K --warmup W   (N > 1: one rank per GPU under
 torch.distributed.run; RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment).  Rank 0 prints ONE JSON line.
+Called plainly with --gpus N > 1 (no WORLD_SIZE in the environment) it starts that launcher itself as a CHILD process --
+before anything here touches the GPU -- and passes on rank 0's line and the exit code (self_launch below).
 
 Workload (BASELINE.json configs[2] geometry, "C3" in SURVEY.md section 8d): 64 antennas x 2 pol, 256 frequencies,
 256 beams, N_TIME = 512 voltage columns per gemm-unit (16 detected outputs x n_ipo 32), input = uniform random
@@ -169,8 +171,8 @@ def time_launches(torch, fn, n, stream):
     return sum(ms) / len(ms), ms[len(ms) // 2], ms[0]
 
 
-def cpu_baselines(n_avg, n_out, seconds):
-    """Host-side baselines, on a bounded sample: (1) the oracle's beamform port (expand + GEMM + detect, OpenMP, all cores)
+def cpu_baselines(n_avg, n_out, seconds, full=True):
+    """Host-side baselines, on a bounded sample (full=False, the N > 1 line: record (1) alone, on all host cores): (1) the oracle's beamform port (expand + GEMM + detect, OpenMP, all cores)
     on gemm-units of the bench workload; (2) the reference's only CPU code on the path, generate_test_data
     (src/test_data_generator.hh:63-95): the PRODUCT's generator for one 1024-unit DEBUG batch on 1 core and on all cores,
     and the oracle's literal restatement of the reference loop (trig for every time column, as `make fast_debug` runs it)."""
@@ -182,6 +184,8 @@ def cpu_baselines(n_avg, n_out, seconds):
     g = orc.Geom(n_avg=n_avg, n_out_per_gemm=n_out)
     pos, dirs = orc.default_positions(g.n_ant), orc.default_directions(g.n_beams)
     w = orc.make_weights(g, pos, dirs, 0)
+    if os.environ.get("OMP_NUM_THREADS") == "1" and "WORLD_SIZE" in os.environ:
+        orc.set_threads(os.cpu_count() or 1)     # a rank under torchrun (which pins OMP_NUM_THREADS=1): still all the cores
     rng = np.random.default_rng(1)
     unit = rng.integers(0, 256, size=(1, g.n_freq, g.n_time, g.n_ant), dtype=np.uint8)
     orc.beamform(g, w, unit)  # warm-up (thread pool, page faults)
@@ -201,6 +205,8 @@ def cpu_baselines(n_avg, n_out, seconds):
         out["nproc"] = os.cpu_count()
     except Exception:   # pragma: no cover
         pass
+    if not full:
+        return out
     # the same port at the parity geometry (C1/C2: N_IPO 2, N_TIME 16), BASELINE.md section 4 item 2: a 3 s sample
     g1 = orc.DEBUG_GEOM
     w1 = orc.make_weights(g1, orc.default_positions(g1.n_ant), orc.default_directions(g1.n_beams), 0)
@@ -247,6 +253,40 @@ def cpu_baselines(n_avg, n_out, seconds):
     return out
 
 
+def launcher_command(n, argv, port):
+    """The command the driver itself uses for N > 1: one rank per GPU of ONE node, rendezvous on 127.0.0.1."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
+            "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: run torch.distributed.run as a child process and exit
+    with its status.  Nothing in this process has initialised the GPU (no torch.cuda call, no HIP call: only a device COUNT),
+    and the ranks are children, never an exec of this process.  stdout / stderr are inherited, so rank 0's one JSON line is
+    this command's one JSON line."""
+    import socket
+    import subprocess
+
+    one_gpu = os.environ.get("DSABF_BENCH_ONE_GPU") == "1"     # test mode: the ranks time-share GPU 0
+    if not one_gpu:
+        import torch
+
+        have = torch.cuda.device_count()                        # counting devices does not initialise the GPU on this image
+        if have < args.gpus:
+            sys.exit("bench.py --gpus %d: this node shows %d GPU(s)" % (args.gpus, have))
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket() as s:                              # a free port of the loopback interface
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")           # dmabuf IPC: what RCCL needs on this pool
+    env.setdefault("OMP_NUM_THREADS", "1")                      # (what torchrun would set, without its warning)
+    cmd = launcher_command(args.gpus, sys.argv[1:], port)
+    print("bench.py: --gpus %d without a launcher: starting %s" % (args.gpus, " ".join(cmd[1:9])), file=sys.stderr, flush=True)
+    sys.exit(subprocess.call(cmd, env=env))
+
+
 class Watchdog:
     """Prints the JSON line exactly once: normally through finish(); if the budget expires first (a supplementary record or a
     gather mode hangs), from a timer thread with whatever has been recorded, then ends the process with status 0."""
@@ -291,15 +331,17 @@ def main():
     args = parse()
     # the pool's host driver only supports dmabuf IPC; without this RCCL's cross-process handles fail
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)          # never returns
     import torch
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
-                     % (args.gpus, args.gpus))
+        if world == 1 and args.gpus > 1:   # WORLD_SIZE=1 in the environment next to --gpus N: a launcher started ONE rank
+            sys.exit("bench.py --gpus %d under a launcher with WORLD_SIZE=1: start it with --nproc-per-node %d, or call "
+                     "bench.py plainly and it launches its ranks itself" % (args.gpus, args.gpus))
         args.gpus = world
     if os.environ.get("DSABF_BENCH_ONE_GPU") == "1":
         local = 0          # test mode: every rank time-shares GPU 0
@@ -837,10 +879,13 @@ def main():
             guarded("debug_geometry", extras_geometries)
             guarded("streaming", extras_streaming)
             guarded("dedisperse_dm", extras_dm)
-        if world == 1 and not args.no_cpu_baseline:
-            print("bench.py: GPU part done; timing the CPU baselines on the host cores (~%.0f s) ..." % (args.cpu_seconds + 15),
-                  file=sys.stderr, flush=True)
-            guarded("cpu_baseline", lambda: out.__setitem__("cpu_baseline", cpu_baselines(n_avg, n_out, args.cpu_seconds)))
+        if not args.no_cpu_baseline:
+            # N = 1: the full set.  N > 1: the same key, the beamform port alone on a shorter sample (the other ranks have
+            # finished; the whole-band beam-block is the unit at every N, so the number is comparable across the lines)
+            secs = args.cpu_seconds if world == 1 else min(args.cpu_seconds, 5.0)
+            print("bench.py: GPU part done; timing the CPU baseline%s on the host cores (~%.0f s) ..."
+                  % ("s" if world == 1 else "", secs + (15 if world == 1 else 2)), file=sys.stderr, flush=True)
+            guarded("cpu_baseline", lambda: out.__setitem__("cpu_baseline", cpu_baselines(n_avg, n_out, secs, full=world == 1)))
         watchdog.finish()
     else:
         watchdog.cancel()

@@ -172,6 +172,34 @@ def test_bench_with_two_ranks_on_one_gpu(fake_rccl, gather, n):
         assert "error" not in modes[k] and modes[k]["value"] > 0, (k, modes[k])
 
 
+def test_bench_launches_its_own_ranks_when_called_plainly(fake_rccl):
+    """`python bench.py --gpus 2` with NO launcher around it (the shape of the driver's N = 1 command):
+    bench.py starts torch.distributed.run itself as a child before anything touches the GPU, rank 0's line is the command's
+    one line, the exit code is the launcher's.  The line carries the same keys as the N = 1 line: roofline (live HIP-event
+    kernel time), cpu_baseline (bounded sample, rank 0's host cores), the library's own rank count, every gather mode."""
+    import json
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(DSABF_RCCL_LIB=fake_rccl, DSABF_BENCH_ONE_GPU="1", FAKERCCL_MAILBOX_MB="64")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--units", "4",
+                        "--dist-backend", "gloo", "--min-warm-seconds", "0.1", "--cpu-seconds", "1"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-4000:]
+    assert "without a launcher: starting -m torch.distributed.run" in r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["config"]["freq_per_gpu"] == 128
+    assert d["rccl"]["ranks"] == 2
+    roof = d["roofline"]
+    assert roof["bound"] == "mfma" and roof["kernel_ms_avg"] > 0 and 0 < roof["frac"] < 1
+    # the per-rank kernel works on half the band: half the algorithmic ops of the whole-band beam-blocks of one step
+    assert roof["algorithmic_ops_per_launch"] == 8 * 256 * 64 * 32 * 256 * (4 * 16) // 2
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["value"] > 0 and cb["unit"] == "beam-blocks/s" and cb["cores"] >= 1
+    assert all("error" not in v for k, v in d["gather_modes"].items() if k != "note")
+
+
 def test_bench_exits_nonzero_when_the_communicator_cannot_be_created():
     """a scaling line must never come from a second code path.  With an RCCL that cannot be loaded the
     two-rank bench must FAIL (round 2 fell back to a torch.distributed gather and noted it in config.gather_note)."""
