@@ -1,5 +1,8 @@
-"""world_size-2 CPU test (gloo) of the multi-GPU path: frequency sharding + the detected-power gather must
-reassemble exactly the single-device result (no arithmetic happens in the collective)."""
+"""Multi-process CPU test (gloo, world sizes 2 / 4 / 8) of the multi-GPU path: frequency sharding + the detected-power gather
+must reassemble exactly the single-device result (no arithmetic happens in the collective).  The messages exchanged are the
+PRODUCT's: every rank asks libdsabf.so for its bf_gather_plan and executes it with torch.distributed point-to-point
+operations -- the same walk bf_gather_detected does with ncclSend / ncclRecv (csrc/bf_comm.cpp).  The oracle stands in for
+the device (this box has no GPU); tests/test_gpu_multirank.py runs the same partition with the HIP kernel."""
 import os
 import socket
 import subprocess
@@ -33,22 +36,54 @@ assert lw.shape[0] == f1 - f0 and lp.shape == (4, f1 - f0, g.n_time, g.n_ant)
 local = torch.from_numpy(orc.beamform(gl, lw, lp).reshape(-1, gl.n_freq, g.n_beams))
 assert np.array_equal(local.numpy(), full[:, f0:f1])
 og = local.shape[0]
-for mode in ("alltoall", "root"):
-    gat = shard.DetectedGather(torch, dist, mode, og, gl.n_freq, g.n_beams, "cpu")
-    for it in range(3):                       # double-buffered reuse
-        slot = it & 1
-        gat.finish(slot)
-        gat.start(slot, local * (it + 1))
-    for slot, it in ((0, 2), (1, 1)):
-        res = gat.finish(slot)
-        if mode == "alltoall":
-            want = full[rank * og // world:(rank + 1) * og // world] * np.float32(it + 1)
-            assert res.shape == (og // world, g.n_freq, g.n_beams)
-            assert np.array_equal(res.numpy(), want), (mode, rank)
-        elif rank == 0:
-            assert np.array_equal(res.numpy(), full * np.float32(it + 1)), (mode, rank)
+# ---- the PRODUCT's gather plan (bf_gather_plan, csrc/bf_comm.cpp) executed between real processes: every SEND / RECV / COPY
+# message of this rank's plan, in plan order, as gloo point-to-point operations on CPU tensors -- posted non-blocking and
+# completed together, which is what bf_gather_detected does with ncclSend / ncclRecv inside one ncclGroup.  Gloo, like RCCL,
+# matches the messages of one (sender, receiver) pair in issue order; nothing else orders them.
+import ctypes as C
+from dsabeamformer_amd._lib import BfGatherMsg, load
+lib = load()
+SEND, RECV, COPY = 0, 1, 2
+row_floats = gl.n_freq * g.n_beams
+def plan_of(layout, root):
+    n = lib.bf_gather_plan(layout, og, row_floats, world, rank, root, None, 0)
+    arr = (BfGatherMsg * max(n, 1))()
+    assert lib.bf_gather_plan(layout, og, row_floats, world, rank, root, arr, n) == n
+    return [(m.kind, m.peer, m.local_offset, m.full_offset, m.count) for m in arr[:n]]
+def gather(layout, root, src_flat):
+    held = lib.bf_gather_rows_held(og, world, rank, root)
+    buf = torch.full((world * held * row_floats,), float("nan")) if held else None
+    reqs = []
+    for kind, peer, loff, foff, count in plan_of(layout, root):
+        if kind == SEND:
+            reqs.append(dist.isend(src_flat[loff:loff + count], dst=peer))
+        elif kind == RECV:
+            reqs.append(dist.irecv(buf[foff:foff + count], src=peer))
         else:
-            assert res is None
+            assert kind == COPY and peer == rank
+            buf[foff:foff + count] = src_flat[loff:loff + count]
+    for q in reqs:
+        q.wait()
+    return held, buf
+shards = np.stack([full[:, a * gl.n_freq:(a + 1) * gl.n_freq] for a in range(world)])     # [rank][row][f_local][b]
+for layout in (0, 1):                                   # BF_GATHER_LAYOUT_FREQ_MAJOR / _RANK_MAJOR
+    for root in (0, world - 1, -1, -2):                  # one owner (first / last rank), everybody, distributed owners
+        for it in (1, 2):                                # back to back: a second gather must not overtake the first
+            src = (local * float(it)).reshape(-1).contiguous()
+            held, buf = gather(layout, root, src)
+            want_held = og // world if root == -2 else og if root in (-1, rank) else 0
+            assert held == want_held, (layout, root, rank, held)
+            if not held:
+                assert buf is None
+                continue
+            first = rank * held if root == -2 else 0
+            got = buf.numpy()
+            assert not np.isnan(got).any(), (layout, root, rank)
+            if layout == 0:                              # the reference's [o][f][b] over the whole band
+                assert np.array_equal(got.reshape(held, g.n_freq, g.n_beams), full[first:first + held] * np.float32(it)), (layout, root, rank)
+            else:                                        # sub-band-major [rank][row][f_local][b]
+                assert np.array_equal(got.reshape(world, held, gl.n_freq, g.n_beams), shards[:, first:first + held] * np.float32(it)), (layout, root, rank)
+        dist.barrier()
 # sub-band dedispersion: each rank sums its own channels (delays against the band-wide reference frequency), the
 # partials are added in rank order -> identical on every rank and equal to the banded oracle sum
 series = full                                                       # [t][F][B] detected series, t = og outputs
