@@ -1,0 +1,106 @@
+"""CPU-box guard on the code-object properties the measured speed depends on (VERDICT r03 "weak" 7): the shipped gfx950 objects
+(dsabeamformer_amd/build/*.hip.o, compiled by build.py with its per-file LLVM scheduling strategies and launch_bounds budgets)
+are unbundled and read with llvm-readelf / llvm-objdump.  A compiler bump or an innocent edit that adds scratch, drops a wave
+per SIMD or duplicates / loses MFMAs in the unrolled chunk loop fails HERE instead of showing up as a slower GPU bench."""
+import os
+import sys
+import tempfile
+
+import pytest
+
+from conftest import ROOT
+
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import isa_report  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def objects():
+    from dsabeamformer_amd import build
+
+    build.build()
+    wd = tempfile.mkdtemp(prefix="isaguard")
+    cos = {}
+    for obj in isa_report.shipped_objects():
+        co = isa_report.code_object(obj, wd)
+        if co:
+            cos[os.path.basename(obj)[:-len(".hip.o")]] = (co, isa_report.kernels(co))
+    return cos
+
+
+def fused(ant, nipo, mode, paired, waves, ns, write_c=False):
+    a = "Li%dE" % ant if ant > 0 else "Lin%dE" % -ant
+    return "_ZN5dsabf14fused16_kernelIL%sLi%dELb%dELi%dELb%dELi%dELi%dEEEvNS_9FusedArgsE" % (
+        a[1:], nipo, int(write_c), mode, int(paired), waves, ns)
+
+
+# (translation unit, kernel, VGPR budget = 512 / waves per SIMD the launch shape counts on, MFMAs in the unrolled chunk loop)
+#   MFMAs per 128-sample chunk and wave: 8 row tiles x column tiles x (general: 4 = 2 chains x re | im; pair: 4 real products
+#   per PAIR tile) x k-steps
+HOT = [
+    ("bf_fused16_a64", fused(64, 32, 0, True, 4, 4), 128, 8 * 2 * 4 * 1),       # C3 headline: conjugate-pair kernel, 4 waves / SIMD
+    ("bf_fused16_a64", fused(64, 32, 0, False, 4, 4), 128, 8 * 4 * 4 * 1),      # C3 general kernel (calibrated weights), 4 waves / SIMD
+    ("bf_fused16_a64", fused(64, 32, 2, True, 4, 4), 128, 8 * 2 * 4 * 1),       # contracted readings
+    ("bf_fused16_a64", fused(64, 32, 2, False, 4, 4), 128, 8 * 4 * 4 * 1),
+    ("bf_fused16_a64", fused(64, 2, 0, True, 4, 4), 168, 8 * 2 * 4 * 1),        # C2 DEBUG geometry: 3 waves / SIMD
+    ("bf_fused16_a100_s8", fused(100, 32, 0, True, 4, 8), 256, 8 * 4 * 4 * 2),  # C5 headline: 8 output slots per wave, 2 waves / SIMD
+    ("bf_fused16_a100_w8", fused(100, 32, 0, False, 8, 4), 256, 8 * 4 * 4 * 2),  # C5 general kernel on 8-wave workgroups
+    ("bf_fused16_a128_s8", fused(128, 32, 0, True, 4, 8), 256, 8 * 4 * 4 * 2),
+    ("bf_fused16_a128_w8", fused(128, 32, 0, False, 8, 4), 256, 8 * 4 * 4 * 2),
+]
+
+
+@pytest.mark.parametrize("unit,name,budget,mfmas", HOT, ids=[h[1][25:60] for h in HOT])
+def test_hot_instantiations_keep_their_registers_no_scratch_and_their_mfma_count(objects, unit, name, budget, mfmas):
+    co, ks = objects[unit]
+    assert name in ks, "instantiation missing from %s: %s" % (unit, name)
+    k = ks[name]
+    assert k["private_segment_fixed_size"] == 0, "scratch (a spill) in %s" % name
+    assert k.get("vgpr_spill_count", 0) == 0 and k.get("sgpr_spill_count", 0) == 0
+    assert k["vgpr_count"] + k["agpr_count"] <= budget, (name, k)
+    ops = isa_report.disassembly(co, name)
+    assert isa_report.count(ops, "scratch_") == 0
+    assert isa_report.count(ops, "v_mfma_i32_16x16x64_i8") == mfmas, "the unrolled chunk loop holds %d MFMAs" % isa_report.count(ops, "v_mfma")
+    assert isa_report.count(ops, "v_mfma") == mfmas                    # ... and no other matrix instruction
+    # the detect stays on plain fp32 VALU ops: packed f32 issues beside MFMAs at twice the price (MI355X_MICROARCH.md), and
+    # -ffp-contract=off / -fno-slp-vectorize are what keep the compiler from forming them
+    assert isa_report.count(ops, "v_pk_(add|mul|fma)_f32") == 0
+    if "ELi0ELb" in name:   # canonical reading: x*x + y*y must not be contracted (bit-exact contract with the oracle)
+        assert isa_report.count(ops, r"v_fma_f32|v_fmac_f32") == 0, "a contracted multiply-add in the canonical detect"
+
+
+def test_spills_stay_where_they_are_known(objects):
+    """No fused kernel of the compile-time 64- and 128-antenna classes, of the 16-byte-staged one-k-step run-time class or of
+    the wide (8-slot / 8-wave) 100-antenna launches carries scratch.  The classes that do are listed: the dword-staged run-time
+    classes (13 staging pieces per thread), 100 antennas on 4-wave workgroups at n_ipo 2 / 4 / 64 (general kernel; the wide
+    launches replace it from n_ipo 16 on), one 8-slot run-time instantiation -- a few dwords each, bounded here so that growth
+    shows."""
+    clean_units = ("bf_fused16_a64", "bf_fused16_a128", "bf_fused16_a128_s8", "bf_fused16_a128_w8", "bf_fused16_a128_w8p",
+                   "bf_fused16_a100_s8", "bf_fused16_a100_w8", "bf_fused16_a100_w8p", "bf_fused16_k1p16", "bf_fused16_k2p16",
+                   "bf_fused16_k2p16_w8", "bf_fused16_k2p16_w8p", "bf_fused16_k2p4_w8p")
+    bad, worst = [], 0
+    for unit, (co, ks) in objects.items():
+        for name, k in ks.items():
+            if "fused16_kernel" not in name:
+                continue
+            sc = k["private_segment_fixed_size"]
+            worst = max(worst, sc)
+            if sc and unit in clean_units:
+                bad.append((unit, name, sc))
+    assert not bad, bad
+    assert worst <= 320, "a fused kernel now spills %d bytes per lane" % worst
+
+
+def test_dm_kernels(objects):
+    co, ks = objects["bf_dm_wide"]
+    name = [n for n in ks if "dedisperse_dm_wide_kernel" in n][0]
+    k = ks[name]
+    assert k["private_segment_fixed_size"] == 0 and k["vgpr_count"] <= 128       # 16-wave workgroups: 4 waves per SIMD
+    ops = isa_report.disassembly(co, name)
+    assert isa_report.count(ops, "ds_read2_b64") == 0     # the 8-byte-aligned pair read measured slower (profiles/r03_variants_log.txt)
+    assert isa_report.count(ops, "scratch_") == 0
+    co, ks = objects["bf_kernels"]
+    name = [n for n in ks if "dedisperse_dm_kernel" in n][0]
+    assert ks[name]["private_segment_fixed_size"] == 0 and ks[name]["vgpr_count"] <= 128
+    name = [n for n in ks if "expand_kernel" in n][0]
+    assert ks[name]["vgpr_count"] <= 32 and ks[name]["private_segment_fixed_size"] == 0
