@@ -847,16 +847,12 @@ def main():
             d_delays = torch.from_numpy(delays).cuda()
             d_dd = torch.empty(len(dms) * n_t_out * 256, device="cuda")
             rec = {}
-            for label, env in (("shared_window", None), ("per_thread_window_alone", "0")):
-                if env is not None:
-                    os.environ["DSABF_DM_WIDE"] = env
-                try:
-                    fn = lambda i: b2.dedisperse_dm(d_series, n_t, d_delays, len(dms), n_t_out, d_dd, sptr)  # noqa: E731
-                    for i in range(5):
-                        fn(i)
-                    avg, med, mn = time_launches(torch, fn, 30, stream)
-                finally:
-                    os.environ.pop("DSABF_DM_WIDE", None)
+            for label, wide in (("shared_window", 1), ("per_thread_window_alone", 0)):
+                b2.set_switch("dm_wide", wide)     # per handle (bf_set_switch); the environment is never changed mid-process
+                fn = lambda i: b2.dedisperse_dm(d_series, n_t, d_delays, len(dms), n_t_out, d_dd, sptr)  # noqa: E731
+                for i in range(5):
+                    fn(i)
+                avg, med, mn = time_launches(torch, fn, 30, stream)
                 rec[label] = {"ms_avg": avg, "ms_median": med}
             b2.close()
             alg = 4 * (n_t * 256 * 256 + len(dms) * n_t_out * 256)

@@ -155,6 +155,10 @@ class Beamformer:
                                             C.byref(ops), C.c_void_p(stream)))
         return ops.value
 
+    def set_switch(self, name: str, value: int) -> None:
+        """bf_set_switch: a measurement / test switch of this handle ("tsplit", "lds_pad", "dm_wide", "paired")."""
+        check(self._lib.bf_set_switch(self._h, name.encode(), int(value)))
+
     def kernel_info(self, n_units: int = 1) -> dict:
         g, b, l, v = C.c_int(), C.c_int(), C.c_int(), C.c_int()
         check(self._lib.bf_kernel_info(self._h, n_units, C.byref(g), C.byref(b), C.byref(l), C.byref(v)))

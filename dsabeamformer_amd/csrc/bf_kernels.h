@@ -27,7 +27,12 @@ struct Geometry {
     bool plain_wg_waves = false;                        // DSABF_WG_WAVES=4: 4-wave workgroups everywhere
     bool plain_col_tiles = false;                       // DSABF_COL_TILES=4: 4 output slots per wave everywhere
     bool runtime_ant = false;                           // DSABF_RUNTIME_ANT=1: the run-time antenna classes everywhere
+    // ... and three that only pick among launches of the same kernels; bf_set_switch changes them per handle for A/B runs
+    int tsplit = 0;                                     // DSABF_TSPLIT=n: time splits per frequency (0: fused_launch_shape decides)
+    int lds_pad = 0;                                    // DSABF_LDS_PAD=bytes: extra dynamic LDS (fewer resident workgroups); clamped
+    bool dm_wide = true;                                // DSABF_DM_WIDE=0: the per-thread-window DM kernel alone
 };
+constexpr int kLdsPerCuBytes = 160 * 1024;
 void read_env_switches(Geometry& g);
 
 // Bytes of the MFMA-fragment weight image: [freq][16-beam tile][re|im row][re|im operand][k-step][lane] x 16 B.

@@ -473,6 +473,13 @@ void read_env_switches(Geometry& g)
     g.plain_wg_waves = w && atoi(w) == kWaves16;
     g.plain_col_tiles = t && atoi(t) == kColTiles16;
     g.runtime_ant = r && r[0] == '1';
+    const char* ts = getenv("DSABF_TSPLIT");
+    const char* pad = getenv("DSABF_LDS_PAD");
+    const char* dw = getenv("DSABF_DM_WIDE");
+    g.tsplit = ts ? atoi(ts) : 0;
+    if (g.tsplit < 0) g.tsplit = 0;
+    g.lds_pad = pad ? atoi(pad) : 0;       // (clamped to what the CU has left where it is applied, fused_launch_shape)
+    g.dm_wide = !(dw && dw[0] == '0');
 }
 
 // Output slots (16 beams each) per wave.  The two-k-step conjugate-pair kernels hold 2 waves per SIMD whatever they do (64 KiB of
@@ -553,14 +560,15 @@ LaunchShape fused_launch_shape(const Geometry& g, int n_units, int n_cus, bool w
     int want_fill = (target_wgs_per_cu * n_cus + base - 1) / base;            // enough workgroups to fill the chip
     if (want_fill > max_split) want_fill = max_split;
     if (want < want_fill) want = want_fill;
-    if (const char* e = getenv("DSABF_TSPLIT")) want = atoi(e);  // tuning override (time splits per frequency)
+    if (g.tsplit > 0) want = g.tsplit;  // tuning override (time splits per frequency): DSABF_TSPLIT at bf_create / bf_set_switch
     if (want < 1) want = 1;
     if (want > ls.chunks_total / cpg) want = ls.chunks_total / cpg;
     ls.n_tsplit = want;
     ls.grid = base * ls.n_tsplit;
     ls.block = 64 * wg_waves;
     ls.lds_bytes = 2 * ksteps16(g) * kRowsPerChunk * 128;  // double buffer x k-step planes x 128 rows x (64 re | 64 im)
-    if (const char* e = getenv("DSABF_LDS_PAD")) ls.lds_bytes += atoi(e);   // measurement switch: fewer resident workgroups per CU
+    if (g.lds_pad > 0)   // measurement switch (DSABF_LDS_PAD / bf_set_switch): fewer resident workgroups per CU
+        ls.lds_bytes += g.lds_pad < kLdsPerCuBytes - ls.lds_bytes ? g.lds_pad : kLdsPerCuBytes - ls.lds_bytes;
     return ls;
 }
 
@@ -710,8 +718,8 @@ hipError_t launch_dedisperse_dm(const Geometry& g, const float* d_series, int n_
                                 int n_t_out, float* d_out, int* d_flags, hipStream_t s)
 {
     if (n_dm <= 0 || n_t_out <= 0) return hipSuccess;
-    const char* env = getenv("DSABF_DM_WIDE");      // measurement / test switch: 0 = the per-thread-window kernel alone
-    const bool wide = d_flags && dm_wide_supported(g, n_dm) && !(env && env[0] == '0') &&
+    // g.dm_wide: measurement / test switch (DSABF_DM_WIDE=0 at bf_create, bf_set_switch): the per-thread-window kernel alone
+    const bool wide = d_flags && dm_wide_supported(g, n_dm) && g.dm_wide &&
                       !((uintptr_t)d_series & 15) && !((uintptr_t)d_out & 15) &&   // its 16-byte LDS-DMA pieces / 16-byte stores
                       (size_t)n_t * g.n_freq * g.n_beams * sizeof(float) < ((size_t)1 << 32);   // ... and 32-bit byte offsets into the series
     if (wide) {

@@ -36,7 +36,11 @@ struct bf_handle {
     uint8_t* d_data = nullptr;    // ring: n_blocks_on_gpu x bytes_per_block
     float* d_out = nullptr;       // n_streams x floats_per_detect
     float* d_ded = nullptr;       // n_streams x n_beams
-    int* d_dm_flags = nullptr;    // kDwMaxGroups ints: which trial groups the wide DM kernel takes (bf_dedisperse_dm_device)
+    // Scratch of the DM-trial dedispersion, ONE PER STREAM the caller has used (kDmScratchBytes each: which trial groups the
+    // wide kernel takes + a 512-byte row of zeros).  The wide kernel writes the flags and the per-thread-window kernel reads
+    // them later on the same stream: calls on one stream are ordered by the stream, calls on different streams must not share.
+    std::vector<std::pair<hipStream_t, int*>> dm_scratch;
+    bool force_general = false;   // bf_set_switch("paired", 0): never select the conjugate-pair kernel
     std::vector<float*> d_out_blk;  // per compute queue, n_gemms_per_block x floats_per_detect: bf_enqueue_block (lazy)
     std::vector<float*> d_ded_blk;  // per compute queue, n_gemms_per_block x n_beams: bf_enqueue_block_dedisperse (lazy)
     std::vector<float*> d_full_blk; // per compute queue, the gathered block (world x as large): bf_block_gather_device (lazy)
@@ -269,7 +273,7 @@ int bf_destroy(bf_handle* h)
     (void)hipFree(h->d_data);
     (void)hipFree(h->d_out);
     (void)hipFree(h->d_ded);
-    (void)hipFree(h->d_dm_flags);
+    for (auto& sc : h->dm_scratch) (void)hipFree(sc.second);
     for (float* p : h->d_out_blk) (void)hipFree(p);
     for (float* p : h->d_full_blk) (void)hipFree(p);
     for (float* p : h->d_ded_blk) (void)hipFree(p);
@@ -297,9 +301,10 @@ static int finish_weights(bf_handle* h, const int8_t* d_w, hipStream_t s)
         return fail(BF_ERR_INVALID, "weights contain an imaginary part of -128 (must be >= -127)");
     }
     // Beam sets symmetric about the boresight (the reference's linear fan and grid) have W[B-1-b] = conj(W[b]) exactly;
-    // the device check above decides per weight set, DSABF_PAIRED=0 in the environment forces the general kernel.
-    const char* env = getenv("DSABF_PAIRED");
-    h->geom.paired = h->d_wimage_p != nullptr && bad[1] == 0 && !(env && env[0] == '0');
+    // the device check above decides per weight set; DSABF_PAIRED=0 in the environment, or bf_set_switch(h, "paired", 0) before
+    // the weights are set, forces the general kernel.
+    const char* env = getenv("DSABF_PAIRED");   // read per weight set (not per launch): the choice is part of setting weights
+    h->geom.paired = h->d_wimage_p != nullptr && bad[1] == 0 && !h->force_general && !(env && env[0] == '0');
     h->weights_set = true;
     return BF_OK;
 }
@@ -671,13 +676,33 @@ int bf_dedisperse_device(bf_handle* h, const float* d_out_unit, float* d_ded, vo
     return BF_OK;
 }
 
-// scratch of the DM-trial dedispersion: kDwMaxGroups flag ints + one 512-byte row of zeros (dsabf::kDmScratchBytes)
-static hipError_t dm_scratch(bf_handle* h)
+// Scratch of the DM-trial dedispersion for calls on stream `s`: kDwMaxGroups flag ints + one 512-byte row of zeros
+// (dsabf::kDmScratchBytes), zeroed ON THAT STREAM when it is first used -- ordered before the kernels that read it, also on a
+// non-blocking stream (a memset on the null stream would not be).
+static hipError_t dm_scratch(bf_handle* h, hipStream_t s, int** out)
 {
-    if (h->d_dm_flags) return hipSuccess;
-    hipError_t e = hipMalloc((void**)&h->d_dm_flags, dsabf::kDmScratchBytes);
-    if (e == hipSuccess) e = hipMemset(h->d_dm_flags, 0, dsabf::kDmScratchBytes);
-    return e;
+    for (auto& sc : h->dm_scratch)
+        if (sc.first == s) {
+            *out = sc.second;
+            return hipSuccess;
+        }
+    if (h->dm_scratch.size() >= 64) {   // a caller that keeps creating streams: nothing of ours may still be in flight
+        hipError_t e = hipDeviceSynchronize();
+        if (e != hipSuccess) return e;
+        for (auto& sc : h->dm_scratch) (void)hipFree(sc.second);
+        h->dm_scratch.clear();
+    }
+    int* p = nullptr;
+    hipError_t e = hipMalloc((void**)&p, dsabf::kDmScratchBytes);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(p, 0, dsabf::kDmScratchBytes, s);
+    if (e != hipSuccess) {
+        (void)hipFree(p);
+        return e;
+    }
+    h->dm_scratch.emplace_back(s, p);
+    *out = p;
+    return hipSuccess;
 }
 
 int bf_dedisperse_dm_device(bf_handle* h, const float* d_series, int n_t, const int32_t* d_delays, int n_dm, int n_t_out,
@@ -686,8 +711,9 @@ int bf_dedisperse_dm_device(bf_handle* h, const float* d_series, int n_t, const 
     if (!h || !d_series || !d_delays || !d_out) return fail(BF_ERR_INVALID, "NULL argument");
     if (n_t <= 0 || n_dm < 0 || n_t_out < 0 || n_t_out > n_t) return fail(BF_ERR_INVALID, "need 0 <= n_t_out <= n_t, n_dm >= 0");
     ON_DEVICE(h);
-    HIP_TRY(dm_scratch(h));
-    HIP_TRY(dsabf::launch_dedisperse_dm(h->geom, d_series, n_t, d_delays, n_dm, n_t_out, d_out, h->d_dm_flags, as_stream(hip_stream)));
+    int* flags = nullptr;
+    HIP_TRY(dm_scratch(h, as_stream(hip_stream), &flags));
+    HIP_TRY(dsabf::launch_dedisperse_dm(h->geom, d_series, n_t, d_delays, n_dm, n_t_out, d_out, flags, as_stream(hip_stream)));
     return BF_OK;
 }
 
@@ -711,8 +737,28 @@ int bf_dedisperse_dm_band_device(bf_handle* h, const float* d_series, int n_t, i
     ON_DEVICE(h);
     dsabf::Geometry g = h->geom;
     g.n_freq = n_freq_total;
-    HIP_TRY(dm_scratch(h));
-    HIP_TRY(dsabf::launch_dedisperse_dm(g, d_series, n_t, d_delays, n_dm, n_t_out, d_out, h->d_dm_flags, as_stream(hip_stream)));
+    int* flags = nullptr;
+    HIP_TRY(dm_scratch(h, as_stream(hip_stream), &flags));
+    HIP_TRY(dsabf::launch_dedisperse_dm(g, d_series, n_t, d_delays, n_dm, n_t_out, d_out, flags, as_stream(hip_stream)));
+    return BF_OK;
+}
+
+int bf_set_switch(bf_handle* h, const char* name, int value)
+{
+    if (!h || !name) return fail(BF_ERR_INVALID, "NULL argument");
+    if (!strcmp(name, "tsplit")) {
+        if (value < 0) return fail(BF_ERR_INVALID, "tsplit must be >= 0 (0: the library decides)");
+        h->geom.tsplit = value;
+    } else if (!strcmp(name, "lds_pad")) {
+        if (value < 0 || value > dsabf::kLdsPerCuBytes) return fail(BF_ERR_INVALID, "lds_pad must be 0 .. %d bytes", dsabf::kLdsPerCuBytes);
+        h->geom.lds_pad = value;
+    } else if (!strcmp(name, "dm_wide")) {
+        h->geom.dm_wide = value != 0;
+    } else if (!strcmp(name, "paired")) {
+        h->force_general = value == 0;   // takes effect at the next bf_set_weights (the kernel is chosen per weight set)
+    } else {
+        return fail(BF_ERR_INVALID, "unknown switch \"%s\" (tsplit, lds_pad, dm_wide, paired)", name);
+    }
     return BF_OK;
 }
 

@@ -288,6 +288,14 @@ int bf_mfma_peak_device(bf_handle *h, const void *d_operands, size_t operand_byt
 
 /* Introspection for benchmarks/roofline reports. */
 int bf_kernel_info(const bf_handle *h, int n_units, int *grid, int *block, int *lds_bytes, int *vgprs);
+/* Measurement / test switches of ONE handle (A/B runs inside one process).  They select among launches and kernels that
+ * produce the same bits; none of them is needed in production.  The environment variables of the same meaning are read ONCE,
+ * at bf_create (DSABF_TSPLIT, DSABF_LDS_PAD, DSABF_DM_WIDE) -- never in a launch path.
+ *   "tsplit"   n >= 0   time splits per frequency of the fused launch (0: the library decides)
+ *   "lds_pad"  bytes    extra dynamic LDS per workgroup (fewer resident workgroups per CU); clamped to what a CU has
+ *   "dm_wide"  0 / 1    0: bf_dedisperse_dm*_device runs the per-thread-window kernel alone
+ *   "paired"   0 / 1    0: the next bf_set_weights selects the general kernel even for conjugate-symmetric weights */
+int bf_set_switch(bf_handle *h, const char *name, int value);
 int bf_kernel_name(const bf_handle *h, char *buf, size_t buflen); /* which fused kernel this geometry runs */
 /* The same answers WITHOUT a handle or a device: which kernel and launch shape a configuration would run for n_units gemm-units
  * on a chip of n_cus compute units (MI355X: 256); paired != 0: as for a conjugate-symmetric weight set (honoured where a

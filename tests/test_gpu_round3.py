@@ -222,7 +222,7 @@ def test_pulse_dispersed_with_the_notebooks_own_delays_is_recovered(torch, bfmod
 @pytest.mark.parametrize("case", ["fine_64", "ragged_beams_trials", "mixed_groups", "negative_and_tail", "tiny"])
 def test_shared_window_dm_kernel_bit_exact(torch, bfmod, orc, case, monkeypatch):
     """The round-3 DM-trial kernel (csrc/bf_dm_wide.hip: 32 trials x 16 times x 128 beams per workgroup, windows staged by
-    LDS-DMA and shared by all trials) against the oracle and against the per-thread-window kernel alone (DSABF_DM_WIDE=0):
+    LDS-DMA and shared by all trials) against the oracle and against the per-thread-window kernel alone (bf_set_switch "dm_wide" 0):
     the same bits.  Cases: a fine ladder (every group fits); beams that do not fill the last 128-beam tile with a trial count
     that does not fill the last pair / group; groups that fit next to groups that do not (the two kernels share one launch);
     delays that start negative (rows before the series read +0) with outputs running past its end; a tiny problem."""
@@ -253,15 +253,12 @@ def test_shared_window_dm_kernel_bit_exact(torch, bfmod, orc, case, monkeypatch)
         want = orc.dedisperse_dm(series, delays, n_t_out)
         got = {}
         for mode in ("shared", "thread"):
-            if mode == "thread":
-                monkeypatch.setenv("DSABF_DM_WIDE", "0")
-            else:
-                monkeypatch.delenv("DSABF_DM_WIDE", raising=False)
+            bf.set_switch("dm_wide", 0 if mode == "thread" else 1)   # per handle (bf_set_switch): never the environment mid-process
             d_out = torch.full((n_dm, n_t_out, n_b), float("nan"), dtype=torch.float32, device="cuda")
             bf.dedisperse_dm(d_series, n_t, d_delays, n_dm, n_t_out, d_out, s)
             torch.cuda.synchronize()
             got[mode] = d_out.cpu().numpy()
-        monkeypatch.delenv("DSABF_DM_WIDE", raising=False)
+        bf.set_switch("dm_wide", 1)
         assert np.array_equal(got["shared"], want), (case, n_t_out)
         assert np.array_equal(got["thread"], want), (case, n_t_out)
     bf.close()

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """DM-trial dedispersion: the round-3 shared-window kernel (bf_dm_wide.hip) against the per-thread-window kernel alone
-(DSABF_DM_WIDE=0), same inputs, interleaved; fine and coarse ladders.  Also checks that both give the same bits.
+(bf_set_switch dm_wide 0), same inputs, interleaved; fine and coarse ladders.  Also checks that both give the same bits.
 GPU box, repo root:  python tools/dm_ab.py > gpurun_out/r03/dm_ab.txt"""
 import os
 import sys
@@ -42,16 +42,12 @@ for label, dm_max, n_t, n_dm in (("DM<=250 x64", 250.0, 1024, 64), ("DM<=250 x25
     res, outs = {}, {}
     for rnd in range(3):
         for mode in ("wide", "thread"):
-            if mode == "thread":
-                os.environ["DSABF_DM_WIDE"] = "0"
-            else:
-                os.environ.pop("DSABF_DM_WIDE", None)
+            bf.set_switch("dm_wide", 0 if mode == "thread" else 1)
             for _ in range(3):
                 bf.dedisperse_dm(d_series, n_t, d_delays, len(dms), n_t_out, d_dd, s)
             res.setdefault(mode, []).append(timed())
             if rnd == 0:
                 outs[mode] = d_dd.clone()
-    os.environ.pop("DSABF_DM_WIDE", None)
     same = bool(torch.equal(outs["wide"], outs["thread"]))
     spread32 = max(int((delays[g * 32:(g + 1) * 32].max(0) - delays[g * 32:(g + 1) * 32].min(0)).max()) for g in range((len(dms) + 31) // 32))
     alg = 4 * (n_t * 256 * 256 + len(dms) * n_t_out * 256)

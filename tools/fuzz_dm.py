@@ -44,17 +44,13 @@ for case in range(cases):
     d_series, d_delays = torch.from_numpy(series).cuda(), torch.from_numpy(delays).cuda()
     want = orc.dedisperse_dm(series, delays, n_t_out)
     for mode in ("shared", "thread"):
-        if mode == "thread":
-            os.environ["DSABF_DM_WIDE"] = "0"
-        else:
-            os.environ.pop("DSABF_DM_WIDE", None)
+        bf.set_switch("dm_wide", 0 if mode == "thread" else 1)
         d_out = torch.full((n_dm, n_t_out, n_b), float("nan"), dtype=torch.float32, device="cuda")
         bf.dedisperse_dm(d_series, n_t, d_delays, n_dm, n_t_out, d_out, s)
         torch.cuda.synchronize()
         if not np.array_equal(d_out.cpu().numpy(), want):
             bad += 1
             print("MISMATCH case %d mode %s kind %s n_t %d n_f %d n_b %d n_dm %d n_t_out %d" % (case, mode, kind, n_t, n_f, n_b, n_dm, n_t_out))
-    os.environ.pop("DSABF_DM_WIDE", None)
     kinds[kind] = kinds.get(kind, 0) + 1
     bf.close()
 print("seed %d cases %d (x 2 kernel selections) mismatches %d kinds %s" % (seed, cases, bad, kinds))

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Kernel time per beam-block of one launch over 1 / 2 / 8 / 32 / 128 gemm-units (input resident in HBM), for the time
-splits DSABF_TSPLIT can force -- how fused_launch_shape's choice compares with the alternatives.  GPU box, repo root:
+splits bf_set_switch("tsplit") can force -- how fused_launch_shape's choice compares with the alternatives.  GPU box, repo root:
 python tools/launch_size.py [workload] > gpurun_out/r02_launch_size.txt"""
 import os
 import sys
@@ -36,10 +36,7 @@ for units in ((1, 4, 16, 64) if wl == "c5" else (32, 128) if shard4 else (1, 2, 
     chunks = units * n_time // 128
     rows = []
     for ts in [None] + [t for t in (1, 2, 4, 8, 16, 32, 64) if t <= chunks]:
-        if ts is None:
-            os.environ.pop("DSABF_TSPLIT", None)
-        else:
-            os.environ["DSABF_TSPLIT"] = str(ts)
+        bf.set_switch("tsplit", ts or 0)     # per handle (bf_set_switch); 0: the library's own choice
         info = bf.kernel_info(units)
         fn = lambda i: bf.beamform(d_in[i % 4], units, d_out, stream.cuda_stream)  # noqa: E731
         import time as _t
@@ -51,7 +48,7 @@ for units in ((1, 4, 16, 64) if wl == "c5" else (32, 128) if shard4 else (1, 2, 
                 torch.cuda.synchronize()
         avg, med, mn = bench.time_launches(torch, fn, 200 if units <= 8 else 60, stream)
         rows.append((ts, info["grid"], avg, mn))
-    os.environ.pop("DSABF_TSPLIT", None)
+    bf.set_switch("tsplit", 0)
     print("units %3d (%4d chunks per frequency)" % (units, chunks))
     for ts, grid, avg, mn in rows:
         print("   tsplit %-7s grid %5d  kernel avg %8.2f us  min %8.2f us  = %6.3f us per beam-block%s"
