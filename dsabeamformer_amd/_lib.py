@@ -108,6 +108,7 @@ SIGNATURES = {
     "bf_dedisperse_dm_band_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
                                                C.c_void_p]),
     "bf_set_switch": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
+    "bf_get_counter": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_uint64)]),
     "bf_kernel_info": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
                                  C.POINTER(C.c_int)]),
     "bf_kernel_name": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t]),
@@ -184,8 +185,11 @@ SIGNATURES = {
     "bfh_run_observation_shm": (C.c_int, [C.POINTER(BfConfig), C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p,
                                           C.POINTER(C.c_float), C.POINTER(C.c_uint64), C.POINTER(C.c_int)]),
     "bfh_run_debug_observation": (C.c_int, [C.POINTER(BfConfig), C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p,
-                                            C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_int),
+                                            C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_int),
                                             C.POINTER(C.c_float)]),
+    "bfh_run_debug_observation2": (C.c_int, [C.POINTER(BfConfig), C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p,
+                                             C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_int),
+                                             C.POINTER(C.c_float), C.c_int]),
 }
 
 

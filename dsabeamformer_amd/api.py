@@ -159,6 +159,12 @@ class Beamformer:
         """bf_set_switch: a measurement / test switch of this handle ("tsplit", "lds_pad", "dm_wide", "paired")."""
         check(self._lib.bf_set_switch(self._h, name.encode(), int(value)))
 
+    def counter(self, name: str) -> int:
+        """bf_get_counter: "fused_launches", "queued_units"."""
+        v = C.c_uint64()
+        check(self._lib.bf_get_counter(self._h, name.encode(), C.byref(v)))
+        return int(v.value)
+
     def kernel_info(self, n_units: int = 1) -> dict:
         g, b, l, v = C.c_int(), C.c_int(), C.c_int(), C.c_int()
         check(self._lib.bf_kernel_info(self._h, n_units, C.byref(g), C.byref(b), C.byref(l), C.byref(v)))

@@ -255,8 +255,15 @@ int bfh_obs_describe(bfh_obs* o, char* buf, size_t buflen)
     return BF_OK;
 }
 int bfh_run_debug_observation(const bf_config* cfg, int gpu, const char* positions, const char* directions,
-                              const char* sources, const char* output, int device, int verbose, int per_unit_launches,
-                              float* ded_out, size_t ded_capacity, int* n_pt_sources, float* observation_ms)
+                              const char* sources, const char* output, int device, int verbose, float* ded_out,
+                              size_t ded_capacity, int* n_pt_sources, float* observation_ms)
+{
+    return bfh_run_debug_observation2(cfg, gpu, positions, directions, sources, output, device, verbose, ded_out, ded_capacity,
+                                      n_pt_sources, observation_ms, 0);
+}
+int bfh_run_debug_observation2(const bf_config* cfg, int gpu, const char* positions, const char* directions,
+                               const char* sources, const char* output, int device, int verbose, float* ded_out,
+                               size_t ded_capacity, int* n_pt_sources, float* observation_ms, int per_unit_launches)
 {
     if (!cfg) return BF_ERR_INVALID;
     debug_run_options opt;

@@ -41,6 +41,22 @@ struct bf_handle {
     // them later on the same stream: calls on one stream are ordered by the stream, calls on different streams must not share.
     std::vector<std::pair<hipStream_t, int*>> dm_scratch;
     bool force_general = false;   // bf_set_switch("paired", 0): never select the conjugate-pair kernel
+    // bf_enqueue_gemm_unit coalesces (see flush_units): the caller keeps the reference's one-unit-per-call loop
+    // (src/beamformer.cu:454-519), the device sees one launch per run of consecutive gemm-units.
+    struct pending_unit {
+        int stream_idx, slot, time_slice;
+        float* host_out;      // a4: D2H destination of the unit's detected powers (NULL: none)
+        float* ded_row;       // a8: D2H destination of its DM-0 row (bf_enqueue_dedisperse after the unit), NULL: none
+        bool ded;
+    };
+    std::vector<pending_unit> pending;
+    bool coalesce = true;         // DSABF_COALESCE=0 / bf_set_switch("coalesce", 0): one launch per call, the literal pattern
+    uint64_t flush_seq = 0;       // flushes rotate over the compute queues
+    hipEvent_t flush_done = nullptr;   // end of the previous flush's host copies: the next flush's copies queue behind it
+    bool flush_recorded = false;
+    uint64_t n_fused_launches = 0;        // fused-kernel launches this handle has issued (bf_get_counter)
+    std::vector<const float*> last_out;   // per caller-visible queue: where its most recent gemm-unit's powers are on the device ...
+    std::vector<int> last_q;              // ... and the queue that wrote them
     std::vector<float*> d_out_blk;  // per compute queue, n_gemms_per_block x floats_per_detect: bf_enqueue_block (lazy)
     std::vector<float*> d_ded_blk;  // per compute queue, n_gemms_per_block x n_beams: bf_enqueue_block_dedisperse (lazy)
     std::vector<float*> d_full_blk; // per compute queue, the gathered block (world x as large): bf_block_gather_device (lazy)
@@ -245,6 +261,17 @@ int bf_create(const bf_config* cfg, int device, bf_handle** out)
     CREATE_TRY(hipStreamCreateWithFlags(&h->h2d, hipStreamNonBlocking));
     h->streams.resize(cfg->n_streams, nullptr);
     h->join.resize(cfg->n_streams, nullptr);
+    h->last_out.resize(cfg->n_streams, nullptr);
+    h->last_q.resize(cfg->n_streams, 0);
+    for (int i = 0; i < cfg->n_streams; i++) {
+        h->last_out[i] = h->d_out + bf_floats_per_detect(cfg) * (size_t)i;
+        h->last_q[i] = i;
+    }
+    {
+        const char* env = getenv("DSABF_COALESCE");
+        h->coalesce = !(env && env[0] == '0');
+    }
+    CREATE_TRY(hipEventCreateWithFlags(&h->flush_done, hipEventDisableTiming));
     for (int i = 0; i < cfg->n_streams; i++) {
         CREATE_TRY(hipStreamCreateWithFlags(&h->streams[i], hipStreamNonBlocking));
         CREATE_TRY(hipEventCreateWithFlags(&h->join[i], hipEventDisableTiming));
@@ -257,6 +284,7 @@ int bf_destroy(bf_handle* h)
 {
     if (!h) return BF_OK;
     DeviceScope dev_scope_(h->device);
+    h->pending.clear();   // gemm-units queued but never joined by an event or a sync: their results were never observable
     for (auto s : h->streams)
         if (s) (void)hipStreamSynchronize(s);
     if (h->h2d) (void)hipStreamSynchronize(h->h2d);
@@ -265,6 +293,7 @@ int bf_destroy(bf_handle* h)
     for (auto s : h->streams)
         if (s) (void)hipStreamDestroy(s);
     if (h->h2d) (void)hipStreamDestroy(h->h2d);
+    if (h->flush_done) (void)hipEventDestroy(h->flush_done);
     if (h->t0) (void)hipEventDestroy(h->t0);
     if (h->t1) (void)hipEventDestroy(h->t1);
     (void)hipFree(h->d_wimage);
@@ -439,6 +468,100 @@ int bf_record_transfer_event(bf_handle* h, bf_event* ev)
     return BF_OK;
 }
 
+static int ensure_block_buffers(bf_handle* h, int q, bool ded)
+{
+    const size_t per_det = bf_floats_per_detect(&h->cfg);
+    if (h->d_out_blk.empty()) h->d_out_blk.assign((size_t)h->cfg.n_streams, nullptr);
+    if (!h->d_out_blk[q])
+        HIP_TRY(hipMalloc((void**)&h->d_out_blk[q], per_det * sizeof(float) * (size_t)h->cfg.n_gemms_per_block));
+    if (ded) {
+        if (h->d_ded_blk.empty()) h->d_ded_blk.assign((size_t)h->cfg.n_streams, nullptr);
+        if (!h->d_ded_blk[q])
+            HIP_TRY(hipMalloc((void**)&h->d_ded_blk[q], (size_t)h->cfg.n_beams * sizeof(float) * (size_t)h->cfg.n_gemms_per_block));
+    }
+    return BF_OK;
+}
+
+// Launches what bf_enqueue_gemm_unit / bf_enqueue_dedisperse have queued: per run of consecutive gemm-units of one ring
+// slot ONE fused launch (the reference's loop enqueues time slices 0, 1, 2, ... of a block: one run = the block), one
+// DM-0 launch per run of units that asked for it, and the host copies -- every unit's, in the order they were enqueued,
+// neighbours in device AND host memory as one copy.  All of it on ONE compute queue (they rotate per flush); the host copies
+// wait for the previous flush's, so that two units copied to the same host buffer land in enqueue order as they do on
+// the reference's per-queue streams (src/beamformer.cu:485-488 overwrites beam_out[stream] unit after unit), while this
+// flush's kernel already overlaps the previous flush's copies.
+static int flush_units(bf_handle* h)
+{
+    if (h->pending.empty()) return BF_OK;
+    std::vector<bf_handle::pending_unit> units;
+    units.swap(h->pending);              // (whatever happens below, nothing stays queued)
+    const int q = (int)(h->flush_seq++ % (uint64_t)h->cfg.n_streams);
+    hipStream_t s = h->streams[q];
+    const size_t per_gemm = bf_bytes_per_gemm(&h->cfg), per_det = bf_floats_per_detect(&h->cfg);
+    const size_t n_beams = (size_t)h->cfg.n_beams;
+    bool any_ded = false;
+    for (const auto& u : units) any_ded |= u.ded;
+    if (int rc = ensure_block_buffers(h, q, any_ded)) return rc;
+    float* blk = h->d_out_blk[q];
+    const size_t n = units.size();
+    auto follows = [&](size_t k) {       // unit k continues the run of unit k - 1
+        return units[k].slot == units[k - 1].slot && units[k].time_slice == units[k - 1].time_slice + 1;
+    };
+    for (size_t i = 0; i < n;) {
+        size_t j = i + 1;
+        while (j < n && follows(j)) j++;
+        const uint8_t* in = h->d_data + per_gemm * ((size_t)h->cfg.n_gemms_per_block * units[i].slot + units[i].time_slice);
+        h->n_fused_launches++;
+    HIP_TRY(dsabf::launch_fused(h->geom, h->d_wimage, h->d_wimage_p, in, (int)(j - i), blk + per_det * (size_t)units[i].time_slice,
+                                    h->n_cus, s));
+        for (size_t a = i; a < j;) {     // DM-0 rows of the run: one launch per stretch of units that asked for one
+            if (!units[a].ded) {
+                a++;
+                continue;
+            }
+            size_t b = a + 1;
+            while (b < j && units[b].ded) b++;
+            HIP_TRY(dsabf::launch_dedisperse_units(h->geom, blk + per_det * (size_t)units[a].time_slice, per_det, (int)(b - a),
+                                                   h->d_ded_blk[q] + n_beams * (size_t)units[a].time_slice, s));
+            a = b;
+        }
+        i = j;
+    }
+    if (h->flush_recorded) HIP_TRY(hipStreamWaitEvent(s, h->flush_done, 0));
+    for (size_t i = 0; i < n;) {         // a4: the detected powers
+        if (!units[i].host_out) {
+            i++;
+            continue;
+        }
+        size_t j = i + 1;
+        while (j < n && follows(j) && units[j].host_out == units[j - 1].host_out + per_det) j++;
+        HIP_TRY(hipMemcpyAsync(units[i].host_out, blk + per_det * (size_t)units[i].time_slice, per_det * sizeof(float) * (j - i),
+                               hipMemcpyDeviceToHost, s));
+        i = j;
+    }
+    for (size_t i = 0; i < n;) {         // a8: the DM-0 rows
+        if (!units[i].ded || !units[i].ded_row) {
+            i++;
+            continue;
+        }
+        size_t j = i + 1;
+        while (j < n && follows(j) && units[j].ded && units[j].ded_row == units[j - 1].ded_row + n_beams) j++;
+        HIP_TRY(hipMemcpyAsync(units[i].ded_row, h->d_ded_blk[q] + n_beams * (size_t)units[i].time_slice, n_beams * sizeof(float) * (j - i),
+                               hipMemcpyDeviceToHost, s));
+        i = j;
+    }
+    HIP_TRY(hipEventRecord(h->flush_done, s));
+    h->flush_recorded = true;
+    for (const auto& u : units) {
+        h->last_out[u.stream_idx] = blk + per_det * (size_t)u.time_slice;
+        h->last_q[u.stream_idx] = q;
+    }
+    return BF_OK;
+}
+#define FLUSH_UNITS(h_)                        \
+    do {                                       \
+        if (int rc_ = flush_units(h_)) return rc_; \
+    } while (0)
+
 int bf_enqueue_gemm_unit(bf_handle* h, int stream_idx, int slot, int time_slice, float* host_out)
 {
     if (!h) return fail(BF_ERR_INVALID, "handle is NULL");
@@ -448,14 +571,25 @@ int bf_enqueue_gemm_unit(bf_handle* h, int stream_idx, int slot, int time_slice,
     if (time_slice < 0 || time_slice >= h->cfg.n_gemms_per_block)
         return fail(BF_ERR_INVALID, "time_slice %d out of range", time_slice);
     ON_DEVICE(h);
+    if (h->coalesce) {
+        // a whole block is queued, or this time slice's place in the block buffer is taken: launch what is there first
+        bool clash = h->pending.size() >= (size_t)h->cfg.n_gemms_per_block;
+        for (const auto& u : h->pending) clash |= u.time_slice == time_slice;
+        if (clash) FLUSH_UNITS(h);
+        h->pending.push_back({stream_idx, slot, time_slice, host_out, nullptr, false});
+        return BF_OK;
+    }
     const size_t per_gemm = bf_bytes_per_gemm(&h->cfg);
     const size_t per_det = bf_floats_per_detect(&h->cfg);
     // src/beamformer.cu:464: &d_data[N_BYTES_PRE_EXPANSION_PER_GEMM*(N_GEMMS_PER_BLOCK*block + timeSlice)]
     const uint8_t* in = h->d_data + per_gemm * ((size_t)h->cfg.n_gemms_per_block * slot + time_slice);
     float* out = h->d_out + per_det * (size_t)stream_idx;
     hipStream_t s = h->streams[stream_idx];
+    h->n_fused_launches++;
     HIP_TRY(dsabf::launch_fused(h->geom, h->d_wimage, h->d_wimage_p, in, 1, out, h->n_cus, s));
     if (host_out) HIP_TRY(hipMemcpyAsync(host_out, out, per_det * sizeof(float), hipMemcpyDeviceToHost, s));
+    h->last_out[stream_idx] = out;
+    h->last_q[stream_idx] = stream_idx;
     return BF_OK;
 }
 
@@ -469,6 +603,7 @@ int bf_enqueue_block(bf_handle* h, int stream_idx, int slot, int first_unit, int
         return fail(BF_ERR_INVALID, "gemm-units [%d, %d) are not inside a block of %d", first_unit, first_unit + n_units,
                     h->cfg.n_gemms_per_block);
     ON_DEVICE(h);
+    FLUSH_UNITS(h);
     const size_t per_gemm = bf_bytes_per_gemm(&h->cfg);
     const size_t per_det = bf_floats_per_detect(&h->cfg);
     if (h->d_out_blk.empty()) h->d_out_blk.assign((size_t)h->cfg.n_streams, nullptr);
@@ -477,6 +612,7 @@ int bf_enqueue_block(bf_handle* h, int stream_idx, int slot, int first_unit, int
     const uint8_t* in = h->d_data + per_gemm * ((size_t)h->cfg.n_gemms_per_block * slot + first_unit);
     float* out = h->d_out_blk[stream_idx] + per_det * (size_t)first_unit;
     hipStream_t s = h->streams[stream_idx];
+    h->n_fused_launches++;
     HIP_TRY(dsabf::launch_fused(h->geom, h->d_wimage, h->d_wimage_p, in, n_units, out, h->n_cus, s));
     if (host_out)
         for (int u = 0; u < n_units;) {   // destinations that follow each other in host memory travel as ONE copy
@@ -503,6 +639,7 @@ int bf_enqueue_block_dedisperse(bf_handle* h, int stream_idx, int first_unit, in
     if (h->d_out_blk.empty() || !h->d_out_blk[stream_idx])
         return fail(BF_ERR_STATE, "bf_enqueue_block has not run on queue %d", stream_idx);
     ON_DEVICE(h);
+    FLUSH_UNITS(h);
     const size_t per_det = bf_floats_per_detect(&h->cfg);
     if (h->d_ded_blk.empty()) h->d_ded_blk.assign((size_t)h->cfg.n_streams, nullptr);
     if (!h->d_ded_blk[stream_idx])
@@ -549,6 +686,7 @@ int bf_enqueue_d2h(bf_handle* h, int stream_idx, const float* d_src, float* host
     if (!h || !d_src || !host_dst) return fail(BF_ERR_INVALID, "NULL argument");
     if (stream_idx < 0 || stream_idx >= h->cfg.n_streams) return fail(BF_ERR_INVALID, "stream %d out of range", stream_idx);
     ON_DEVICE(h);
+    FLUSH_UNITS(h);
     HIP_TRY(hipMemcpyAsync(host_dst, d_src, n_floats * sizeof(float), hipMemcpyDeviceToHost, h->streams[stream_idx]));
     return BF_OK;
 }
@@ -557,6 +695,8 @@ int bf_queue_stream(bf_handle* h, int stream_idx, void** hip_stream)
 {
     if (!h || !hip_stream) return fail(BF_ERR_INVALID, "NULL argument");
     if (stream_idx < 0 || stream_idx >= h->cfg.n_streams) return fail(BF_ERR_INVALID, "stream %d out of range", stream_idx);
+    ON_DEVICE(h);
+    FLUSH_UNITS(h);   // the caller is about to order its own work against this queue: nothing of ours may still be only queued
     *hip_stream = h->streams[stream_idx];
     return BF_OK;
 }
@@ -566,10 +706,19 @@ int bf_enqueue_dedisperse(bf_handle* h, int stream_idx, float* host_out_row)
     if (!h) return fail(BF_ERR_INVALID, "handle is NULL");
     if (stream_idx < 0 || stream_idx >= h->cfg.n_streams) return fail(BF_ERR_INVALID, "stream %d out of range", stream_idx);
     ON_DEVICE(h);
-    hipStream_t s = h->streams[stream_idx];
-    const float* out = h->d_out + bf_floats_per_detect(&h->cfg) * (size_t)stream_idx;
+    // the gemm-unit this call refers to -- the most recent one of queue stream_idx -- may still be queued: its DM-0 row is then
+    // part of the same flush (one launch for all the rows of a run)
+    for (size_t k = h->pending.size(); k-- > 0;)
+        if (h->pending[k].stream_idx == stream_idx) {
+            if (h->pending[k].ded) break;   // a second collapse of the same unit: run it directly below
+            h->pending[k].ded = true;
+            h->pending[k].ded_row = host_out_row;
+            return BF_OK;
+        }
+    FLUSH_UNITS(h);
+    hipStream_t s = h->streams[h->last_q[stream_idx]];
     float* ded = h->d_ded + (size_t)h->cfg.n_beams * stream_idx;
-    HIP_TRY(dsabf::launch_dedisperse(h->geom, out, ded, s));
+    HIP_TRY(dsabf::launch_dedisperse(h->geom, h->last_out[stream_idx], ded, s));
     if (host_out_row)
         HIP_TRY(hipMemcpyAsync(host_out_row, ded, (size_t)h->cfg.n_beams * sizeof(float), hipMemcpyDeviceToHost, s));
     return BF_OK;
@@ -579,6 +728,7 @@ int bf_record_analysis_event(bf_handle* h, bf_event* ev)
 {
     if (!h || !ev) return fail(BF_ERR_INVALID, "NULL argument");
     ON_DEVICE(h);
+    FLUSH_UNITS(h);
     const int last = h->cfg.n_streams - 1;
     for (int i = 0; i < last; i++) {
         HIP_TRY(hipEventRecord(h->join[i], h->streams[i]));
@@ -593,6 +743,7 @@ int bf_stream_sync(bf_handle* h, int stream_idx)
 {
     if (!h) return fail(BF_ERR_INVALID, "handle is NULL");
     ON_DEVICE(h);
+    FLUSH_UNITS(h);
     if (stream_idx < 0) {
         HIP_TRY(hipStreamSynchronize(h->h2d));
         for (auto s : h->streams) HIP_TRY(hipStreamSynchronize(s));
@@ -600,6 +751,8 @@ int bf_stream_sync(bf_handle* h, int stream_idx)
     }
     if (stream_idx >= h->cfg.n_streams) return fail(BF_ERR_INVALID, "stream %d out of range", stream_idx);
     HIP_TRY(hipStreamSynchronize(h->streams[stream_idx]));
+    if (h->last_q[stream_idx] != stream_idx)   // its most recent gemm-unit was coalesced into a launch on another queue
+        HIP_TRY(hipStreamSynchronize(h->streams[h->last_q[stream_idx]]));
     return BF_OK;
 }
 
@@ -618,6 +771,7 @@ int bf_timer_stop(bf_handle* h, float* ms)
     if (!h || !ms) return fail(BF_ERR_INVALID, "NULL argument");
     if (!h->t0) return fail(BF_ERR_STATE, "bf_timer_start has not been called");
     ON_DEVICE(h);   // t1 goes onto the handle's device's null stream, where t0 is
+    FLUSH_UNITS(h);
     HIP_TRY(hipEventRecord(h->t1, nullptr));
     HIP_TRY(hipEventSynchronize(h->t1));
     HIP_TRY(hipEventElapsedTime(ms, h->t0, h->t1));
@@ -633,6 +787,7 @@ int bf_beamform_device(bf_handle* h, const void* d_packed, int n_units, float* d
         return fail(BF_ERR_INVALID, "misaligned device pointer: d_packed and d_out must be 16-byte aligned (the kernel loads "
                                     "16-byte pieces and stores 16-byte groups of beams)");
     ON_DEVICE(h);
+    h->n_fused_launches++;
     HIP_TRY(dsabf::launch_fused(h->geom, h->d_wimage, h->d_wimage_p, d_packed, n_units, d_out, h->n_cus, as_stream(hip_stream)));
     return BF_OK;
 }
@@ -746,6 +901,7 @@ int bf_dedisperse_dm_band_device(bf_handle* h, const float* d_series, int n_t, i
 int bf_set_switch(bf_handle* h, const char* name, int value)
 {
     if (!h || !name) return fail(BF_ERR_INVALID, "NULL argument");
+    ON_DEVICE(h);
     if (!strcmp(name, "tsplit")) {
         if (value < 0) return fail(BF_ERR_INVALID, "tsplit must be >= 0 (0: the library decides)");
         h->geom.tsplit = value;
@@ -754,11 +910,26 @@ int bf_set_switch(bf_handle* h, const char* name, int value)
         h->geom.lds_pad = value;
     } else if (!strcmp(name, "dm_wide")) {
         h->geom.dm_wide = value != 0;
+    } else if (!strcmp(name, "coalesce")) {
+        FLUSH_UNITS(h);
+        h->coalesce = value != 0;
     } else if (!strcmp(name, "paired")) {
         h->force_general = value == 0;   // takes effect at the next bf_set_weights (the kernel is chosen per weight set)
     } else {
-        return fail(BF_ERR_INVALID, "unknown switch \"%s\" (tsplit, lds_pad, dm_wide, paired)", name);
+        return fail(BF_ERR_INVALID, "unknown switch \"%s\" (tsplit, lds_pad, dm_wide, paired, coalesce)", name);
     }
+    return BF_OK;
+}
+
+int bf_get_counter(const bf_handle* h, const char* name, uint64_t* value)
+{
+    if (!h || !name || !value) return fail(BF_ERR_INVALID, "NULL argument");
+    if (!strcmp(name, "fused_launches"))
+        *value = h->n_fused_launches;
+    else if (!strcmp(name, "queued_units"))
+        *value = h->pending.size();
+    else
+        return fail(BF_ERR_INVALID, "unknown counter \"%s\" (fused_launches, queued_units)", name);
     return BF_OK;
 }
 

@@ -377,6 +377,10 @@ int run_debug_observation(const bf_config& cfg, const debug_run_options& opt, de
     log << "Time per data chunk: " << observation_time_ms / chunks << " milliseconds.\n";
     log << "Approximate datarate: " << bf_bytes_per_gemm(&cfg) * (double)n_src / observation_time_ms / 1e6 << "GB/s"
         << std::endl;
+    // (not a line of the reference: which caller-side loop the two timing lines above were measured with)
+    log << "Launch pattern: " << (opt.block_launch ? "one bf_enqueue_block per PSRDADA block"
+                                                    : "the reference's loop, one bf_enqueue_gemm_unit per gemm-unit (src/beamformer.cu:454-519)")
+        << std::endl;
 
     bf_stream_sync(h, -1);  // :560-562
     log << "Synchronized" << std::endl;
@@ -591,6 +595,8 @@ int run_observation(const bf_config& cfg, const observation_options& opt, block_
     log << "Code produced outputs for " << chunks << " data chunks.\n";
     log << "Time per data chunk: " << ms / (chunks ? chunks : 1) << " milliseconds.\n";
     log << "Approximate datarate: " << rate << "GB/s" << std::endl;
+    log << "Launch pattern: " << (block_launch ? "bf_enqueue_block" : "the reference's loop, one bf_enqueue_gemm_unit per gemm-unit (src/beamformer.cu:454-519)")
+        << std::endl;
     log << "Synchronized" << std::endl;
     if (res) {
         res->observation_time_ms = ms;

@@ -211,9 +211,9 @@ def run_debug_observation(cfg: BfConfig, gpu: int = 0, positions: str | None = N
     n = C.c_int()
     ms = C.c_float()
     enc = lambda s: s.encode() if s else None  # noqa: E731
-    check(load().bfh_run_debug_observation(C.byref(cfg), gpu, enc(positions), enc(directions), enc(sources), enc(output),
-                                           device, 1 if verbose else 0, 1 if per_unit_launches else 0, _p(ded), ded.size,
-                                           C.byref(n), C.byref(ms)))
+    check(load().bfh_run_debug_observation2(C.byref(cfg), gpu, enc(positions), enc(directions), enc(sources), enc(output),
+                                            device, 1 if verbose else 0, _p(ded), ded.size, C.byref(n), C.byref(ms),
+                                            1 if per_unit_launches else 0))
     return ded[:n.value].copy(), ms.value
 
 

@@ -143,9 +143,21 @@ int bf_record_transfer_event(bf_handle *h, bf_event *ev);
 
 /* Replaces K1-K4 for one gemm-unit, src/beamformer.cu:464-488: expand_input, cublasGemmStridedBatchedEx,
  * detect_sum and the D2H copy of the detected powers.  Reads gemm-unit `time_slice` (0 .. n_gemms_per_block-1)
- * of ring slot `slot`, runs on compute queue `stream_idx`, leaves [n_out_per_gemm][n_freq][n_beams] float32 in
- * the handle's per-queue device buffer and, if host_out != NULL, copies it there asynchronously (host_out should
- * be pinned). */
+ * of ring slot `slot`, produces [n_out_per_gemm][n_freq][n_beams] float32 on the device and, if host_out != NULL,
+ * copies it there asynchronously (host_out should be pinned).
+ * The caller keeps the reference's loop -- one call per gemm-unit, round-robin over the N_STREAMS queues,
+ * src/beamformer.cu:454-519 -- but the calls are COALESCED: units are queued and, per run of consecutive time slices of
+ * one slot (the reference's loop enqueues 0, 1, 2, ... of a block: one run), launched as ONE kernel, with one DM-0 launch for
+ * the units that bf_enqueue_dedisperse was called for and the host copies behind it -- every unit's, in call order, so a
+ * host buffer written by several units ends up holding the last one, as on the reference's per-queue streams.  One-unit
+ * launches cannot fill the chip (0.28 of the int8 peak alone, 0.385 with 8 in flight; a block launch 0.49); same results.
+ * The queued work is launched when a block's worth (n_gemms_per_block units) is queued and at every call that orders or
+ * observes device work: bf_record_analysis_event (the reference calls it after each block, :525), bf_stream_sync,
+ * bf_enqueue_block*, bf_enqueue_d2h, bf_queue_stream, bf_timer_stop.  Contract: a unit's results are complete when an event
+ * of bf_record_analysis_event recorded after the call fires, or after bf_stream_sync -- which is all the reference's loop
+ * relies on; `stream_idx` names the caller-visible queue (bf_enqueue_dedisperse refers to it), not necessarily the HIP
+ * queue the coalesced launch runs on.  bf_set_switch(h, "coalesce", 0) / DSABF_COALESCE=0 at bf_create: the literal
+ * pattern, one launch per call on queue stream_idx. */
 int bf_enqueue_gemm_unit(bf_handle *h, int stream_idx, int slot, int time_slice, float *host_out);
 
 /* Block-granular form of the same: ONE kernel launch over the n_units consecutive gemm-units [first_unit, first_unit +
@@ -294,8 +306,12 @@ int bf_kernel_info(const bf_handle *h, int n_units, int *grid, int *block, int *
  *   "tsplit"   n >= 0   time splits per frequency of the fused launch (0: the library decides)
  *   "lds_pad"  bytes    extra dynamic LDS per workgroup (fewer resident workgroups per CU); clamped to what a CU has
  *   "dm_wide"  0 / 1    0: bf_dedisperse_dm*_device runs the per-thread-window kernel alone
- *   "paired"   0 / 1    0: the next bf_set_weights selects the general kernel even for conjugate-symmetric weights */
+ *   "paired"   0 / 1    0: the next bf_set_weights selects the general kernel even for conjugate-symmetric weights
+ *   "coalesce" 0 / 1    0: bf_enqueue_gemm_unit launches one kernel per call (the reference's literal launch pattern) */
 int bf_set_switch(bf_handle *h, const char *name, int value);
+/* Counters of one handle: "fused_launches" = fused-kernel launches issued so far (what coalescing saves),
+ * "queued_units" = gemm-units bf_enqueue_gemm_unit has queued and not launched yet. */
+int bf_get_counter(const bf_handle *h, const char *name, uint64_t *value);
 int bf_kernel_name(const bf_handle *h, char *buf, size_t buflen); /* which fused kernel this geometry runs */
 /* The same answers WITHOUT a handle or a device: which kernel and launch shape a configuration would run for n_units gemm-units
  * on a chip of n_cus compute units (MI355X: 256); paired != 0: as for a conjugate-symmetric weight set (honoured where a

@@ -78,12 +78,17 @@ int bfh_obs_describe(bfh_obs *o, char *buf, size_t buflen); /* operator<<, src/o
 
 /* The reference's `make debug` run end to end (generate -> H2D -> beamform -> dedisperse -> data.py).
  * Paths may be NULL (defaults src/beamformer.cu:135-147 and BOGUS_DATA).  ded_out (optional) receives
- * [n_pt_sources][n_beams] floats (capacity in floats given by ded_capacity).  per_unit_launches != 0: the reference's own
- * launch pattern (one launch + one copy per gemm-unit round-robin over the queues, src/beamformer.cu:454-519) instead of
- * one launch, one copy and one DM-0 launch per block; the table is the same bit for bit. */
+ * [n_pt_sources][n_beams] floats (capacity in floats given by ded_capacity). */
 int bfh_run_debug_observation(const bf_config *cfg, int gpu, const char *positions, const char *directions,
-                              const char *sources, const char *output, int device, int verbose, int per_unit_launches,
-                              float *ded_out, size_t ded_capacity, int *n_pt_sources, float *observation_ms);
+                              const char *sources, const char *output, int device, int verbose, float *ded_out,
+                              size_t ded_capacity, int *n_pt_sources, float *observation_ms);
+/* The same with the caller-side loop chosen (a NEW entry point: the signature above is the round-2 one and stays binary
+ * compatible).  per_unit_launches != 0: the reference's own loop -- bf_enqueue_gemm_unit + bf_enqueue_dedisperse per
+ * gemm-unit, round-robin over the queues, src/beamformer.cu:454-519 (the library coalesces those calls into one launch per
+ * block, include/dsabf.h) -- instead of bf_enqueue_block + bf_enqueue_block_dedisperse; the table is the same bit for bit. */
+int bfh_run_debug_observation2(const bf_config *cfg, int gpu, const char *positions, const char *directions,
+                               const char *sources, const char *output, int device, int verbose, float *ded_out,
+                               size_t ded_capacity, int *n_pt_sources, float *observation_ms, int per_unit_launches);
 
 /* Production observation loop (src/beamformer.cu:364-534 without -DDEBUG) fed by the in-memory dada_junkdb stand-in:
  * n_blocks pseudo-random PSRDADA-sized blocks from a pinned ring of ring_blocks distinct blocks, default linear

@@ -74,3 +74,116 @@ def test_switches_are_per_handle_and_checked(torch, bfmod):
             a.set_switch(name, value)
     a.close()
     b.close()
+
+
+def _small_streaming_handle(bfmod, orc, seed, paired=False):
+    g = orc.Geom(n_beams=64, n_ant=64, n_freq=6, n_avg=16, n_out_per_gemm=2)
+    cfg = bfmod.production_config(n_avg=g.n_avg, n_out_per_gemm=g.n_out_per_gemm, n_freq=g.n_freq)
+    cfg.n_beams, cfg.n_gemms_per_block, cfg.n_blocks_on_gpu, cfg.n_streams = g.n_beams, 8, 3, 4
+    rng = np.random.default_rng(seed)
+    w = rng.integers(-127, 128, size=(g.n_freq, g.n_ant, g.n_beams, 2), dtype=np.int8)
+    if paired:
+        w[:, :, 32:, 0] = w[:, :, :32, 0][:, :, ::-1]
+        w[:, :, 32:, 1] = -w[:, :, :32, 1][:, :, ::-1]
+    blocks = rng.integers(0, 256, size=(cfg.n_blocks_on_gpu, cfg.n_gemms_per_block, g.n_freq, g.n_time, g.n_ant), dtype=np.uint8)
+    bf = bfmod.Beamformer(cfg)
+    bf.set_weights(w)
+    want = np.stack([orc.beamform(g, w, blocks[s]) for s in range(cfg.n_blocks_on_gpu)])     # [slot][unit][o][f][b]
+    return g, cfg, bf, blocks, want
+
+
+@pytest.mark.parametrize("paired", [False, True])
+def test_the_references_unit_loop_is_coalesced_into_one_launch_per_block(torch, bfmod, orc, paired):
+    """a drop-in caller keeps the reference's loop (src/beamformer.cu:454-519: one K1-K4 enqueue per
+    gemm-unit, round-robin over the N_STREAMS queues, the D2H of every unit into beam_out[stream], K5 for the units that need
+    it, generate_analysis_event after the block) -- and gets ONE fused launch per block.  Same bits as the literal pattern
+    (bf_set_switch "coalesce" 0) and as the oracle; beam_out[stream] ends up holding the LAST unit of that stream, as the
+    reference's overwriting copies leave it."""
+    from dsabeamformer_amd import api
+
+    g, cfg, bf, blocks, want = _small_streaming_handle(bfmod, orc, 41, paired)
+    assert ("PAIRED" in bf.kernel_info(8)["kernel"]) == paired
+    per = bf.floats_per_detect
+    n_st, n_u = cfg.n_streams, cfg.n_gemms_per_block
+    pinned_in = torch.from_numpy(blocks).pin_memory()
+    for slot in range(cfg.n_blocks_on_gpu):
+        bf.submit_block(slot, pinned_in[slot], blocks[slot].nbytes)
+    bf.sync(-1)
+    results = {}
+    for mode in ("coalesced", "literal"):
+        bf.set_switch("coalesce", 1 if mode == "coalesced" else 0)
+        beam_out = torch.zeros((n_st, per), dtype=torch.float32).pin_memory()            # the reference's beam_out (:249)
+        rows = torch.full((cfg.n_blocks_on_gpu * n_u, g.n_beams), -1.0, dtype=torch.float32).pin_memory()   # dedispersed_out (:212)
+        evs = [api.event_create() for _ in range(cfg.n_blocks_on_gpu)]
+        before = bf.counter("fused_launches")
+        for slot in range(cfg.n_blocks_on_gpu):
+            ts_of = list(range(n_st))                                                    # timeSlice[], :319
+            for part in range(n_u // n_st):
+                for st in range(n_st):
+                    bf.enqueue_gemm_unit(st, slot, ts_of[st], beam_out[st])               # :464-488
+                    if (slot * n_u + ts_of[st]) % 5 != 3:                                # check_ready_for_dh2_transfer: not every unit
+                        bf.enqueue_dedisperse(st, rows[slot * n_u + ts_of[st]])          # :498-510
+                    ts_of[st] = (ts_of[st] + n_st) % n_u                                 # :515-519
+            if mode == "coalesced":
+                assert bf.counter("queued_units") == n_u          # nothing launched before the event orders it
+            bf.record_analysis_event(evs[slot])                                          # :525
+            assert bf.counter("queued_units") == 0
+        for e in evs:
+            while api.event_query(e) != 0:
+                pass
+        launches = bf.counter("fused_launches") - before
+        assert launches == (cfg.n_blocks_on_gpu if mode == "coalesced" else cfg.n_blocks_on_gpu * n_u), (mode, launches)
+        results[mode] = (beam_out.numpy().copy(), rows.numpy().copy())
+        for e in evs:
+            api.event_destroy(e)
+    last = cfg.n_blocks_on_gpu - 1
+    for mode, (bo, rw) in results.items():
+        for st in range(n_st):      # the last unit each stream carried: time slice n_u - n_st + st of the last block
+            assert np.array_equal(bo[st].reshape(want.shape[2:]), want[last, n_u - n_st + st]), (mode, st)
+        for slot in range(cfg.n_blocks_on_gpu):
+            for u in range(n_u):
+                k = slot * n_u + u
+                if k % 5 != 3:
+                    assert np.array_equal(rw[k], orc.dedisperse(g, want[slot, u, 0])), (mode, k)
+                else:
+                    assert (rw[k] == -1.0).all(), (mode, k)     # never asked for: never written
+    bf.close()
+
+
+def test_coalescing_handles_any_enqueue_order(torch, bfmod, orc):
+    """Units out of order, the same time slice twice, more than a block's worth before the event, several slots mixed, a
+    collapse requested after its unit was already launched, a single queue synchronised: every host buffer holds its own
+    unit's bits."""
+    g, cfg, bf, blocks, want = _small_streaming_handle(bfmod, orc, 43)
+    per = bf.floats_per_detect
+    pinned_in = torch.from_numpy(blocks).pin_memory()
+    for slot in range(cfg.n_blocks_on_gpu):
+        bf.submit_block(slot, pinned_in[slot], blocks[slot].nbytes)
+    bf.sync(-1)
+    seq = [(0, 0, 0), (1, 0, 2), (2, 0, 4), (3, 0, 1), (0, 0, 3),            # (queue, slot, time slice): strides and gaps
+           (1, 1, 3),                                                       # slice 3 again, another slot: a clash -> flush first
+           (2, 1, 4), (3, 1, 5), (0, 2, 6), (1, 2, 7),                      # a run that changes slot half way
+           (2, 0, 5), (3, 0, 6), (0, 0, 7), (1, 1, 0), (2, 1, 1), (3, 1, 2), (0, 2, 0), (1, 2, 1)]   # > 8 queued before any event
+    outs = torch.zeros((len(seq), per), dtype=torch.float32).pin_memory()
+    rows = torch.zeros((len(seq), g.n_beams), dtype=torch.float32).pin_memory()
+    before = bf.counter("fused_launches")
+    for k, (q, slot, ts) in enumerate(seq):
+        bf.enqueue_gemm_unit(q, slot, ts, outs[k])
+        if k % 2 == 0:
+            bf.enqueue_dedisperse(q, rows[k])
+    bf.sync(1)                                      # one queue only: still everything that was queued is launched ...
+    assert bf.counter("queued_units") == 0
+    bf.sync(-1)
+    assert bf.counter("fused_launches") - before < len(seq)
+    for k, (q, slot, ts) in enumerate(seq):
+        assert np.array_equal(outs[k].numpy().reshape(want.shape[2:]), want[slot, ts]), k
+        if k % 2 == 0:
+            assert np.array_equal(rows[k].numpy(), orc.dedisperse(g, want[slot, ts, 0])), k
+    # a collapse asked for AFTER its unit was launched (the event came first): the unit's powers are still where it left them
+    late = torch.zeros(g.n_beams, dtype=torch.float32).pin_memory()
+    bf.enqueue_gemm_unit(2, 1, 6, None)
+    bf.sync(-1)
+    bf.enqueue_dedisperse(2, late)
+    bf.sync(2)
+    assert np.array_equal(late.numpy(), orc.dedisperse(g, want[1, 6, 0]))
+    bf.close()
