@@ -812,7 +812,8 @@ def main():
             n_blk = 64
             st = {}
             host.run_observation_junk(pc, 8, ring_blocks=4, device=local, burn_in=2)   # one-off costs outside the records
-            for label, env in (("block_launches", {}), ("reference_unit_launches", {"DSABF_UNIT_LAUNCH": "1"})):
+            for label, env in (("block_launches", {}), ("reference_unit_launches", {"DSABF_UNIT_LAUNCH": "1"}),
+                               ("reference_unit_launches_literal", {"DSABF_UNIT_LAUNCH": "1", "DSABF_COALESCE": "0"})):
                 os.environ.update(env)
                 try:
                     r = host.run_observation_junk(pc, n_blk, ring_blocks=4, device=local, burn_in=4)
@@ -826,7 +827,10 @@ def main():
                              "output_gbs": out_b / (r["ms"] * 1e-3) / 1e9, "observation_ms": r["ms"], "blocks": n_blk}
             st["note"] = ("run_observation, production geometry (N_AVERAGING 16, 128 MiB blocks), in-memory junk source, "
                           "pinned host buffers: H2D of every block and D2H of every gemm-unit's detected powers included -- the "
-                          "reference's 'Time per data chunk'; never the headline.  Real-time budget: 0.131 ms per beam-block.  "
+                          "reference's 'Time per data chunk'; never the headline.  block_launches: the caller uses bf_enqueue_block; "
+                          "reference_unit_launches: the caller keeps the reference's loop (one bf_enqueue_gemm_unit per gemm-unit "
+                          "round-robin over 8 queues, src/beamformer.cu:454-519) and the library coalesces it into one launch per "
+                          "block; ..._literal: the same loop with DSABF_COALESCE=0, one launch per call.  Real-time budget: 0.131 ms per beam-block.  "
                           "PCIe-bound either way; interleaved sweep over the launch granularities: profiles/r02_streaming.txt (round 2)")
             out["streaming"] = st
 
