@@ -31,6 +31,7 @@ struct Geometry {
     int tsplit = 0;                                     // DSABF_TSPLIT=n: time splits per frequency (0: fused_launch_shape decides)
     int lds_pad = 0;                                    // DSABF_LDS_PAD=bytes: extra dynamic LDS (fewer resident workgroups); clamped
     bool dm_wide = true;                                // DSABF_DM_WIDE=0: the per-thread-window DM kernel alone
+    bool force_generic = false;                         // DSABF_GENERIC=1: fusedg_kernel (bf_fusedg.hip) for every geometry
 };
 constexpr int kLdsPerCuBytes = 160 * 1024;
 void read_env_switches(Geometry& g);
@@ -95,6 +96,17 @@ constexpr int kDwMaxFreq = 1024;     // channels the wide kernel's LDS tables ho
 bool dm_wide_supported(const Geometry& g, int n_dm);
 hipError_t launch_dedisperse_dm_wide(const Geometry& g, const float* d_series, int n_t, const int* d_delays, int n_dm,
                                      int n_t_out, float* d_out, int* d_flags, hipStream_t s);
+
+// ---- fusedg_kernel (bf_fusedg.hip): every geometry of the reference's contract the specialised instantiations do not cover --
+constexpr int kGenericMaxAnt = 2048;
+bool use_generic(const Geometry& g);      // does this geometry run fusedg_kernel?  (bf_kernels.hip)
+bool generic_supported(const Geometry& g, const char** why);
+int generic_ksteps(const Geometry& g);
+int generic_interleave(const Geometry& g);
+LaunchShape generic_launch_shape(const Geometry& g, int n_units, int n_cus);
+hipError_t launch_fused_generic(const Geometry& g, const void* d_image, const void* d_packed, int n_units, float* d_out, int n_cus,
+                                bool write_c, hipStream_t s);
+int generic_vgprs(const Geometry& g);
 
 int fused_vgprs(const Geometry& g);  // from hipFuncGetAttributes, for reports
 const char* fused_kernel_name(const Geometry& g, char* buf, size_t n);

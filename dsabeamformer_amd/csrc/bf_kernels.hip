@@ -378,11 +378,12 @@ __global__ void weight_relayout16_kernel(const int8_t* __restrict__ w, v4i* __re
 
 
 // ---- which instantiation a geometry runs ---------------------------------------------------------------------------------
-int ksteps16(const Geometry& g) { return g.n_ant > 64 ? 2 : 1; }
+int ksteps16(const Geometry& g) { return (g.n_ant + 63) / 64; }
 // MFMA column tiles per wave the beams are dealt to round-robin (beam_of_tile), 0 = tile t is beams 16 t ...: interleaved when every
 // wave owns whole groups of 16 * NS beams.  paired: the layout of the conjugate-pair image / kernel (NS / 2 pair tiles per wave).
 int interleaved(const Geometry& g, bool paired)
 {
+    if (use_generic(g)) return paired ? 0 : generic_interleave(g);
     const int ns = fused_col_tiles(g, paired);
     if (!DSABF_INTERLEAVE || g.n_beams % (16 * ns)) return 0;
     return paired ? ns / 2 : ns;
@@ -394,6 +395,7 @@ int detect_mode_of(const Geometry& g) { return g.fast_detect ? kDetFast : g.cont
 // other multiple of 4 up to 128 runs the run-time-count class of its k-step count and row alignment.
 FusedVariant select_variant(const Geometry& g, bool write_c)
 {
+    if (use_generic(g)) return FusedVariant{};
     if (!nipo_supported(g.n_ipo) || g.n_ant <= 0 || g.n_ant > 128 || g.n_ant % 4) return FusedVariant{};
     const bool paired = g.paired && !write_c;
     const int mode = detect_mode_of(g);
@@ -441,13 +443,23 @@ hipError_t dispatch_fused(const Geometry& g, bool write_c, const FusedArgs& args
 
 }  // namespace
 
+// fusedg_kernel takes what the specialised instantiations of fused16_kernel do not cover: more than two k-steps, accumulation
+// windows that are not a power of two (or longer than 64), short windows in gemm-units that are not whole 16-sample runs.
+bool use_generic(const Geometry& g)
+{
+    return g.force_generic || g.n_ant > 128 || !nipo_supported(g.n_ipo) || (g.n_ipo < 16 && g.n_time % 16);
+}
+
 size_t weight_image_bytes(const Geometry& g)
 {
     return (size_t)g.n_freq * g.n_ctiles * (DSABF_GEN3 ? 3 : 4) * ksteps16(g) * 64 * 16;  // [f][ct16][Wr, -Wi, Wi][k-step][lane] x 16 B
 }
 
 // the conjugate-pair kernel works on tiles of 16 base beams + their 16 mirror images
-bool pairing_supported(const Geometry& g) { return DSABF_PAIRED && g.n_beams % 32 == 0 && select_variant(g, false).launch != nullptr; }
+bool pairing_supported(const Geometry& g)
+{
+    return DSABF_PAIRED && !use_generic(g) && g.n_beams % 32 == 0 && select_variant(g, false).launch != nullptr;
+}
 size_t weight_pair_image_bytes(const Geometry& g)
 {
     return pairing_supported(g) ? (size_t)g.n_freq * (g.n_beams / 32) * 3 * ksteps16(g) * 64 * 16 : 0;
@@ -459,9 +471,7 @@ bool fused_supported(const Geometry& g, const char** why)
     if (!why) why = &dummy;
     if (g.n_beams <= 0 || g.n_beams % 4) { *why = "N_BEAMS must be a positive multiple of 4"; return false; }      // src/beamformer.hh:155
     if (g.n_ant <= 0 || g.n_ant % 4) { *why = "N_ANTENNAS must be a positive multiple of 4"; return false; }       // src/beamformer.hh:156
-    if (g.n_ant > 128) { *why = "more than 128 antennas (two k-steps of 64) are not implemented"; return false; }
-    if (!nipo_supported(g.n_ipo)) { *why = "n_pol * n_avg must be one of 2, 4, 8, 16, 32, 64"; return false; }
-    if (g.n_ipo < 16 && g.n_time % 16) { *why = "n_out_per_gemm * n_pol * n_avg must be a multiple of 16"; return false; }
+    if (use_generic(g)) return generic_supported(g, why);
     return true;
 }
 
@@ -480,6 +490,8 @@ void read_env_switches(Geometry& g)
     if (g.tsplit < 0) g.tsplit = 0;
     g.lds_pad = pad ? atoi(pad) : 0;       // (clamped to what the CU has left where it is applied, fused_launch_shape)
     g.dm_wide = !(dw && dw[0] == '0');
+    const char* gen = getenv("DSABF_GENERIC");
+    g.force_generic = gen && gen[0] == '1';
 }
 
 // Output slots (16 beams each) per wave.  The two-k-step conjugate-pair kernels hold 2 waves per SIMD whatever they do (64 KiB of
@@ -512,6 +524,7 @@ int fused_wg_waves(const Geometry& g, bool write_c)
 
 LaunchShape fused_launch_shape(const Geometry& g, int n_units, int n_cus, bool write_c)
 {
+    if (use_generic(g)) return generic_launch_shape(g, n_units, n_cus);
     LaunchShape ls{};
     const int wg_waves = fused_wg_waves(g, write_c);
     const int beams_per_wg = wg_waves * 16 * fused_col_tiles(g, g.paired && !write_c);
@@ -598,6 +611,7 @@ hipError_t launch_fused(const Geometry& g, const void* d_image, const void* d_pa
                         int n_units, float* d_out, int n_cus, hipStream_t s)
 {
     if (n_units <= 0) return hipSuccess;
+    if (use_generic(g)) return launch_fused_generic(g, d_image, d_packed, n_units, d_out, n_cus, false, s);
     if ((long long)n_units * g.n_time > 0x7fffffffLL / 2) return hipErrorInvalidValue;
     if (g.paired && !(pairing_supported(g) && d_pair_image)) return hipErrorInvalidValue;
     const LaunchShape ls = fused_launch_shape(g, n_units, n_cus);
@@ -610,6 +624,7 @@ hipError_t launch_gemm_only(const Geometry& g, const void* d_image, const void* 
 {
     Geometry gg = g;
     gg.paired = false;  // the stage-parity path always runs the general kernel on the general image
+    if (use_generic(gg)) return launch_fused_generic(gg, d_image, d_packed, 1, d_c, n_cus, true, s);
     const LaunchShape ls = fused_launch_shape(gg, 1, n_cus, true);
     const FusedArgs a = make_args(gg, d_image, d_packed, 1, d_c, ls);
     return dispatch_fused(gg, true, a, ls, s);
@@ -740,6 +755,11 @@ hipError_t launch_dedisperse_dm(const Geometry& g, const float* d_series, int n_
 
 const char* fused_kernel_name(const Geometry& g, char* buf, size_t n)
 {
+    if (use_generic(g)) {
+        snprintf(buf, n, "dsabf::fusedg_kernel<ANT=%d (%d k-steps, %d-byte staging),NIPO=%d%s> (v_mfma_i32_16x16x64_i8)", g.n_ant,
+                 generic_ksteps(g), g.n_ant % 16 ? 4 : 16, g.n_ipo, g.fast_detect ? ",FAST" : g.contracted_detect ? ",CONTRACTED" : "");
+        return buf;
+    }
     const bool rt = !(g.n_ant == 64 || g.n_ant == 100 || g.n_ant == 128);   // (the geometry's class; DSABF_RUNTIME_ANT is not shown)
     snprintf(buf, n, "dsabf::fused16_kernel<ANT=%d%s,NIPO=%d%s%s%s> (v_mfma_i32_16x16x64_i8)", g.n_ant, rt ? "(run-time)" : "",
              g.n_ipo, (g.fast_detect && g.n_ipo >= 16) ? ",FAST" : g.contracted_detect ? ",CONTRACTED" : "",
@@ -750,6 +770,7 @@ const char* fused_kernel_name(const Geometry& g, char* buf, size_t n)
 
 int fused_vgprs(const Geometry& g)
 {
+    if (use_generic(g)) return generic_vgprs(g);
     hipFuncAttributes attr{};
     const void* fn = select_variant(g, false).fn;
     if (!fn || hipFuncGetAttributes(&attr, fn) != hipSuccess) return -1;

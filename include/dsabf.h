@@ -44,10 +44,10 @@ extern "C" {
  * values (debug != 0: `make debug`, n_avg = 1; debug == 0: production, n_avg = 16). */
 typedef struct bf_config {
     int n_beams;           /* N_BEAMS            src/beamformer.hh:47   multiple of 4 (:155) */
-    int n_ant;             /* N_ANTENNAS         src/beamformer.hh:48   multiple of 4 (:156), at most 128 */
+    int n_ant;             /* N_ANTENNAS         src/beamformer.hh:48   multiple of 4 (:156), at most 2048 */
     int n_freq;            /* N_FREQUENCIES      src/beamformer.hh:49   frequencies owned by THIS handle/GPU */
     int n_pol;             /* N_POL              src/beamformer.hh:52 */
-    int n_avg;             /* N_AVERAGING        src/beamformer.hh:55-60  n_pol*n_avg in {2,4,8,16,32,64} */
+    int n_avg;             /* N_AVERAGING        src/beamformer.hh:55-60  any; n_pol*n_avg in {2,...,64} powers of 2: specialised kernels */
     int n_out_per_gemm;    /* N_OUTPUTS_PER_GEMM src/beamformer.hh:111 */
     int n_gemms_per_block; /* N_GEMMS_PER_BLOCK  src/beamformer.hh:114 */
     int n_blocks_on_gpu;   /* N_BLOCKS_ON_GPU    src/beamformer.hh:124 */

@@ -67,9 +67,20 @@ def test_error_convention_without_gpu(lib):
     assert lib.bf_create(C.byref(cfg), 0, C.byref(h)) == -1
     assert b"n_beams" in lib.bf_last_error() or b"N_BEAMS" in lib.bf_last_error()
     cfg.n_beams = 256
-    cfg.n_avg = 3  # n_ipo = 6: no kernel instantiation
+    cfg.n_ant = 2052  # the exactly convertible range of the int32 sums ends at 2048 antennas
     assert lib.bf_create(C.byref(cfg), 0, C.byref(h)) == -1
+    assert b"2048 antennas" in lib.bf_last_error()
     assert not h.value
+    cfg.n_ant, cfg.n_avg = 64, 3  # n_ipo = 6: since round 4 a supported geometry (fusedg_kernel) -> the refusal is the missing GPU
+    assert lib.bf_create(C.byref(cfg), 0, C.byref(h)) == -3
+    assert not h.value
+    # which kernel a geometry runs is host arithmetic (bf_launch_plan): the reference's whole contract has one
+    name = C.create_string_buffer(200)
+    for n_ant, n_avg, expect in ((64, 16, b"fused16_kernel"), (100, 16, b"fused16_kernel"), (64, 3, b"fusedg_kernel"),
+                                 (132, 16, b"fusedg_kernel<ANT=132 (3 k-steps, 4-byte staging)"), (256, 16, b"(4 k-steps, 16-byte staging)")):
+        cfg.n_ant, cfg.n_avg = n_ant, n_avg
+        assert lib.bf_launch_plan(C.byref(cfg), 0, 4, 256, None, None, None, name, 200) == 0
+        assert expect in name.value, name.value
     assert lib.bf_beamform_device(None, None, 1, None, None) == -1
     assert lib.bf_destroy(None) == 0
 
