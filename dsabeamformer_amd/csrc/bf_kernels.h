@@ -107,6 +107,8 @@ LaunchShape generic_launch_shape(const Geometry& g, int n_units, int n_cus);
 hipError_t launch_fused_generic(const Geometry& g, const void* d_image, const void* d_packed, int n_units, float* d_out, int n_cus,
                                 bool write_c, hipStream_t s);
 int generic_vgprs(const Geometry& g);
+size_t generic_image_extra_bytes(const Geometry& g);     // the offset-nibble corrections behind the fragment image
+hipError_t launch_generic_colsum(const Geometry& g, const int8_t* d_w, void* d_image, hipStream_t s);
 
 int fused_vgprs(const Geometry& g);  // from hipFuncGetAttributes, for reports
 const char* fused_kernel_name(const Geometry& g, char* buf, size_t n);

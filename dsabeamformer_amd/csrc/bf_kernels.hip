@@ -452,7 +452,8 @@ bool use_generic(const Geometry& g)
 
 size_t weight_image_bytes(const Geometry& g)
 {
-    return (size_t)g.n_freq * g.n_ctiles * (DSABF_GEN3 ? 3 : 4) * ksteps16(g) * 64 * 16;  // [f][ct16][Wr, -Wi, Wi][k-step][lane] x 16 B
+    return (size_t)g.n_freq * g.n_ctiles * (DSABF_GEN3 ? 3 : 4) * ksteps16(g) * 64 * 16 +   // [f][ct16][Wr, -Wi, Wi][k-step][lane] x 16 B
+           (use_generic(g) ? generic_image_extra_bytes(g) : 0);
 }
 
 // the conjugate-pair kernel works on tiles of 16 base beams + their 16 mirror images
@@ -638,9 +639,13 @@ hipError_t launch_weight_relayout(const Geometry& g, const int8_t* d_w, void* d_
                                   hipStream_t s)
 {
     clear_stale_error();
-    const size_t total = weight_image_bytes(g) / 16;
+    const size_t total = (weight_image_bytes(g) - (use_generic(g) ? generic_image_extra_bytes(g) : 0)) / 16;
     int grid = (int)((total + 255) / 256);
     if (grid > 4096) grid = 4096;
+    if (use_generic(g)) {
+        hipError_t e = launch_generic_colsum(g, d_w, d_image, s);
+        if (e != hipSuccess) return e;
+    }
     if (pairing_supported(g) && d_pair_image) {
         const size_t n_fa = (size_t)g.n_freq * g.n_ant;
         int pgrid = (int)((n_fa * (g.n_beams / 2) + 255) / 256);

@@ -56,6 +56,8 @@ run(128, 256, 256, 16, 16, 16, True, "128 ant, fusedg")
 # beyond two k-steps: only the generic kernel
 for n_ant in (132, 192, 256, 320, 512, 1024):
     run(n_ant, 256, 256, 16, 16, max(2, 2048 // n_ant), None, "%d antennas" % n_ant)
+for n_ant in (192, 256, 512):       # the same with launches of 1 GiB of voltages (the bench's step size)
+    run(n_ant, 256, 256, 16, 16, 8192 // n_ant, None, "%d antennas, 1 GiB launch" % n_ant)
 run(256, 512, 1024, 16, 8, 4, None, "256 ant, C5-like band")
 # accumulation windows that are not a power of two (64 antennas)
 for n_avg in (3, 5, 12, 20, 48):

@@ -1,0 +1,34 @@
+#!/bin/bash
+# usage (GPU box, repo root): tools/generic_pmc.sh <outdir-under-gpurun_out> n_ant n_avg units
+# separate rocprofv3 --pmc passes (never combined with trace domains) over tools/generic_one.py; summary.txt per counter
+R=$PWD; OUT=$R/gpurun_out/$1; shift
+mkdir -p $OUT; export TMPDIR=/tmp; cd /tmp
+i=0
+for C in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_VALU_MFMA_I8 SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY" \
+         "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_VALU_MFMA_COEXEC_CYCLES SQ_INSTS_LDS SQ_INSTS_SALU" \
+         "GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM" \
+         "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum" "SQ_INSTS_SMEM SQ_WAIT_INST_ANY SQ_ACTIVE_INST_MISC SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS"; do
+  i=$((i+1))
+  timeout 300 rocprofv3 --pmc $C --output-format csv -d $OUT/pass$i -- python3 $R/tools/generic_one.py "$@" > $OUT/pass$i.log 2>&1
+done
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/tools/generic_one.py "$@" > $OUT/stats.log 2>&1
+cd $R
+python3 - "$OUT" <<'PY'
+import csv, glob, sys, collections
+out = sys.argv[1]
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(out + "/pass*/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"]
+        if "fused" not in k: continue
+        agg[k.split("(")[0][-60:]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+with open(out + "/summary.txt", "w") as fp:
+    for k, d in agg.items():
+        fp.write(k + "\n")
+        for c, v in sorted(d.items()):
+            v = v[len(v)//3:] if len(v) > 3 else v
+            fp.write("  %-32s mean %.6g  (n=%d)\n" % (c, sum(v)/len(v), len(v)))
+    for f in glob.glob(out + "/stats/**/*kernel_stats.csv", recursive=True):
+        fp.write(open(f).read())
+print(open(out + "/summary.txt").read())
+PY
