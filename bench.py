@@ -861,13 +861,24 @@ def main():
             b2.close()
             alg = 4 * (n_t * 256 * 256 + len(dms) * n_t_out * 256)
             ms = rec["shared_window"]["ms_avg"]
+            # The bound: every output is a chain of n_freq fp32 adds, each with one 4-byte
+            # operand that cannot come from a register (the trial's row offset is run-time data) -- so the floors are the VALU add
+            # rate, 64 lanes per clock per CU (v_pk_add_f32 issues at half rate: the same 64), and the LDS operand rate, 256 B
+            # per clock per CU with ds_read_b128 = the same 64 operands.  HBM is NOT the bound (the series is read about once: the
+            # algorithmic bytes are reported as `traffic`-style figures beside it).
+            adds = float(len(dms)) * n_t_out * 256 * 256
+            peak_adds = 256 * 64 * 2.4e9 / 1e9           # G adds/s at the nominal clock the MFMA peak assumes
             rec.update({"workload": "%d DM trials (notebook ladder to DM 250) x %d output samples x 256 freq x 256 beams, series of %d "
                                     "beam-blocks" % (len(dms), n_t_out, n_t),
-                        "roofline": {"bound": "hbm", "achieved": alg / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                     "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                        "roofline": {"bound": "lds/valu", "achieved": adds / (ms * 1e-3) / 1e9, "peak": peak_adds, "unit": "Gadd/s",
+                                     "frac": adds / (ms * 1e-3) / 1e9 / peak_adds, "traffic": None,
+                                     "adds_per_launch": adds,
                                      "algorithmic_bytes_per_launch": alg,
+                                     "hbm_gbs_algorithmic": alg / (ms * 1e-3) / 1e9, "hbm_frac_algorithmic": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                      "kernel": "dsabf::dedisperse_dm_wide_kernel (+ dedisperse_dm_kernel for "
-                                               "trial groups whose delays do not fit a window)"},
+                                               "trial groups whose delays do not fit a window)",
+                                     "note": "peak = 256 CUs x 64 fp32 adds (= 64 LDS operands of 4 bytes) per clock x 2.4 GHz; one "
+                                             "add and one LDS operand per (trial, time, beam, channel)"},
                         "note": "not the headline; ascending-f fp32 sum per (trial, time, beam), bit-exact vs the oracle in both "
                                 "kernels; the delay law and the ladder are pinned by executing the reference's notebook "
                                 "(tests/golden/make_dispersion_golden.py)"})

@@ -91,6 +91,40 @@ def test_spills_stay_where_they_are_known(objects):
     assert worst <= 320, "a fused kernel now spills %d bytes per lane" % worst
 
 
+def test_generic_kernel_budget(objects):
+    """fusedg_kernel (every geometry outside the specialised classes): two 4-wave workgroups per CU = 2 waves per SIMD = 256
+    registers, no scratch in the detect instantiations (a scratch access is a vmcnt event in the middle of the MFMA stream),
+    128 MFMAs = two copies of the 64-MFMA plane (the B register sets swap roles), no conditional branch between the MFMAs of a
+    plane's tile loop that would hide loads from the s_waitcnt pass: no `s_waitcnt vmcnt(0)` in front of an MFMA."""
+    co, ks = objects["bf_fusedg"]
+    names = [n for n in ks if "fusedg_kernel" in n]
+    assert len(names) == 8
+    for n in names:
+        k = ks[n]
+        write_c = n.endswith("Lb1EEEvNS0_7GenArgsE")
+        assert k["vgpr_count"] + k["agpr_count"] <= 256, (n, k)
+        if not write_c:
+            assert k["private_segment_fixed_size"] == 0, (n, k)
+            ops = isa_report.disassembly(co, n)
+            assert isa_report.count(ops, "v_mfma_i32_16x16x64_i8") == 128
+            assert isa_report.count(ops, "v_pk_(add|mul|fma)_f32") == 0
+    # the wait in front of an MFMA group is for LDS data only (lgkmcnt); vmcnt(0) there means a load got under a branch again
+    import subprocess
+
+    txt = subprocess.check_output([os.path.join(isa_report.LLVM, "llvm-objdump"), "-d", "--no-show-raw-insn",
+                                   "--disassemble-symbols=" + [n for n in names if "Lb1ELi0ELb0E" in n][0], co], text=True)
+    lines = [l.strip() for l in txt.splitlines()]
+    bad = 0
+    for i, l in enumerate(lines):
+        if l.startswith("v_mfma") and not lines[i - 1].startswith("v_mfma"):
+            j = i - 1
+            while j > 0 and lines[j].startswith(("s_nop", "v_mov", "v_add", "s_add", "s_mov")):
+                j -= 1
+            if lines[j].startswith("s_waitcnt") and "vmcnt(0)" in lines[j]:
+                bad += 1
+    assert bad <= 2, "%d MFMA groups wait for vmcnt(0)" % bad     # (the first group of a plane may wait for its B fragments)
+
+
 def test_dm_kernels(objects):
     co, ks = objects["bf_dm_wide"]
     name = [n for n in ks if "dedisperse_dm_wide_kernel" in n][0]
