@@ -886,6 +886,28 @@ def main():
 
         if world == 1 and args.detect == "canonical" and args.workload in ("c3", "prod") and not args.no_extras:
             guarded("general_kernel", extras_variants)
+        def north_star_summary():
+            """north_star: '>= 50 % int8 MFMA utilisation' -- which kernel / detect reading meets it in THIS run, one line each:
+            algorithmic fraction of the nominal 5.0 POP/s from the records above (executed fraction = half for the pair kernel)."""
+            rows = {"pair_kernel_canonical (headline)": out["roofline"]["frac"] if paired else None}
+            for key, label in (("contracted_detect_mode", "pair_kernel_contracted" if paired else "general_kernel_contracted"),
+                               ("fast_detect_mode", "pair_kernel_fast" if paired else "general_kernel_fast"),
+                               ("general_kernel", "general_kernel_canonical"),
+                               ("contracted_detect_mode_general_kernel", "general_kernel_contracted"),
+                               ("calibrated_weights", "general_kernel_canonical_calibrated_weights"),
+                               ("calibrated_weights_contracted", "general_kernel_contracted_calibrated_weights")):
+                if isinstance(out.get(key), dict) and "frac" in out[key]:
+                    rows[label] = out[key]["frac"]
+            if not paired:
+                rows["general_kernel_canonical (headline)"] = out["roofline"]["frac"]
+            rows = {k: v for k, v in rows.items() if v is not None}
+            out["north_star_check"] = {"target": 0.50, "frac_by_reading": rows, "meets": sorted(k for k, v in rows.items() if v >= 0.50),
+                                       "misses": sorted(k for k, v in rows.items() if v < 0.50),
+                                       "note": "algorithmic int8 ops / kernel time / 5.0 POP/s, this run, this box (boxes differ by ~2.5 %); "
+                                               "canonical = the bit-exact reading of the CPU oracle (g++), contracted = nvcc's -fmad reading"}
+
+        if world == 1 and args.detect == "canonical" and args.workload in ("c3", "prod") and not args.no_extras:
+            guarded("north_star_check", north_star_summary)
         if world == 1 and args.workload == "c3" and not args.no_extras:
             guarded("debug_geometry", extras_geometries)
             guarded("streaming", extras_streaming)

@@ -21,6 +21,9 @@
 #ifndef DSABF_GEN3
 #define DSABF_GEN3 1      // general weight image holds 3 fragments per tile (Wr, -Wi, Wi) instead of 4 (Wr, -Wi, Wi, Wr again)
 #endif
+#ifndef DSABF_PIN
+#define DSABF_PIN 0       // experiment (round 4, profiles/r04_ab_pin.txt): pin the issue order of a row tile's MFMAs and VALU ops with
+#endif                    // sched_group_barrier: 1 = 1 MFMA : 7 VALU, 2 = 4 : 26, 3 = 8 : 53, 4 = 2 : 13.  0 = the scheduler's own order
 #ifndef DSABF_OCC16
 #define DSABF_OCC16 3     // default register budget of the one-k-step variants (168 VGPRs: 3 waves per SIMD); fused_min_waves()
                           // raises it to 4 where 128 registers suffice
@@ -600,6 +603,18 @@ __global__ __launch_bounds__(64 * WAVES, (fused_min_waves<AIN, NIPO, WRITE_C, NS
                 }
                 store_short(t8);
                 staging(t8);
+#if DSABF_PIN
+                {   // one row tile = NT * (PAIRED ? 4 : 4 * KS ...) MFMAs and ~100 VALU ops: lay them out in fixed groups
+                    constexpr int M = DSABF_PIN == 1 ? 1 : DSABF_PIN == 2 ? 4 : DSABF_PIN == 3 ? 8 : 2;
+                    constexpr int V = DSABF_PIN == 1 ? 7 : DSABF_PIN == 2 ? 26 : DSABF_PIN == 3 ? 53 : 13;
+                    constexpr int NM = NT * 4 * KS;
+#pragma unroll
+                    for (int i = 0; i < NM / M; i++) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, M, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, V, 0);
+                    }
+                }
+#endif
             }
         }
         __syncthreads();
