@@ -29,9 +29,18 @@ REF = "/root/reference/sandbox/Dispersion Theory.ipynb"
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
+# The notebook is untrusted upstream content and its cells are exec()'d below: it is pinned by content.  A notebook that differs
+# from the one this script was written against (and reviewed: cells 1, 2 and 5 only compute numpy arrays) is refused.
+REF_SHA256 = "bfff3221ead7c8b6cfae71cedbeb475fb8c886286611997ae0d9d59fe2fe32fc"
+
+
 def cell_source(idx):
-    with open(REF) as fp:
-        nb = json.load(fp)
+    import hashlib
+
+    raw = open(REF, "rb").read()
+    if hashlib.sha256(raw).hexdigest() != REF_SHA256:
+        raise SystemExit("refusing to execute %s: its SHA-256 is not the reviewed notebook's" % REF)
+    nb = json.loads(raw.decode("utf-8"))
     cell = nb["cells"][idx]
     assert cell["cell_type"] == "code"
     return "\n".join(l for l in "".join(cell["source"]).splitlines() if not l.lstrip().startswith("%")) + "\n"   # 1

@@ -55,9 +55,19 @@ REF = "/root/reference/sandbox"
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
+# The notebooks are untrusted upstream content and their cells are exec()'d below: they are pinned by content.  A notebook
+# that differs from the one this script was written against (and reviewed) is refused.
+REF_SHA256 = {"2D Beamformer.ipynb": "5a79592292d440d2737169a7450c22e2028f0c49fb9080e87b2f0834328ebbbb",
+              "Beamformer Theory.ipynb": "e5c2cc651bed3fd472c61447793f51edaabe3396d67f3aeed6377d8dd1621f57"}
+
+
 def cell_source(nb_name, idx):
-    with open(os.path.join(REF, nb_name)) as fp:
-        nb = json.load(fp)
+    import hashlib
+
+    raw = open(os.path.join(REF, nb_name), "rb").read()
+    if hashlib.sha256(raw).hexdigest() != REF_SHA256.get(nb_name):
+        raise SystemExit("refusing to execute %s: its SHA-256 is not the reviewed notebook's" % nb_name)
+    nb = json.loads(raw.decode("utf-8"))
     cell = nb["cells"][idx]
     assert cell["cell_type"] == "code", (nb_name, idx)
     return "".join(cell["source"])
