@@ -11,14 +11,15 @@
 // Here
 //   * a row is fetched from global memory ONCE per workgroup and serves all 32 trials of the tile (reuse 32 x 16 /
 //     (16 + spread) instead of 4 x 16 / 24): the vector-memory path drops out of the picture;
-//   * a wave owns TWO trials, one per half-wave, x 4 beams per lane: one ds_read_b128 (256 B/clk/CU, against 128 for the
-//     b32 reads of the per-thread-window kernel) fetches row d_A + i for lanes 0-31 and row d_B + i for lanes 32-63 -- the
-//     trial's offset into the window is just part of the lane's LDS address, so there is no dynamic register index and no
-//     specialised code: 16 reads + 64 adds per channel and wave;
-//   * what binds is the LDS read rate: 16 waves x 16 reads x 4 cycles = 1024 cycles per channel and tile, twice the VALU
-//     time of the adds (4 waves per SIMD x 64 x 2 cycles).  (Letting the two trials of a pair SHARE the rows they have in
-//     common -- 16 + delta reads for both -- would halve that, but needs one unrolled body per delta; the compiler merges
-//     the bodies' common parts back together and spills: profiles/r03_variants_log.txt.)
+//   * a wave owns TWO neighbouring trials with all its lanes x 2 beams per lane, and the two SHARE the rows they have in
+//     common (round 4): the wave reads rows d_A .. d_A + 18 of the window once (19 ds_read_b64, whatever the trials' distance)
+//     and trial B adds r[i + delta], delta = d_B - d_A in 0 ... 3 on any fine ladder -- wave-uniform, so a scalar branch over
+//     four straight-line blocks with static register indices (round 3 gave each trial a half-wave and its own 16 reads; one
+//     body per delta with delta-dependent READS made the compiler merge the bodies and spill -- here no memory operation
+//     depends on delta);
+//   * bounds: one fp32 add and one 4-byte LDS operand per (trial, time, beam, channel).  The adds: 64 lanes per clock and CU
+//     (v_pk_add_f32 issues at half rate: the same) = 1024 cycles per channel and tile; the operands: round 3 1024 cycles at
+//     256 B/clk/CU, now 19/32 of that.
 // The sum of one (trial, time, beam) still runs over ascending f in ONE register, one add per channel: the same bits as
 // dedisperse_dm_kernel and as the oracle (orc_dedisperse_dm).
 //
@@ -31,6 +32,9 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <type_traits>
+
+#include "bf_dm_wide_body.inc"   // the per-channel bodies as inline-asm text (tools/gen_dm_body.py)
 
 namespace dsabf {
 
@@ -57,6 +61,7 @@ constexpr int kDwMaxRows = 4 * kDwRowsPerDma * kDwWaves < 224 ? 4 * kDwRowsPerDm
 #define DSABF_DW_BATCH 4
 #endif
 constexpr int kDwBatch = DSABF_DW_BATCH;   // LDS reads per register set (x 4 registers); two sets alternate
+constexpr int kDwSlackRows = 4;      // rows a wave may read past its window (never used: see the adds)
 constexpr int kDwNbuf = 3;           // window buffers in LDS: channel f is consumed while f + 1 and f + 2 are landing
 constexpr int kDwPairsPerWave = (kDwMaxRows / kDwRowsPerDma + kDwWaves - 1) / kDwWaves;   // LDS-DMA instructions a wave issues per window at most
 constexpr int kDwLdsBytes = 160 * 1024 / (16 / kDwWaves) - 1024;   // the CU's LDS over the workgroups its 16 wave slots hold,
@@ -66,7 +71,8 @@ constexpr int kDwLdsBytes = 160 * 1024 / (16 / kDwWaves) - 1024;   // the CU's L
 __host__ __device__ inline int dw_table_bytes(int n_freq) { return (n_freq * (kDwTrials + 8) + 511) & ~511; }
 __host__ __device__ inline int dw_rows_cap(int n_freq)
 {
-    const int r = ((kDwLdsBytes - dw_table_bytes(n_freq)) / (kDwNbuf * kDwRowBytes)) & ~(kDwRowsPerDma - 1);   // whole DMAs
+    // (4 rows of slack behind the last buffer: a wave reads up to 20 rows from its first trial's offset, see the adds)
+    const int r = ((kDwLdsBytes - dw_table_bytes(n_freq) - kDwSlackRows * kDwRowBytes) / (kDwNbuf * kDwRowBytes)) & ~(kDwRowsPerDma - 1);   // whole DMAs
     return r > kDwMaxRows ? kDwMaxRows : r;
 }
 
@@ -202,65 +208,59 @@ __global__ __launch_bounds__(kDwThreads) void dedisperse_dm_wide_kernel(const fl
         asm volatile("" ::: "memory");
     };
 
-    // ---- the adds: half-wave h of wave w owns trial 2 w + h, 4 beams per lane, 16 output times -----------------------------
-    const int k_mine = 2 * wave + (lane >> 5);
-    const unsigned char* my_offs = offs + k_mine * n_freq;
-    const int bq = bg * kDwBeams + kDwBpl * (lane & 31);  // this lane's beams in the adds (n_beams % 4 == 0 ...: all live or none
-    const int lane_col = (lane & 31) * 4 * kDwBpl;        //  -- for 2 per lane because bq is even and n_beams a multiple of 4)
-    vbf acc[kDwTb];   // (vector adds = v_pk_add_f32: measured 5 % FASTER here than scalar v_add_f32, profiles/r03_variants_log.txt)
+    // ---- the adds: wave w owns trials 2 w and 2 w + 1 with ALL its lanes (2 beams per lane), 16 output times --------------------
+    // Round 4.  The two trials of a wave need rows d_A .. d_A + 15 and d_B .. d_B + 15 of the channel's window, and on any fine
+    // DM ladder d_B - d_A = delta is 0 ... 3: the wave reads rows d_A .. d_A + 15 (+ 4 more if delta > 0) ONCE and trial B adds
+    // row i + delta out of the same registers -- delta is wave-uniform, so that is a scalar branch over four straight-line
+    // bodies with static register indices in each.  LDS reads per add fall from 1 to 0.5 - 0.63 (round 3: one half-wave per trial, 16 ds_read_b128 per channel and wave: the LDS read rate and the VALU
+    // rate were both AT their floor of 1024 cycles per channel and tile and did not overlap: 0.25 ms).  A pair further apart
+    // (coarse ladders that still fit a window) re-reads 16 rows for trial B.
+    constexpr int kAddBpl = 2;                            // beams per lane in the adds
+    typedef float v2a __attribute__((ext_vector_type(2)));
+    const int kA = 2 * wave, kB = 2 * wave + 1;
+    const unsigned char* offsA = offs + kA * n_freq;
+    const unsigned char* offsB = offs + kB * n_freq;
+    const int bq = bg * kDwBeams + kAddBpl * lane;        // this lane's beams (n_beams % 4 == 0 and bq even: both live or none)
+    const int lane_col = lane * 4 * kAddBpl;
+    // The accumulators -- [trial A | B][time i]{beam, beam + 1} = elements 2 i, 2 i + 1 -- and the two row batches are pinned to
+    // the registers the asm bodies name (bf_dm_wide_body.inc): physical-register operands of ONE asm statement per channel.
+    typedef float v8a __attribute__((ext_vector_type(8)));
+    typedef float v32a __attribute__((ext_vector_type(32)));
+    v32a accA, accB;
 #pragma unroll
-    for (int i = 0; i < kDwTb; i++) acc[i] = vbf{};
+    for (int i = 0; i < 32; i++) accA[i] = accB[i] = 0.0f;
+    static_assert(kDwTb == 16, "the shared-row bodies (tools/gen_dm_body.py) are written for 16 output times");
+    static_assert(DW_ASM_BASE == 40, "the operand constraints below name the registers of tools/gen_dm_body.py");
 
     dma_window(0, 0, tab[0]);
     if (n_freq > 1) dma_window(1, 1 % kDwNbuf, tab[1]);
-    int off = my_offs[0];
+    int oA = offsA[0], oB = offsB[0];
     v2i tnext = tab[min(2, n_freq - 1)];                  // the window the first iteration will fetch
     wait_dma_but(0);
     block_barrier();
-    static_assert(kDwTb % (2 * kDwBatch) == 0, "batches of reads alternate over two register sets");
     int slot = 0, slot2 = 2 % kDwNbuf;                    // ring positions of channel f and of channel f + 2
     for (int f = 0; f < n_freq; f++) {
-        const char* p = win + slot * win_bytes + off * kDwRowBytes + lane_col;
-        vbf ra[kDwBatch], rb[kDwBatch];
-        auto rd = [&](vbf (&r)[kDwBatch], int h) {
-#pragma unroll
-            for (int i = 0; i < kDwBatch; i++) lds_row(r[i], p + (h + i) * kDwRowBytes);
-        };
-        // `pin` fixes the order of the batches -- left alone the scheduler issues all 16 reads first (64 registers), spills,
-        // and the spill reloads drain the DMA queue (vmcnt(0)).
-        auto add_pin = [&](const vbf (&r)[kDwBatch], int h) {
-#pragma unroll
-            for (int i = 0; i < kDwBatch; i++) acc[h + i] = acc[h + i] + r[i];
-#pragma unroll
-            for (int i = 0; i < kDwBatch; i++) asm volatile("" : "+v"(acc[h + i]) : : "memory");
-        };
-        // The 16 waves leave the barrier together, so whatever a wave does before its first LDS data arrives is dead time for
-        // the whole CU: the bookkeeping reads (next offset, the window after next: the compiler's own, so they come FIRST and
-        // every LDS operation after them is one of the explicit row reads dw_wait counts) and the data reads go out at once,
-        // and the DMA of window f + 2 -- address arithmetic on values fetched one iteration ago -- is issued in their shadow.
-        // Two register sets of kDwBatch rows then take turns.
-        const int off_next = my_offs[min(f + 1, n_freq - 1)];
+        // bookkeeping reads first (the compiler's own LDS operations: everything after them is one of the bodies' row reads;
+        // LDS returns in order, so the bodies' counted waits also cover whatever of these is still in flight)
+        const int oA_next = offsA[min(f + 1, n_freq - 1)], oB_next = offsB[min(f + 1, n_freq - 1)];
         const v2i tafter = tab[min(f + 3, n_freq - 1)];
-        asm volatile("" ::: "memory");
-        rd(ra, 0);
-        rd(rb, kDwBatch);
-        // ring slot of f + 2 was last read in iteration f - 1: every wave is past that iteration's barrier
+        const int uA = __builtin_amdgcn_readfirstlane(oA), uB = __builtin_amdgcn_readfirstlane(oB);
+        const int delta = uB - uA;                        // wave-uniform
+        const unsigned pa = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)(win + slot * win_bytes + uA * kDwRowBytes + lane_col);
+        const unsigned pb = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)(win + slot * win_bytes + uB * kDwRowBytes + lane_col);
+        // rows 0 .. 7 of trial A's window are requested at once ...
+        v8a ra, rb;
+        asm volatile(DW_BODY_HEAD : "={v[104:111]}"(ra), "={v[112:119]}"(rb) : [pa] "v"(pa) : "memory");
+        // ... and the DMA of window f + 2 is issued in their shadow (ring slot of f + 2 was last read in iteration f - 1: every
+        // wave is past that iteration's barrier)
         const int newest = f + 2 < n_freq ? pairs_of(tnext) : 0;
         if (f + 2 < n_freq) dma_window(f + 2, slot2, tnext);
-#pragma unroll
-        for (int h = 0; h < kDwTb; h += 2 * kDwBatch) {
-            dw_wait<kDwBatch>(ra);                        // rb's reads may still be in flight
-            add_pin(ra, h);
-            if (h + 2 * kDwBatch < kDwTb) {
-                rd(ra, h + 2 * kDwBatch);
-                dw_wait<kDwBatch>(rb);
-            } else {
-                dw_wait<0>(rb);
-            }
-            add_pin(rb, h + kDwBatch);
-            if (h + 3 * kDwBatch < kDwTb) rd(rb, h + 3 * kDwBatch);
-        }
-        off = off_next;
+        asm volatile(DW_BODY_ALL
+                     : "+{v[40:71]}"(accA), "+{v[72:103]}"(accB), "+{v[104:111]}"(ra), "+{v[112:119]}"(rb)
+                     : [pa] "v"(pa), [pb] "v"(pb), [d] "s"(delta)
+                     : "memory", "scc");
+        oA = oA_next;
+        oB = oB_next;
         tnext = tafter;
         slot = slot + 1 == kDwNbuf ? 0 : slot + 1;
         slot2 = slot2 + 1 == kDwNbuf ? 0 : slot2 + 1;
@@ -268,11 +268,16 @@ __global__ __launch_bounds__(kDwThreads) void dedisperse_dm_wide_kernel(const fl
         block_barrier();                                  // ... and so have everybody else's
     }
 
-    if (bq >= n_beams || k_mine >= nk) return;
-    float* o = out + ((size_t)(dm0 + k_mine) * n_t_out + t0) * n_beams + bq;
+    if (bq >= n_beams) return;
 #pragma unroll
-    for (int i = 0; i < kDwTb; i++)
-        if (t0 + i < n_t_out) *reinterpret_cast<vbf*>(o + (size_t)i * n_beams) = acc[i];
+    for (int tr = 0; tr < 2; tr++) {
+        const int k_mine = tr ? kB : kA;
+        if (k_mine >= nk) continue;
+        float* o = out + ((size_t)(dm0 + k_mine) * n_t_out + t0) * n_beams + bq;
+#pragma unroll
+        for (int i = 0; i < kDwTb; i++)
+            if (t0 + i < n_t_out) *reinterpret_cast<v2a*>(o + (size_t)i * n_beams) = tr ? v2a{accB[2 * i], accB[2 * i + 1]} : v2a{accA[2 * i], accA[2 * i + 1]};
+    }
 }
 
 }  // namespace
@@ -292,7 +297,7 @@ hipError_t launch_dedisperse_dm_wide(const Geometry& g, const float* d_series, i
     (void)hipGetLastError();
     const size_t tiles = (size_t)n_g * (size_t)((n_t_out + kDwTb - 1) / kDwTb) * (size_t)((g.n_beams + kDwBeams - 1) / kDwBeams);
     if (tiles > (size_t)1 << 30) return hipErrorInvalidValue;
-    const int lds = dw_table_bytes(g.n_freq) + kDwNbuf * rows_cap * kDwRowBytes;
+    const int lds = dw_table_bytes(g.n_freq) + kDwNbuf * rows_cap * kDwRowBytes + kDwSlackRows * kDwRowBytes;
     const float* zero_row = reinterpret_cast<const float*>(d_flags + kDwMaxGroups);   // 512 B of zeros behind the flags
     static std::atomic<unsigned> done_mask{0};
     int dev = 0;
