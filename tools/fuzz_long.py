@@ -3,7 +3,8 @@
 128, any n_beams % 4, n_ipo 2..64), random launch shapes, conjugate-pair or general weights, canonical or contracted
 detect, through bf_beamform_device, each compared bit for bit with the CPU oracle in the same reading.  Not part of the
 test suite (the suite runs seeded subsets).  Round 1: 3 seeds x 150 cases on the then whitelist, 0 mismatches.
-usage: SEED=1 CASES=150 [FUZZ_WIDE=1] python tools/fuzz_long.py"""
+Round 4: FUZZ_GENERIC=1 draws antenna counts up to 636 and accumulation windows 1 ... 138 (fusedg_kernel).
+usage: SEED=1 CASES=150 [FUZZ_WIDE=1 | FUZZ_GENERIC=1] python tools/fuzz_long.py"""
 import os
 import sys
 
@@ -24,6 +25,14 @@ for case in range(N):
     n_ipo = 2 * n_avg
     n_out = int(rng.integers(1, 7)) * max(1, 16 // n_ipo)
     n_beams = 32 * int(rng.integers(1, 13)) if rng.integers(2) else 4 * int(rng.integers(1, 100))
+    n_pol = 2
+    if os.environ.get("FUZZ_GENERIC") == "1":   # round 4: the geometries fusedg_kernel takes -- any antenna count, any window
+        n_ant = 4 * int(rng.integers(33, 160)) if rng.integers(3) else 4 * int(rng.integers(1, 33))
+        n_pol = int(rng.choice([1, 2, 2, 2]))
+        n_avg = int(rng.integers(1, 70)) if rng.integers(2) else int(rng.choice([3, 5, 6, 7, 12, 20, 24, 48]))
+        n_ipo = n_pol * n_avg
+        n_out = int(rng.integers(1, 9))
+        n_beams = 32 * int(rng.integers(1, 13)) if rng.integers(2) else 4 * int(rng.integers(1, 100))
     if os.environ.get("FUZZ_WIDE") == "1":   # bias towards the 8-wave workgroups of the two-k-step classes (fused_wg_waves)
         n_ant = int(rng.choice([100, 128])) if rng.integers(3) == 0 else 4 * int(rng.integers(17, 33))
         n_avg = int(rng.choice([8, 16, 32]))
@@ -32,7 +41,8 @@ for case in range(N):
         n_beams = 32 * int(rng.integers(9, 36)) if rng.integers(2) else 4 * int(rng.integers(65, 280))
         if rng.integers(3) == 0:
             n_beams = 512 * int(rng.integers(1, 3))
-    g = orc.Geom(n_beams=n_beams, n_ant=n_ant, n_freq=int(rng.integers(1, 18 if n_beams <= 400 else 6)), n_avg=n_avg, n_out_per_gemm=n_out)
+    g = orc.Geom(n_beams=n_beams, n_ant=n_ant, n_freq=int(rng.integers(1, 18 if n_beams <= 400 and n_ant <= 128 else 6)), n_pol=n_pol, n_avg=n_avg,
+                 n_out_per_gemm=n_out)
     n_units = int(rng.integers(1, 1 + max(1, 900 // g.n_time)))
     w = rng.integers(-127, 128, size=(g.n_freq, g.n_ant, g.n_beams, 2), dtype=np.int8)
     paired = bool(rng.integers(2)) and n_beams % 32 == 0
@@ -43,13 +53,15 @@ for case in range(N):
     mode = int(rng.choice([0, 2]))
     packed = rng.integers(0, 256, size=(n_units, g.n_freq, g.n_time, g.n_ant), dtype=np.uint8)
     os.environ["DSABF_TSPLIT"] = str(int(rng.integers(1, 5)))
-    bf = bfm.Beamformer(bfm.debug_config(n_beams=g.n_beams, n_ant=g.n_ant, n_freq=g.n_freq, n_avg=g.n_avg,
+    bf = bfm.Beamformer(bfm.debug_config(n_beams=g.n_beams, n_ant=g.n_ant, n_freq=g.n_freq, n_pol=g.n_pol, n_avg=g.n_avg,
                                           n_out_per_gemm=g.n_out_per_gemm, detect_mode=mode))
     bf.set_weights(w)
     info = bf.kernel_info(n_units)
     name = info["kernel"]
-    assert ("PAIRED" in name) == paired, (name, paired)
-    key = ("rt" if "(run-time)" in name else str(n_ant), n_ipo, paired, mode, "slots8" if "SLOTS=8" in name else "waves8" if "WAVES=8" in name else "plain")
+    generic = "fusedg_kernel" in name
+    assert generic or ("PAIRED" in name) == paired, (name, paired)
+    key = ("generic" if generic else "rt" if "(run-time)" in name else str(n_ant), n_ipo, paired, mode,
+           "generic" if generic else "slots8" if "SLOTS=8" in name else "waves8" if "WAVES=8" in name else "plain")
     classes[key] = classes.get(key, 0) + 1
     d_in = torch.from_numpy(packed).cuda()
     with orc.detect_contract(orc.CONTRACT_NVCC if mode == 2 else orc.CONTRACT_NONE):
@@ -64,4 +76,5 @@ for case in range(N):
     bf.close()
 print("seed", os.environ.get("SEED", "1"), "cases", N, "mismatches", bad, "distinct (antenna class, n_ipo, paired, mode, launch) combinations", len(classes),
       "cases on 8-wave workgroups", sum(v for k, v in classes.items() if k[4] == "waves8"),
-      "on 8 slots per wave", sum(v for k, v in classes.items() if k[4] == "slots8"))
+      "on 8 slots per wave", sum(v for k, v in classes.items() if k[4] == "slots8"),
+      "on fusedg_kernel", sum(v for k, v in classes.items() if k[4] == "generic"))
