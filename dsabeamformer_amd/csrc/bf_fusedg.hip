@@ -41,7 +41,10 @@ namespace {
 #ifndef DSABF_G_ABL
 #define DSABF_G_ABL 0   // timing-only ablations (results invalid): 1 no detect, 2 no staging writes, 4 B fragments loaded once, 8 no barrier
 #endif
-constexpr int kGWaves = 4;                 // waves per workgroup: TWO workgroups are resident per CU (204-235 registers), unsynchronised --
+#ifndef DSABF_G_WAVES
+#define DSABF_G_WAVES 4
+#endif
+constexpr int kGWaves = DSABF_G_WAVES;                 // waves per workgroup: TWO workgroups are resident per CU (204-235 registers), unsynchronised --
                                            // one's barriers, B-fragment waits and detect phases overlap the other's MFMAs
 constexpr int kGThreads = 64 * kGWaves;
 constexpr int kGNT = 2;                    // 16-beam column tiles per wave: 4 waves x 32 beams = 128 beams per workgroup
@@ -280,7 +283,8 @@ __global__ __launch_bounds__(kGThreads, 2) void fusedg_kernel(GenArgs a)
                 // is requested into the registers just emptied
                 if (!(DSABF_G_ABL & 2)) {
                     if (t8 == 1) write_piece(nxt, stage, 0);
-                    if (t8 == 2) write_piece(nxt, stage, 1);
+                    if constexpr (PPT > 1)
+                        if (t8 == 2) write_piece(nxt, stage, 1);
                 }
                 if (t8 == 3) load_plane(stage);     // plane p + 2
                 __builtin_amdgcn_sched_barrier(0);
