@@ -22,13 +22,13 @@ def test_defaults_are_the_contract(monkeypatch):
 
 
 def test_committed_pmc_summaries_give_the_quoted_traffic_and_mfma_busy():
-    """roofline.traffic / mfma_busy_frac come from profiles/r03_*_pmc_summary.txt: the files must parse, and the derived
+    """roofline.traffic / mfma_busy_frac come from profiles/r04_*_pmc_summary.txt: the files must parse, and the derived
     numbers must be what DESIGN.md section 4 quotes (traffic within 1 % of the algorithmic bytes for C3 and C2)."""
-    c3 = bench.pmc_summary("r03_c3_paired_pmc_summary.txt")
-    gen = bench.pmc_summary("r03_c3_general_pmc_summary.txt")
-    c5 = bench.pmc_summary("r03_c5_pmc_summary.txt")
-    c5g = bench.pmc_summary("r03_c5_general_pmc_summary.txt")
-    c2 = bench.pmc_summary("r03_c2_pmc_summary.txt")
+    c3 = bench.pmc_summary("r04_c3_paired_pmc_summary.txt")
+    gen = bench.pmc_summary("r04_c3_general_pmc_summary.txt")
+    c5 = bench.pmc_summary("r04_c5_pmc_summary.txt")
+    c5g = bench.pmc_summary("r04_c5_general_pmc_summary.txt")
+    c2 = bench.pmc_summary("r04_c2_pmc_summary.txt")
     assert c3 and gen and c5 and c5g and c2
     # the general kernel of the 100-antenna geometry keeps the matrix pipe busy more than half the time (22 % of that on the
     # zero weights behind antenna 99); round 3: 3-fragment image, 8-wave workgroups, iterative-maxocc scheduling: 58 -> 63 %
@@ -116,9 +116,9 @@ def test_committed_bench_lines_agree_with_the_committed_rocprof_kernel_stats():
     for rocprof, a profiled one: 5 %; 8 % for the 50-us launches of C2), and roofline.frac must follow from it."""
     import csv
 
-    for wl, stats, units_blocks in (("c3", "r03_c3_paired_kernel_stats.csv", 2048), ("c5", "r03_c5_kernel_stats.csv", 128),
-                                    ("c2", "r03_c2_kernel_stats.csv", 1024)):
-        line = [l for l in open(os.path.join(ROOT, "profiles", "r03_%s_bench.json" % wl)) if l.startswith("{")][-1]
+    for wl, stats, units_blocks in (("c3", "r04_c3_paired_kernel_stats.csv", 2048), ("c5", "r04_c5_kernel_stats.csv", 128),
+                                    ("c2", "r04_c2_kernel_stats.csv", 1024)):
+        line = [l for l in open(os.path.join(ROOT, "profiles", "r04_%s_bench.json" % wl)) if l.startswith("{")][-1]
         d = json.loads(line)
         roof = d["roofline"]
         rows = [r for r in csv.DictReader(open(os.path.join(ROOT, "profiles", stats))) if "fused16_kernel" in r["Name"]]

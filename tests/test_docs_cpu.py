@@ -6,7 +6,8 @@ import re
 
 from conftest import ROOT
 
-DOCS = ["DESIGN.md", "README.md", "INTEGRATION.md", os.path.join("tools", "README.md"), os.path.join("oracle", "README.md")]
+DOCS = ["DESIGN.md", "README.md", "INTEGRATION.md", os.path.join("tools", "README.md"), os.path.join("oracle", "README.md"),
+        os.path.join("docs", "LOG_r04.md")]
 PREFIXES = ("profiles/", "tools/", "tests/", "include/", "examples/", "oracle/", "dsabeamformer_amd/", "csrc/")
 
 
@@ -48,3 +49,16 @@ def test_every_cited_file_exists():
                 if not ok:
                     missing.append((doc, quoted))
     assert not missing, missing
+
+
+def test_design_md_stays_readable():
+    """DESIGN.md is the design (<= 300 lines, no table cell of kilobytes); the per-round narratives live
+    in docs/LOG_r0N.md."""
+    lines = open(os.path.join(ROOT, "DESIGN.md")).read().splitlines()
+    assert len(lines) <= 300, len(lines)
+    for l in lines:
+        if l.startswith("|"):
+            for cell in l.strip("|").split("|"):
+                assert len(cell) <= 420, cell[:80]
+    for n in (1, 2, 3, 4):
+        assert os.path.exists(os.path.join(ROOT, "docs", "LOG_r0%d.md" % n))

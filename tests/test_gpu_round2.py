@@ -217,11 +217,15 @@ def test_geometry_fuzz_over_the_whole_contract(torch, bfmod, orc):
 def test_geometry_refusals_name_the_reference_rule(bfmod):
     from dsabeamformer_amd._lib import DsabfError
 
-    for kw, text in ((dict(n_beams=250), "N_BEAMS"), (dict(n_ant=66), "N_ANTENNAS"), (dict(n_ant=132), "128"),
-                     (dict(n_avg=3), "n_pol * n_avg")):
+    for kw, text in ((dict(n_beams=250), "N_BEAMS"), (dict(n_ant=66), "N_ANTENNAS"), (dict(n_ant=2052), "2048 antennas")):
         with pytest.raises(DsabfError) as e:
             bfmod.Beamformer(bfmod.debug_config(**kw))
         assert text in str(e.value), (kw, str(e.value))
+    # round 4: what rounds 1-3 refused inside the reference's contract now has a kernel (csrc/bf_fusedg.hip)
+    for kw in (dict(n_ant=132), dict(n_avg=3), dict(n_avg=1, n_out_per_gemm=3)):
+        bf = bfmod.Beamformer(bfmod.debug_config(n_freq=2, n_beams=32, **kw))
+        assert "fusedg_kernel" in bf.kernel_info(1)["kernel"]
+        bf.close()
 
 
 # ---- block-granular launches -----------------------------------------------------------------------------------------------
