@@ -57,10 +57,6 @@ constexpr int kDwRowBytes = kDwBeams * 4;
 constexpr int kDwRowsPerDma = 1024 / kDwRowBytes;   // window rows one LDS-DMA instruction moves (16 B per lane, 1 KiB): 2 or 4
 typedef float vbf __attribute__((ext_vector_type(kDwBpl)));   // a lane's beams
 constexpr int kDwMaxRows = 4 * kDwRowsPerDma * kDwWaves < 224 ? 4 * kDwRowsPerDma * kDwWaves : 224;   // rows per window buffer at most (byte offsets; <= 4 DMAs per wave)
-#ifndef DSABF_DW_BATCH
-#define DSABF_DW_BATCH 4
-#endif
-constexpr int kDwBatch = DSABF_DW_BATCH;   // LDS reads per register set (x 4 registers); two sets alternate
 constexpr int kDwSlackRows = 4;      // rows a wave may read past its window (never used: see the adds)
 constexpr int kDwNbuf = 3;           // window buffers in LDS: channel f is consumed while f + 1 and f + 2 are landing
 constexpr int kDwPairsPerWave = (kDwMaxRows / kDwRowsPerDma + kDwWaves - 1) / kDwWaves;   // LDS-DMA instructions a wave issues per window at most

@@ -46,12 +46,16 @@ constexpr int kAntK1P16 = -1;  // <= 64 antennas, n_ant % 16 == 0: one k-step, 1
 constexpr int kAntK1P4 = -2;   // <= 64 antennas, n_ant % 4 == 0:  one k-step, 4-byte staging pieces
 constexpr int kAntK2P16 = -3;  // 65..128 antennas, n_ant % 16 == 0: two k-steps
 constexpr int kAntK2P4 = -4;   // 65..128 antennas, n_ant % 4 == 0
+constexpr int kAntK4P16 = -5;  // 193..256 antennas, n_ant % 16 == 0: four k-steps (the "deep" classes, round 4)
+constexpr int kAntK3P16 = -6;  // 129..192 antennas, n_ant % 16 == 0: three k-steps
 
 constexpr unsigned kMagicBits = 0x4B400000u;        // float 12582912 = 1.5 * 2^23
 constexpr float kMagic = 12582912.0f;
 constexpr float kAlpha = (float)(1.0 / 127.0);      // h_inv_max_value.x, src/beamformer.cu:191
 constexpr float kAlpha16 = kAlpha * 0.0625f;        // exact (power-of-two scaling)
 constexpr float kNegMagicAlpha16 = -(kMagic * kAlpha16);
+constexpr float kNegMagicAlpha = -(kMagic * kAlpha);   // the deep classes stage TRUE nibbles (|16 n| would leave the seed's range)
+static_assert((double)kMagic * (double)kAlpha == (double)(kMagic * kAlpha), "K * alpha must be exactly representable");
 static_assert((double)kMagic * (double)kAlpha16 == (double)(kMagic * kAlpha16),
               "K * alpha/16 must be exactly representable for the single-fma conversion");
 
@@ -160,7 +164,21 @@ constexpr int kColTilesWide16 = 8;           // ... of the two-k-step conjugate-
 // cost does not depend on the antenna count -- is amortised over twice the MACs.  100 antennas run as 128 with zero
 // weights behind antenna 99; their packed rows (100 B) are only dword-aligned, so they are staged in 4-byte pieces.
 template <int AIN>
-constexpr bool ant_two_ksteps() { return AIN > 64 || AIN == kAntK2P16 || AIN == kAntK2P4; }
+constexpr int ant_ksteps()
+{
+    if (AIN > 0) return (AIN + 63) / 64;
+    return AIN == kAntK4P16 ? 4 : AIN == kAntK3P16 ? 3 : (AIN == kAntK2P16 || AIN == kAntK2P4) ? 2 : 1;
+}
+template <int AIN>
+constexpr bool ant_two_ksteps() { return ant_ksteps<AIN>() == 2; }
+// Three and four k-steps (129 ... 256 antennas; round 4): the same weight-stationary kernel, always on 8-wave workgroups (their
+// LDS image -- 2 buffers x 3 | 4 planes of 16 KiB -- leaves one workgroup per CU).  A wave owns TWO output slots (general kernel:
+// 24 weight registers per k-step; four slots = two pair tiles for the conjugate-pair kernel), its voltages are staged as true
+// nibble values (sign-extended once per workgroup: the 16 x nibble operands of the shallower classes would carry |16 n| past the
+// 2^22 the float seed covers), and the detect -- whose cost does not depend on the antenna count -- is amortised over 3 - 4 x
+// the MACs of the 64-antenna kernel.
+template <int AIN>
+constexpr bool ant_deep() { return ant_ksteps<AIN>() > 2; }
 
 // Waves per SIMD the register allocation is held to (= resident workgroups per CU).  Two k-steps: 2 (their 64 KiB of LDS
 // allow no more).  One k-step: 3 -- except where 4 fit without a spill: since round 3's 3-fragment weight image the general
@@ -170,7 +188,7 @@ constexpr bool ant_two_ksteps() { return AIN > 64 || AIN == kAntK2P16 || AIN == 
 template <int AIN, int NIPO, bool WRITE_C, int NS = kColTiles16>
 constexpr int fused_min_waves()
 {
-    if (NS == 8 || ant_two_ksteps<AIN>()) return 2;
+    if (NS == 8 || ant_ksteps<AIN>() >= 2) return 2;
     if (DSABF_OCC16 == 3 && (AIN == 64 || AIN == kAntK1P16) && (NIPO == 8 || NIPO == 16 || NIPO == 32) && !WRITE_C) return 4;
     return DSABF_OCC16;
 }
@@ -188,10 +206,14 @@ __global__ __launch_bounds__(64 * WAVES, (fused_min_waves<AIN, NIPO, WRITE_C, NS
     constexpr bool CONTRACTED = MODE == kDetContracted;
     static_assert(!FAST || (NIPO >= 16 && !WRITE_C), "the fast detect exists for n_ipo >= 16 only");
     static_assert(!(PAIRED && WRITE_C), "the stage-parity path always runs the general kernel");
-    static_assert(AIN >= kAntK2P4 && AIN != 0 && (AIN < 0 || AIN % 4 == 0) && AIN <= 128, "antenna class");
+    static_assert(AIN >= kAntK3P16 && AIN != 0 && (AIN < 0 || AIN % 4 == 0) && AIN <= 256, "antenna class");
+    static_assert(!ant_deep<AIN>() || (WAVES == 8 && NIPO >= 16 && !WRITE_C && (AIN < 0 || AIN % 16 == 0)), "deep classes: 8 waves, long windows, 16-byte rows");
+    constexpr bool TRUE_NIB = ant_deep<AIN>();           // operands are the nibble values themselves, not 16 x
+    constexpr float kA = TRUE_NIB ? kAlpha : kAlpha16;   // accumulator unit -> alpha
+    constexpr float kNKA = TRUE_NIB ? kNegMagicAlpha : kNegMagicAlpha16;
     constexpr bool RT = AIN < 0;                         // antenna count known only at run time
     constexpr int RB = 128;
-    constexpr int KS = ant_two_ksteps<AIN>() ? 2 : 1;    // k-steps of 64 antennas
+    constexpr int KS = ant_ksteps<AIN>();                // k-steps of 64 antennas
     constexpr int PLANE = kRowsPerChunk * RB;            // LDS bytes of one k-step's chunk image
     constexpr int BUF = KS * PLANE;
     constexpr bool DW = RT ? (AIN == kAntK1P4 || AIN == kAntK2P4) : (AIN % 16) != 0;  // rows only dword-aligned: 4-byte pieces
@@ -358,8 +380,13 @@ __global__ __launch_bounds__(64 * WAVES, (fused_min_waves<AIN, NIPO, WRITE_C, NS
 #pragma unroll
                 for (int d = 0; d < 4; d++) {
                     const unsigned w = (unsigned)stage[k][d];
-                    re[d] = (int)(w & 0xF0F0F0F0u);
-                    im[d] = (int)((w << 4) & 0xF0F0F0F0u);
+                    if constexpr (TRUE_NIB) {   // sign-extend the nibbles inside their bytes: ((v ^ 8) - 8) without a borrow across bytes
+                        re[d] = (int)(((((w >> 4) & 0x0F0F0F0Fu) ^ 0x88888888u) - 0x08080808u) ^ 0x80808080u);
+                        im[d] = (int)((((w & 0x0F0F0F0Fu) ^ 0x88888888u) - 0x08080808u) ^ 0x80808080u);
+                    } else {
+                        re[d] = (int)(w & 0xF0F0F0F0u);
+                        im[d] = (int)((w << 4) & 0xF0F0F0F0u);
+                    }
                 }
                 *reinterpret_cast<v4i*>(buf + lds_re[k]) = re;
                 *reinterpret_cast<v4i*>(buf + (lds_re[k] ^ 64)) = im;
@@ -390,6 +417,8 @@ __global__ __launch_bounds__(64 * WAVES, (fused_min_waves<AIN, NIPO, WRITE_C, NS
             } else if constexpr (PAIRED) {       // NS == 8: four base beams ascending, their four mirrors descending
                 __builtin_nontemporal_store(v4f{x[0], x[2], x[4], x[6]}, reinterpret_cast<v4f*>(row + slot_beam[0]));
                 __builtin_nontemporal_store(v4f{x[7], x[5], x[3], x[1]}, reinterpret_cast<v4f*>(row + slot_beam[7]));
+            } else if constexpr (NS == 2) {       // two neighbouring beams per lane
+                __builtin_nontemporal_store(v2f{x[0], x[1]}, reinterpret_cast<v2f*>(row + slot_beam[0]));
             } else {
 #pragma unroll
                 for (int q = 0; q < NS; q += 4)
@@ -447,8 +476,7 @@ __global__ __launch_bounds__(64 * WAVES, (fused_min_waves<AIN, NIPO, WRITE_C, NS
                     for (int r = 0; r < 4; r++) {
                         const unsigned sidx = o * (unsigned)L + (unsigned)(q4 + r);
                         if (o * (unsigned)L < a.S && beam < a.n_beams) {
-                            v2f cv = {__builtin_fmaf(fr[r], kAlpha16, kNegMagicAlpha16),
-                                      __builtin_fmaf(fi[r], kAlpha16, kNegMagicAlpha16)};
+                            v2f cv = {__builtin_fmaf(fr[r], kA, kNKA), __builtin_fmaf(fi[r], kA, kNKA)};
                             *reinterpret_cast<v2f*>(a.out + 2 * (((size_t)f * a.T + sidx) * a.n_beams + beam)) = cv;
                         }
                     }
@@ -465,15 +493,15 @@ __global__ __launch_bounds__(64 * WAVES, (fused_min_waves<AIN, NIPO, WRITE_C, NS
                     asm volatile("" : "+v"(sacc));
                     sum[sl] = sacc;
                     if (q4 + 4 == L) {
-                        pend[gi][sl] = sacc * (kAlpha16 * kAlpha16);
+                        pend[gi][sl] = sacc * (kA * kA);
                         pend_chunk[gi] = c;
                     }
                 } else {
                     float p[4];
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
-                        const float x = __builtin_fmaf(fr[r], kAlpha16, kNegMagicAlpha16);
-                        const float y = __builtin_fmaf(fi[r], kAlpha16, kNegMagicAlpha16);
+                        const float x = __builtin_fmaf(fr[r], kA, kNKA);
+                        const float y = __builtin_fmaf(fi[r], kA, kNKA);
                         const float yy = y * y;
                         if constexpr (CONTRACTED) {
                             p[r] = __builtin_fmaf(x, x, yy);   // nvcc's reading of x*x + y*y (-fmad=true): mul, then fma
@@ -752,6 +780,36 @@ FusedVariant fused16_variant_s8(int n_ipo, int mode)
         default: return FusedVariant{};
     }
 }
+
+// The deep classes (three / four k-steps): 8-wave workgroups; general kernel with 2 output slots per wave, conjugate-pair kernel
+// with 4 (two pair tiles); n_ipo 16 / 32 / 64.
+template <int AIN, int NIPO>
+FusedVariant fused16_variant_deep_nipo(int mode, bool paired)
+{
+    if (paired) {
+        if (mode == kDetFast) return make_variant<AIN, NIPO, false, kDetFast, true, kWavesWide16, 4>();
+        if (mode == kDetContracted) return make_variant<AIN, NIPO, false, kDetContracted, true, kWavesWide16, 4>();
+        return make_variant<AIN, NIPO, false, kDetCanonical, true, kWavesWide16, 4>();
+    }
+    if (mode == kDetFast) return make_variant<AIN, NIPO, false, kDetFast, false, kWavesWide16, 2>();
+    if (mode == kDetContracted) return make_variant<AIN, NIPO, false, kDetContracted, false, kWavesWide16, 2>();
+    return make_variant<AIN, NIPO, false, kDetCanonical, false, kWavesWide16, 2>();
+}
+template <int AIN>
+FusedVariant fused16_variant_deep(int n_ipo, int mode, bool paired)
+{
+    static_assert(ant_deep<AIN>(), "three or four k-steps");
+    switch (n_ipo) {
+        case 16: return fused16_variant_deep_nipo<AIN, 16>(mode, paired);
+        case 32: return fused16_variant_deep_nipo<AIN, 32>(mode, paired);
+        case 64: return fused16_variant_deep_nipo<AIN, 64>(mode, paired);
+        default: return FusedVariant{};
+    }
+}
+FusedVariant fused16_variant_a192(int n_ipo, int mode, bool paired);
+FusedVariant fused16_variant_a256(int n_ipo, int mode, bool paired);
+FusedVariant fused16_variant_k4p16(int n_ipo, int mode, bool paired);
+FusedVariant fused16_variant_k3p16(int n_ipo, int mode, bool paired);
 
 // One definition per antenna class, each in its own translation unit (bf_fused16_*.hip).
 FusedVariant fused16_variant_a64(int n_ipo, bool write_c, int mode, bool paired);

@@ -49,8 +49,6 @@ constexpr int kGWaves = DSABF_G_WAVES;                 // waves per workgroup: T
 constexpr int kGThreads = 64 * kGWaves;
 constexpr int kGNT = 2;                    // 16-beam column tiles per wave: 4 waves x 32 beams = 128 beams per workgroup
 constexpr int kGPlane = kRowsPerChunk * 128;   // LDS bytes of one staged plane: 128 rows x (64 re | 64 im)
-constexpr float kNegMagicAlpha = -(kMagic * kAlpha);
-static_assert((double)kMagic * (double)kAlpha == (double)(kMagic * kAlpha), "K * alpha must be exactly representable");
 
 typedef int v2i_g __attribute__((ext_vector_type(2)));
 

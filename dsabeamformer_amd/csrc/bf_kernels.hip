@@ -379,6 +379,12 @@ __global__ void weight_relayout16_kernel(const int8_t* __restrict__ w, v4i* __re
 
 // ---- which instantiation a geometry runs ---------------------------------------------------------------------------------
 int ksteps16(const Geometry& g) { return (g.n_ant + 63) / 64; }
+// The deep classes of fused16_kernel (three / four k-steps, bf_fused16.hpp): 129 ... 256 antennas in 16-byte rows, windows of
+// 16 / 32 / 64 samples.  (The stage-parity launch and every other geometry beyond 128 antennas run fusedg_kernel.)
+bool deep_class(const Geometry& g)
+{
+    return !g.force_generic && !g.no_deep && g.n_ant > 128 && g.n_ant <= 256 && g.n_ant % 16 == 0 && (g.n_ipo == 16 || g.n_ipo == 32 || g.n_ipo == 64);
+}
 // MFMA column tiles per wave the beams are dealt to round-robin (beam_of_tile), 0 = tile t is beams 16 t ...: interleaved when every
 // wave owns whole groups of 16 * NS beams.  paired: the layout of the conjugate-pair image / kernel (NS / 2 pair tiles per wave).
 int interleaved(const Geometry& g, bool paired)
@@ -396,6 +402,14 @@ int detect_mode_of(const Geometry& g) { return g.fast_detect ? kDetFast : g.cont
 FusedVariant select_variant(const Geometry& g, bool write_c)
 {
     if (use_generic(g)) return FusedVariant{};
+    if (deep_class(g)) {
+        if (write_c) return FusedVariant{};
+        const bool paired = g.paired;
+        const int mode = detect_mode_of(g);
+        if (!g.runtime_ant && g.n_ant == 192) return fused16_variant_a192(g.n_ipo, mode, paired);
+        if (!g.runtime_ant && g.n_ant == 256) return fused16_variant_a256(g.n_ipo, mode, paired);
+        return g.n_ant > 192 ? fused16_variant_k4p16(g.n_ipo, mode, paired) : fused16_variant_k3p16(g.n_ipo, mode, paired);
+    }
     if (!nipo_supported(g.n_ipo) || g.n_ant <= 0 || g.n_ant > 128 || g.n_ant % 4) return FusedVariant{};
     const bool paired = g.paired && !write_c;
     const int mode = detect_mode_of(g);
@@ -447,18 +461,19 @@ hipError_t dispatch_fused(const Geometry& g, bool write_c, const FusedArgs& args
 // windows that are not a power of two (or longer than 64), short windows in gemm-units that are not whole 16-sample runs.
 bool use_generic(const Geometry& g)
 {
-    return g.force_generic || g.n_ant > 128 || !nipo_supported(g.n_ipo) || (g.n_ipo < 16 && g.n_time % 16);
+    return g.force_generic || (g.n_ant > 128 && !deep_class(g)) || !nipo_supported(g.n_ipo) || (g.n_ipo < 16 && g.n_time % 16);
 }
 
 size_t weight_image_bytes(const Geometry& g)
 {
     return (size_t)g.n_freq * g.n_ctiles * (DSABF_GEN3 ? 3 : 4) * ksteps16(g) * 64 * 16 +   // [f][ct16][Wr, -Wi, Wi][k-step][lane] x 16 B
-           (use_generic(g) ? generic_image_extra_bytes(g) : 0);
+           ((use_generic(g) || deep_class(g)) ? generic_image_extra_bytes(g) : 0);
 }
 
 // the conjugate-pair kernel works on tiles of 16 base beams + their 16 mirror images
 bool pairing_supported(const Geometry& g)
 {
+    if (deep_class(g) && g.n_beams % 512) return false;   // the deep pair kernel's workgroups are 8 waves x 64 beams
     return DSABF_PAIRED && !use_generic(g) && g.n_beams % 32 == 0 && select_variant(g, false).launch != nullptr;
 }
 size_t weight_pair_image_bytes(const Geometry& g)
@@ -493,6 +508,8 @@ void read_env_switches(Geometry& g)
     g.dm_wide = !(dw && dw[0] == '0');
     const char* gen = getenv("DSABF_GENERIC");
     g.force_generic = gen && gen[0] == '1';
+    const char* nd = getenv("DSABF_DEEP");
+    g.no_deep = nd && nd[0] == '0';
 }
 
 // Output slots (16 beams each) per wave.  The two-k-step conjugate-pair kernels hold 2 waves per SIMD whatever they do (64 KiB of
@@ -504,6 +521,7 @@ void read_env_switches(Geometry& g)
 // profiles/r03_variants_log.txt).
 int fused_col_tiles(const Geometry& g, bool paired)
 {
+    if (deep_class(g)) return paired ? 4 : 2;
     const bool rt = g.runtime_ant;
     // the instantiations that fit their registers (ns8_fits, bf_fused16.hpp): 16-byte-staged rows, or the compile-time 100 antennas
     const bool fits = g.n_ant % 16 == 0 || (!rt && g.n_ant == 100 && g.n_ipo < 64);
@@ -518,6 +536,7 @@ int fused_col_tiles(const Geometry& g, bool paired)
 // barriers); so do the store-bound short windows, the stage-parity launch and the 8-slot pair kernel above.
 int fused_wg_waves(const Geometry& g, bool write_c)
 {
+    if (deep_class(g) && !write_c) return kWavesWide16;
     const bool can = !write_c && ksteps16(g) == 2 && g.n_ipo >= 16 && kWaves16 == 4 && kColTiles16 == 4 &&
                      ((g.n_beams + 255) / 256) % 2 == 0 && fused_col_tiles(g, g.paired) == kColTiles16;
     return (can && !g.plain_wg_waves) ? kWavesWide16 : kWaves16;
@@ -551,7 +570,7 @@ LaunchShape fused_launch_shape(const Geometry& g, int n_units, int n_cus, bool w
     // At least 2 chunk-groups per workgroup (the weight-fragment load and the prologue are paid per workgroup; two
     // k-steps = twice the fragments: at least 4) -- unless that leaves fewer than 4 (2) workgroups per CU: a single
     // gemm-unit is 4 chunks per frequency, 1 chunk each is then 6 % faster (profiles/r02_launch_size.txt).
-    const bool two_k = ksteps16(g) == 2;
+    const bool two_k = ksteps16(g) >= 2;
     const bool wide = wg_waves == kWavesWide16;   // one resident workgroup per CU
     const bool ns8 = fused_col_tiles(g, g.paired && !write_c) == kColTilesWide16;   // two resident, long like the wide ones
     const int min_groups = two_k ? 4 : 2;
@@ -625,7 +644,8 @@ hipError_t launch_gemm_only(const Geometry& g, const void* d_image, const void* 
 {
     Geometry gg = g;
     gg.paired = false;  // the stage-parity path always runs the general kernel on the general image
-    if (use_generic(gg)) return launch_fused_generic(gg, d_image, d_packed, 1, d_c, n_cus, true, s);
+    if (use_generic(gg) || deep_class(gg))   // (the deep classes share fusedg_kernel's image: same k-steps, same 2-beam interleave)
+        return launch_fused_generic(gg, d_image, d_packed, 1, d_c, n_cus, true, s);
     const LaunchShape ls = fused_launch_shape(gg, 1, n_cus, true);
     const FusedArgs a = make_args(gg, d_image, d_packed, 1, d_c, ls);
     return dispatch_fused(gg, true, a, ls, s);
@@ -639,10 +659,11 @@ hipError_t launch_weight_relayout(const Geometry& g, const int8_t* d_w, void* d_
                                   hipStream_t s)
 {
     clear_stale_error();
-    const size_t total = (weight_image_bytes(g) - (use_generic(g) ? generic_image_extra_bytes(g) : 0)) / 16;
+    const bool with_corr = use_generic(g) || deep_class(g);   // the generic kernel's offset-nibble corrections behind the fragments
+    const size_t total = (weight_image_bytes(g) - (with_corr ? generic_image_extra_bytes(g) : 0)) / 16;
     int grid = (int)((total + 255) / 256);
     if (grid > 4096) grid = 4096;
-    if (use_generic(g)) {
+    if (with_corr) {
         hipError_t e = launch_generic_colsum(g, d_w, d_image, s);
         if (e != hipSuccess) return e;
     }
@@ -765,7 +786,7 @@ const char* fused_kernel_name(const Geometry& g, char* buf, size_t n)
                  generic_ksteps(g), g.n_ant % 16 ? 4 : 16, g.n_ipo, g.fast_detect ? ",FAST" : g.contracted_detect ? ",CONTRACTED" : "");
         return buf;
     }
-    const bool rt = !(g.n_ant == 64 || g.n_ant == 100 || g.n_ant == 128);   // (the geometry's class; DSABF_RUNTIME_ANT is not shown)
+    const bool rt = !(g.n_ant == 64 || g.n_ant == 100 || g.n_ant == 128 || g.n_ant == 192 || g.n_ant == 256);   // (the geometry's class; DSABF_RUNTIME_ANT is not shown)
     snprintf(buf, n, "dsabf::fused16_kernel<ANT=%d%s,NIPO=%d%s%s%s> (v_mfma_i32_16x16x64_i8)", g.n_ant, rt ? "(run-time)" : "",
              g.n_ipo, (g.fast_detect && g.n_ipo >= 16) ? ",FAST" : g.contracted_detect ? ",CONTRACTED" : "",
              g.paired ? ",PAIRED" : "",

@@ -221,7 +221,10 @@ def test_any_antenna_count_beyond_128_bit_exact(torch, bfmod, orc, n_ant, n_avg)
         w[0, :, 5] = -127
     bf = bfmod.Beamformer(_cfg_of(bfmod, g))
     bf.set_weights(w)
-    assert "fusedg_kernel" in bf.kernel_info(3)["kernel"] and ("%d k-steps" % -(-n_ant // 64)) in bf.kernel_info(3)["kernel"]
+    name = bf.kernel_info(3)["kernel"]
+    deep = n_ant <= 256 and n_ant % 16 == 0 and n_avg == 16          # the three / four k-step classes of fused16_kernel
+    assert ("fused16_kernel<ANT=%d" % n_ant in name and "WAVES=8" in name) if deep else \
+        ("fusedg_kernel" in name and ("%d k-steps" % -(-n_ant // 64)) in name), name
     want = orc.beamform(g, w, packed)
     got = _beamform(torch, bf, packed, want.size).reshape(want.shape)
     assert np.array_equal(got, want)
@@ -310,3 +313,117 @@ def test_generic_kernel_stage_parity_beams_and_time_splits(torch, bfmod, orc, mo
             assert np.array_equal(d_c.cpu().numpy().reshape(-1), np.asarray(c_want).reshape(-1))
         bf.close()
     monkeypatch.delenv("DSABF_TSPLIT", raising=False)
+
+
+@pytest.mark.parametrize("per_unit", [False, True])
+def test_debug_flow_end_to_end_on_a_geometry_only_the_generic_kernel_covers(bfmod, orc, tmp_path, per_unit):
+    """The reference's `make debug` main() (generator -> H2D -> fused kernel -> DM-0 collapse -> data.py) on 132 antennas and
+    N_AVERAGING 3: through the scheduler and the streaming entry points into fusedg_kernel, with block launches and with the
+    reference's per-gemm-unit loop (coalesced); the whole table equals the oracle's."""
+    from dsabeamformer_amd import host
+
+    n_ant, n_beams, n_src = 132, 96, 64
+    rng = np.random.default_rng(77)
+    pos = np.zeros((n_ant, 3), np.float32)
+    pos[:, 0] = np.linspace(-400.0, 400.0, n_ant) + rng.uniform(-2, 2, n_ant)
+    pos[:, 1] = rng.uniform(-30, 30, n_ant)
+    dirs = np.stack([np.linspace(-3.0, 3.0, n_beams) * np.pi / 180, rng.uniform(-0.5, 0.5, n_beams) * np.pi / 180], 1).astype(np.float32)
+    src = np.stack([np.linspace(-2.9, 2.9, n_src) * np.pi / 180, np.zeros(n_src)], 1).astype(np.float32)
+    pfile, dfile, sfile = tmp_path / "pos.txt", tmp_path / "dir.txt", tmp_path / "src.txt"
+    pfile.write_text("%d\n" % n_ant + "".join("%r %r %r\n" % (float(p[0]), float(p[1]), float(p[2])) for p in pos))
+    dfile.write_text("%d\n" % n_beams + "".join("%r %r\n" % (float(d[0]), float(d[1])) for d in dirs))
+    sfile.write_text("%d\n" % n_src + "".join("%r %r\n" % (float(s[0]), float(s[1])) for s in src))
+    cfg = bfmod.debug_config(n_ant=n_ant, n_beams=n_beams, n_freq=16, n_avg=3, n_out_per_gemm=4, n_gemms_per_block=16,
+                             n_blocks_on_gpu=4, n_streams=4)
+    ded, _ms = host.run_debug_observation(cfg, gpu=0, positions=str(pfile), directions=str(dfile), sources=str(sfile),
+                                          output=str(tmp_path / "data.py"), max_sources=n_src, per_unit_launches=per_unit)
+    assert ded.shape == (n_src, n_beams)
+    g = orc.Geom(n_beams=n_beams, n_ant=n_ant, n_freq=16, n_avg=3, n_out_per_gemm=4)
+    p32, d32, s32 = orc.read_positions(str(pfile), n_ant), orc.read_directions(str(dfile), n_beams), orc.read_directions(str(sfile))
+    w = orc.make_weights(g, p32, d32, 0)
+    units = orc.generate_test_data(g, p32, s32, 0, 0, n_src)
+    out = orc.beamform(g, w, units)
+    want = np.stack([orc.dedisperse(g, out[u]) for u in range(n_src)])
+    assert np.array_equal(ded, want)
+    assert ded.max() > 0 and np.isfinite(ded).all()
+
+
+# ---- the deep classes of fused16_kernel: three / four k-steps, weights stationary (129 ... 256 antennas) -----------------------
+@pytest.mark.parametrize("n_ant", [144, 192, 208, 256])
+@pytest.mark.parametrize("n_avg,paired", [(16, False), (8, False), (32, False), (16, True), (32, True)])
+def test_deep_classes_bit_exact_and_equal_to_the_generic_kernel(torch, bfmod, orc, monkeypatch, n_ant, n_avg, paired):
+    """129 ... 256 antennas in 16-byte rows with windows of 16 / 32 / 64 samples run fused16_kernel with three or four k-steps:
+    8-wave workgroups, two output slots per wave (general) or two pair tiles (conjugate-symmetric weights, beams in groups
+    of 512), true-nibble operands.  Bit-exact vs the oracle in both bit-exact readings, within tolerance in the fast one, and
+    the same bits as fusedg_kernel (DSABF_DEEP=0) on the same handle geometry; several chunks per workgroup, a ragged tail."""
+    n_beams = 512 if paired else 288
+    g = orc.Geom(n_beams=n_beams, n_ant=n_ant, n_freq=2, n_avg=n_avg, n_out_per_gemm=3)
+    rng = np.random.default_rng(n_ant * 3 + n_avg + paired)
+    w = rng.integers(-127, 128, size=(g.n_freq, g.n_ant, g.n_beams, 2), dtype=np.int8)
+    if paired:
+        w[:, :, 256:, 0] = w[:, :, :256, 0][:, :, ::-1]
+        w[:, :, 256:, 1] = -w[:, :, :256, 1][:, :, ::-1]
+    if n_ant == 256:                  # the extreme sums: |n| = 2032 * 256 in one beam
+        w[0, :, 7] = -127
+    packed = rng.integers(0, 256, size=(5, g.n_freq, g.n_time, g.n_ant), dtype=np.uint8)
+    if n_ant == 256:
+        packed[2, 0] = 0x88
+    monkeypatch.setenv("DSABF_TSPLIT", "2")
+    got = {}
+    for mode, contract in ((0, orc.CONTRACT_NONE), (2, orc.CONTRACT_NVCC), (1, None)):
+        bf = bfmod.Beamformer(_cfg_of(bfmod, g, detect_mode=mode))
+        bf.set_weights(w)
+        name = bf.kernel_info(5)["kernel"]
+        assert "fused16_kernel<ANT=%d" % n_ant in name and ("PAIRED" in name) == paired and "WAVES=8" in name, name
+        out = _beamform(torch, bf, packed, 5 * g.out_per_gemm)
+        bf.close()
+        if contract is not None:
+            with orc.detect_contract(contract):
+                want = orc.beamform(g, w, packed)
+            assert np.array_equal(out.reshape(want.shape), want), (mode,)
+        else:
+            exact = orc.beamform_exact(g, w, packed)
+            rel = np.abs(out.reshape(exact.shape).astype(np.float64) - exact) / np.maximum(exact, 1e-300)
+            assert rel.max() <= (g.n_ipo + 1) * 2.0 ** -23
+        got[mode] = out
+    monkeypatch.setenv("DSABF_DEEP", "0")
+    for mode in (0, 1, 2):
+        bf = bfmod.Beamformer(_cfg_of(bfmod, g, detect_mode=mode))
+        bf.set_weights(w)
+        assert "fusedg_kernel" in bf.kernel_info(5)["kernel"]
+        assert np.array_equal(_beamform(torch, bf, packed, 5 * g.out_per_gemm), got[mode]), mode
+        bf.close()
+    monkeypatch.delenv("DSABF_DEEP", raising=False)
+    monkeypatch.delenv("DSABF_TSPLIT", raising=False)
+
+
+def test_deep_class_stage_parity_and_streaming(torch, bfmod, orc):
+    """bf_gemm_device on a deep-class handle (fusedg_kernel's stage-parity launch on the shared fragment image), and the
+    streaming entry points (a block through bf_enqueue_block and through the coalesced per-unit loop) at 192 antennas."""
+    g = orc.Geom(n_beams=96, n_ant=192, n_freq=3, n_avg=8, n_out_per_gemm=2)
+    cfg = _cfg_of(bfmod, g, n_gemms_per_block=4, n_blocks_on_gpu=2, n_streams=2)
+    rng = np.random.default_rng(12)
+    w = rng.integers(-127, 128, size=(g.n_freq, g.n_ant, g.n_beams, 2), dtype=np.int8)
+    block = rng.integers(0, 256, size=(4, g.n_freq, g.n_time, g.n_ant), dtype=np.uint8)
+    bf = bfmod.Beamformer(cfg)
+    bf.set_weights(w)
+    assert "fused16_kernel<ANT=192" in bf.kernel_info(4)["kernel"]
+    s = torch.cuda.current_stream().cuda_stream
+    d_c = torch.full((g.n_freq, g.n_time, g.n_beams, 2), float("nan"), dtype=torch.float32, device="cuda")
+    bf.gemm(torch.from_numpy(block[1]).cuda(), d_c, s)
+    torch.cuda.synchronize()
+    assert np.array_equal(d_c.cpu().numpy().reshape(-1), np.asarray(orc.gemm(g, w, orc.expand(block[1]))).reshape(-1))
+    want = orc.beamform(g, w, block)
+    pinned = torch.from_numpy(block).pin_memory()
+    bf.submit_block(1, pinned, block.nbytes)
+    bf.sync(-1)
+    outs = torch.zeros((4, g.out_per_gemm), dtype=torch.float32).pin_memory()
+    bf.enqueue_block(0, 1, 0, 4, [outs[u] for u in range(4)])
+    bf.sync(-1)
+    assert np.array_equal(outs.numpy().reshape(want.shape), want)
+    outs2 = torch.zeros((4, g.out_per_gemm), dtype=torch.float32).pin_memory()
+    for u in range(4):
+        bf.enqueue_gemm_unit(u % 2, 1, u, outs2[u])
+    bf.sync(-1)
+    assert np.array_equal(outs2.numpy(), outs.numpy())
+    bf.close()

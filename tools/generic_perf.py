@@ -16,7 +16,7 @@ stream = torch.cuda.current_stream()
 rng = np.random.default_rng(3)
 
 
-def run(n_ant, n_beams, n_freq, n_avg, n_out, units, generic=None, label=""):
+def run(n_ant, n_beams, n_freq, n_avg, n_out, units, generic=None, label="", paired=False):
     if generic is None:
         os.environ.pop("DSABF_GENERIC", None)
     else:
@@ -26,6 +26,10 @@ def run(n_ant, n_beams, n_freq, n_avg, n_out, units, generic=None, label=""):
     bf = bfm.Beamformer(cfg)
     os.environ.pop("DSABF_GENERIC", None)
     w = rng.integers(-127, 128, size=(n_freq, n_ant, n_beams, 2), dtype=np.int8)     # general weights (no conjugate symmetry)
+    if paired:
+        h = n_beams // 2
+        w[:, :, h:, 0] = w[:, :, :h, 0][:, :, ::-1]
+        w[:, :, h:, 1] = -w[:, :, :h, 1][:, :, ::-1]
     bf.set_weights(w)
     n_ipo = 2 * n_avg
     n_time = n_out * n_ipo
@@ -53,7 +57,14 @@ run(64, 256, 256, 16, 16, 32, None, "C3 shape, fused16 general")
 run(64, 256, 256, 16, 16, 32, True, "C3 shape, fusedg")
 run(128, 256, 256, 16, 16, 16, None, "128 ant, fused16 general")
 run(128, 256, 256, 16, 16, 16, True, "128 ant, fusedg")
-# beyond two k-steps: only the generic kernel
+# three / four k-steps: the deep classes of fused16_kernel (general and conjugate-pair) next to fusedg_kernel
+for n_ant in (144, 192, 224, 256):
+    run(n_ant, 256, 256, 16, 16, 8192 // n_ant, None, "%d ant, fused16 deep general" % n_ant)
+    run(n_ant, 256, 256, 16, 16, 8192 // n_ant, True, "%d ant, fusedg" % n_ant)
+run(256, 512, 256, 16, 16, 16, None, "256 ant x 512 beams, deep general")
+run(256, 512, 256, 16, 16, 16, None, "256 ant x 512 beams, deep pair", paired=True)
+run(192, 512, 256, 16, 16, 16, None, "192 ant x 512 beams, deep pair", paired=True)
+# beyond that: only the generic kernel
 for n_ant in (132, 192, 256, 320, 512, 1024):
     run(n_ant, 256, 256, 16, 16, max(2, 2048 // n_ant), None, "%d antennas" % n_ant)
 for n_ant in (192, 256, 512):       # the same with launches of 1 GiB of voltages (the bench's step size)
