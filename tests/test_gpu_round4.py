@@ -360,11 +360,11 @@ def test_deep_classes_bit_exact_and_equal_to_the_generic_kernel(torch, bfmod, or
     g = orc.Geom(n_beams=n_beams, n_ant=n_ant, n_freq=2, n_avg=n_avg, n_out_per_gemm=3)
     rng = np.random.default_rng(n_ant * 3 + n_avg + paired)
     w = rng.integers(-127, 128, size=(g.n_freq, g.n_ant, g.n_beams, 2), dtype=np.int8)
+    if n_ant == 256:                  # the extreme sums: |n| = 2032 * 256 in one beam (and, when paired, in its mirror image)
+        w[0, :, 7] = -127
     if paired:
         w[:, :, 256:, 0] = w[:, :, :256, 0][:, :, ::-1]
         w[:, :, 256:, 1] = -w[:, :, :256, 1][:, :, ::-1]
-    if n_ant == 256:                  # the extreme sums: |n| = 2032 * 256 in one beam
-        w[0, :, 7] = -127
     packed = rng.integers(0, 256, size=(5, g.n_freq, g.n_time, g.n_ant), dtype=np.uint8)
     if n_ant == 256:
         packed[2, 0] = 0x88
