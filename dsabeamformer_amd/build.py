@@ -27,7 +27,10 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 # with iterative-maxocc -4.3 % (C5), -5.0 % contracted, -6.3 % on a C5 rank shard (iterative-ilp: -2.5 / -2.2 / -3.6 %); the
 # conjugate-pair kernel (bf_fused16_*_w8p.hip) with iterative-ilp -4.2 % (iterative-maxocc: -1.8 %).  Every other kernel is
 # neutral or worse with either (C3 +-0.5 ... +1.1 %, the 8-slot pair kernel +0.2 ... +0.5 %) and keeps max-ilp.
-SCHED_BY_SUFFIX = {"_w8.hip": "iterative-maxocc", "_w8p.hip": "iterative-ilp"}
+# Round 4: the deep classes (three / four k-steps, 8-wave workgroups; bf_fused16_{a192,a256,k3p16,k4p16}.hip) with iterative-ilp: general
+# kernel -6.3 % at 256 antennas (iterative-maxocc -3.8 %), conjugate-pair kernel -3.1 % (profiles/r04_deep_sched.txt).
+SCHED_BY_SUFFIX = {"_w8.hip": "iterative-maxocc", "_w8p.hip": "iterative-ilp", "_a192.hip": "iterative-ilp", "_a256.hip": "iterative-ilp",
+                   "_k3p16.hip": "iterative-ilp", "_k4p16.hip": "iterative-ilp"}
 
 
 def flags_for(src: str) -> list[str]:

@@ -47,6 +47,9 @@ HOT = [
     ("bf_fused16_a100_w8", fused(100, 32, 0, False, 8, 4), 256, 8 * 4 * 4 * 2),  # C5 general kernel on 8-wave workgroups
     ("bf_fused16_a128_s8", fused(128, 32, 0, True, 4, 8), 256, 8 * 4 * 4 * 2),
     ("bf_fused16_a128_w8", fused(128, 32, 0, False, 8, 4), 256, 8 * 4 * 4 * 2),
+    ("bf_fused16_a256", fused(256, 32, 0, False, 8, 2), 256, 8 * 2 * 4 * 4),      # deep general: 2 slots per wave, 4 k-steps
+    ("bf_fused16_a256", fused(256, 32, 0, True, 8, 4), 256, 8 * 2 * 4 * 4),       # deep pair: 2 pair tiles per wave
+    ("bf_fused16_a192", fused(192, 32, 0, False, 8, 2), 256, 8 * 2 * 4 * 3),
 ]
 
 
@@ -77,7 +80,8 @@ def test_spills_stay_where_they_are_known(objects):
     shows."""
     clean_units = ("bf_fused16_a64", "bf_fused16_a128", "bf_fused16_a128_s8", "bf_fused16_a128_w8", "bf_fused16_a128_w8p",
                    "bf_fused16_a100_s8", "bf_fused16_a100_w8", "bf_fused16_a100_w8p", "bf_fused16_k1p16", "bf_fused16_k2p16",
-                   "bf_fused16_k2p16_w8", "bf_fused16_k2p16_w8p", "bf_fused16_k2p4_w8p")
+                   "bf_fused16_k2p16_w8", "bf_fused16_k2p16_w8p", "bf_fused16_k2p4_w8p", "bf_fused16_a192", "bf_fused16_a256",
+                   "bf_fused16_k3p16", "bf_fused16_k4p16")
     bad, worst = [], 0
     for unit, (co, ks) in objects.items():
         for name, k in ks.items():

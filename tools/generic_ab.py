@@ -17,13 +17,19 @@ if sys.argv[1] == "--child":
     import dsabeamformer_amd as bfm
 
     n_ant, n_avg, units = (int(x) for x in sys.argv[2:5])
+    n_beams = int(os.environ.get("G_BEAMS", "256"))          # G_BEAMS / G_PAIRED: beam count, conjugate-symmetric weights
     cfg = bfm.production_config(n_avg=n_avg, n_out_per_gemm=16, n_freq=256)
-    cfg.n_ant = n_ant
+    cfg.n_ant, cfg.n_beams = n_ant, n_beams
     bf = bfm.Beamformer(cfg)
-    bf.set_weights(np.random.default_rng(3).integers(-127, 128, size=(256, n_ant, 256, 2), dtype=np.int8))
+    w = np.random.default_rng(3).integers(-127, 128, size=(256, n_ant, n_beams, 2), dtype=np.int8)
+    if os.environ.get("G_PAIRED") == "1":
+        h = n_beams // 2
+        w[:, :, h:, 0] = w[:, :, :h, 0][:, :, ::-1]
+        w[:, :, h:, 1] = -w[:, :, :h, 1][:, :, ::-1]
+    bf.set_weights(w)
     n_time = 16 * 2 * n_avg
     d_in = [torch.randint(0, 256, (units * 256 * n_time * n_ant,), dtype=torch.uint8, device="cuda") for _ in range(2)]
-    d_out = torch.empty(units * 16 * 256 * 256, dtype=torch.float32, device="cuda")
+    d_out = torch.empty(units * 16 * 256 * n_beams, dtype=torch.float32, device="cuda")
     st = torch.cuda.current_stream()
     fn = lambda i: bf.beamform(d_in[i & 1], units, d_out, st.cuda_stream)  # noqa: E731
     for i in range(10):
@@ -50,7 +56,7 @@ for rnd in range(3):
         d = json.loads(line[-1])
         res[name].append(d["avg"])
         info[name] = d
-ops = 8.0 * 256 * int(n_ant) * 16 * 2 * int(n_avg) * 256 * int(units)
+ops = 8.0 * int(os.environ.get("G_BEAMS", "256")) * int(n_ant) * 16 * 2 * int(n_avg) * 256 * int(units)
 for name, _ in variants:
     if res[name]:
         t = sorted(res[name])[len(res[name]) // 2]
