@@ -317,8 +317,12 @@ int bf_get_config(const bf_handle* h, bf_config* cfg)
     return BF_OK;
 }
 
+static int flush_units(bf_handle* h);
+
 static int finish_weights(bf_handle* h, const int8_t* d_w, hipStream_t s)
 {
+    if (int rc = flush_units(h)) return rc;   // gemm-units still queued were enqueued under the OLD weights: launch them first
+    for (auto q : h->streams) HIP_TRY(hipStreamSynchronize(q));   // ... and let them finish before the images change
     HIP_TRY(hipMemsetAsync(h->d_flag, 0, 2 * sizeof(int), s));
     HIP_TRY(dsabf::launch_weight_relayout(h->geom, d_w, h->d_wimage, h->d_wimage_p, h->d_flag, s));
     int bad[2] = {0, 0};

@@ -427,3 +427,21 @@ def test_deep_class_stage_parity_and_streaming(torch, bfmod, orc):
     bf.sync(-1)
     assert np.array_equal(outs2.numpy(), outs.numpy())
     bf.close()
+
+
+def test_units_queued_before_a_weight_change_run_under_the_old_weights(torch, bfmod, orc):
+    g, cfg, bf, blocks, want = _small_streaming_handle(bfmod, orc, 47)
+    pinned_in = torch.from_numpy(blocks).pin_memory()
+    bf.submit_block(0, pinned_in[0], blocks[0].nbytes)
+    bf.sync(-1)
+    outs = torch.zeros((2, bf.floats_per_detect), dtype=torch.float32).pin_memory()
+    bf.enqueue_gemm_unit(0, 0, 3, outs[0])
+    assert bf.counter("queued_units") == 1
+    w2 = np.random.default_rng(48).integers(-127, 128, size=(g.n_freq, g.n_ant, g.n_beams, 2), dtype=np.int8)
+    bf.set_weights(w2)                                  # launches what is queued, waits for it, then swaps the images
+    assert bf.counter("queued_units") == 0
+    bf.enqueue_gemm_unit(1, 0, 3, outs[1])
+    bf.sync(-1)
+    assert np.array_equal(outs[0].numpy().reshape(want.shape[2:]), want[0, 3])
+    assert np.array_equal(outs[1].numpy().reshape(want.shape[2:]), orc.beamform(g, w2, blocks[0][3:4])[0])
+    bf.close()
