@@ -142,3 +142,10 @@ def test_dm_kernels(objects):
     assert ks[name]["private_segment_fixed_size"] == 0 and ks[name]["vgpr_count"] <= 128
     name = [n for n in ks if "expand_kernel" in n][0]
     assert ks[name]["vgpr_count"] <= 32 and ks[name]["private_segment_fixed_size"] == 0
+
+
+def test_generated_dm_body_is_what_the_generator_writes():
+    """csrc/bf_dm_wide_body.inc is generated (tools/gen_dm_body.py) and committed: the two must not drift apart."""
+    import gen_dm_body
+
+    assert open(gen_dm_body.PATH).read() == gen_dm_body.render()
