@@ -656,7 +656,7 @@ def main():
                                            "per sender, freq-major = the reference's [o][f][b], one message per (row, sender); "
                                            "root = everything to rank 0, alltoall = rank j owns rows j*n/N.. of the whole band")
 
-        def variant(detect_mode, paired_env=None, wl=None, n_units=None, reps=None, calibrated=False):
+        def variant(detect_mode, paired_env=None, wl=None, n_units=None, reps=None, calibrated=False, n_ant=None):
             """Kernel-time record of another variant / workload on this GPU (HIP events around every launch)."""
             old = os.environ.get("DSABF_PAIRED")
             if paired_env is not None:
@@ -666,6 +666,8 @@ def main():
                 c2 = bfm.production_config(n_avg=na, n_out_per_gemm=no, n_freq=n_freq, detect_mode=detect_mode)
                 if wl == "c5":
                     c2.n_ant, c2.n_beams, c2.n_freq = 100, 512, 128
+                if n_ant:
+                    c2.n_ant = n_ant
                 b2 = bfm.Beamformer(c2, device=local)
                 w2 = product_weights(c2, 0)
                 b2.set_weights(calibrated_weights(w2) if calibrated else w2)
@@ -760,6 +762,14 @@ def main():
                               "N_TIME 256, 16 gemm-units per launch; beam-blocks here are 512 beams x 128 freq")
             s5["pmc_source"] = "profiles/r04_c5_pmc_summary.txt is the whole-band launch (16 gemm-units x 1024 freq), not this shard"
             out["c5_shard"] = s5
+            # the same C3 shape with 256 antennas (four k-steps: the deep classes of fused16_kernel) -- the
+            # detect is amortised over 4 x the MACs.  The linear fan is conjugate-symmetric (pair kernel); the calibrated set is not.
+            a256 = {}
+            for key, cal in (("fan_pair_kernel", False), ("calibrated_general_kernel", True)):
+                r = variant(0, n_units=32, reps=40, calibrated=cal, n_ant=256)
+                a256[key] = {k: r[k] for k in ("kernel", "kernel_ms_avg", "grid", "vgprs", "tops", "frac")}
+            a256["workload"] = "256 ant x 2 pol, 256 freq, 256 beams, N_TIME 512, 32 gemm-units per launch (1 GiB of voltages)"
+            out["antennas_256"] = a256
             # launch granularity: what one launch over 1 / 8 / 32 gemm-units costs per beam-block (input resident)
             ls = {}
             for nu in (1, 8, 32, 128):

@@ -411,7 +411,10 @@ __global__ __launch_bounds__(64 * WAVES, (fused_min_waves<AIN, NIPO, WRITE_C, NS
             // store instruction covers whole 128-byte lines (16 lanes x 16 B, or 16 x 8 B), so streaming them past L2
             // costs nothing at C3 / C5 (+0.3 %) and lifts the store-bound DEBUG geometry from 0.60 to 0.73 of 8 TB/s
             // (profiles/r02_variants_log.txt).  The scalar stores of non-interleaved tiles cover partial lines: plain.
-            if constexpr (PAIRED && NS == 4) {   // slots 0, 2 = base beams bb, bb + 1; slots 1, 3 = their mirrors B-1-bb, B-2-bb
+            if constexpr (PAIRED && NS == 2) {   // one pair tile per wave (deep classes, beams not in groups of 512): beam bb and its mirror
+                row[slot_beam[0]] = x[0];
+                row[slot_beam[1]] = x[1];
+            } else if constexpr (PAIRED && NS == 4) {   // slots 0, 2 = base beams bb, bb + 1; slots 1, 3 = their mirrors B-1-bb, B-2-bb
                 __builtin_nontemporal_store(v2f{x[0], x[2]}, reinterpret_cast<v2f*>(row + slot_beam[0]));
                 __builtin_nontemporal_store(v2f{x[3], x[1]}, reinterpret_cast<v2f*>(row + slot_beam[3]));
             } else if constexpr (PAIRED) {       // NS == 8: four base beams ascending, their four mirrors descending
@@ -784,8 +787,13 @@ FusedVariant fused16_variant_s8(int n_ipo, int mode)
 // The deep classes (three / four k-steps): 8-wave workgroups; general kernel with 2 output slots per wave, conjugate-pair kernel
 // with 4 (two pair tiles); n_ipo 16 / 32 / 64.
 template <int AIN, int NIPO>
-FusedVariant fused16_variant_deep_nipo(int mode, bool paired)
+FusedVariant fused16_variant_deep_nipo(int mode, bool paired, int ns)
 {
+    if (paired && ns == 2) {   // one pair tile per wave: 8 waves x 32 beams = 256 beams per workgroup
+        if (mode == kDetFast) return make_variant<AIN, NIPO, false, kDetFast, true, kWavesWide16, 2>();
+        if (mode == kDetContracted) return make_variant<AIN, NIPO, false, kDetContracted, true, kWavesWide16, 2>();
+        return make_variant<AIN, NIPO, false, kDetCanonical, true, kWavesWide16, 2>();
+    }
     if (paired) {
         if (mode == kDetFast) return make_variant<AIN, NIPO, false, kDetFast, true, kWavesWide16, 4>();
         if (mode == kDetContracted) return make_variant<AIN, NIPO, false, kDetContracted, true, kWavesWide16, 4>();
@@ -796,20 +804,21 @@ FusedVariant fused16_variant_deep_nipo(int mode, bool paired)
     return make_variant<AIN, NIPO, false, kDetCanonical, false, kWavesWide16, 2>();
 }
 template <int AIN>
-FusedVariant fused16_variant_deep(int n_ipo, int mode, bool paired)
+FusedVariant fused16_variant_deep(int n_ipo, int mode, bool paired, int ns)
 {
     static_assert(ant_deep<AIN>(), "three or four k-steps");
     switch (n_ipo) {
-        case 16: return fused16_variant_deep_nipo<AIN, 16>(mode, paired);
-        case 32: return fused16_variant_deep_nipo<AIN, 32>(mode, paired);
-        case 64: return fused16_variant_deep_nipo<AIN, 64>(mode, paired);
+        case 16: return fused16_variant_deep_nipo<AIN, 16>(mode, paired, ns);
+        case 32: return fused16_variant_deep_nipo<AIN, 32>(mode, paired, ns);
+        case 64: return fused16_variant_deep_nipo<AIN, 64>(mode, paired, ns);
         default: return FusedVariant{};
     }
 }
-FusedVariant fused16_variant_a192(int n_ipo, int mode, bool paired);
-FusedVariant fused16_variant_a256(int n_ipo, int mode, bool paired);
-FusedVariant fused16_variant_k4p16(int n_ipo, int mode, bool paired);
-FusedVariant fused16_variant_k3p16(int n_ipo, int mode, bool paired);
+// ns: output slots per wave (general 2; conjugate-pair 4 where the beams come in groups of 512, else 2)
+FusedVariant fused16_variant_a192(int n_ipo, int mode, bool paired, int ns);
+FusedVariant fused16_variant_a256(int n_ipo, int mode, bool paired, int ns);
+FusedVariant fused16_variant_k4p16(int n_ipo, int mode, bool paired, int ns);
+FusedVariant fused16_variant_k3p16(int n_ipo, int mode, bool paired, int ns);
 
 // One definition per antenna class, each in its own translation unit (bf_fused16_*.hip).
 FusedVariant fused16_variant_a64(int n_ipo, bool write_c, int mode, bool paired);

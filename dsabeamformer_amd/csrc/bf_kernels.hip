@@ -406,9 +406,10 @@ FusedVariant select_variant(const Geometry& g, bool write_c)
         if (write_c) return FusedVariant{};
         const bool paired = g.paired;
         const int mode = detect_mode_of(g);
-        if (!g.runtime_ant && g.n_ant == 192) return fused16_variant_a192(g.n_ipo, mode, paired);
-        if (!g.runtime_ant && g.n_ant == 256) return fused16_variant_a256(g.n_ipo, mode, paired);
-        return g.n_ant > 192 ? fused16_variant_k4p16(g.n_ipo, mode, paired) : fused16_variant_k3p16(g.n_ipo, mode, paired);
+        const int ns = fused_col_tiles(g, paired);
+        if (!g.runtime_ant && g.n_ant == 192) return fused16_variant_a192(g.n_ipo, mode, paired, ns);
+        if (!g.runtime_ant && g.n_ant == 256) return fused16_variant_a256(g.n_ipo, mode, paired, ns);
+        return g.n_ant > 192 ? fused16_variant_k4p16(g.n_ipo, mode, paired, ns) : fused16_variant_k3p16(g.n_ipo, mode, paired, ns);
     }
     if (!nipo_supported(g.n_ipo) || g.n_ant <= 0 || g.n_ant > 128 || g.n_ant % 4) return FusedVariant{};
     const bool paired = g.paired && !write_c;
@@ -473,7 +474,6 @@ size_t weight_image_bytes(const Geometry& g)
 // the conjugate-pair kernel works on tiles of 16 base beams + their 16 mirror images
 bool pairing_supported(const Geometry& g)
 {
-    if (deep_class(g) && g.n_beams % 512) return false;   // the deep pair kernel's workgroups are 8 waves x 64 beams
     return DSABF_PAIRED && !use_generic(g) && g.n_beams % 32 == 0 && select_variant(g, false).launch != nullptr;
 }
 size_t weight_pair_image_bytes(const Geometry& g)
@@ -521,7 +521,7 @@ void read_env_switches(Geometry& g)
 // profiles/r03_variants_log.txt).
 int fused_col_tiles(const Geometry& g, bool paired)
 {
-    if (deep_class(g)) return paired ? 4 : 2;
+    if (deep_class(g)) return (paired && g.n_beams % 512 == 0 && !g.plain_col_tiles) ? 4 : 2;   // pair: 2 pair tiles per wave where 8 waves x 64 beams fill
     const bool rt = g.runtime_ant;
     // the instantiations that fit their registers (ns8_fits, bf_fused16.hpp): 16-byte-staged rows, or the compile-time 100 antennas
     const bool fits = g.n_ant % 16 == 0 || (!rt && g.n_ant == 100 && g.n_ipo < 64);

@@ -350,21 +350,24 @@ def test_debug_flow_end_to_end_on_a_geometry_only_the_generic_kernel_covers(bfmo
 
 # ---- the deep classes of fused16_kernel: three / four k-steps, weights stationary (129 ... 256 antennas) -----------------------
 @pytest.mark.parametrize("n_ant", [144, 192, 208, 256])
-@pytest.mark.parametrize("n_avg,paired", [(16, False), (8, False), (32, False), (16, True), (32, True)])
+@pytest.mark.parametrize("n_avg,paired", [(16, False), (8, False), (32, False), (16, True), (32, True), (16, 256), (8, 96)])
 def test_deep_classes_bit_exact_and_equal_to_the_generic_kernel(torch, bfmod, orc, monkeypatch, n_ant, n_avg, paired):
     """129 ... 256 antennas in 16-byte rows with windows of 16 / 32 / 64 samples run fused16_kernel with three or four k-steps:
     8-wave workgroups, two output slots per wave (general) or two pair tiles (conjugate-symmetric weights, beams in groups
     of 512), true-nibble operands.  Bit-exact vs the oracle in both bit-exact readings, within tolerance in the fast one, and
     the same bits as fusedg_kernel (DSABF_DEEP=0) on the same handle geometry; several chunks per workgroup, a ragged tail."""
-    n_beams = 512 if paired else 288
+    # paired: True = 512 beams (two pair tiles per wave), a number = that many beams (one pair tile per wave, a ragged workgroup)
+    n_beams = 512 if paired is True else paired if paired else 288
+    paired = bool(paired)
     g = orc.Geom(n_beams=n_beams, n_ant=n_ant, n_freq=2, n_avg=n_avg, n_out_per_gemm=3)
     rng = np.random.default_rng(n_ant * 3 + n_avg + paired)
     w = rng.integers(-127, 128, size=(g.n_freq, g.n_ant, g.n_beams, 2), dtype=np.int8)
     if n_ant == 256:                  # the extreme sums: |n| = 2032 * 256 in one beam (and, when paired, in its mirror image)
         w[0, :, 7] = -127
     if paired:
-        w[:, :, 256:, 0] = w[:, :, :256, 0][:, :, ::-1]
-        w[:, :, 256:, 1] = -w[:, :, :256, 1][:, :, ::-1]
+        hb = n_beams // 2
+        w[:, :, hb:, 0] = w[:, :, :hb, 0][:, :, ::-1]
+        w[:, :, hb:, 1] = -w[:, :, :hb, 1][:, :, ::-1]
     packed = rng.integers(0, 256, size=(5, g.n_freq, g.n_time, g.n_ant), dtype=np.uint8)
     if n_ant == 256:
         packed[2, 0] = 0x88

@@ -64,6 +64,8 @@ for n_ant in (144, 192, 224, 256):
 run(256, 512, 256, 16, 16, 16, None, "256 ant x 512 beams, deep general")
 run(256, 512, 256, 16, 16, 16, None, "256 ant x 512 beams, deep pair", paired=True)
 run(192, 512, 256, 16, 16, 16, None, "192 ant x 512 beams, deep pair", paired=True)
+run(256, 256, 256, 16, 16, 32, None, "256 ant x 256 beams, deep pair (1 tile/wave)", paired=True)
+run(192, 256, 256, 16, 16, 42, None, "192 ant x 256 beams, deep pair (1 tile/wave)", paired=True)
 # beyond that: only the generic kernel
 for n_ant in (132, 192, 256, 320, 512, 1024):
     run(n_ant, 256, 256, 16, 16, max(2, 2048 // n_ant), None, "%d antennas" % n_ant)
