@@ -622,10 +622,22 @@ __global__ __launch_bounds__(64 * WAVES, (fused_min_waves<AIN, NIPO, WRITE_C, NS
                     if (c + 2 < c_end) load_chunk(c + 2);
                 }
             };
+#ifndef DSABF_FRAG_AHEAD
+#define DSABF_FRAG_AHEAD 0   // experiment: deep classes request row tile t8 + 1's LDS fragments before tile t8's MFMAs (2 register sets)
+#endif
+            constexpr bool AHEAD = DSABF_FRAG_AHEAD && ant_deep<AIN>();
+            [[maybe_unused]] v4i fa0[2][KS], fa1[2][KS];
+            if constexpr (AHEAD) read_frag(0, fa0[0], fa1[0]);
 #pragma unroll
             for (int t8 = 0; t8 < 8; t8++) {   // (requesting tile t8+1's LDS fragments one tile early was tried: pair kernel
                 v4i a0[KS], a1[KS];            //  -2 % (129 VGPRs: 3 instead of 4 waves per SIMD), general +-0, r02 variants log)
-                read_frag(t8, a0, a1);
+                if constexpr (AHEAD) {
+                    if (t8 + 1 < 8) read_frag(t8 + 1, fa0[(t8 + 1) & 1], fa1[(t8 + 1) & 1]);
+#pragma unroll
+                    for (int h = 0; h < KS; h++) a0[h] = fa0[t8 & 1][h], a1[h] = fa1[t8 & 1][h];
+                } else {
+                    read_frag(t8, a0, a1);
+                }
 #pragma unroll
                 for (int t = 0; t < NT; t++) {   // (the compiler issues the first MFMAs of all chains before the dependent
                     v4i re[SPS], im[SPS];        //  second ones by itself; forcing that order changed nothing, r02 variants log)
