@@ -4,7 +4,8 @@
 detect, through bf_beamform_device, each compared bit for bit with the CPU oracle in the same reading.  Not part of the
 test suite (the suite runs seeded subsets).  Round 1: 3 seeds x 150 cases on the then whitelist, 0 mismatches.
 Round 4: FUZZ_GENERIC=1 draws antenna counts up to 636 and accumulation windows 1 ... 138 (fusedg_kernel).
-usage: SEED=1 CASES=150 [FUZZ_WIDE=1 | FUZZ_GENERIC=1] python tools/fuzz_long.py"""
+FUZZ_DEEP=1: 144 ... 256 antennas in 16-byte rows, windows 16 / 32 / 64 (the deep classes).
+usage: SEED=1 CASES=150 [FUZZ_WIDE=1 | FUZZ_GENERIC=1 | FUZZ_DEEP=1] python tools/fuzz_long.py"""
 import os
 import sys
 
@@ -33,6 +34,12 @@ for case in range(N):
         n_ipo = n_pol * n_avg
         n_out = int(rng.integers(1, 9))
         n_beams = 32 * int(rng.integers(1, 13)) if rng.integers(2) else 4 * int(rng.integers(1, 100))
+    if os.environ.get("FUZZ_DEEP") == "1":      # round 4: the three / four k-step classes of fused16_kernel (129 ... 256 antennas)
+        n_ant = 16 * int(rng.integers(9, 17))
+        n_pol, n_avg = 2, int(rng.choice([8, 16, 32]))
+        n_ipo = 2 * n_avg
+        n_out = int(rng.integers(1, 6))
+        n_beams = 512 * int(rng.integers(1, 3)) if rng.integers(3) == 0 else 32 * int(rng.integers(1, 20)) if rng.integers(2) else 4 * int(rng.integers(1, 150))
     if os.environ.get("FUZZ_WIDE") == "1":   # bias towards the 8-wave workgroups of the two-k-step classes (fused_wg_waves)
         n_ant = int(rng.choice([100, 128])) if rng.integers(3) == 0 else 4 * int(rng.integers(17, 33))
         n_avg = int(rng.choice([8, 16, 32]))
