@@ -73,6 +73,8 @@ struct FusedArgs {
     int chunks_total;                // 128-sample chunks per frequency in this launch
     int n_tsplit;                    // workgroups along time
     int interleave;                  // MFMA column tiles per wave if beams are dealt to them round-robin (beam_of_tile), else 0
+    // run-time accumulation window (template NIPO = 0): n_ipo, samples per stream = rt_kout * rt_L, windows per stream, chunks per stream group
+    int rt_L, rt_Ls, rt_kout, rt_cpg;
 };
 
 // Which beam MFMA column c of MFMA column tile `tile` computes.  A wave owns 16 * NS consecutive beams (paired: 8 * NS base
@@ -204,7 +206,14 @@ __global__ __launch_bounds__(64 * WAVES, (fused_min_waves<AIN, NIPO, WRITE_C, NS
     constexpr int THREADS = 64 * WAVES;
     constexpr bool FAST = MODE == kDetFast;
     constexpr bool CONTRACTED = MODE == kDetContracted;
-    static_assert(!FAST || (NIPO >= 16 && !WRITE_C), "the fast detect exists for n_ipo >= 16 only");
+    // NIPO = 0: the accumulation window is a RUN-TIME value (any n_pol * n_avg that is not one of the compile-time windows; round 4).
+    // A lane group's 32 rows of a chunk are then rt_kout whole windows back to back (or one window over rt_cpg chunks), padded
+    // to 32 rows -- the stream scheme of fusedg_kernel in this kernel's weight-stationary loop; window starts and ends are
+    // wave-uniform run-time flags per row.
+    constexpr bool RTW = NIPO == 0;
+    constexpr int MAPN = RTW ? 32 : NIPO;                // row <-> stream mapping and LDS swizzle: as for windows >= 32
+    static_assert(!FAST || ((NIPO >= 16 || RTW) && !WRITE_C), "the fast detect exists for n_ipo >= 16 only");
+    static_assert(!RTW || (WAVES == kWaves16 && NS == kColTiles16 && !ant_deep<AIN>()), "run-time windows: the plain launch shape");
     static_assert(!(PAIRED && WRITE_C), "the stage-parity path always runs the general kernel");
     static_assert(AIN >= kAntK3P16 && AIN != 0 && (AIN < 0 || AIN % 4 == 0) && AIN <= 256, "antenna class");
     static_assert(!ant_deep<AIN>() || (WAVES == 8 && NIPO >= 16 && !WRITE_C && (AIN < 0 || AIN % 16 == 0)), "deep classes: 8 waves, long windows, 16-byte rows");
@@ -226,7 +235,7 @@ __global__ __launch_bounds__(64 * WAVES, (fused_min_waves<AIN, NIPO, WRITE_C, NS
     constexpr int NT = PAIRED ? NS / 2 : NS;             // MFMA column tiles per wave (a paired tile feeds 2 slots)
     constexpr bool LONG = NIPO >= 16;
     constexpr int L = LONG ? NIPO : 16;                  // samples per stream
-    constexpr int LR = NIPO >= 32 ? 32 : 16;             // stream rows held by one chunk
+    constexpr int LR = (NIPO >= 32 || RTW) ? 32 : 16;    // stream rows held by one chunk
     constexpr int CPG = L > 32 ? L / 32 : 1;             // chunks per group of 4 streams
     constexpr int PPT = (TOTALP_MAX + THREADS - 1) / THREADS;  // pieces per thread per chunk (2; 4; 13 for 100 antennas)
     using stage_t = std::conditional_t<DW, int, v4i>;
@@ -241,9 +250,10 @@ __global__ __launch_bounds__(64 * WAVES, (fused_min_waves<AIN, NIPO, WRITE_C, NS
 
     int f, bg, ts;
     decode_block(a, f, bg, ts);
-    const int units_total = a.chunks_total / CPG;
-    const int c_begin = (int)(((long long)units_total * ts) / a.n_tsplit) * CPG;
-    const int c_end = (int)(((long long)units_total * (ts + 1)) / a.n_tsplit) * CPG;
+    const int cpg_rt = RTW ? a.rt_cpg : CPG;            // (constant-folded unless the window is a run-time value)
+    const int units_total = a.chunks_total / cpg_rt;
+    const int c_begin = (int)(((long long)units_total * ts) / a.n_tsplit) * cpg_rt;
+    const int c_end = (int)(((long long)units_total * (ts + 1)) / a.n_tsplit) * cpg_rt;
 
     // ---- which beams this lane produces, and the weight fragments ------------------------------------------
     int slot_beam[NS];                                    // beam index of output slot s (>= n_beams: none)
@@ -291,7 +301,9 @@ __global__ __launch_bounds__(64 * WAVES, (fused_min_waves<AIN, NIPO, WRITE_C, NS
 
     // ---- staging (the chunk's 128 samples are contiguous in time for n_ipo <= 32) ------------------------------
     auto run_sample0 = [&](int c, int run) -> unsigned {   // first global sample of stream-run `run` of chunk c
-        if constexpr (NIPO >= 32)
+        if constexpr (RTW)
+            return (4u * (unsigned)(c / cpg_rt) + (unsigned)run) * (unsigned)a.rt_Ls + 32u * (unsigned)(c % cpg_rt);
+        else if constexpr (NIPO >= 32)
             return (4u * (unsigned)(c / CPG) + (unsigned)run) * (unsigned)L + 32u * (unsigned)(c % CPG);
         else
             return (unsigned)c * 128u + 16u * (unsigned)run;
@@ -302,7 +314,7 @@ __global__ __launch_bounds__(64 * WAVES, (fused_min_waves<AIN, NIPO, WRITE_C, NS
     // per-lane part (row and piece) is a constant 32-bit offset: no vector integer arithmetic (the generic
     // path costs ~17 VALU ops, 6 of them quarter-rate 32-bit multiplies, per load).
     constexpr unsigned SPAN = (NIPO == 64) ? 256u : 128u;
-    const bool fast_addr = DSABF_FASTADDR && ((unsigned)a.T % SPAN) == 0;
+    const bool fast_addr = DSABF_FASTADDR && !RTW && ((unsigned)a.T % SPAN) == 0;
     // Piece k of this thread is piece pc = tid + 256 k of the chunk: row pc / PPR, position pc % PPR.  Its byte offset
     // from the chunk's first sample is PB * pc (rows are PPR * PB bytes and consecutive) -- except for n_ipo = 64, whose
     // chunk rows are four runs of 32 samples, 64 apart.  The 16*im image sits 4 pieces away from the 16*re image (after it
@@ -316,7 +328,7 @@ __global__ __launch_bounds__(64 * WAVES, (fused_min_waves<AIN, NIPO, WRITE_C, NS
         if constexpr (NIPO == 64) lane_off64[k] = (unsigned)((row / LR) * L + (row % LR)) * A + pi * PB;
         const int blk = DW ? pi / 4 : pi;                            // 16-antenna block of the piece
         const int h = blk / 4, kp = blk % 4, sub = DW ? 4 * (pi % 4) : 0;
-        lds_re[k] = h * PLANE + row * RB + 16 * swz16<NIPO>(kp + 4 * (h & 1), row) + sub;  // plane 1: halves swapped
+        lds_re[k] = h * PLANE + row * RB + 16 * swz16<MAPN>(kp + 4 * (h & 1), row) + sub;  // plane 1: halves swapped
     }
     auto lane_off = [&](int k) -> unsigned {
         if constexpr (NIPO == 64)
@@ -360,7 +372,9 @@ __global__ __launch_bounds__(64 * WAVES, (fused_min_waves<AIN, NIPO, WRITE_C, NS
             const int row = (pc / PPR) % kRowsPerChunk, pi = pc % PPR;   //  the path of small DEBUG-style gemm-units only)
             const unsigned s0 = run_sample0(c, row / LR) + (unsigned)(row % LR);
             stage[k] = stage_t{};
-            if (s0 < a.S && piece_live(k)) {
+            bool row_ok = s0 < a.S;
+            if constexpr (RTW) row_ok = row_ok && 32u * (unsigned)(c % cpg_rt) + (unsigned)(row % LR) < (unsigned)a.rt_Ls;   // not a padding row
+            if (row_ok && piece_live(k)) {
                 const unsigned u = a.t_shift >= 0 ? (s0 >> a.t_shift) : (s0 / (unsigned)a.T);
                 const unsigned t = s0 - u * (unsigned)a.T;
                 stage[k] = *reinterpret_cast<const stage_t*>(a.in + ((size_t)((size_t)u * a.n_freq + f) * a.T + t) * A + pi * PB);
@@ -466,6 +480,18 @@ __global__ __launch_bounds__(64 * WAVES, (fused_min_waves<AIN, NIPO, WRITE_C, NS
             if (c + 2 < c_end) load_chunk(c + 2);
         } else {
             [[maybe_unused]] float ov[2][NS];   // n_ipo < 16: the outputs the current tile completed, per slot
+            // run-time window (RTW): where the windows of this lane group's stream start and end in the current row tile, the
+            // sums that ended there, and the stream-relative index of their outputs -- wave-uniform
+            [[maybe_unused]] bool rt_st[4] = {false, false, false, false}, rt_en[4] = {false, false, false, false};
+            [[maybe_unused]] unsigned rt_o[4] = {0, 0, 0, 0};
+            [[maybe_unused]] float rt_x[4][NS];
+            [[maybe_unused]] int rt_m = 0;            // position of the next row inside its window
+            [[maybe_unused]] unsigned rt_oq = 0;      // windows of the stream that ended before the next row
+            if constexpr (RTW) {
+                const unsigned p0 = 32u * (unsigned)(c % cpg_rt);
+                rt_m = (int)(p0 % (unsigned)a.rt_L);
+                rt_oq = p0 / (unsigned)a.rt_L;
+            }
             // detect + accumulate the 4 samples (fr, fi: accumulator bit patterns K + 16 n) of output slot sl
             auto detect = [&](const int t8, const v4f fr, const v4f fi, const int sl) {
                 // stream position of this tile's rows and whether it starts / ends an output
@@ -474,7 +500,42 @@ __global__ __launch_bounds__(64 * WAVES, (fused_min_waves<AIN, NIPO, WRITE_C, NS
                 const unsigned grp = (NIPO >= 32) ? (unsigned)(c / CPG) : (2u * (unsigned)c + gi);
                 const unsigned o = 4u * grp + (unsigned)g4;           // this lane's stream (output index if LONG)
                 const int beam = slot_beam[sl];
-                if constexpr (WRITE_C) {
+                if constexpr (WRITE_C && RTW) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const unsigned pos = 32u * (unsigned)(c % cpg_rt) + 4u * t8 + r;
+                        const unsigned sidx = (4u * (unsigned)(c / cpg_rt) + (unsigned)g4) * (unsigned)a.rt_Ls + pos;
+                        if (pos < (unsigned)a.rt_Ls && sidx < a.S && beam < a.n_beams) {
+                            v2f cv = {__builtin_fmaf(fr[r], kA, kNKA), __builtin_fmaf(fi[r], kA, kNKA)};
+                            *reinterpret_cast<v2f*>(a.out + 2 * (((size_t)f * a.T + sidx) * a.n_beams + beam)) = cv;
+                        }
+                    }
+                } else if constexpr (RTW) {
+                    // run-time window: rt_st[r] / rt_en[r] say whether a window starts / ends at register r of this row tile
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        if constexpr (FAST) {
+                            const float dr = fr[r] - kMagic, di = fi[r] - kMagic;
+                            float sacc = rt_st[r] ? 0.0f : sum[sl];
+                            sacc = __builtin_fmaf(dr, dr, sacc);
+                            sum[sl] = __builtin_fmaf(di, di, sacc);
+                            if (rt_en[r]) rt_x[r][sl] = sum[sl] * (kA * kA);
+                        } else {
+                            const float x = __builtin_fmaf(fr[r], kA, kNKA);
+                            const float y = __builtin_fmaf(fi[r], kA, kNKA);
+                            const float yy = y * y;
+                            float pp;
+                            if constexpr (CONTRACTED) {
+                                pp = __builtin_fmaf(x, x, yy);
+                            } else {
+                                const float xx = x * x;
+                                pp = xx + yy;
+                            }
+                            sum[sl] = rt_st[r] ? pp : sum[sl] + pp;
+                            if (rt_en[r]) rt_x[r][sl] = sum[sl];
+                        }
+                    }
+                } else if constexpr (WRITE_C) {
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
                         const unsigned sidx = o * (unsigned)L + (unsigned)(q4 + r);
@@ -548,7 +609,7 @@ __global__ __launch_bounds__(64 * WAVES, (fused_min_waves<AIN, NIPO, WRITE_C, NS
             };
             // stores of the outputs a short-window (n_ipo < 16) tile completed
             auto store_short = [&](const int t8) {
-                if constexpr (!LONG && !WRITE_C) {
+                if constexpr (!LONG && !WRITE_C && !RTW) {
                     const int gi = t8 >> 2, q4 = 4 * (t8 & 3);
                     const unsigned o = 4u * (2u * (unsigned)c + gi) + (unsigned)g4;   // this lane's 16-sample stream
                     if (o * 16u < a.S) {
@@ -567,11 +628,11 @@ __global__ __launch_bounds__(64 * WAVES, (fused_min_waves<AIN, NIPO, WRITE_C, NS
 
             // LDS fragments of row-tile t8: a0[h] = 16*re, a1[h] = 16*im of 16 antennas x 16 samples per lane group, k-step h
             auto read_frag = [&](const int t8, v4i (&a0)[KS], v4i (&a1)[KS]) {
-                const int row = lds_row16<NIPO>(t8, c16);
+                const int row = lds_row16<MAPN>(t8, c16);
 #pragma unroll
                 for (int h = 0; h < KS; h++) {  // plane 1 keeps (im | re): the two planes' staging writes then never collide
-                    a0[h] = *reinterpret_cast<const v4i*>(cur + h * PLANE + row * RB + 16 * swz16<NIPO>(g4 + 4 * (h & 1), row));
-                    a1[h] = *reinterpret_cast<const v4i*>(cur + h * PLANE + row * RB + 16 * swz16<NIPO>(g4 + 4 * ((h & 1) ^ 1), row));
+                    a0[h] = *reinterpret_cast<const v4i*>(cur + h * PLANE + row * RB + 16 * swz16<MAPN>(g4 + 4 * (h & 1), row));
+                    a1[h] = *reinterpret_cast<const v4i*>(cur + h * PLANE + row * RB + 16 * swz16<MAPN>(g4 + 4 * ((h & 1) ^ 1), row));
                 }
             };
             // acc = seed + sum over the k-steps of x[h] * w[h]  (one MFMA per k-step, chained through srcC)
@@ -638,11 +699,31 @@ __global__ __launch_bounds__(64 * WAVES, (fused_min_waves<AIN, NIPO, WRITE_C, NS
                 } else {
                     read_frag(t8, a0, a1);
                 }
+                if constexpr (RTW) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        rt_st[r] = rt_m == 0;
+                        rt_en[r] = ++rt_m == a.rt_L;
+                        if (rt_en[r]) {
+                            rt_m = 0;
+                            rt_o[r] = rt_oq++;
+                        }
+                    }
+                }
 #pragma unroll
                 for (int t = 0; t < NT; t++) {   // (the compiler issues the first MFMAs of all chains before the dependent
                     v4i re[SPS], im[SPS];        //  second ones by itself; forcing that order changed nothing, r02 variants log)
                     issue(a0, a1, t, re, im);
                     consume(t8, t, re, im);
+                }
+                if constexpr (RTW && !WRITE_C) {   // the windows that ended in this row tile: their sums leave at once
+                    const unsigned sigma = 4u * (unsigned)(c / cpg_rt) + (unsigned)g4;      // this lane's stream
+#pragma unroll
+                    for (int r = 0; r < 4; r++)
+                        if (rt_en[r]) {
+                            const unsigned o = sigma * (unsigned)a.rt_kout + rt_o[r];
+                            if ((unsigned long long)o * (unsigned)a.rt_L < a.S) store_slots(a.out + (size_t)o * FB + (size_t)f * a.n_beams, rt_x[r]);
+                        }
                 }
                 store_short(t8);
                 staging(t8);
@@ -716,7 +797,7 @@ FusedVariant fused16_variant_nipo(bool write_c, int mode, bool paired)
         if constexpr (WAVES == kWaves16) return make_variant<AIN, NIPO, true, kDetCanonical, false, WAVES>();
         return FusedVariant{};
     }
-    if constexpr (NIPO >= 16) {
+    if constexpr (NIPO >= 16 || NIPO == 0) {   // (a run-time window: the caller asks for the fast detect only from 16 samples on)
         if (mode == kDetFast)
             return paired ? make_variant<AIN, NIPO, false, kDetFast, true, WAVES>() : make_variant<AIN, NIPO, false, kDetFast, false, WAVES>();
     }
@@ -738,7 +819,7 @@ FusedVariant fused16_variant(int n_ipo, bool write_c, int mode, bool paired)
         case 16: return fused16_variant_nipo<AIN, 16, kWaves16>(write_c, mode, paired);
         case 32: return fused16_variant_nipo<AIN, 32, kWaves16>(write_c, mode, paired);
         case 64: return fused16_variant_nipo<AIN, 64, kWaves16>(write_c, mode, paired);
-        default: return FusedVariant{};
+        default: return fused16_variant_nipo<AIN, 0, kWaves16>(write_c, mode, paired);   // run-time window (the caller passes n_ipo = 0)
     }
 }
 

@@ -32,6 +32,7 @@ struct Geometry {
     int lds_pad = 0;                                    // DSABF_LDS_PAD=bytes: extra dynamic LDS (fewer resident workgroups); clamped
     bool dm_wide = true;                                // DSABF_DM_WIDE=0: the per-thread-window DM kernel alone
     bool force_generic = false;                         // DSABF_GENERIC=1: fusedg_kernel (bf_fusedg.hip) for every geometry
+    bool no_rtw = false;                                // DSABF_RTW=0: no run-time-window instantiations of fused16_kernel (-> fusedg_kernel)
     bool no_deep = false;                               // DSABF_DEEP=0: no three / four k-step classes of fused16_kernel (-> fusedg_kernel)
 };
 constexpr int kLdsPerCuBytes = 160 * 1024;

@@ -395,6 +395,12 @@ int interleaved(const Geometry& g, bool paired)
     return paired ? ns / 2 : ns;
 }
 bool nipo_supported(int n_ipo) { return n_ipo == 2 || n_ipo == 4 || n_ipo == 8 || n_ipo == 16 || n_ipo == 32 || n_ipo == 64; }
+// Accumulation windows that have no compile-time instantiation (or short windows in gemm-units that are not whole 16-sample
+// runs) run fused16_kernel's run-time-window instantiations (template NIPO = 0), up to 128 antennas; DSABF_RTW=0: fusedg_kernel.
+bool rtw_class(const Geometry& g)
+{
+    return !g.force_generic && !g.no_rtw && g.n_ant <= 128 && g.n_ipo > 0 && (!nipo_supported(g.n_ipo) || (g.n_ipo < 16 && g.n_time % 16));
+}
 int detect_mode_of(const Geometry& g) { return g.fast_detect ? kDetFast : g.contracted_detect ? kDetContracted : kDetCanonical; }
 
 // 64, 100 and 128 antennas (the reference, BASELINE config 5 and the full k-step) have compile-time instantiations; every
@@ -411,9 +417,10 @@ FusedVariant select_variant(const Geometry& g, bool write_c)
         if (!g.runtime_ant && g.n_ant == 256) return fused16_variant_a256(g.n_ipo, mode, paired, ns);
         return g.n_ant > 192 ? fused16_variant_k4p16(g.n_ipo, mode, paired, ns) : fused16_variant_k3p16(g.n_ipo, mode, paired, ns);
     }
-    if (!nipo_supported(g.n_ipo) || g.n_ant <= 0 || g.n_ant > 128 || g.n_ant % 4) return FusedVariant{};
+    if ((!nipo_supported(g.n_ipo) && !rtw_class(g)) || g.n_ant <= 0 || g.n_ant > 128 || g.n_ant % 4) return FusedVariant{};
     const bool paired = g.paired && !write_c;
-    const int mode = detect_mode_of(g);
+    const int sel_ipo = rtw_class(g) ? 0 : g.n_ipo;     // 0: the run-time-window instantiations (every fused16_variant's default)
+    const int mode = (detect_mode_of(g) == kDetFast && g.n_ipo < 16) ? kDetCanonical : detect_mode_of(g);   // fast: from 16 samples on
     const bool rt = g.runtime_ant;
     const bool ns8 = kColTiles16 != kColTilesWide16 && fused_col_tiles(g, paired) == kColTilesWide16;   // (a -DDSABF_NS=8 build: every kernel)
     if (ns8) {
@@ -432,13 +439,13 @@ FusedVariant select_variant(const Geometry& g, bool write_c)
         return g.n_ant % 16 == 0 ? fused16_variant_k2p16_w8(g.n_ipo, mode) : fused16_variant_k2p4_w8(g.n_ipo, mode);
     }
     if (!rt) {
-        if (g.n_ant == 64) return fused16_variant_a64(g.n_ipo, write_c, mode, paired);
-        if (g.n_ant == 100) return fused16_variant_a100(g.n_ipo, write_c, mode, paired);
-        if (g.n_ant == 128) return fused16_variant_a128(g.n_ipo, write_c, mode, paired);
+        if (g.n_ant == 64) return fused16_variant_a64(sel_ipo, write_c, mode, paired);
+        if (g.n_ant == 100) return fused16_variant_a100(sel_ipo, write_c, mode, paired);
+        if (g.n_ant == 128) return fused16_variant_a128(sel_ipo, write_c, mode, paired);
     }
     if (g.n_ant <= 64)
-        return g.n_ant % 16 == 0 ? fused16_variant_k1p16(g.n_ipo, write_c, mode, paired) : fused16_variant_k1p4(g.n_ipo, write_c, mode, paired);
-    return g.n_ant % 16 == 0 ? fused16_variant_k2p16(g.n_ipo, write_c, mode, paired) : fused16_variant_k2p4(g.n_ipo, write_c, mode, paired);
+        return g.n_ant % 16 == 0 ? fused16_variant_k1p16(sel_ipo, write_c, mode, paired) : fused16_variant_k1p4(sel_ipo, write_c, mode, paired);
+    return g.n_ant % 16 == 0 ? fused16_variant_k2p16(sel_ipo, write_c, mode, paired) : fused16_variant_k2p4(sel_ipo, write_c, mode, paired);
 }
 
 int ilog2_exact(int v)
@@ -462,7 +469,8 @@ hipError_t dispatch_fused(const Geometry& g, bool write_c, const FusedArgs& args
 // windows that are not a power of two (or longer than 64), short windows in gemm-units that are not whole 16-sample runs.
 bool use_generic(const Geometry& g)
 {
-    return g.force_generic || (g.n_ant > 128 && !deep_class(g)) || !nipo_supported(g.n_ipo) || (g.n_ipo < 16 && g.n_time % 16);
+    if (g.force_generic || (g.n_ant > 128 && !deep_class(g))) return true;
+    return (!nipo_supported(g.n_ipo) || (g.n_ipo < 16 && g.n_time % 16)) && !rtw_class(g);
 }
 
 size_t weight_image_bytes(const Geometry& g)
@@ -510,6 +518,8 @@ void read_env_switches(Geometry& g)
     g.force_generic = gen && gen[0] == '1';
     const char* nd = getenv("DSABF_DEEP");
     g.no_deep = nd && nd[0] == '0';
+    const char* nr = getenv("DSABF_RTW");
+    g.no_rtw = nr && nr[0] == '0';
 }
 
 // Output slots (16 beams each) per wave.  The two-k-step conjugate-pair kernels hold 2 waves per SIMD whatever they do (64 KiB of
@@ -525,7 +535,8 @@ int fused_col_tiles(const Geometry& g, bool paired)
     const bool rt = g.runtime_ant;
     // the instantiations that fit their registers (ns8_fits, bf_fused16.hpp): 16-byte-staged rows, or the compile-time 100 antennas
     const bool fits = g.n_ant % 16 == 0 || (!rt && g.n_ant == 100 && g.n_ipo < 64);
-    const bool can = paired && fits && kColTiles16 == 4 && kWaves16 == 4 && ksteps16(g) == 2 && g.n_ipo >= 16 && g.n_beams % 512 == 0;
+    const bool can = paired && fits && kColTiles16 == 4 && kWaves16 == 4 && ksteps16(g) == 2 && g.n_ipo >= 16 && nipo_supported(g.n_ipo) &&
+                     g.n_beams % 512 == 0;
     return (can && !g.plain_col_tiles) ? kColTilesWide16 : kColTiles16;
 }
 
@@ -537,7 +548,7 @@ int fused_col_tiles(const Geometry& g, bool paired)
 int fused_wg_waves(const Geometry& g, bool write_c)
 {
     if (deep_class(g) && !write_c) return kWavesWide16;
-    const bool can = !write_c && ksteps16(g) == 2 && g.n_ipo >= 16 && kWaves16 == 4 && kColTiles16 == 4 &&
+    const bool can = !write_c && ksteps16(g) == 2 && g.n_ipo >= 16 && nipo_supported(g.n_ipo) && kWaves16 == 4 && kColTiles16 == 4 &&
                      ((g.n_beams + 255) / 256) % 2 == 0 && fused_col_tiles(g, g.paired) == kColTiles16;
     return (can && !g.plain_wg_waves) ? kWavesWide16 : kWaves16;
 }
@@ -552,7 +563,13 @@ LaunchShape fused_launch_shape(const Geometry& g, int n_units, int n_cus, bool w
     const long long S = (long long)n_units * g.n_time;
     long long rows;
     int cpg = 1;  // chunks per output group: a workgroup's chunk range must cover whole groups
-    if (g.n_ipo >= 16) {
+    if (rtw_class(g)) {                                  // run-time window: streams of kout whole windows, 32 rows per chunk
+        const int kout = g.n_ipo <= 32 ? 32 / g.n_ipo : 1;
+        const long long Ls = (long long)kout * g.n_ipo;
+        cpg = (int)((Ls + 31) / 32);
+        const long long groups = ((S + Ls - 1) / Ls + 3) / 4;
+        rows = groups * cpg * kRowsPerChunk;
+    } else if (g.n_ipo >= 16) {
         const long long groups = (S / g.n_ipo + 3) / 4;  // a lane group carries one output: 4 outputs advance together
         rows = groups * 4 * g.n_ipo;
         if (4 * g.n_ipo > kRowsPerChunk) cpg = 4 * g.n_ipo / kRowsPerChunk;
@@ -624,6 +641,12 @@ static FusedArgs make_args(const Geometry& g, const void* d_image, const void* d
     a.chunks_total = ls.chunks_total;
     a.n_tsplit = ls.n_tsplit;
     a.interleave = interleaved(g, g.paired);
+    if (rtw_class(g)) {
+        a.rt_L = g.n_ipo;
+        a.rt_kout = g.n_ipo <= 32 ? 32 / g.n_ipo : 1;
+        a.rt_Ls = a.rt_kout * a.rt_L;
+        a.rt_cpg = (a.rt_Ls + 31) / 32;
+    }
     return a;
 }
 
@@ -787,8 +810,8 @@ const char* fused_kernel_name(const Geometry& g, char* buf, size_t n)
         return buf;
     }
     const bool rt = !(g.n_ant == 64 || g.n_ant == 100 || g.n_ant == 128 || g.n_ant == 192 || g.n_ant == 256);   // (the geometry's class; DSABF_RUNTIME_ANT is not shown)
-    snprintf(buf, n, "dsabf::fused16_kernel<ANT=%d%s,NIPO=%d%s%s%s> (v_mfma_i32_16x16x64_i8)", g.n_ant, rt ? "(run-time)" : "",
-             g.n_ipo, (g.fast_detect && g.n_ipo >= 16) ? ",FAST" : g.contracted_detect ? ",CONTRACTED" : "",
+    snprintf(buf, n, "dsabf::fused16_kernel<ANT=%d%s,NIPO=%d%s%s%s%s> (v_mfma_i32_16x16x64_i8)", g.n_ant, rt ? "(run-time)" : "",
+             g.n_ipo, rtw_class(g) ? "(run-time)" : "", (g.fast_detect && g.n_ipo >= 16) ? ",FAST" : g.contracted_detect ? ",CONTRACTED" : "",
              g.paired ? ",PAIRED" : "",
              fused_col_tiles(g, g.paired) == kColTilesWide16 ? ",SLOTS=8" : fused_wg_waves(g) == kWavesWide16 ? ",WAVES=8" : "");
     return buf;

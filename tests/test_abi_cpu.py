@@ -71,12 +71,12 @@ def test_error_convention_without_gpu(lib):
     assert lib.bf_create(C.byref(cfg), 0, C.byref(h)) == -1
     assert b"2048 antennas" in lib.bf_last_error()
     assert not h.value
-    cfg.n_ant, cfg.n_avg = 64, 3  # n_ipo = 6: since round 4 a supported geometry (fusedg_kernel) -> the refusal is the missing GPU
+    cfg.n_ant, cfg.n_avg = 64, 3  # n_ipo = 6: since round 4 a supported geometry -> the refusal is the missing GPU
     assert lib.bf_create(C.byref(cfg), 0, C.byref(h)) == -3
     assert not h.value
     # which kernel a geometry runs is host arithmetic (bf_launch_plan): the reference's whole contract has one
     name = C.create_string_buffer(200)
-    for n_ant, n_avg, expect in ((64, 16, b"fused16_kernel"), (100, 16, b"fused16_kernel"), (64, 3, b"fusedg_kernel"),
+    for n_ant, n_avg, expect in ((64, 16, b"fused16_kernel"), (100, 16, b"fused16_kernel"), (64, 3, b"fused16_kernel<ANT=64,NIPO=6(run-time)>"),
                                  (132, 16, b"fusedg_kernel<ANT=132 (3 k-steps, 4-byte staging)"), (320, 16, b"(5 k-steps, 16-byte staging)"),
                                  (256, 16, b"fused16_kernel<ANT=256,NIPO=32,WAVES=8>"), (144, 8, b"fused16_kernel<ANT=144(run-time),NIPO=16,WAVES=8>")):
         cfg.n_ant, cfg.n_avg = n_ant, n_avg

@@ -222,9 +222,9 @@ def test_geometry_refusals_name_the_reference_rule(bfmod):
             bfmod.Beamformer(bfmod.debug_config(**kw))
         assert text in str(e.value), (kw, str(e.value))
     # round 4: what rounds 1-3 refused inside the reference's contract now has a kernel (csrc/bf_fusedg.hip)
-    for kw in (dict(n_ant=132), dict(n_avg=3), dict(n_avg=1, n_out_per_gemm=3)):
+    for kw, kern in ((dict(n_ant=132), "fusedg_kernel"), (dict(n_avg=3), "NIPO=6(run-time)"), (dict(n_avg=1, n_out_per_gemm=3), "NIPO=2(run-time)")):
         bf = bfmod.Beamformer(bfmod.debug_config(n_freq=2, n_beams=32, **kw))
-        assert "fusedg_kernel" in bf.kernel_info(1)["kernel"]
+        assert kern in bf.kernel_info(1)["kernel"]
         bf.close()
 
 

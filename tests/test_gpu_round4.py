@@ -242,10 +242,12 @@ def test_any_accumulation_window_bit_exact(torch, bfmod, orc, n_pol, n_avg, n_an
     rng = np.random.default_rng(97 * n_avg + n_pol + n_ant)
     w = rng.integers(-127, 128, size=(g.n_freq, g.n_ant, g.n_beams, 2), dtype=np.int8)
     packed = rng.integers(0, 256, size=(3, g.n_freq, g.n_time, g.n_ant), dtype=np.uint8)
+    # up to 128 antennas: the run-time-window instantiations of fused16_kernel; beyond: fusedg_kernel
+    expect = "fused16_kernel<ANT=%d,NIPO=%d(run-time)" % (n_ant, g.n_ipo) if n_ant <= 128 else "fusedg_kernel"
     for mode, contract in ((0, orc.CONTRACT_NONE), (2, orc.CONTRACT_NVCC)):
         bf = bfmod.Beamformer(_cfg_of(bfmod, g, detect_mode=mode))
         bf.set_weights(w)
-        assert "fusedg_kernel" in bf.kernel_info(3)["kernel"]
+        assert expect in bf.kernel_info(3)["kernel"], bf.kernel_info(3)["kernel"]
         with orc.detect_contract(contract):
             want = orc.beamform(g, w, packed)
         got = _beamform(torch, bf, packed, want.size).reshape(want.shape)
@@ -447,4 +449,57 @@ def test_units_queued_before_a_weight_change_run_under_the_old_weights(torch, bf
     bf.sync(-1)
     assert np.array_equal(outs[0].numpy().reshape(want.shape[2:]), want[0, 3])
     assert np.array_equal(outs[1].numpy().reshape(want.shape[2:]), orc.beamform(g, w2, blocks[0][3:4])[0])
+    bf.close()
+
+
+@pytest.mark.parametrize("n_ant", [64, 36, 100, 128, 80])
+@pytest.mark.parametrize("n_pol,n_avg,n_out", [(2, 3, 5), (2, 12, 3), (2, 20, 2), (1, 7, 9), (2, 1, 3), (2, 50, 1), (1, 1, 5), (2, 4, 3)])
+def test_run_time_window_instantiations_equal_the_generic_kernel(torch, bfmod, orc, monkeypatch, n_ant, n_pol, n_avg, n_out):
+    """Windows without a compile-time instantiation -- and short windows in gemm-units that are not whole 16-sample runs (n_ipo 2
+    with 3 outputs, n_ipo 8 with 3) -- run fused16_kernel<..., NIPO = 0> up to 128 antennas: every antenna class, general and
+    conjugate-pair weights, all three detect modes, several chunks per workgroup; the bits of fusedg_kernel (DSABF_RTW=0) and,
+    in the two bit-exact readings, of the oracle."""
+    g = orc.Geom(n_beams=96, n_ant=n_ant, n_freq=2, n_pol=n_pol, n_avg=n_avg, n_out_per_gemm=n_out)
+    rng = np.random.default_rng(n_ant * 11 + n_avg * 3 + n_out)
+    w = rng.integers(-127, 128, size=(g.n_freq, g.n_ant, g.n_beams, 2), dtype=np.int8)
+    if (n_ant + n_avg) % 2:                            # conjugate-symmetric weights: the pair kernel
+        w[:, :, 48:, 0] = w[:, :, :48, 0][:, :, ::-1]
+        w[:, :, 48:, 1] = -w[:, :, :48, 1][:, :, ::-1]
+    n_units = max(2, -(-700 // g.n_time))
+    packed = rng.integers(0, 256, size=(n_units, g.n_freq, g.n_time, g.n_ant), dtype=np.uint8)
+    monkeypatch.setenv("DSABF_TSPLIT", "2")
+    res = {}
+    for rtw in (True, False):
+        if rtw:
+            monkeypatch.delenv("DSABF_RTW", raising=False)
+        else:
+            monkeypatch.setenv("DSABF_RTW", "0")
+        for mode in (0, 1, 2):
+            bf = bfmod.Beamformer(_cfg_of(bfmod, g, detect_mode=mode))
+            bf.set_weights(w)
+            name = bf.kernel_info(n_units)["kernel"]
+            assert ("fused16_kernel" in name and "NIPO=%d(run-time)" % g.n_ipo in name) if rtw else "fusedg_kernel" in name, name
+            res[rtw, mode] = _beamform(torch, bf, packed, n_units * g.out_per_gemm)
+            bf.close()
+    monkeypatch.delenv("DSABF_RTW", raising=False)
+    monkeypatch.delenv("DSABF_TSPLIT", raising=False)
+    for mode in (0, 1, 2):
+        assert np.array_equal(res[True, mode], res[False, mode]), mode
+    for mode, contract in ((0, orc.CONTRACT_NONE), (2, orc.CONTRACT_NVCC)):
+        with orc.detect_contract(contract):
+            assert np.array_equal(res[True, mode].reshape(-1), orc.beamform(g, w, packed).reshape(-1)), mode
+
+
+def test_run_time_window_stage_parity(torch, bfmod, orc):
+    """bf_gemm_device (the reference's d_C) through the run-time-window instantiation: n_ipo 6, 100 antennas."""
+    g = orc.Geom(n_beams=40, n_ant=100, n_freq=3, n_avg=3, n_out_per_gemm=7)
+    rng = np.random.default_rng(5)
+    w = rng.integers(-127, 128, size=(g.n_freq, g.n_ant, g.n_beams, 2), dtype=np.int8)
+    unit = rng.integers(0, 256, size=(g.n_freq, g.n_time, g.n_ant), dtype=np.uint8)
+    bf = bfmod.Beamformer(_cfg_of(bfmod, g))
+    bf.set_weights(w)
+    d_c = torch.full((g.n_freq, g.n_time, g.n_beams, 2), float("nan"), dtype=torch.float32, device="cuda")
+    bf.gemm(torch.from_numpy(unit).cuda(), d_c, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(d_c.cpu().numpy().reshape(-1), np.asarray(orc.gemm(g, w, orc.expand(unit))).reshape(-1))
     bf.close()

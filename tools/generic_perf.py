@@ -74,4 +74,6 @@ for n_ant in (192, 256, 512):       # the same with launches of 1 GiB of voltage
 run(256, 512, 1024, 16, 8, 4, None, "256 ant, C5-like band")
 # accumulation windows that are not a power of two (64 antennas)
 for n_avg in (3, 5, 12, 20, 48):
-    run(64, 256, 256, n_avg, max(1, 256 // n_avg), 32, None, "n_avg %d" % n_avg)
+    run(64, 256, 256, n_avg, max(1, 256 // n_avg), 32, None, "n_avg %d, fused16 run-time window" % n_avg)
+    run(64, 256, 256, n_avg, max(1, 256 // n_avg), 32, True, "n_avg %d, fusedg" % n_avg)
+run(100, 512, 256, 12, 10, 16, None, "100 ant n_avg 12, fused16 run-time window")
