@@ -51,7 +51,7 @@ struct bf_handle {
     };
     std::vector<pending_unit> pending;
     bool coalesce = true;         // DSABF_COALESCE=0 / bf_set_switch("coalesce", 0): one launch per call, the literal pattern
-    uint64_t flush_seq = 0;       // flushes rotate over the compute queues
+    uint64_t flush_seq = 0;       // flushes alternate between the first two compute queues
     hipEvent_t flush_done = nullptr;   // end of the previous flush's host copies: the next flush's copies queue behind it
     bool flush_recorded = false;
     uint64_t n_fused_launches = 0;        // fused-kernel launches this handle has issued (bf_get_counter)
@@ -498,7 +498,9 @@ static int flush_units(bf_handle* h)
     if (h->pending.empty()) return BF_OK;
     std::vector<bf_handle::pending_unit> units;
     units.swap(h->pending);              // (whatever happens below, nothing stays queued)
-    const int q = (int)(h->flush_seq++ % (uint64_t)h->cfg.n_streams);
+    // two queues take turns (each owns a block-sized device buffer, allocated at first use): flush i + 1's kernel runs under
+    // flush i's host copies; more queues would only hold more buffers
+    const int q = (int)(h->flush_seq++ % (uint64_t)(h->cfg.n_streams < 2 ? 1 : 2));
     hipStream_t s = h->streams[q];
     const size_t per_gemm = bf_bytes_per_gemm(&h->cfg), per_det = bf_floats_per_detect(&h->cfg);
     const size_t n_beams = (size_t)h->cfg.n_beams;
