@@ -669,15 +669,25 @@ __global__ __launch_bounds__(64 * WAVES, (fused_min_waves<AIN, NIPO, WRITE_C, NS
                     im[0] = dot(a1, bw[t][DSABF_GEN3 ? 0 : 3], dot(a0, bw[t][2], kc));   // Wi*Vr + Wr*Vi
                 }
             };
+#ifndef DSABF_ABL16
+#define DSABF_ABL16 0   // timing-only ablations (results invalid): 1 no detect (one add per accumulator keeps it alive), 2 no LDS staging writes, 4 no per-chunk barrier
+#endif
             auto consume = [&](const int t8, const int t, const v4i (&re)[SPS], const v4i (&im)[SPS]) {
 #pragma unroll
-                for (int e = 0; e < SPS; e++)   // paired: slot 2t = beam b, slot 2t+1 = beam B-1-b
-                    detect(t8, __builtin_bit_cast(v4f, re[e]), __builtin_bit_cast(v4f, im[e]), SPS * t + e);
+                for (int e = 0; e < SPS; e++) {  // paired: slot 2t = beam b, slot 2t+1 = beam B-1-b
+                    if constexpr (DSABF_ABL16 & 1) {
+                        const v4i x = re[e] + im[e];
+                        sum[SPS * t + e] += __builtin_bit_cast(float, x[0] ^ x[1] ^ x[2] ^ x[3]);
+                        if (t8 == 7) { pend[0][SPS * t + e] = sum[SPS * t + e]; pend_chunk[0] = c; }
+                    } else {
+                        detect(t8, __builtin_bit_cast(v4f, re[e]), __builtin_bit_cast(v4f, im[e]), SPS * t + e);
+                    }
+                }
             };
             // staging work in the shadow of the MFMA stream: the next chunk's LDS image after tile 1, the parked stores
             // of the previous chunk and the prefetch of chunk c+2 after tile 3
             auto staging = [&](const int t8) {
-                if (t8 == 1 && c + 1 < c_end) write_chunk(nxt);
+                if (t8 == 1 && c + 1 < c_end && !(DSABF_ABL16 & 2)) write_chunk(nxt);
                 if (t8 == 3) {
                     flush_pending();
                     if (c + 2 < c_end) load_chunk(c + 2);
@@ -741,7 +751,7 @@ __global__ __launch_bounds__(64 * WAVES, (fused_min_waves<AIN, NIPO, WRITE_C, NS
 #endif
             }
         }
-        __syncthreads();
+        if (!(DSABF_ABL16 & 4)) __syncthreads();
     }
     flush_pending();
 #if DSABF_CLOCKPROBE
