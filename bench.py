@@ -540,7 +540,7 @@ def main():
                 p_avg, _, p_min = time_launches(torch, peak_fn, 50, stream)
                 peak_measured = peak_ops[0] / (p_avg * 1e-3) / 1e12
                 roof.update({"peak_measured": peak_measured, "frac_of_measured_peak": achieved / peak_measured,
-                             "peak_measured_note": "back-to-back v_mfma_i32_16x16x64_i8, 16 independent chains per wave, 4 waves "
+                             "peak_measured_note": "back-to-back v_mfma_i32_16x16x64_i8, 2 accumulator chains per wave issued chain by chain, 4 waves "
                                                    "per SIMD, operands = this workload's bytes (A = 16 * nibble, B = random "
                                                    "int8), %.3f ms per launch of %.3g ops, measured after the timed region"
                                                    % (p_avg, peak_ops[0])})

@@ -636,9 +636,15 @@ __global__ __launch_bounds__(64 * WAVES, (fused_min_waves<AIN, NIPO, WRITE_C, NS
                 }
             };
             // acc = seed + sum over the k-steps of x[h] * w[h]  (one MFMA per k-step, chained through srcC)
+#ifndef DSABF_MFMA_ORDER
+#define DSABF_MFMA_ORDER 0   // 1: pin the MFMAs to their SOURCE order -- chain by chain, dependent MFMAs back to back -- while every
+#endif                       //    other instruction stays free to move (tools/ubench_chains.hip: consecutive MFMAs on one accumulator run faster)
             auto dot = [&](const v4i (&x)[KS], const v4i (&w)[KS], v4i acc) {
 #pragma unroll
-                for (int h = 0; h < KS; h++) acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(x[h], w[h], acc, 0, 0, 0);
+                for (int h = 0; h < KS; h++) {
+                    acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(x[h], w[h], acc, 0, 0, 0);
+                    if constexpr (DSABF_MFMA_ORDER != 0) __builtin_amdgcn_sched_barrier(0x7F6);   // everything but MFMAs may cross
+                }
                 return acc;
             };
             // One step = the MFMAs of column tile t on row-tile fragments (a0, a1); its SPS output slots land in

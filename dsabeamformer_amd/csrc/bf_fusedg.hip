@@ -141,16 +141,19 @@ __global__ __launch_bounds__(kGThreads, 2) void fusedg_kernel(GenArgs a)
                 bw[t][k] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, b_lane, (((tt * 3 + k) * KS) + h) * 1024, 0));
         }
     };
-    // the offset-nibble corrections of this lane's columns, per slot and component (added to the finished sums in the detect)
-    int corr[kGNT][2];
+    // a chunk's accumulators start at seed + the offset-nibble correction of this lane's column, per slot and component: the finished
+    // sums are seed + sum W (v + 8) - 8 sum W = seed + n, and their bits ARE the float K + n (no integer add in the detect)
+    v4i seed[kGNT][2];
 #pragma unroll
     for (int t = 0; t < kGNT; t++) {
         const v2i_g cr = a.corr[((size_t)f * a.n_ctiles + min(ct0 + t, a.n_ctiles - 1)) * 16 + c16];
-        corr[t][0] = cr[0];
-        corr[t][1] = cr[1];
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const int sd = (int)kMagicBits + cr[k];
+            seed[t][k] = v4i{sd, sd, sd, sd};
+            asm volatile("" : "+v"(seed[t][k]));
+        }
     }
-    v4i kc = {(int)kMagicBits, (int)kMagicBits, (int)kMagicBits, (int)kMagicBits};   // srcC of a chunk's first MFMAs
-    asm volatile("" : "+v"(kc));
 
     // ---- staging: this thread's pieces of a plane ---------------------------------------------------------------------------
     int lds_re[PPT];       // LDS byte offset of the piece's re image inside a plane; the im image is at ^ 64
@@ -251,8 +254,7 @@ __global__ __launch_bounds__(kGThreads, 2) void fusedg_kernel(GenArgs a)
         // A fragments one row tile ahead (two register sets), the order pinned: the scheduler otherwise either reads every
         // tile's fragments at the top of the plane (64 registers beside 128 accumulators: spills) or each tile's just in time
         // (its LDS latency in front of every 8 MFMAs).
-        auto tiles = [&](auto first_tag) {
-            constexpr bool FIRST = decltype(first_tag)::value;
+        auto tiles = [&]() {
             v4i fa[2][2];
             auto read_frag = [&](int t8, v4i (&fr)[2]) {
                 const int row = lds_row16<32>(t8, c16);
@@ -268,8 +270,8 @@ __global__ __launch_bounds__(kGThreads, 2) void fusedg_kernel(GenArgs a)
                     const v4i a0 = fa[t8 & 1][0], a1 = fa[t8 & 1][1];
 #pragma unroll
                     for (int t = 0; t < kGNT; t++) {
-                        acc[t8][t][0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, bc[t][0], FIRST ? kc : acc[t8][t][0], 0, 0, 0);   // + Wr Vr
-                        acc[t8][t][1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, bc[t][2], FIRST ? kc : acc[t8][t][1], 0, 0, 0);   // + Wi Vr
+                        acc[t8][t][0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, bc[t][0], acc[t8][t][0], 0, 0, 0);   // + Wr Vr
+                        acc[t8][t][1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, bc[t][2], acc[t8][t][1], 0, 0, 0);   // + Wi Vr
                     }
 #pragma unroll
                     for (int t = 0; t < kGNT; t++) {
@@ -288,15 +290,18 @@ __global__ __launch_bounds__(kGThreads, 2) void fusedg_kernel(GenArgs a)
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
-        // (peeling the first k-step -- srcC = the seed instead of 128 register moves per chunk -- was tried: four copies of the tile
+        // (peeling the first k-step -- srcC = the seeds instead of 128 register moves per chunk -- was tried: four copies of the tile
         //  loop instead of two, and the register allocator spills 175 registers across the join)
         if (h == 0) {
 #pragma unroll
             for (int t8 = 0; t8 < 8; t8++)
 #pragma unroll
-                for (int t = 0; t < kGNT; t++) acc[t8][t][0] = acc[t8][t][1] = kc;
+                for (int t = 0; t < kGNT; t++) {
+                    acc[t8][t][0] = seed[t][0];
+                    acc[t8][t][1] = seed[t][1];
+                }
         }
-        tiles(std::false_type{});
+        tiles();
         if ((DSABF_G_ABL & 1) && h + 1 == KS) {   // keep the accumulators alive: one store of their sum
             v4i x = kzero4;
 #pragma unroll
@@ -315,8 +320,7 @@ __global__ __launch_bounds__(kGThreads, 2) void fusedg_kernel(GenArgs a)
                 float pw[kGNT][4];
 #pragma unroll
                 for (int t = 0; t < kGNT; t++) {
-                    // seed + sum W (v + 8) - 8 sum W = seed + n: one integer add per value, then the bits ARE the float K + n
-                    const v4f fr = __builtin_bit_cast(v4f, acc[t8][t][0] + corr[t][0]), fi = __builtin_bit_cast(v4f, acc[t8][t][1] + corr[t][1]);
+                    const v4f fr = __builtin_bit_cast(v4f, acc[t8][t][0]), fi = __builtin_bit_cast(v4f, acc[t8][t][1]);
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
                         if constexpr (WRITE_C) {
@@ -350,7 +354,7 @@ __global__ __launch_bounds__(kGThreads, 2) void fusedg_kernel(GenArgs a)
 #pragma unroll
                         for (int t = 0; t < kGNT; t++) {
                             if constexpr (FAST) {
-                                const v4f fr = __builtin_bit_cast(v4f, acc[t8][t][0] + corr[t][0]), fi = __builtin_bit_cast(v4f, acc[t8][t][1] + corr[t][1]);
+                                const v4f fr = __builtin_bit_cast(v4f, acc[t8][t][0]), fi = __builtin_bit_cast(v4f, acc[t8][t][1]);
                                 const float dr = fr[r] - kMagic, di = fi[r] - kMagic;
                                 float s0 = start ? 0.0f : sum[t];
                                 s0 = __builtin_fmaf(dr, dr, s0);

@@ -719,10 +719,12 @@ hipError_t launch_expand(const void* d_in, size_t nbytes, void* d_out, hipStream
 
 // ---- the matrix pipe by itself ("a back-to-back v_mfma micro-benchmark; report utilisation against both nominal
 // and measured peak") -------------------------------------------------------------------------------------------------------------
-// 4 waves per SIMD, 16 independent accumulator chains of v_mfma_i32_16x16x64_i8 per wave and nothing else in the loop; the operands
-// are the caller's bytes -- A as the fused kernel sees voltages (16 * nibble), B as it sees weights (any int8) -- because the
-// clock the chip holds under this load depends on the operand bits (tools/ubench_shape.hip: constant operands 4.6 POP/s, random
-// ones 3.6-4.1).  The sums are stored so that nothing is optimised away.
+// 4 waves per SIMD, two accumulator chains of v_mfma_i32_16x16x64_i8 per wave issued chain by chain (8 dependent MFMAs on one
+// accumulator, then 8 on the other) and nothing else in the loop: the order the pipe runs fastest in (tools/ubench_chains.hip,
+// profiles/r04_ubench_chains.txt: 1-2 chains 0.94-0.95 of 5.0 POP/s, 16 chains of 2 round robin -- this kernel up to round 3 --
+// 0.63).  The operands are the caller's bytes -- A as the fused kernel sees voltages (16 * nibble), B as it sees weights (any
+// int8) -- because the clock the chip holds under this load depends on the operand bits (tools/ubench_shape.hip).  The
+// accumulators run on across iterations (int32 wrap-around is harmless here) and are stored so that nothing is optimised away.
 __global__ __launch_bounds__(256, 4) void mfma_peak_kernel(const v4i* __restrict__ src, int* __restrict__ sink, int iters)
 {
     v4i a[4], b[8];
@@ -733,20 +735,17 @@ __global__ __launch_bounds__(256, 4) void mfma_peak_kernel(const v4i* __restrict
         const v4i r = src[(512 + (blockIdx.x & 63) * 4 + i) * 256 + threadIdx.x];
         a[i] = v4i{r[0] & (int)0xF0F0F0F0u, r[1] & (int)0xF0F0F0F0u, r[2] & (int)0xF0F0F0F0u, r[3] & (int)0xF0F0F0F0u};
     }
-    int acc = 0;
+    v4i c[2] = {v4i{0, 0, 0, 0}, v4i{0, 0, 0, 0}};
     for (int it = 0; it < iters; it++) {
-        v4i c[8];
 #pragma unroll
-        for (int t = 0; t < 8; t++) c[t] = v4i{0, 0, 0, 0};
+        for (int t = 0; t < 2; t++)
 #pragma unroll
-        for (int m = 0; m < 2; m++)
-#pragma unroll
-            for (int t = 0; t < 8; t++) c[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[(t + m) & 3], b[(t + 2 * m) & 7], c[t], 0, 0, 0);
-#pragma unroll
-        for (int t = 0; t < 8; t++) acc += c[t][0] + c[t][3];
-        asm volatile("" : "+v"(acc));
+            for (int m = 0; m < 8; m++) {
+                c[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[(t + m) & 3], b[(m + 3 * t) & 7], c[t], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
     }
-    sink[blockIdx.x * 256 + threadIdx.x] = acc;
+    sink[blockIdx.x * 256 + threadIdx.x] = c[0][0] + c[0][3] + c[1][1] + c[1][2];
 }
 
 // src: kMfmaPeakSrcBytes of caller data; sink: kMfmaPeakSinkBytes of scratch.  *ops = int8 ops (2 per MAC) the launch executes.
