@@ -217,7 +217,11 @@ __global__ __launch_bounds__(64 * WAVES, (fused_min_waves<AIN, NIPO, WRITE_C, NS
     static_assert(!(PAIRED && WRITE_C), "the stage-parity path always runs the general kernel");
     static_assert(AIN >= kAntK3P16 && AIN != 0 && (AIN < 0 || AIN % 4 == 0) && AIN <= 256, "antenna class");
     static_assert(!ant_deep<AIN>() || (WAVES == 8 && NIPO >= 16 && !WRITE_C && (AIN < 0 || AIN % 16 == 0)), "deep classes: 8 waves, long windows, 16-byte rows");
-    constexpr bool TRUE_NIB = ant_deep<AIN>();           // operands are the nibble values themselves, not 16 x
+#ifndef DSABF_DEEP_OFFSET
+#define DSABF_DEEP_OFFSET 1   // 0: the deep classes stage sign-extended nibbles (9 VALU per dword, and the pipe holds a lower clock on them:
+#endif                        //    profiles/r04_ubench_encoding.txt) instead of offset nibbles v + 8 with the correction in the accumulator seeds
+    constexpr bool TRUE_NIB = ant_deep<AIN>();           // operands count in units of the nibble value itself, not 16 x
+    constexpr bool OFFSET_NIB = TRUE_NIB && DSABF_DEEP_OFFSET != 0;   // ... as v + 8 in [0, 15]
     constexpr float kA = TRUE_NIB ? kAlpha : kAlpha16;   // accumulator unit -> alpha
     constexpr float kNKA = TRUE_NIB ? kNegMagicAlpha : kNegMagicAlpha16;
     constexpr bool RT = AIN < 0;                         // antenna count known only at run time
@@ -298,6 +302,40 @@ __global__ __launch_bounds__(64 * WAVES, (fused_min_waves<AIN, NIPO, WRITE_C, NS
     v4i kc = {(int)kMagicBits, (int)kMagicBits, (int)kMagicBits, (int)kMagicBits};
     asm volatile("" : "+v"(kc));
     const v4i kzero = {0, 0, 0, 0};
+    // Offset nibbles: sum W (v + 8) = sum W v + 8 sum W, so the chains start at seed - 8 * (this lane's column sum of the weight
+    // fragment they multiply): summed here from the B fragments themselves (16 antennas per lane and k-step, the four lane groups
+    // hold the other 48), once per workgroup.  General: sd[t][0] -> re = Wr Vr - Wi Vi, sd[t][1] -> im = Wi Vr + Wr Vi;
+    // paired: sd[t][0] -> P1, P3 (Wr), sd[t][1] -> P2, P4 (Wi, no magic).
+    [[maybe_unused]] v4i sd[OFFSET_NIB ? NT : 1][2];
+    if constexpr (OFFSET_NIB) {
+        auto colsum = [&](const v4i (&w)[KS]) {
+            int sacc = 0;
+#pragma unroll
+            for (int h = 0; h < KS; h++)
+#pragma unroll
+                for (int d = 0; d < 4; d++)
+#pragma unroll
+                    for (int b = 0; b < 4; b++) sacc += (int)(signed char)((unsigned)w[h][d] >> (8 * b));
+            sacc += __shfl_xor(sacc, 16);
+            sacc += __shfl_xor(sacc, 32);
+            return sacc;
+        };
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            int s0, s1;
+            if constexpr (PAIRED) {
+                s0 = (int)kMagicBits - 8 * colsum(bw[t][0]);
+                s1 = -8 * colsum(bw[t][1]);
+            } else {
+                const int wr = colsum(bw[t][0]), nwi = colsum(bw[t][1]), wi = colsum(bw[t][2]);
+                s0 = (int)kMagicBits - 8 * (wr + nwi);
+                s1 = (int)kMagicBits - 8 * (wi + (DSABF_GEN3 ? wr : colsum(bw[t][NGC - 1])));
+            }
+            sd[t][0] = v4i{s0, s0, s0, s0};
+            sd[t][1] = v4i{s1, s1, s1, s1};
+            asm volatile("" : "+v"(sd[t][0]), "+v"(sd[t][1]));
+        }
+    }
 
     // ---- staging (the chunk's 128 samples are contiguous in time for n_ipo <= 32) ------------------------------
     auto run_sample0 = [&](int c, int run) -> unsigned {   // first global sample of stream-run `run` of chunk c
@@ -394,7 +432,11 @@ __global__ __launch_bounds__(64 * WAVES, (fused_min_waves<AIN, NIPO, WRITE_C, NS
 #pragma unroll
                 for (int d = 0; d < 4; d++) {
                     const unsigned w = (unsigned)stage[k][d];
-                    if constexpr (TRUE_NIB) {   // sign-extend the nibbles inside their bytes: ((v ^ 8) - 8) without a borrow across bytes
+                    if constexpr (OFFSET_NIB) {   // v + 8 = the nibble's bits with the top one flipped
+                        const unsigned x = w ^ 0x88888888u;
+                        re[d] = (int)((x >> 4) & 0x0F0F0F0Fu);
+                        im[d] = (int)(x & 0x0F0F0F0Fu);
+                    } else if constexpr (TRUE_NIB) {   // sign-extend the nibbles inside their bytes: ((v ^ 8) - 8) without a borrow across bytes
                         re[d] = (int)(((((w >> 4) & 0x0F0F0F0Fu) ^ 0x88888888u) - 0x08080808u) ^ 0x80808080u);
                         im[d] = (int)((((w & 0x0F0F0F0Fu) ^ 0x88888888u) - 0x08080808u) ^ 0x80808080u);
                     } else {
@@ -651,14 +693,16 @@ __global__ __launch_bounds__(64 * WAVES, (fused_min_waves<AIN, NIPO, WRITE_C, NS
             // re[] / im[] as accumulator bit patterns K + 16 n.
             constexpr int SPS = PAIRED ? 2 : 1;                 // output slots per step
             auto issue = [&](const v4i (&a0)[KS], const v4i (&a1)[KS], const int t, v4i (&re)[SPS], v4i (&im)[SPS]) {
+                const v4i k0 = OFFSET_NIB ? sd[OFFSET_NIB ? t : 0][0] : kc;                         // chain seeds (see sd above)
+                const v4i k1 = OFFSET_NIB ? sd[OFFSET_NIB ? t : 0][1] : (PAIRED ? kzero : kc);
                 if constexpr (PAIRED) {
-                    const v4i p1 = dot(a0, bw[t][0], kc);     // Wr*Vr + K
-                    const v4i p3 = dot(a1, bw[t][0], kc);     // Wr*Vi + K
+                    const v4i p1 = dot(a0, bw[t][0], k0);     // Wr*Vr + K
+                    const v4i p3 = dot(a1, bw[t][0], k0);     // Wr*Vi + K
                     if constexpr (DSABF_PAIR_MFMA >= 5) {   // +-P2 chained on the MFMA pipe (bw[t][2] = -Wi)
                         re[0] = dot(a1, bw[t][2], p1);
                         re[1] = dot(a1, bw[t][1], p1);
                     } else {
-                        const v4i p2 = dot(a1, bw[t][1], kzero);  // Wi*Vi
+                        const v4i p2 = dot(a1, bw[t][1], k1);  // Wi*Vi
                         re[0] = p1 - p2;
                         re[1] = p1 + p2;
                     }
@@ -666,13 +710,13 @@ __global__ __launch_bounds__(64 * WAVES, (fused_min_waves<AIN, NIPO, WRITE_C, NS
                         im[0] = dot(a0, bw[t][1], p3);
                         im[1] = dot(a0, bw[t][2], p3);
                     } else {
-                        const v4i p4 = dot(a0, bw[t][1], kzero);  // Wi*Vr
+                        const v4i p4 = dot(a0, bw[t][1], k1);  // Wi*Vr
                         im[0] = p3 + p4;
                         im[1] = p3 - p4;
                     }
                 } else {
-                    re[0] = dot(a1, bw[t][1], dot(a0, bw[t][0], kc));              // Wr*Vr - Wi*Vi
-                    im[0] = dot(a1, bw[t][DSABF_GEN3 ? 0 : 3], dot(a0, bw[t][2], kc));   // Wi*Vr + Wr*Vi
+                    re[0] = dot(a1, bw[t][1], dot(a0, bw[t][0], k0));              // Wr*Vr - Wi*Vi
+                    im[0] = dot(a1, bw[t][DSABF_GEN3 ? 0 : 3], dot(a0, bw[t][2], k1));   // Wi*Vr + Wr*Vi
                 }
             };
 #ifndef DSABF_ABL16
