@@ -754,6 +754,7 @@ __global__ __launch_bounds__(64 * WAVES, (fused_min_waves<AIN, NIPO, WRITE_C, NS
                 v4i a0[KS], a1[KS];            //  -2 % (129 VGPRs: 3 instead of 4 waves per SIMD), general +-0, r02 variants log)
                 if constexpr (AHEAD) {
                     if (t8 + 1 < 8) read_frag(t8 + 1, fa0[(t8 + 1) & 1], fa1[(t8 + 1) & 1]);
+                    if constexpr (DSABF_FRAG_AHEAD >= 2) __builtin_amdgcn_sched_barrier(0);   // ... and keep the requests there
 #pragma unroll
                     for (int h = 0; h < KS; h++) a0[h] = fa0[t8 & 1][h], a1[h] = fa1[t8 & 1][h];
                 } else {
@@ -787,6 +788,7 @@ __global__ __launch_bounds__(64 * WAVES, (fused_min_waves<AIN, NIPO, WRITE_C, NS
                 }
                 store_short(t8);
                 staging(t8);
+                if constexpr (AHEAD && DSABF_FRAG_AHEAD >= 2) __builtin_amdgcn_sched_barrier(0);
 #if DSABF_PIN
                 {   // one row tile = NT * (PAIRED ? 4 : 4 * KS ...) MFMAs and ~100 VALU ops: lay them out in fixed groups
                     constexpr int M = DSABF_PIN == 1 ? 1 : DSABF_PIN == 2 ? 4 : DSABF_PIN == 3 ? 8 : 2;
