@@ -28,6 +28,14 @@ __global__ __launch_bounds__(256) void srcc_kernel(const v4i* __restrict__ src, 
 #pragma unroll
         for (int t = 0; t < 16; t++) {
             if constexpr (MODE <= 1) asm volatile("" : "+v"(a[t & 1]));       // ... nor inside one
+            if constexpr (MODE == 4) {   // 8 chains of 2, chain by chain: a seeded MFMA, then one that continues its accumulator (the general kernel's re / im rows)
+                if ((t & 1) == 0) asm volatile("" : "+v"(a[0]));
+                d[t >> 1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[t & 1], b[t & 1], (t & 1) ? d[t >> 1] : kc, 0, 0, 0);
+            }
+            if constexpr (MODE == 5) {   // the same 8 chains, all first MFMAs before the second ones (the compiler's order)
+                if (t < 8) asm volatile("" : "+v"(a[0]));
+                d[t & 7] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[t >> 3], b[t >> 3], (t >> 3) ? d[t & 7] : kc, 0, 0, 0);
+            }
             if constexpr (MODE == 0) d[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[t & 1], b[(t >> 1) & 1], kc, 0, 0, 0);
             if constexpr (MODE == 1) d[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[t & 1], b[(t >> 1) & 1], v4i{0, 0, 0, 0}, 0, 0, 0);
             if constexpr (MODE == 2) d[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[t & 1], b[(t >> 1) & 1], d[t], 0, 0, 0);
@@ -51,7 +59,8 @@ __global__ __launch_bounds__(256) void srcc_kernel(const v4i* __restrict__ src, 
 template <int MODE, int K>
 void run(const v4i* d_src, float* d_sink, int n_cus, double clk_ghz)
 {
-    const char* names[] = {"srcC = one VGPR tuple, 16 dsts", "srcC = inline 0, 16 dsts     ", "srcC = dst, 16 accumulators  ", "srcC = dst, 1 accumulator    "};
+    const char* names[] = {"srcC = one VGPR tuple, 16 dsts", "srcC = inline 0, 16 dsts     ", "srcC = dst, 16 accumulators  ", "srcC = dst, 1 accumulator    ",
+                           "8 chains of 2, chain by chain", "8 chains of 2, firsts first  "};
     for (int wps : {2, 4}) {
         const int grid = n_cus * wps, iters = 2000;
         hipEvent_t e0, e1;
@@ -84,6 +93,7 @@ int main()
     const int n = p.multiProcessorCount;
     const double g = 2.0;   // nominal figure for the cycles column only
     run<0, 0>(d_src, d_sink, n, g); run<1, 0>(d_src, d_sink, n, g); run<2, 0>(d_src, d_sink, n, g); run<3, 0>(d_src, d_sink, n, g);
+    run<4, 0>(d_src, d_sink, n, g); run<5, 0>(d_src, d_sink, n, g); run<4, 7>(d_src, d_sink, n, g); run<5, 7>(d_src, d_sink, n, g);
     run<0, 7>(d_src, d_sink, n, g); run<1, 7>(d_src, d_sink, n, g); run<2, 7>(d_src, d_sink, n, g); run<3, 7>(d_src, d_sink, n, g);
     run<0, 17>(d_src, d_sink, n, g); run<1, 17>(d_src, d_sink, n, g); run<2, 17>(d_src, d_sink, n, g); run<3, 17>(d_src, d_sink, n, g);
     return 0;
