@@ -34,6 +34,9 @@
 
 #include <cstdio>
 
+#ifndef DSABF_G_ORDER
+#define DSABF_G_ORDER 1   // 0: the four accumulators of a row tile round robin (A fragment by A fragment)
+#endif
 namespace dsabf {
 
 namespace {
@@ -268,6 +271,22 @@ __global__ __launch_bounds__(kGThreads, 2) void fusedg_kernel(GenArgs a)
                 __builtin_amdgcn_sched_barrier(0);
                 {   // (a wave behind the last beam computes too, on its first tile's weights: no branch around the MFMAs)
                     const v4i a0 = fa[t8 & 1][0], a1 = fa[t8 & 1][1];
+#if DSABF_G_ORDER
+                    // chain by chain: an accumulator's two MFMAs of this plane back to back -- the second continues the first inside
+                    // the matrix unit instead of reading the accumulator back from the VGPRs (tools/ubench_chains.hip: 16 chains of
+                    // 2 at two waves per SIMD, 0.585 round robin -> 0.676 chain by chain)
+#pragma unroll
+                    for (int t = 0; t < kGNT; t++) {
+                        acc[t8][t][0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, bc[t][0], acc[t8][t][0], 0, 0, 0);   // + Wr Vr
+                        __builtin_amdgcn_sched_barrier(0x7F6);
+                        acc[t8][t][0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, bc[t][1], acc[t8][t][0], 0, 0, 0);   // - Wi Vi
+                        __builtin_amdgcn_sched_barrier(0x7F6);
+                        acc[t8][t][1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, bc[t][2], acc[t8][t][1], 0, 0, 0);   // + Wi Vr
+                        __builtin_amdgcn_sched_barrier(0x7F6);
+                        acc[t8][t][1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, bc[t][0], acc[t8][t][1], 0, 0, 0);   // + Wr Vi
+                        __builtin_amdgcn_sched_barrier(0x7F6);
+                    }
+#else
 #pragma unroll
                     for (int t = 0; t < kGNT; t++) {
                         acc[t8][t][0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, bc[t][0], acc[t8][t][0], 0, 0, 0);   // + Wr Vr
@@ -278,6 +297,7 @@ __global__ __launch_bounds__(kGThreads, 2) void fusedg_kernel(GenArgs a)
                         acc[t8][t][0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, bc[t][1], acc[t8][t][0], 0, 0, 0);   // - Wi Vi
                         acc[t8][t][1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, bc[t][0], acc[t8][t][1], 0, 0, 0);   // + Wr Vi
                     }
+#endif
                 }
                 // plane p + 1 goes to LDS one piece per row tile (behind the last plane: a copy nobody reads), then plane p + 2
                 // is requested into the registers just emptied

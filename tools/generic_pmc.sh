@@ -29,6 +29,7 @@ with open(out + "/summary.txt", "w") as fp:
             v = v[len(v)//3:] if len(v) > 3 else v
             fp.write("  %-32s mean %.6g  (n=%d)\n" % (c, sum(v)/len(v), len(v)))
     for f in glob.glob(out + "/stats/**/*kernel_stats.csv", recursive=True):
-        fp.write(open(f).read())
+        for i, line in enumerate(open(f)):
+            if i == 0 or "dsabf" in line: fp.write(line)
 print(open(out + "/summary.txt").read())
 PY

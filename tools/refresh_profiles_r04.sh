@@ -37,13 +37,16 @@ find $O/prof_dm -name "*kernel_stats.csv" | head -1 | xargs -I{} sh -c "grep -E 
 rm -rf $O/prof_dm
 (cd $R && bash tools/dm_pmc.sh r04p/pmc_dm > /dev/null 2>&1 && cp $O/pmc_dm/summary.txt $O/r04_dm_pmc_summary.txt; rm -rf $O/pmc_dm)
 # fusedg_kernel at 256 antennas (4 k-steps), 1 GiB launch: kernel trace + counters; the antenna / window sweep
-(cd $R && bash tools/generic_pmc.sh r04p/pmc_g256 256 16 32 > /dev/null 2>&1 && cp $O/pmc_g256/summary.txt $O/r04_generic256_pmc_summary.txt; rm -rf $O/pmc_g256)
+(cd $R && export DSABF_DEEP=0 && bash tools/generic_pmc.sh r04p/pmc_g256 256 16 32 > /dev/null 2>&1 && cp $O/pmc_g256/summary.txt $O/r04_generic256_pmc_summary.txt; rm -rf $O/pmc_g256)
+# the deep class of fused16_kernel on the same shape (the default routing)
+(cd $R && bash tools/generic_pmc.sh r04p/pmc_d256 256 16 32 > /dev/null 2>&1 && cp $O/pmc_d256/summary.txt $O/r04_deep256_pmc_summary.txt; rm -rf $O/pmc_d256)
 cd $R
 python tools/generic_perf.py > $O/r04_generic_perf.txt 2>/dev/null
 # parity at length on the final build: the specialised classes, the wide launches, the generic kernel, the DM kernels
 SEED=41 CASES=600 python tools/fuzz_long.py > $O/r04_fuzz_long.txt 2>&1
 SEED=42 CASES=400 FUZZ_WIDE=1 python tools/fuzz_long.py >> $O/r04_fuzz_long.txt 2>&1
 SEED=43 CASES=600 FUZZ_GENERIC=1 python tools/fuzz_long.py > $O/r04_fuzz_generic.txt 2>&1
+SEED=45 CASES=400 FUZZ_DEEP=1 python tools/fuzz_long.py >> $O/r04_fuzz_generic.txt 2>&1
 SEED=44 CASES=300 python tools/fuzz_dm.py > $O/r04_fuzz_dm.txt 2>&1
 python -m pytest tests -m gpu -q 2>&1 | tail -4 > $O/r04_gputest_tail.txt
 cd $R; rm -f $O/*.log; ls -la $O
