@@ -21,9 +21,6 @@
 #ifndef DSABF_GEN3
 #define DSABF_GEN3 1      // general weight image holds 3 fragments per tile (Wr, -Wi, Wi) instead of 4 (Wr, -Wi, Wi, Wr again)
 #endif
-#ifndef DSABF_PIN
-#define DSABF_PIN 0       // experiment (round 4, profiles/r04_ab_pin.txt): pin the issue order of a row tile's MFMAs and VALU ops with
-#endif                    // sched_group_barrier: 1 = 1 MFMA : 7 VALU, 2 = 4 : 26, 3 = 8 : 53, 4 = 2 : 13.  0 = the scheduler's own order
 #ifndef DSABF_OCC16
 #define DSABF_OCC16 3     // default register budget of the one-k-step variants (168 VGPRs: 3 waves per SIMD); fused_min_waves()
                           // raises it to 4 where 128 registers suffice
@@ -678,15 +675,9 @@ __global__ __launch_bounds__(64 * WAVES, (fused_min_waves<AIN, NIPO, WRITE_C, NS
                 }
             };
             // acc = seed + sum over the k-steps of x[h] * w[h]  (one MFMA per k-step, chained through srcC)
-#ifndef DSABF_MFMA_ORDER
-#define DSABF_MFMA_ORDER 0   // 1: pin the MFMAs to their SOURCE order -- chain by chain, dependent MFMAs back to back -- while every
-#endif                       //    other instruction stays free to move (tools/ubench_chains.hip: consecutive MFMAs on one accumulator run faster)
             auto dot = [&](const v4i (&x)[KS], const v4i (&w)[KS], v4i acc) {
 #pragma unroll
-                for (int h = 0; h < KS; h++) {
-                    acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(x[h], w[h], acc, 0, 0, 0);
-                    if constexpr (DSABF_MFMA_ORDER != 0) __builtin_amdgcn_sched_barrier(0x7F6);   // everything but MFMAs may cross
-                }
+                for (int h = 0; h < KS; h++) acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(x[h], w[h], acc, 0, 0, 0);
                 return acc;
             };
             // One step = the MFMAs of column tile t on row-tile fragments (a0, a1); its SPS output slots land in
@@ -743,23 +734,10 @@ __global__ __launch_bounds__(64 * WAVES, (fused_min_waves<AIN, NIPO, WRITE_C, NS
                     if (c + 2 < c_end) load_chunk(c + 2);
                 }
             };
-#ifndef DSABF_FRAG_AHEAD
-#define DSABF_FRAG_AHEAD 0   // experiment: deep classes request row tile t8 + 1's LDS fragments before tile t8's MFMAs (2 register sets)
-#endif
-            constexpr bool AHEAD = DSABF_FRAG_AHEAD && ant_deep<AIN>();
-            [[maybe_unused]] v4i fa0[2][KS], fa1[2][KS];
-            if constexpr (AHEAD) read_frag(0, fa0[0], fa1[0]);
 #pragma unroll
             for (int t8 = 0; t8 < 8; t8++) {   // (requesting tile t8+1's LDS fragments one tile early was tried: pair kernel
-                v4i a0[KS], a1[KS];            //  -2 % (129 VGPRs: 3 instead of 4 waves per SIMD), general +-0, r02 variants log)
-                if constexpr (AHEAD) {
-                    if (t8 + 1 < 8) read_frag(t8 + 1, fa0[(t8 + 1) & 1], fa1[(t8 + 1) & 1]);
-                    if constexpr (DSABF_FRAG_AHEAD >= 2) __builtin_amdgcn_sched_barrier(0);   // ... and keep the requests there
-#pragma unroll
-                    for (int h = 0; h < KS; h++) a0[h] = fa0[t8 & 1][h], a1[h] = fa1[t8 & 1][h];
-                } else {
-                    read_frag(t8, a0, a1);
-                }
+                v4i a0[KS], a1[KS];            //  -2 % (129 VGPRs: 3 instead of 4 waves per SIMD), general +-0, r02 variants log;
+                read_frag(t8, a0, a1);         //  deep classes, requested and pinned one tile early: +-0.5 %, r04 variants log)
                 if constexpr (RTW) {
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
@@ -788,19 +766,6 @@ __global__ __launch_bounds__(64 * WAVES, (fused_min_waves<AIN, NIPO, WRITE_C, NS
                 }
                 store_short(t8);
                 staging(t8);
-                if constexpr (AHEAD && DSABF_FRAG_AHEAD >= 2) __builtin_amdgcn_sched_barrier(0);
-#if DSABF_PIN
-                {   // one row tile = NT * (PAIRED ? 4 : 4 * KS ...) MFMAs and ~100 VALU ops: lay them out in fixed groups
-                    constexpr int M = DSABF_PIN == 1 ? 1 : DSABF_PIN == 2 ? 4 : DSABF_PIN == 3 ? 8 : 2;
-                    constexpr int V = DSABF_PIN == 1 ? 7 : DSABF_PIN == 2 ? 26 : DSABF_PIN == 3 ? 53 : 13;
-                    constexpr int NM = NT * 4 * KS;
-#pragma unroll
-                    for (int i = 0; i < NM / M; i++) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, M, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x002, V, 0);
-                    }
-                }
-#endif
             }
         }
         if (!(DSABF_ABL16 & 4)) __syncthreads();
