@@ -44,6 +44,9 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 typedef int v2i __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 
+#ifndef DSABF_DW_PROBE
+#define DSABF_DW_PROBE 0   // diagnostic build: s_memtime around the phases of a channel (tools/dm_probe.py)
+#endif
 #ifndef DSABF_DW_TB
 #define DSABF_DW_TB 16
 #endif
@@ -235,6 +238,9 @@ __global__ __launch_bounds__(kDwThreads) void dedisperse_dm_wide_kernel(const fl
     wait_dma_but(0);
     block_barrier();
     int slot = 0, slot2 = 2 % kDwNbuf;                    // ring positions of channel f and of channel f + 2
+#if DSABF_DW_PROBE
+    unsigned long long pt_body = 0, pt_dma = 0, pt_bar = 0, pt0 = __builtin_amdgcn_s_memtime();
+#endif
     for (int f = 0; f < n_freq; f++) {
         // bookkeeping reads first (the compiler's own LDS operations: everything after them is one of the bodies' row reads;
         // LDS returns in order, so the bodies' counted waits also cover whatever of these is still in flight)
@@ -260,9 +266,26 @@ __global__ __launch_bounds__(kDwThreads) void dedisperse_dm_wide_kernel(const fl
         tnext = tafter;
         slot = slot + 1 == kDwNbuf ? 0 : slot + 1;
         slot2 = slot2 + 1 == kDwNbuf ? 0 : slot2 + 1;
+#if DSABF_DW_PROBE
+        const unsigned long long pt1 = __builtin_amdgcn_s_memtime();
+#endif
         wait_dma_but(newest);                             // this wave's pieces of window f + 1 have landed ...
+#if DSABF_DW_PROBE
+        const unsigned long long pt2 = __builtin_amdgcn_s_memtime();
+#endif
         block_barrier();                                  // ... and so have everybody else's
+#if DSABF_DW_PROBE
+        const unsigned long long pt3 = __builtin_amdgcn_s_memtime();
+        pt_body += pt1 - pt0, pt_dma += pt2 - pt1, pt_bar += pt3 - pt2, pt0 = pt3;
+#endif
     }
+#if DSABF_DW_PROBE   // diagnostic build only (results invalid): tile 0's waves leave their per-channel cycle averages in out[wave * 4 ...]
+    if (v == 0 && lane == 0) {
+        out[wave * 4 + 0] = (float)pt_body / n_freq, out[wave * 4 + 1] = (float)pt_dma / n_freq, out[wave * 4 + 2] = (float)pt_bar / n_freq;
+        out[wave * 4 + 3] = (float)(pt_body + pt_dma + pt_bar) / n_freq;
+    }
+    return;
+#endif
 
     if (bq >= n_beams) return;
 #pragma unroll
