@@ -58,6 +58,7 @@ struct bf_handle {
     std::vector<const float*> last_out;   // per caller-visible queue: where its most recent gemm-unit's powers are on the device ...
     std::vector<int> last_q;              // ... and the queue that wrote them
     std::vector<float*> d_out_blk;  // per compute queue, n_gemms_per_block x floats_per_detect: bf_enqueue_block (lazy)
+    std::vector<char> blk_ran;      // per compute queue: bf_enqueue_block has launched into d_out_blk[q]
     std::vector<float*> d_ded_blk;  // per compute queue, n_gemms_per_block x n_beams: bf_enqueue_block_dedisperse (lazy)
     std::vector<float*> d_full_blk; // per compute queue, the gathered block (world x as large): bf_block_gather_device (lazy)
     int full_world = 0;
@@ -613,8 +614,12 @@ int bf_enqueue_block(bf_handle* h, int stream_idx, int slot, int first_unit, int
     const size_t per_gemm = bf_bytes_per_gemm(&h->cfg);
     const size_t per_det = bf_floats_per_detect(&h->cfg);
     if (h->d_out_blk.empty()) h->d_out_blk.assign((size_t)h->cfg.n_streams, nullptr);
-    if (!h->d_out_blk[stream_idx])
-        HIP_TRY(hipMalloc((void**)&h->d_out_blk[stream_idx], per_det * sizeof(float) * (size_t)h->cfg.n_gemms_per_block));
+    if (h->blk_ran.empty()) h->blk_ran.assign((size_t)h->cfg.n_streams, 0);
+    if (!h->d_out_blk[stream_idx])   // a caller rotates over the queues block after block: every queue's buffer NOW -- a hipMalloc
+        for (int q = 0; q < h->cfg.n_streams; q++)   // in the middle of a stream of blocks stalls the device (measured: 9.4 -> 10.9 us per beam-block)
+            if (!h->d_out_blk[q])
+                HIP_TRY(hipMalloc((void**)&h->d_out_blk[q], per_det * sizeof(float) * (size_t)h->cfg.n_gemms_per_block));
+    h->blk_ran[stream_idx] = 1;
     const uint8_t* in = h->d_data + per_gemm * ((size_t)h->cfg.n_gemms_per_block * slot + first_unit);
     float* out = h->d_out_blk[stream_idx] + per_det * (size_t)first_unit;
     hipStream_t s = h->streams[stream_idx];
@@ -642,14 +647,16 @@ int bf_enqueue_block_dedisperse(bf_handle* h, int stream_idx, int first_unit, in
     if (first_unit < 0 || n_units <= 0 || first_unit + n_units > h->cfg.n_gemms_per_block)
         return fail(BF_ERR_INVALID, "gemm-units [%d, %d) are not inside a block of %d", first_unit, first_unit + n_units,
                     h->cfg.n_gemms_per_block);
-    if (h->d_out_blk.empty() || !h->d_out_blk[stream_idx])
+    if (h->blk_ran.empty() || !h->blk_ran[stream_idx])
         return fail(BF_ERR_STATE, "bf_enqueue_block has not run on queue %d", stream_idx);
     ON_DEVICE(h);
     FLUSH_UNITS(h);
     const size_t per_det = bf_floats_per_detect(&h->cfg);
     if (h->d_ded_blk.empty()) h->d_ded_blk.assign((size_t)h->cfg.n_streams, nullptr);
-    if (!h->d_ded_blk[stream_idx])
-        HIP_TRY(hipMalloc((void**)&h->d_ded_blk[stream_idx], (size_t)h->cfg.n_beams * sizeof(float) * (size_t)h->cfg.n_gemms_per_block));
+    if (!h->d_ded_blk[stream_idx])   // (all queues at once: see bf_enqueue_block)
+        for (int q = 0; q < h->cfg.n_streams; q++)
+            if (!h->d_ded_blk[q])
+                HIP_TRY(hipMalloc((void**)&h->d_ded_blk[q], (size_t)h->cfg.n_beams * sizeof(float) * (size_t)h->cfg.n_gemms_per_block));
     hipStream_t s = h->streams[stream_idx];
     float* ded = h->d_ded_blk[stream_idx] + (size_t)h->cfg.n_beams * first_unit;
     HIP_TRY(dsabf::launch_dedisperse_units(h->geom, h->d_out_blk[stream_idx] + per_det * (size_t)first_unit, per_det, n_units, ded, s));
@@ -667,6 +674,8 @@ int bf_block_output_device(bf_handle* h, int stream_idx, float** d_out)
     if (!h->d_out_blk[stream_idx])
         HIP_TRY(hipMalloc((void**)&h->d_out_blk[stream_idx],
                           bf_floats_per_detect(&h->cfg) * sizeof(float) * (size_t)h->cfg.n_gemms_per_block));
+    if (h->blk_ran.empty()) h->blk_ran.assign((size_t)h->cfg.n_streams, 0);
+    h->blk_ran[stream_idx] = 1;   // (the caller may fill the buffer itself and ask for its DM-0 rows)
     *d_out = h->d_out_blk[stream_idx];
     return BF_OK;
 }

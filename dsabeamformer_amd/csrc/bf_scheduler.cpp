@@ -513,7 +513,11 @@ int run_observation(const bf_config& cfg, const observation_options& opt, block_
                 const int n_units = cfg.n_gemms_per_block;
                 unit_dst.assign((size_t)n_units, nullptr);
                 for (int first = 0; first < n_units; first += upl) {
-                    const int q = (int)(launch_seq++ % (uint64_t)n_streams);
+                    // whole blocks alternate between TWO queues (block i + 1's kernel under block i's copies, as in the DEBUG flow):
+                    // more queues only put more concurrent host copies beside the H2D stream (9.6 -> 9.2 us per beam-block, and
+                    // 11.6 -> 9.x with other streams alive in the process: tools/stream_queues.py); sub-block launches rotate over all
+                    const int n_rot = upl == n_units ? std::min(n_streams, 2) : n_streams;
+                    const int q = (int)(launch_seq++ % (uint64_t)n_rot);
                     for (int u = first; u < first + upl; u++) {
                         unit_dst[u] = &beam_out[(size_t)q * beam_out_stride];
                         if (opt.sink) {
