@@ -156,6 +156,10 @@ def test_block_dedisperse_equals_per_unit_dedisperse(torch, bfmod, orc):
     bf.enqueue_block(2, 1, 0, cfg.n_gemms_per_block, [outs[u] for u in range(cfg.n_gemms_per_block)])   # one coalesced copy
     bf.enqueue_block_dedisperse(2, 0, 5, rows)             # units 0..4
     bf.enqueue_block_dedisperse(2, 5, 3, rows[5:])         # units 5..7
+    # the first block launch allocates EVERY queue's buffer (round 4), but a queue that has launched nothing still has nothing
+    # to collapse: refused, as before
+    with pytest.raises(bfmod.DsabfError, match="has not run on queue 3"):
+        bf.enqueue_block_dedisperse(3, 0, 1, rows)
     bf.sync(-1)
     want = orc.beamform(g, w, block)
     assert np.array_equal(outs.numpy().reshape(want.shape), want)
