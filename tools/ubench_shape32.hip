@@ -110,5 +110,7 @@ int main()
     run<16, 4, 2>(a, b, d_sink, c); run<32, 4, 2>(a, b, d_sink, c);
     run<16, 8, 3>(a, b, d_sink, c); run<32, 8, 3>(a, b, d_sink, c);
     run<16, 16, 7>(a, b, d_sink, c); run<32, 16, 7>(a, b, d_sink, c);
+    run<16, 16, 3>(a, b, d_sink, c);   // fusedg_kernel's pattern (32 accumulators in runs of 2; 16 here) against runs of 4 above at the same K
+    run<16, 32, 3>(a, b, d_sink, c);   // ... with all 32 accumulators (runs of 1 per iteration of this loop)
     return 0;
 }
