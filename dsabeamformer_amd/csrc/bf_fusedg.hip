@@ -18,12 +18,13 @@
 //   * The detect runs once per chunk, after the last k-step, on the finished accumulators -- its cost does not depend on the
 //     antenna count, so it is amortised over ks x the MACs: the more antennas, the closer to the matrix pipe's rate.
 //   * Voltages are staged as OFFSET nibbles u = v + 8 (0..15: the packed nibble with its sign bit flipped -- an AND and an XOR
-//     per four samples, no sign extension), not x16 as in fused16_kernel, and the offset is taken back in the detect:
-//     sum W (u - 8) = sum W u - 8 sum W, and 8 sum W is a constant per (frequency, beam, re | im) that weight_colsum_kernel
-//     tabulates when the weights are set -- one integer add per finished value, paid once per chunk like the rest of the detect.
-//     A chunk's first MFMA takes the seed as srcC (no accumulator initialisation); seed + n with |n| <= 2032 * n_ant < 2^22 up
-//     to 2064 antennas, so the magic-seed conversion (int32 0x4B400000 + n = the bits of the float 1.5 * 2^23 + n, then ONE fma
-//     for fl(n / 127)) holds for every supported antenna count.
+//     per four samples, no sign extension), not x16 as in fused16_kernel: sum W (u - 8) = sum W u - 8 sum W, and 8 sum W is a
+//     constant per (frequency, beam, re | im) that weight_colsum_kernel tabulates when the weights are set.  A chunk's
+//     accumulators START at seed - 8 sum W (one register move each, as a plain seed would cost), so the finished sums are
+//     seed + n with |n| <= 2032 * n_ant < 2^22 up to 2064 antennas: the magic-seed conversion (int32 0x4B400000 + n = the bits
+//     of the float 1.5 * 2^23 + n, then ONE fma for fl(n / 127)) holds for every supported antenna count.
+//   * An accumulator's two MFMAs of a plane are issued back to back (the second continues the first inside the matrix unit):
+//     what the pipe charges for is every accumulator that enters and leaves it (profiles/r04_ubench_chains.txt).
 //   * Any n_ipo.  A lane group's 32 rows of a chunk are one STREAM: `kout` whole accumulation windows back to back
 //     (kout = 32 / n_ipo windows of n_ipo samples when they fit, else one window over cpg = ceil(n_ipo / 32) chunks), so a
 //     window never straddles two lane groups and its sum is one lane's sequential fp32 chain in time order, as the reference
