@@ -7,7 +7,7 @@ import re
 from conftest import ROOT
 
 DOCS = ["DESIGN.md", "README.md", "INTEGRATION.md", os.path.join("tools", "README.md"), os.path.join("oracle", "README.md"),
-        os.path.join("docs", "LOG_r04.md")]
+        os.path.join("docs", "LOG_r04.md"), os.path.join("docs", "PERF_MODEL.md")]
 PREFIXES = ("profiles/", "tools/", "tests/", "include/", "examples/", "oracle/", "dsabeamformer_amd/", "csrc/")
 
 
