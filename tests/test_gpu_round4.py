@@ -189,6 +189,77 @@ def test_coalescing_handles_any_enqueue_order(torch, bfmod, orc):
     bf.close()
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_random_call_sequences_leave_every_host_buffer_with_its_own_units_bits(torch, bfmod, orc, seed):
+    """Randomised walk over the streaming entry points -- per-unit enqueues (with and without a host destination), DM-0 requests,
+    block launches, analysis events, queue and device syncs, the coalesce switch flipped mid-stream -- with a private host
+    buffer per request: whatever the order, every buffer ends up with the bits of the unit it was asked for."""
+    from dsabeamformer_amd import api
+
+    g, cfg, bf, blocks, want = _small_streaming_handle(bfmod, orc, 50 + seed, paired=bool(seed & 1))
+    per = bf.floats_per_detect
+    n_u, n_q, n_slots = cfg.n_gemms_per_block, cfg.n_streams, cfg.n_blocks_on_gpu
+    pinned_in = torch.from_numpy(blocks).pin_memory()
+    for slot in range(n_slots):
+        bf.submit_block(slot, pinned_in[slot], blocks[slot].nbytes)
+    bf.sync(-1)
+    rng = np.random.default_rng(seed)
+    n_ops = 60
+    outs = torch.zeros((n_ops * n_u, per), dtype=torch.float32).pin_memory()
+    rows = torch.zeros((n_ops * n_u, g.n_beams), dtype=torch.float32).pin_memory()
+    expect_out, expect_row = {}, {}          # buffer index -> (slot, unit)
+    nxt = [0, 0]                             # next free out / row buffer
+    last_unit = {}                           # queue -> (slot, unit) of its latest gemm-unit (what a DM-0 request collapses)
+    events = []
+    for _ in range(n_ops):
+        op = rng.choice(["unit", "unit", "unit", "unit_nohost", "ded", "ded", "block", "event", "sync_q", "sync_all", "switch"])
+        q = int(rng.integers(n_q))
+        if op in ("unit", "unit_nohost"):
+            slot, ts = int(rng.integers(n_slots)), int(rng.integers(n_u))
+            dst = None
+            if op == "unit":
+                dst = outs[nxt[0]]
+                expect_out[nxt[0]] = (slot, ts)
+                nxt[0] += 1
+            bf.enqueue_gemm_unit(q, slot, ts, dst)
+            last_unit[q] = (slot, ts)
+        elif op == "ded" and q in last_unit:
+            bf.enqueue_dedisperse(q, rows[nxt[1]])
+            expect_row[nxt[1]] = last_unit[q]
+            nxt[1] += 1
+        elif op == "block":
+            slot, first = int(rng.integers(n_slots)), int(rng.integers(n_u))
+            n = int(rng.integers(1, n_u - first + 1))
+            dsts = []
+            for u in range(first, first + n):
+                dsts.append(outs[nxt[0]])
+                expect_out[nxt[0]] = (slot, u)
+                nxt[0] += 1
+            bf.enqueue_block(q, slot, first, n, dsts)
+            last_unit.pop(q, None)           # (a DM-0 request behind a block launch is bf_enqueue_block_dedisperse's business)
+        elif op == "event":
+            ev = api.event_create()
+            bf.record_analysis_event(ev)
+            events.append(ev)
+        elif op == "sync_q":
+            bf.sync(q)
+        elif op == "sync_all":
+            bf.sync(-1)
+        elif op == "switch":
+            bf.set_switch("coalesce", int(rng.integers(2)))
+    bf.sync(-1)
+    assert bf.counter("queued_units") == 0
+    for ev in events:
+        assert api.event_query(ev) == 0
+        api.event_destroy(ev)
+    for k, (slot, u) in expect_out.items():
+        assert np.array_equal(outs[k].numpy().reshape(want.shape[2:]), want[slot, u]), (seed, k, slot, u)
+    for k, (slot, u) in expect_row.items():
+        assert np.array_equal(rows[k].numpy(), orc.dedisperse(g, want[slot, u, 0])), (seed, k, slot, u)
+    assert len(expect_out) > 10
+    bf.close()
+
+
 # ---- fusedg_kernel (csrc/bf_fusedg.hip): the reference's whole geometry contract ------------------------------------------------
 def _cfg_of(bfmod, g, **over):
     cfg = bfmod.debug_config(n_beams=g.n_beams, n_ant=g.n_ant, n_freq=g.n_freq, n_pol=g.n_pol, n_avg=g.n_avg,
