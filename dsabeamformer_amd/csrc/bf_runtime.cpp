@@ -494,6 +494,33 @@ static int ensure_block_buffers(bf_handle* h, int q, bool ded)
 // wait for the previous flush's, so that two units copied to the same host buffer land in enqueue order as they do on
 // the reference's per-queue streams (src/beamformer.cu:485-488 overwrites beam_out[stream] unit after unit), while this
 // flush's kernel already overlaps the previous flush's copies.
+// A launch on compute queue q is about to overwrite gemm-units [ts0, ts1) of that queue's block buffer.  A caller-visible queue
+// whose MOST RECENT gemm-unit's powers still live there -- bf_enqueue_dedisperse may yet be called for it: "the unit last
+// enqueued on stream_idx", include/dsabf.h -- and that is not given a newer unit by this very launch (`reassigned`) gets them
+// moved to its own slot of d_out first: behind whatever queue s still has in flight on that slot (a literal-pattern unit's
+// host copy), in front of the launch.  Never happens in the reference's loop (a time slice belongs to one queue there).
+static int preserve_last_units(bf_handle* h, int q, size_t ts0, size_t ts1, const std::vector<char>* reassigned)
+{
+    if (h->d_out_blk.empty() || !h->d_out_blk[q]) return BF_OK;
+    const size_t per_det = bf_floats_per_detect(&h->cfg);
+    const float* lo = h->d_out_blk[q] + per_det * ts0;
+    const float* hi = h->d_out_blk[q] + per_det * ts1;
+    for (int s = 0; s < h->cfg.n_streams; s++) {
+        if (reassigned && (*reassigned)[(size_t)s]) continue;
+        const float* p = h->last_out[s];
+        if (p < lo || p >= hi) continue;
+        float* keep = h->d_out + per_det * (size_t)s;
+        if (s != q) {
+            HIP_TRY(hipEventRecord(h->join[s], h->streams[s]));
+            HIP_TRY(hipStreamWaitEvent(h->streams[q], h->join[s], 0));
+        }
+        HIP_TRY(hipMemcpyAsync(keep, p, per_det * sizeof(float), hipMemcpyDeviceToDevice, h->streams[q]));
+        h->last_out[s] = keep;
+        h->last_q[s] = q;
+    }
+    return BF_OK;
+}
+
 static int flush_units(bf_handle* h)
 {
     if (h->pending.empty()) return BF_OK;
@@ -513,10 +540,13 @@ static int flush_units(bf_handle* h)
     auto follows = [&](size_t k) {       // unit k continues the run of unit k - 1
         return units[k].slot == units[k - 1].slot && units[k].time_slice == units[k - 1].time_slice + 1;
     };
+    std::vector<char> reassigned((size_t)h->cfg.n_streams, 0);   // queues that get a newer "most recent unit" from this flush
+    for (const auto& u : units) reassigned[(size_t)u.stream_idx] = 1;
     for (size_t i = 0; i < n;) {
         size_t j = i + 1;
         while (j < n && follows(j)) j++;
         const uint8_t* in = h->d_data + per_gemm * ((size_t)h->cfg.n_gemms_per_block * units[i].slot + units[i].time_slice);
+        if (int rc = preserve_last_units(h, q, (size_t)units[i].time_slice, (size_t)units[i].time_slice + (j - i), &reassigned)) return rc;
         h->n_fused_launches++;
     HIP_TRY(dsabf::launch_fused(h->geom, h->d_wimage, h->d_wimage_p, in, (int)(j - i), blk + per_det * (size_t)units[i].time_slice,
                                     h->n_cus, s));
@@ -592,6 +622,13 @@ int bf_enqueue_gemm_unit(bf_handle* h, int stream_idx, int slot, int time_slice,
     const uint8_t* in = h->d_data + per_gemm * ((size_t)h->cfg.n_gemms_per_block * slot + time_slice);
     float* out = h->d_out + per_det * (size_t)stream_idx;
     hipStream_t s = h->streams[stream_idx];
+    if (h->last_out[stream_idx] == out && h->last_q[stream_idx] != stream_idx) {
+        // this queue's slot holds powers that preserve_last_units moved here on ANOTHER queue (and a DM-0 request may be reading
+        // them there): overwrite it behind that queue's work
+        const int lq = h->last_q[stream_idx];
+        HIP_TRY(hipEventRecord(h->join[lq], h->streams[lq]));
+        HIP_TRY(hipStreamWaitEvent(s, h->join[lq], 0));
+    }
     h->n_fused_launches++;
     HIP_TRY(dsabf::launch_fused(h->geom, h->d_wimage, h->d_wimage_p, in, 1, out, h->n_cus, s));
     if (host_out) HIP_TRY(hipMemcpyAsync(host_out, out, per_det * sizeof(float), hipMemcpyDeviceToHost, s));
@@ -620,6 +657,7 @@ int bf_enqueue_block(bf_handle* h, int stream_idx, int slot, int first_unit, int
             if (!h->d_out_blk[q])
                 HIP_TRY(hipMalloc((void**)&h->d_out_blk[q], per_det * sizeof(float) * (size_t)h->cfg.n_gemms_per_block));
     h->blk_ran[stream_idx] = 1;
+    if (int rc = preserve_last_units(h, stream_idx, (size_t)first_unit, (size_t)first_unit + (size_t)n_units, nullptr)) return rc;
     const uint8_t* in = h->d_data + per_gemm * ((size_t)h->cfg.n_gemms_per_block * slot + first_unit);
     float* out = h->d_out_blk[stream_idx] + per_det * (size_t)first_unit;
     hipStream_t s = h->streams[stream_idx];

@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""The randomised walk over the streaming entry points (tests/test_gpu_round4.py::test_random_call_sequences_...) for many
+seeds.  GPU box, repo root:  SEED=100 CASES=300 python tools/fuzz_calls.py"""
+import os
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+import torch  # noqa: E402
+
+import dsabeamformer_amd as bfm  # noqa: E402
+import oracle as orc  # noqa: E402
+import test_gpu_round4 as t  # noqa: E402
+
+seed0, cases = int(os.environ.get("SEED", "100")), int(os.environ.get("CASES", "200"))
+bad = 0
+for s in range(seed0, seed0 + cases):
+    try:
+        t.test_random_call_sequences_leave_every_host_buffer_with_its_own_units_bits(torch, bfm, orc, s)
+    except AssertionError as e:
+        if "> 10" in str(e) or "assert" in str(e) and "len(" in str(e):
+            continue                 # (a walk with too few host buffers: not a parity failure)
+        bad += 1
+        print("seed", s, "FAILED:", str(e)[:200], flush=True)
+print("seeds %d..%d: %d walks, %d parity failures" % (seed0, seed0 + cases - 1, cases, bad))
