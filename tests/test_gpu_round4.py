@@ -207,22 +207,27 @@ def test_random_call_sequences_leave_every_host_buffer_with_its_own_units_bits(t
     n_ops = 60
     outs = torch.zeros((n_ops * n_u, per), dtype=torch.float32).pin_memory()
     rows = torch.zeros((n_ops * n_u, g.n_beams), dtype=torch.float32).pin_memory()
-    expect_out, expect_row = {}, {}          # buffer index -> (slot, unit)
+    # a second weight set, swapped in mid-stream by some walks: a request is answered under the weights in force when it was made
+    w_sets = [None, np.random.default_rng(900 + seed).integers(-127, 128, size=(g.n_freq, g.n_ant, g.n_beams, 2), dtype=np.int8)]
+    wants = [want, None]
+    which = 0
+    expect_out, expect_row = {}, {}          # buffer index -> (slot, unit, weight set)
     nxt = [0, 0]                             # next free out / row buffer
     last_unit = {}                           # queue -> (slot, unit) of its latest gemm-unit (what a DM-0 request collapses)
     events = []
     for _ in range(n_ops):
-        op = rng.choice(["unit", "unit", "unit", "unit_nohost", "ded", "ded", "block", "event", "sync_q", "sync_all", "switch"])
+        op = rng.choice(["unit", "unit", "unit", "unit_nohost", "ded", "ded", "block", "event", "sync_q", "sync_all", "switch"]
+                        + (["weights"] if seed % 3 == 0 else []))
         q = int(rng.integers(n_q))
         if op in ("unit", "unit_nohost"):
             slot, ts = int(rng.integers(n_slots)), int(rng.integers(n_u))
             dst = None
             if op == "unit":
                 dst = outs[nxt[0]]
-                expect_out[nxt[0]] = (slot, ts)
+                expect_out[nxt[0]] = (slot, ts, which)
                 nxt[0] += 1
             bf.enqueue_gemm_unit(q, slot, ts, dst)
-            last_unit[q] = (slot, ts)
+            last_unit[q] = (slot, ts, which)
         elif op == "ded" and q in last_unit:
             bf.enqueue_dedisperse(q, rows[nxt[1]])
             expect_row[nxt[1]] = last_unit[q]
@@ -233,7 +238,7 @@ def test_random_call_sequences_leave_every_host_buffer_with_its_own_units_bits(t
             dsts = []
             for u in range(first, first + n):
                 dsts.append(outs[nxt[0]])
-                expect_out[nxt[0]] = (slot, u)
+                expect_out[nxt[0]] = (slot, u, which)
                 nxt[0] += 1
             bf.enqueue_block(q, slot, first, n, dsts)
             last_unit.pop(q, None)           # (a DM-0 request behind a block launch is bf_enqueue_block_dedisperse's business)
@@ -247,15 +252,24 @@ def test_random_call_sequences_leave_every_host_buffer_with_its_own_units_bits(t
             bf.sync(-1)
         elif op == "switch":
             bf.set_switch("coalesce", int(rng.integers(2)))
+        elif op == "weights":
+            if w_sets[0] is None:            # (first swap: remember the set the handle was built with, and the other set's answers)
+                w_sets[0] = np.random.default_rng(50 + seed).integers(-127, 128, size=w_sets[1].shape, dtype=np.int8)
+                if seed & 1:
+                    w_sets[0][:, :, 32:, 0] = w_sets[0][:, :, :32, 0][:, :, ::-1]
+                    w_sets[0][:, :, 32:, 1] = -w_sets[0][:, :, :32, 1][:, :, ::-1]
+                wants[1] = np.stack([orc.beamform(g, w_sets[1], blocks[sl]) for sl in range(n_slots)])
+            which ^= 1
+            bf.set_weights(w_sets[which])
     bf.sync(-1)
     assert bf.counter("queued_units") == 0
     for ev in events:
         assert api.event_query(ev) == 0
         api.event_destroy(ev)
-    for k, (slot, u) in expect_out.items():
-        assert np.array_equal(outs[k].numpy().reshape(want.shape[2:]), want[slot, u]), (seed, k, slot, u)
-    for k, (slot, u) in expect_row.items():
-        assert np.array_equal(rows[k].numpy(), orc.dedisperse(g, want[slot, u, 0])), (seed, k, slot, u)
+    for k, (slot, u, ws) in expect_out.items():
+        assert np.array_equal(outs[k].numpy().reshape(want.shape[2:]), wants[ws][slot, u]), (seed, k, slot, u, ws)
+    for k, (slot, u, ws) in expect_row.items():
+        assert np.array_equal(rows[k].numpy(), orc.dedisperse(g, wants[ws][slot, u, 0])), (seed, k, slot, u, ws)
     assert len(expect_out) > 10
     bf.close()
 
