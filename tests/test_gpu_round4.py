@@ -1,4 +1,6 @@
 """GPU tests (-m gpu) of the round-4 surface; every call goes through the C-ABI of libdsabf.so."""
+import os
+
 import numpy as np
 import pytest
 
@@ -53,6 +55,52 @@ def test_dm_calls_in_flight_on_two_streams_of_one_handle_do_not_share_scratch(to
             assert not np.isnan(got).any(), (k, rnd, "a trial group was written by neither kernel")
             assert np.array_equal(got, want[k]), (k, rnd)
     bf.close()
+
+
+def test_dm_calls_on_more_streams_than_the_handle_keeps_scratch_for(torch, bfmod, orc):
+    """The per-stream DM scratch is evicted when a caller has used 64 streams (a device-wide sync first: nothing of the handle
+    may still read it): 70 streams, mixed fine / coarse ladders in flight, every result the oracle's."""
+    rng = np.random.default_rng(12)
+    n_t, n_f, n_b, n_dm = 200, 16, 64, 40
+    fine = (np.arange(n_dm)[:, None] * np.linspace(0.4, 0.0, n_f)[None, :]).astype(np.int32)
+    coarse = (np.arange(n_dm)[:, None] * np.linspace(1.0, 0.0, n_f)[None, :]).astype(np.int32)
+    coarse[1::2] += 120
+    series = (rng.random((n_t, n_f, n_b), dtype=np.float32) * 1e3).astype(np.float32)
+    lad = {"fine": fine, "coarse": coarse}
+    n_out = {k: n_t - int(v.max()) for k, v in lad.items()}
+    want = {k: orc.dedisperse_dm(series, v, n_out[k]) for k, v in lad.items()}
+    bf = bfmod.Beamformer(bfmod.debug_config(n_beams=n_b, n_freq=n_f))
+    d_series = torch.from_numpy(series).cuda()
+    d_del = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in lad.items()}
+    # raw HIP streams (torch.cuda.Stream() hands out 32 pooled ones): the runtime torch already loaded
+    import ctypes
+
+    hip = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+
+    class _S:                                        # (just enough of torch.cuda.Stream for the loop below)
+        def __init__(self):
+            h = ctypes.c_void_p()
+            assert hip.hipStreamCreate(ctypes.byref(h)) == 0
+            self.cuda_stream = h.value
+
+    streams = [_S() for _ in range(70)]
+    outs = []
+    for i in range(len(streams)):
+        k = "fine" if i % 3 else "coarse"
+        outs.append((k, torch.full((n_dm, n_out[k], n_b), float("nan"), dtype=torch.float32, device="cuda")))
+    torch.cuda.synchronize()                         # (the fills ran on torch's current stream)
+    assert len({st.cuda_stream for st in streams}) == 70
+    for st, (k, o) in zip(streams, outs):
+        bf.dedisperse_dm(d_series, n_t, d_del[k], n_dm, n_out[k], o, st.cuda_stream)
+    for i in (0, 5, 69, 64, 1):                      # ... and again on streams on both sides of the eviction
+        k, o = outs[i]
+        bf.dedisperse_dm(d_series, n_t, d_del[k], n_dm, n_out[k], o, streams[i].cuda_stream)
+    torch.cuda.synchronize()
+    for i, (k, o) in enumerate(outs):
+        assert np.array_equal(o.cpu().numpy(), want[k]), (i, k)
+    bf.close()
+    for st in streams:
+        assert hip.hipStreamDestroy(ctypes.c_void_p(st.cuda_stream)) == 0
 
 
 def test_switches_are_per_handle_and_checked(torch, bfmod):
