@@ -290,6 +290,13 @@ def test_random_call_sequences_leave_every_host_buffer_with_its_own_units_bits(t
                 nxt[0] += 1
             bf.enqueue_block(q, slot, first, n, dsts)
             last_unit.pop(q, None)           # (a DM-0 request behind a block launch is bf_enqueue_block_dedisperse's business)
+            if rng.integers(3) == 0:         # ... the DM-0 rows of a stretch of the block just launched, in one launch
+                a = first + int(rng.integers(n))
+                m = int(rng.integers(1, first + n - a + 1))
+                bf.enqueue_block_dedisperse(q, a, m, rows[nxt[1]:nxt[1] + m])
+                for u in range(a, a + m):
+                    expect_row[nxt[1]] = (slot, u, which)
+                    nxt[1] += 1
         elif op == "event":
             ev = api.event_create()
             bf.record_analysis_event(ev)
