@@ -124,9 +124,10 @@ def test_switches_are_per_handle_and_checked(torch, bfmod):
     b.close()
 
 
-def _small_streaming_handle(bfmod, orc, seed, paired=False):
-    g = orc.Geom(n_beams=64, n_ant=64, n_freq=6, n_avg=16, n_out_per_gemm=2)
+def _small_streaming_handle(bfmod, orc, seed, paired=False, n_ant=64, n_avg=16):
+    g = orc.Geom(n_beams=64, n_ant=n_ant, n_freq=6, n_avg=n_avg, n_out_per_gemm=2)
     cfg = bfmod.production_config(n_avg=g.n_avg, n_out_per_gemm=g.n_out_per_gemm, n_freq=g.n_freq)
+    cfg.n_ant = n_ant
     cfg.n_beams, cfg.n_gemms_per_block, cfg.n_blocks_on_gpu, cfg.n_streams = g.n_beams, 8, 3, 4
     rng = np.random.default_rng(seed)
     w = rng.integers(-127, 128, size=(g.n_freq, g.n_ant, g.n_beams, 2), dtype=np.int8)
@@ -244,7 +245,10 @@ def test_random_call_sequences_leave_every_host_buffer_with_its_own_units_bits(t
     buffer per request: whatever the order, every buffer ends up with the bits of the unit it was asked for."""
     from dsabeamformer_amd import api
 
-    g, cfg, bf, blocks, want = _small_streaming_handle(bfmod, orc, 50 + seed, paired=bool(seed & 1))
+    # seeds from 10000 on (tools/fuzz_calls.py) walk other kernel families too: two k-steps, dword rows, the deep class, fusedg_kernel,
+    # run-time windows
+    n_ant, n_avg = ((64, 16), (100, 16), (192, 16), (132, 16), (64, 3), (320, 8))[(seed // 7) % 6] if seed >= 10000 else (64, 16)
+    g, cfg, bf, blocks, want = _small_streaming_handle(bfmod, orc, 50 + seed, paired=bool(seed & 1), n_ant=n_ant, n_avg=n_avg)
     per = bf.floats_per_detect
     n_u, n_q, n_slots = cfg.n_gemms_per_block, cfg.n_streams, cfg.n_blocks_on_gpu
     pinned_in = torch.from_numpy(blocks).pin_memory()
@@ -309,7 +313,7 @@ def test_random_call_sequences_leave_every_host_buffer_with_its_own_units_bits(t
             bf.set_switch("coalesce", int(rng.integers(2)))
         elif op == "weights":
             if w_sets[0] is None:            # (first swap: remember the set the handle was built with, and the other set's answers)
-                w_sets[0] = np.random.default_rng(50 + seed).integers(-127, 128, size=w_sets[1].shape, dtype=np.int8)
+                w_sets[0] = np.random.default_rng(50 + seed).integers(-127, 128, size=w_sets[1].shape, dtype=np.int8)   # (= _small_streaming_handle's)
                 if seed & 1:
                     w_sets[0][:, :, 32:, 0] = w_sets[0][:, :, :32, 0][:, :, ::-1]
                     w_sets[0][:, :, 32:, 1] = -w_sets[0][:, :, :32, 1][:, :, ::-1]
