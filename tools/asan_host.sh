@@ -16,7 +16,7 @@ C=dsabeamformer_amd/csrc
 $CXX -O1 -g -std=c++17 -fPIC -ffp-contract=off -fsanitize=address,undefined -fno-omit-frame-pointer -Iinclude \
     -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -shared -o /tmp/libhost_asan.so $C/bf_geometry.cpp $C/bf_generator.cpp \
     $C/bf_scheduler.cpp $C/bf_sinks.cpp $C/bf_host_c.cpp $C/bf_runtime.cpp $C/bf_comm.cpp $C/bf_shmring.cpp $C/bf_dada.cpp \
-    dsabeamformer_amd/build/bf_kernels.hip.o dsabeamformer_amd/build/bf_dm_wide.hip.o dsabeamformer_amd/build/bf_fused16_*.hip.o -lpthread -lrt -ldl || exit 1
+    dsabeamformer_amd/build/bf_kernels.hip.o dsabeamformer_amd/build/bf_dm_wide.hip.o dsabeamformer_amd/build/bf_fusedg.hip.o dsabeamformer_amd/build/bf_fused16_*.hip.o -lpthread -lrt -ldl || exit 1
 cp /tmp/libhost_asan.so dsabeamformer_amd/libdsabf.so
 status=0
 ASAN_OPTIONS=detect_leaks=0:verify_asan_link_order=0 LD_PRELOAD=$($CXX -print-file-name=libclang_rt.asan-x86_64.so) \

@@ -11,7 +11,7 @@ C=dsabeamformer_amd/csrc
 $CXX -O1 -g -std=c++17 -fPIC -ffp-contract=off -fsanitize=thread -fno-omit-frame-pointer -Iinclude \
     -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -shared -o /tmp/libhost_tsan.so $C/bf_geometry.cpp $C/bf_generator.cpp \
     $C/bf_scheduler.cpp $C/bf_sinks.cpp $C/bf_host_c.cpp $C/bf_runtime.cpp $C/bf_comm.cpp $C/bf_shmring.cpp $C/bf_dada.cpp \
-    dsabeamformer_amd/build/bf_kernels.hip.o dsabeamformer_amd/build/bf_dm_wide.hip.o dsabeamformer_amd/build/bf_fused16_*.hip.o -lpthread -lrt -ldl || exit 1
+    dsabeamformer_amd/build/bf_kernels.hip.o dsabeamformer_amd/build/bf_dm_wide.hip.o dsabeamformer_amd/build/bf_fusedg.hip.o dsabeamformer_amd/build/bf_fused16_*.hip.o -lpthread -lrt -ldl || exit 1
 cp /tmp/libhost_tsan.so dsabeamformer_amd/libdsabf.so
 TSAN_OPTIONS="report_signal_unsafe=0 halt_on_error=0 exitcode=66 log_path=/tmp/tsan_report" LD_PRELOAD=$($CXX -print-file-name=libclang_rt.tsan-x86_64.so) \
     python -m pytest tests/test_host_cpu.py -x -q -k "sink or ring or shm or generator or observation" 2>&1 | tee /tmp/tsan.log | tail -5
