@@ -333,6 +333,39 @@ def test_random_call_sequences_leave_every_host_buffer_with_its_own_units_bits(t
     bf.close()
 
 
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_production_loop_to_file_under_random_launch_patterns(bfmod, orc, tmp_path, monkeypatch, seed):
+    """run_observation with a file sink under random block / queue counts and every launch pattern it offers (whole blocks,
+    sub-block launches, the reference's per-unit loop coalesced or literal): the detected stream in the file is the oracle's,
+    every gemm-unit, in index order."""
+    from dsabeamformer_amd import host
+
+    rng = np.random.default_rng(700 + seed)
+    n_u = int(rng.choice([4, 8, 16]))
+    n_st = int(rng.choice([s for s in (1, 2, 4, 8) if s <= n_u]))
+    n_blocks, ring_blocks = int(rng.integers(3, 10)), int(rng.integers(2, 5))
+    pattern = rng.choice(["block", "sub", "units", "units_literal"])
+    if pattern == "sub":
+        monkeypatch.setenv("DSABF_UNITS_PER_LAUNCH", str(int(rng.choice([1, 2, n_u // 2]))))
+    elif pattern in ("units", "units_literal"):
+        monkeypatch.setenv("DSABF_UNIT_LAUNCH", "1")
+        if pattern == "units_literal":
+            monkeypatch.setenv("DSABF_COALESCE", "0")
+    n_avg = int(rng.choice([16, 8]))
+    cfg = bfmod.production_config(n_freq=8, n_avg=n_avg, n_out_per_gemm=int(rng.choice([2, 4])))
+    cfg.n_beams, cfg.n_gemms_per_block, cfg.n_streams = 64, n_u, n_st
+    path = str(tmp_path / "detected.bin")
+    r = host.run_observation_junk_to_file(cfg, n_blocks, path, ring_blocks=ring_blocks, seed=1000 + seed, gpu=1)
+    assert r["gemms_written"] == n_blocks * n_u, (pattern, n_u, n_st)
+    hdr, data = host.read_detected_file(path)
+    assert data.shape == (n_blocks * n_u, cfg.n_out_per_gemm, 8, 64)
+    g = orc.Geom(n_beams=64, n_ant=64, n_freq=8, n_avg=n_avg, n_out_per_gemm=cfg.n_out_per_gemm)
+    w = orc.make_weights(g, orc.default_positions(64), orc.default_directions(64), 1)
+    for blk in range(n_blocks):
+        want = orc.beamform(g, w, r["ring"][blk % ring_blocks])
+        assert np.array_equal(data[blk * n_u:(blk + 1) * n_u].reshape(want.shape), want), (pattern, n_u, n_st, n_blocks, ring_blocks, blk)
+
+
 # ---- fusedg_kernel (csrc/bf_fusedg.hip): the reference's whole geometry contract ------------------------------------------------
 def _cfg_of(bfmod, g, **over):
     cfg = bfmod.debug_config(n_beams=g.n_beams, n_ant=g.n_ant, n_freq=g.n_freq, n_pol=g.n_pol, n_avg=g.n_avg,

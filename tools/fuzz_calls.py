@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """The randomised walk over the streaming entry points (tests/test_gpu_round4.py::test_random_call_sequences_...) for many
-seeds.  GPU box, repo root:  SEED=100 CASES=300 python tools/fuzz_calls.py"""
+seeds.  GPU box, repo root:  SEED=100 CASES=300 python tools/fuzz_calls.py
+FUZZ=loops: test_production_loop_to_file_under_random_launch_patterns (the whole observation loop to a file sink) instead."""
 import os
 import sys
 
@@ -14,6 +15,34 @@ import test_gpu_round4 as t  # noqa: E402
 
 seed0, cases = int(os.environ.get("SEED", "100")), int(os.environ.get("CASES", "200"))
 bad = 0
+if os.environ.get("FUZZ") == "loops":      # run_observation to a file sink under random block / queue counts and launch patterns
+    import pathlib
+    import tempfile
+
+    class Env:                              # (pytest's monkeypatch, as much of it as the test uses)
+        def __init__(self):
+            self.set = []
+
+        def setenv(self, k, v):
+            os.environ[k] = v
+            self.set.append(k)
+
+        def undo(self):
+            for k in self.set:
+                os.environ.pop(k, None)
+
+    for s in range(seed0, seed0 + cases):
+        env = Env()
+        with tempfile.TemporaryDirectory() as d:
+            try:
+                t.test_production_loop_to_file_under_random_launch_patterns(bfm, orc, pathlib.Path(d), env, s)
+            except AssertionError as e:
+                bad += 1
+                print("seed", s, "FAILED:", str(e)[:200], flush=True)
+            finally:
+                env.undo()
+    print("observation loops, seeds %d..%d: %d runs, %d parity failures" % (seed0, seed0 + cases - 1, cases, bad))
+    sys.exit(0)
 for s in range(seed0, seed0 + cases):
     try:
         t.test_random_call_sequences_leave_every_host_buffer_with_its_own_units_bits(torch, bfm, orc, s)
