@@ -527,6 +527,44 @@ def test_debug_flow_end_to_end_on_a_geometry_only_the_generic_kernel_covers(bfmo
     assert ded.max() > 0 and np.isfinite(ded).all()
 
 
+@pytest.mark.parametrize("seed", list(range(10)))
+def test_debug_flow_with_random_catalogues_geometries_and_launch_patterns(bfmod, orc, tmp_path, seed):
+    """`make debug` end to end with a source catalogue that does not fill its last block, a random antenna class / window /
+    block size / queue count, block launches or the reference's per-unit loop: the whole table equals the oracle's."""
+    from dsabeamformer_amd import host
+
+    rng = np.random.default_rng(1300 + seed)
+    n_ant = int(rng.choice([64, 64, 100, 128, 132, 192]))
+    n_beams = int(rng.choice([32, 64, 96]))
+    n_avg, n_out = int(rng.choice([1, 3, 8, 16])), int(rng.choice([2, 4, 8]))
+    n_u = int(rng.choice([4, 8, 16]))
+    n_st = int(rng.choice([q for q in (1, 2, 4, 8) if q <= n_u]))
+    n_src = int(rng.integers(1, 3 * n_u + 2))
+    per_unit = bool(rng.integers(2))
+    pos = np.zeros((n_ant, 3), np.float32)
+    pos[:, 0] = np.linspace(-400.0, 400.0, n_ant) + rng.uniform(-2, 2, n_ant)
+    pos[:, 1] = rng.uniform(-30, 30, n_ant)
+    dirs = np.stack([np.linspace(-3.0, 3.0, n_beams) * np.pi / 180, rng.uniform(-0.5, 0.5, n_beams) * np.pi / 180], 1).astype(np.float32)
+    src = np.stack([rng.uniform(-2.9, 2.9, n_src) * np.pi / 180, rng.uniform(-0.3, 0.3, n_src) * np.pi / 180], 1).astype(np.float32)
+    pfile, dfile, sfile = tmp_path / "pos.txt", tmp_path / "dir.txt", tmp_path / "src.txt"
+    pfile.write_text("%d\n" % n_ant + "".join("%r %r %r\n" % (float(p[0]), float(p[1]), float(p[2])) for p in pos))
+    dfile.write_text("%d\n" % n_beams + "".join("%r %r\n" % (float(d[0]), float(d[1])) for d in dirs))
+    sfile.write_text("%d\n" % n_src + "".join("%r %r\n" % (float(x[0]), float(x[1])) for x in src))
+    cfg = bfmod.debug_config(n_ant=n_ant, n_beams=n_beams, n_freq=8, n_avg=n_avg, n_out_per_gemm=n_out, n_gemms_per_block=n_u,
+                             n_blocks_on_gpu=int(rng.integers(2, 5)), n_streams=n_st)
+    what = (n_ant, n_beams, n_avg, n_out, n_u, n_st, n_src, per_unit)
+    ded, _ms = host.run_debug_observation(cfg, gpu=0, positions=str(pfile), directions=str(dfile), sources=str(sfile),
+                                          output=str(tmp_path / "data.py"), max_sources=max(n_src, 1), per_unit_launches=per_unit)
+    assert ded.shape == (n_src, n_beams), what
+    g = orc.Geom(n_beams=n_beams, n_ant=n_ant, n_freq=8, n_avg=n_avg, n_out_per_gemm=n_out)
+    p32, d32, s32 = orc.read_positions(str(pfile), n_ant), orc.read_directions(str(dfile), n_beams), orc.read_directions(str(sfile))
+    w = orc.make_weights(g, p32, d32, 0)
+    units = orc.generate_test_data(g, p32, s32, 0, 0, n_src)
+    out = orc.beamform(g, w, units)
+    want = np.stack([orc.dedisperse(g, out[u]) for u in range(n_src)])
+    assert np.array_equal(ded, want), what
+
+
 # ---- the deep classes of fused16_kernel: three / four k-steps, weights stationary (129 ... 256 antennas) -----------------------
 @pytest.mark.parametrize("n_ant", [144, 192, 208, 256])
 @pytest.mark.parametrize("n_avg,paired", [(16, False), (8, False), (32, False), (16, True), (32, True), (16, 256), (8, 96)])

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """The randomised walk over the streaming entry points (tests/test_gpu_round4.py::test_random_call_sequences_...) for many
 seeds.  GPU box, repo root:  SEED=100 CASES=300 python tools/fuzz_calls.py
-FUZZ=loops: test_production_loop_to_file_under_random_launch_patterns (the whole observation loop to a file sink) instead."""
+FUZZ=loops: test_production_loop_to_file_under_random_launch_patterns (the whole observation loop to a file sink) instead;
+FUZZ=debug: test_debug_flow_with_random_catalogues_geometries_and_launch_patterns."""
 import os
 import sys
 
@@ -42,6 +43,19 @@ if os.environ.get("FUZZ") == "loops":      # run_observation to a file sink unde
             finally:
                 env.undo()
     print("observation loops, seeds %d..%d: %d runs, %d parity failures" % (seed0, seed0 + cases - 1, cases, bad))
+    sys.exit(0)
+if os.environ.get("FUZZ") == "debug":      # the DEBUG flow end to end on random catalogues / geometries / launch patterns
+    import pathlib
+    import tempfile
+
+    for s in range(seed0, seed0 + cases):
+        with tempfile.TemporaryDirectory() as d:
+            try:
+                t.test_debug_flow_with_random_catalogues_geometries_and_launch_patterns(bfm, orc, pathlib.Path(d), s)
+            except AssertionError as e:
+                bad += 1
+                print("seed", s, "FAILED:", str(e)[:200], flush=True)
+    print("DEBUG flows, seeds %d..%d: %d runs, %d parity failures" % (seed0, seed0 + cases - 1, cases, bad))
     sys.exit(0)
 for s in range(seed0, seed0 + cases):
     try:
