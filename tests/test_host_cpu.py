@@ -305,6 +305,41 @@ def test_detected_sink_ring_and_file_format(host, bfm, tmp_path):
     assert np.array_equal(data.reshape(9, per), want)
 
 
+@pytest.mark.parametrize("seed", list(range(8)))
+def test_detected_sink_under_random_acquire_and_commit_orders(host, bfm, tmp_path, seed):
+    """dsabf::file_sink: gemm-units acquired in a random order inside the ring's window, committed in index order at random
+    moments, acquires outside the window refused -- the file holds every unit once, in index order."""
+    rng = np.random.default_rng(40 + seed)
+    cfg = bfm.debug_config()
+    cfg.n_beams, cfg.n_freq, cfg.n_out_per_gemm, cfg.n_gemms_per_block = 16, 3, int(rng.integers(1, 4)), 4
+    per = cfg.n_out_per_gemm * cfg.n_freq * cfg.n_beams
+    slots, n = int(rng.integers(2, 9)), int(rng.integers(5, 40))
+    path = str(tmp_path / "detected.bin")
+    sink = host.FileSink(cfg, path, gpu=1, slots=slots)
+    want = rng.standard_normal((n, per)).astype(np.float32)
+    committed, acquired = 0, set()
+    while committed < n:
+        window = [g for g in range(committed, min(n, committed + slots)) if g not in acquired]
+        if window and (rng.integers(3) or committed not in acquired):
+            g = int(rng.choice(window))
+            view = sink.acquire(g)
+            assert view is not None, (g, committed, slots)
+            view[:] = want[g]
+            acquired.add(g)
+        elif committed in acquired:
+            assert sink.commit(committed)
+            committed += 1
+        beyond = committed + slots + int(rng.integers(0, 3))
+        assert sink.acquire(beyond) is None                     # no slot for a unit beyond the window
+        if committed:
+            assert sink.acquire(int(rng.integers(committed))) is None   # ... nor for one already delivered
+            assert not sink.commit(committed - 1)
+    sink.close()
+    hdr, data = host.read_detected_file(path)
+    assert os.path.getsize(path) == host.DETECTED_HEADER_BYTES + want.nbytes
+    assert np.array_equal(data.reshape(n, per), want)
+
+
 def _ring_name(tag):
     return "dsabf_test_%s_%d" % (tag, os.getpid())
 
