@@ -119,8 +119,9 @@ def test_generator_batches_gating_and_overrun(host, orc, bfm, linear_inputs):
     gen.close()
 
 
-def _simulate(obs, gen_blocks, per_block=32, n_streams=8, transfer_lag=1, analysis_lag=2, max_iter=100000):
-    """The reference's DEBUG while-loop (src/beamformer.cu:364-534) with fake device completion."""
+def _simulate(obs, gen_blocks, per_block=32, n_streams=8, transfer_lag=1, analysis_lag=2, max_iter=100000, rng=None):
+    """The reference's DEBUG while-loop (src/beamformer.cu:364-534) with fake device completion.
+    rng: every event gets its own random lag of 1 ... transfer_lag / analysis_lag iterations (completion stays in order)."""
     time_slice = list(range(n_streams))
     log = []
     pend_t, pend_a = [], []
@@ -137,10 +138,12 @@ def _simulate(obs, gen_blocks, per_block=32, n_streams=8, transfer_lag=1, analys
                 log.append(("H2D", obs.get_next_gpu_transfer_block(), c["TQ"]))
                 assert obs.get_next_gpu_transfer_block() == c["TQ"] % 8
                 obs.generate_transfer_event()
-                pend_t.append(it)
+                pend_t.append(it if rng is None else it + transfer_lag - int(rng.integers(1, transfer_lag + 1)))
             obs.check_transfers_complete()
         # device progress: a transfer completes `transfer_lag` iterations after it was queued
-        done_t = len([x for x in pend_t if it - x >= transfer_lag])
+        done_t = 0
+        while done_t < len(pend_t) and it - pend_t[done_t] >= transfer_lag:   # (in order: a stream's events complete FIFO)
+            done_t += 1
         obs.fake_complete(done_t, 0)
         pend_t = pend_t[done_t:]
         obs.check_transfer_events()
@@ -154,12 +157,33 @@ def _simulate(obs, gen_blocks, per_block=32, n_streams=8, transfer_lag=1, analys
                     if time_slice[st] >= per_block:
                         time_slice[st] -= per_block
             obs.generate_analysis_event()
-            pend_a.append(it)
-        done_a = len([x for x in pend_a if it - x >= analysis_lag])
+            pend_a.append(it if rng is None else it + analysis_lag - int(rng.integers(1, analysis_lag + 1)))
+        done_a = 0
+        while done_a < len(pend_a) and it - pend_a[done_a] >= analysis_lag:
+            done_a += 1
         obs.fake_complete(0, done_a)
         pend_a = pend_a[done_a:]
         obs.check_analysis_events()
     return log
+
+
+@pytest.mark.parametrize("seed", list(range(6)))
+def test_observation_loop_scheduler_under_random_completion_lags(host, bfm, seed):
+    """The same loop with every transfer / analysis event completing after its own random lag: same order of work, same
+    invariants (checked inside _simulate), every block once."""
+    rng = np.random.default_rng(60 + seed)
+    n_src = int(rng.integers(1, 700))
+    cfg = bfm.debug_config()
+    obs = make_obs(host, cfg, debug=True)
+    obs.set_n_pt_sources(n_src)
+    log = _simulate(obs, gen_blocks=10 ** 9, transfer_lag=int(rng.integers(1, 7)), analysis_lag=int(rng.integers(1, 9)), rng=rng)
+    n_blocks = -(-n_src // 32)
+    assert obs.counters() == {"A": n_blocks, "AQ": n_blocks, "T": n_blocks, "TQ": n_blocks}
+    gemms = [e for e in log if e[0] == "GEMM"]
+    assert [e[3] for e in gemms] == [b * 32 + p * 8 + s for b in range(n_blocks) for p in range(4) for s in range(8)]
+    assert [e[3] for e in gemms if e[4]] == list(range(n_src))
+    assert [e[2] for e in log if e[0] == "H2D"] == list(range(n_blocks))
+    obs.close()
 
 
 @pytest.mark.parametrize("n_src,tl,al", [(1024, 1, 2), (1024, 3, 1), (100, 1, 5), (33, 2, 2)])
