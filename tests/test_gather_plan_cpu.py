@@ -1,5 +1,5 @@
 """CPU tests of the gather's layout arithmetic (bf_gather_offset / bf_gather_plan, include/dsabf.h): the device part of
-bf_gather_detected only walks this plan with ncclSend / ncclRecv, so simulating the plan with numpy for R = 1, 2, 4, 8 ranks
+bf_gather_detected only walks this plan with ncclSend / ncclRecv, so simulating the plan with numpy for R = 1 ... 8 ranks
 proves where every float of every rank lands.  SURVEY.md 8e: rank r's row o sits at o*F*B + r*(F/R)*B in [o][f][b]."""
 import ctypes as C
 
@@ -19,14 +19,14 @@ def _plan(lib, layout, n_rows, row_floats, world, rank, root):
     return [(m.kind, m.peer, m.local_offset, m.full_offset, m.count) for m in arr[:n]]
 
 
-@pytest.mark.parametrize("world", [1, 2, 4, 8])
+@pytest.mark.parametrize("world", [1, 2, 3, 4, 5, 6, 7, 8])
 @pytest.mark.parametrize("layout", [FREQ_MAJOR, RANK_MAJOR])
 @pytest.mark.parametrize("root", [0, -1, "last", -2])
 def test_simulated_gather_reproduces_the_full_band(world, layout, root):
     """root 0 / last: gather to one owner; -1: everybody receives everything; -2: distributed owners (all-to-all)."""
     lib = load()
     root = world - 1 if root == "last" else root
-    n_out, n_units, f_local, n_beams = 4, 4, 5, 12
+    n_out, n_units, f_local, n_beams = 4, (world if root == -2 else 4), 5, 12      # (distributed owners: rows divisible by the ranks)
     n_rows, row_floats = n_units * n_out, f_local * n_beams
     rng = np.random.default_rng(world * 10 + layout)
     full_ofb = rng.random((n_rows, world * f_local, n_beams)).astype(np.float32)      # the whole band, [o][f][b]
