@@ -130,7 +130,11 @@ __global__ __launch_bounds__(kDwThreads) void dedisperse_dm_wide_kernel(const fl
             lo = min(lo, d);
             hi = max(hi, d);
         }
-        tab[f] = v2i{lo, hi - lo + kDwTb};
+        // .y: rows of the window; bit 16: every row of every DMA piece of the window lies inside the series (the common case:
+        // the staging loop then needs no range test and no per-lane address)
+        const int rows = hi - lo + kDwTb, rows_up = (rows + kDwRowsPerDma - 1) / kDwRowsPerDma * kDwRowsPerDma;
+        const bool inside = (long long)t0 + lo >= 0 && (long long)t0 + lo + rows_up <= n_t && (bg + 1) * kDwBeams <= n_beams;   // (and every beam of the tile live)
+        tab[f] = v2i{lo, rows | (inside ? 0x10000 : 0)};
         fits &= (long long)hi - lo + kDwTb <= rows_cap && lo > -(1 << 30) && hi < (1 << 30);   // (and row arithmetic stays in int)
         for (int k = 0; k < kDwTrials; k++)               // a missing trial repeats the last one (computed, never stored)
             offs[k * n_freq + f] = (unsigned char)(delays[(size_t)(dm0 + min(k, nk - 1)) * n_freq + f] - lo);
@@ -151,10 +155,6 @@ __global__ __launch_bounds__(kDwThreads) void dedisperse_dm_wide_kernel(const fl
     const int bs = bg * kDwBeams + 4 * (lane % kLpr);
     const size_t row_stride = (size_t)n_freq * n_beams;
     const int win_bytes = rows_cap * kDwRowBytes;
-    auto pairs_of = [&](v2i t) {                          // DMA instructions THIS wave issues for a window of t.y rows
-        const int np = (__builtin_amdgcn_readfirstlane(t.y) + kDwRowsPerDma - 1) / kDwRowsPerDma;
-        return np > wave ? (np - wave + kDwWaves - 1) / kDwWaves : 0;
-    };
     // Addressing is split so that the per-lane part is loop-invariant: lane_src already holds the lane's row inside a DMA
     // (lane / lanes-per-row) and its beams; what changes per DMA -- first row of the piece, channel -- is wave-uniform and
     // stays on the scalar unit (a per-lane row * stride would be two quarter-rate 64-bit multiplies per instruction).  The
@@ -165,11 +165,31 @@ __global__ __launch_bounds__(kDwThreads) void dedisperse_dm_wide_kernel(const fl
     const bool beams_ok = bs < n_beams;
     const bool all_beams_ok = __builtin_amdgcn_readfirstlane((int)__all(beams_ok ? 1 : 0)) != 0;   // wave-uniform
     const unsigned row_stride_b = (unsigned)(row_stride * sizeof(float));   // uniform
-    auto dma_window = [&](int f, int slot, v2i t) {       // t = tab[f], already in registers; slot = f % kDwNbuf
-        const int nr = __builtin_amdgcn_readfirstlane(t.y);
+    // the common case on the scalar unit alone: a buffer descriptor over the series, the lane's constant offset as the only vector
+    // operand, (window row, channel, piece) in the scalar offset -- 5 scalar instructions and the DMA per piece, no range test
+    const __amdgpu_buffer_rsrc_t s_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(series), 0, -1, 0x00020000);
+    const unsigned wave_piece_b = (unsigned)(kDwRowsPerDma * wave) * row_stride_b;          // this wave's first piece, bytes from the window's first row
+    // returns the number of DMA instructions THIS wave issued (what wait_dma_but has to leave in flight one iteration later)
+    auto dma_window = [&](int f, int slot_b, v2i t) -> int { // t = tab[f], already in registers; slot_b = (f % kDwNbuf) * win_bytes
+        int issued = 0;
+        const int ty_ = __builtin_amdgcn_readfirstlane(t.y);
+        const int nr = ty_ & 0xFFFF;
         const int first = t0 + __builtin_amdgcn_readfirstlane(t.x);
         const unsigned col_b = (unsigned)f * (unsigned)n_beams * (unsigned)sizeof(float);   // uniform
-        char* buf = win + slot * win_bytes;
+        char* buf = win + slot_b;
+        if (ty_ & 0x10000) {
+            const unsigned soff0 = (unsigned)first * row_stride_b + col_b + wave_piece_b;
+#pragma unroll
+            for (int j = 0; j < kDwPairsPerWave; j++) {
+                const int pr = wave + kDwWaves * j;       // wave-uniform
+                if (kDwRowsPerDma * pr < nr) {
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(s_rsrc, (lds_ptr)(buf + kDwRowsPerDma * pr * kDwRowBytes), 16, (int)lane_off,
+                                                         (int)(soff0 + (unsigned)(kDwRowsPerDma * kDwWaves * j) * row_stride_b), 0, 0);
+                    issued = j + 1;
+                }
+            }
+            return issued;
+        }
 #pragma unroll
         for (int j = 0; j < kDwPairsPerWave; j++) {
             const int pr = wave + kDwWaves * j;           // wave-uniform
@@ -186,19 +206,29 @@ __global__ __launch_bounds__(kDwThreads) void dedisperse_dm_wide_kernel(const fl
                               : reinterpret_cast<const char*>(lane_zero);
                 }
                 __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(src), (lds_ptr)(buf + kDwRowsPerDma * pr * kDwRowBytes), 16, 0, 0);
+                issued = j + 1;
             }
         }
+        return issued;
     };
     // The compiler must neither drain the DMA queue at a barrier (a fence would: vmcnt(0)) nor move LDS reads across one:
     // raw s_barrier between compiler-level memory barriers, the waits written out.
+    // (one asm statement: as a C++ switch the five cases cost ~15 scalar instructions of flag shuffling per channel, and every
+    //  instruction a wave executes per channel is ~0.7 % of the kernel's time)
     auto wait_dma_but = [&](int newest) {                 // until at most `newest` of this wave's DMA instructions are in flight
-        switch (newest) {
-            case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-            case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
-            case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-            case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-            default: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-        }
+        asm volatile(
+            "s_cmp_lt_u32 %0, 2\n s_cbranch_scc1 .Ldww01_%=\n"
+            "s_cmp_lt_u32 %0, 3\n s_cbranch_scc1 .Ldww2_%=\n"
+            "s_cmp_lt_u32 %0, 4\n s_cbranch_scc1 .Ldww3_%=\n"
+            "s_waitcnt vmcnt(4)\n s_branch .Ldwwe_%=\n"
+            ".Ldww3_%=:\n s_waitcnt vmcnt(3)\n s_branch .Ldwwe_%=\n"
+            ".Ldww2_%=:\n s_waitcnt vmcnt(2)\n s_branch .Ldwwe_%=\n"
+            ".Ldww01_%=:\n s_cmp_eq_u32 %0, 0\n s_cbranch_scc1 .Ldww0_%=\n s_waitcnt vmcnt(1)\n s_branch .Ldwwe_%=\n"
+            ".Ldww0_%=:\n s_waitcnt vmcnt(0)\n"
+            ".Ldwwe_%=:\n"
+            :
+            : "s"(newest)
+            : "memory", "scc");
     };
     static_assert(kDwPairsPerWave <= 4, "wait_dma_but covers up to 4 instructions per window");
     auto block_barrier = [&]() {
@@ -232,31 +262,32 @@ __global__ __launch_bounds__(kDwThreads) void dedisperse_dm_wide_kernel(const fl
     static_assert(DW_ASM_BASE == 40, "the operand constraints below name the registers of tools/gen_dm_body.py");
 
     dma_window(0, 0, tab[0]);
-    if (n_freq > 1) dma_window(1, 1 % kDwNbuf, tab[1]);
+    if (n_freq > 1) dma_window(1, (1 % kDwNbuf) * win_bytes, tab[1]);
     int oA = offsA[0], oB = offsB[0];
     v2i tnext = tab[min(2, n_freq - 1)];                  // the window the first iteration will fetch
     wait_dma_but(0);
     block_barrier();
-    int slot = 0, slot2 = 2 % kDwNbuf;                    // ring positions of channel f and of channel f + 2
+    int slot = 0, slot2 = (2 % kDwNbuf) * win_bytes;      // ring positions of channel f and of channel f + 2, as byte offsets into win
+    const int ring_bytes = kDwNbuf * win_bytes;
 #if DSABF_DW_PROBE
     unsigned long long pt_body = 0, pt_dma = 0, pt_bar = 0, pt0 = __builtin_amdgcn_s_memtime();
 #endif
     for (int f = 0; f < n_freq; f++) {
         // bookkeeping reads first (the compiler's own LDS operations: everything after them is one of the bodies' row reads;
         // LDS returns in order, so the bodies' counted waits also cover whatever of these is still in flight)
-        const int oA_next = offsA[min(f + 1, n_freq - 1)], oB_next = offsB[min(f + 1, n_freq - 1)];
-        const v2i tafter = tab[min(f + 3, n_freq - 1)];
+        // (behind the last channel these read the next table's first bytes: inside the LDS allocation, never used)
+        const int oA_next = offsA[f + 1], oB_next = offsB[f + 1];
+        const v2i tafter = tab[f + 3];
         const int uA = __builtin_amdgcn_readfirstlane(oA), uB = __builtin_amdgcn_readfirstlane(oB);
         const int delta = uB - uA;                        // wave-uniform
-        const unsigned pa = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)(win + slot * win_bytes + uA * kDwRowBytes + lane_col);
-        const unsigned pb = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)(win + slot * win_bytes + uB * kDwRowBytes + lane_col);
+        const unsigned pa = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)(win + slot + uA * kDwRowBytes + lane_col);
+        const unsigned pb = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)(win + slot + uB * kDwRowBytes + lane_col);
         // rows 0 .. 7 of trial A's window are requested at once ...
         v8a ra, rb;
         asm volatile(DW_BODY_HEAD : "={v[104:111]}"(ra), "={v[112:119]}"(rb) : [pa] "v"(pa) : "memory");
         // ... and the DMA of window f + 2 is issued in their shadow (ring slot of f + 2 was last read in iteration f - 1: every
         // wave is past that iteration's barrier)
-        const int newest = f + 2 < n_freq ? pairs_of(tnext) : 0;
-        if (f + 2 < n_freq) dma_window(f + 2, slot2, tnext);
+        const int newest = f + 2 < n_freq ? dma_window(f + 2, slot2, tnext) : 0;
         asm volatile(DW_BODY_ALL
                      : "+{v[40:71]}"(accA), "+{v[72:103]}"(accB), "+{v[104:111]}"(ra), "+{v[112:119]}"(rb)
                      : [pa] "v"(pa), [pb] "v"(pb), [d] "s"(delta)
@@ -264,8 +295,8 @@ __global__ __launch_bounds__(kDwThreads) void dedisperse_dm_wide_kernel(const fl
         oA = oA_next;
         oB = oB_next;
         tnext = tafter;
-        slot = slot + 1 == kDwNbuf ? 0 : slot + 1;
-        slot2 = slot2 + 1 == kDwNbuf ? 0 : slot2 + 1;
+        slot = slot + win_bytes == ring_bytes ? 0 : slot + win_bytes;
+        slot2 = slot2 + win_bytes == ring_bytes ? 0 : slot2 + win_bytes;
 #if DSABF_DW_PROBE
         const unsigned long long pt1 = __builtin_amdgcn_s_memtime();
 #endif
