@@ -106,7 +106,7 @@ __global__ __launch_bounds__(kDwThreads) void dedisperse_dm_wide_kernel(const fl
                                                                         int rows_cap)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    unsigned char* offs = reinterpret_cast<unsigned char*>(lds);                         // [trial][f]: delay - base[f] (< 128)
+    unsigned char* offs = reinterpret_cast<unsigned char*>(lds);                         // [trial pair][f][A | B]: delay - base[f] (< 256): a wave's two offsets are ONE 16-bit read
     v2i* tab = reinterpret_cast<v2i*>(lds + kDwTrials * n_freq);                          // [f] {smallest delay of the group, rows of the window}
     char* win = lds + dw_table_bytes(n_freq);                                             // kDwNbuf x rows_cap x 512 B
 
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(kDwThreads) void dedisperse_dm_wide_kernel(const fl
         tab[f] = v2i{lo, rows | (inside ? 0x10000 : 0)};
         fits &= (long long)hi - lo + kDwTb <= rows_cap && lo > -(1 << 30) && hi < (1 << 30);   // (and row arithmetic stays in int)
         for (int k = 0; k < kDwTrials; k++)               // a missing trial repeats the last one (computed, never stored)
-            offs[k * n_freq + f] = (unsigned char)(delays[(size_t)(dm0 + min(k, nk - 1)) * n_freq + f] - lo);
+            offs[((k >> 1) * n_freq + f) * 2 + (k & 1)] = (unsigned char)(delays[(size_t)(dm0 + min(k, nk - 1)) * n_freq + f] - lo);
     }
     // Does the group fit -- at every channel, do the delays of its trials span no more than a window holds?  Every tile of
     // the group reaches the same verdict from the same delays; one of them records it for dedisperse_dm_kernel, which runs
@@ -247,8 +247,7 @@ __global__ __launch_bounds__(kDwThreads) void dedisperse_dm_wide_kernel(const fl
     constexpr int kAddBpl = 2;                            // beams per lane in the adds
     typedef float v2a __attribute__((ext_vector_type(2)));
     const int kA = 2 * wave, kB = 2 * wave + 1;
-    const unsigned char* offsA = offs + kA * n_freq;
-    const unsigned char* offsB = offs + kB * n_freq;
+    const unsigned short* offsAB = reinterpret_cast<const unsigned short*>(offs) + wave * n_freq;   // [f]: A's offset | B's << 8
     const int bq = bg * kDwBeams + kAddBpl * lane;        // this lane's beams (n_beams % 4 == 0 and bq even: both live or none)
     const int lane_col = lane * 4 * kAddBpl;
     // The accumulators -- [trial A | B][time i]{beam, beam + 1} = elements 2 i, 2 i + 1 -- and the two row batches are pinned to
@@ -263,7 +262,7 @@ __global__ __launch_bounds__(kDwThreads) void dedisperse_dm_wide_kernel(const fl
 
     dma_window(0, 0, tab[0]);
     if (n_freq > 1) dma_window(1, (1 % kDwNbuf) * win_bytes, tab[1]);
-    int oA = offsA[0], oB = offsB[0];
+    int oAB = offsAB[0];
     v2i tnext = tab[min(2, n_freq - 1)];                  // the window the first iteration will fetch
     wait_dma_but(0);
     block_barrier();
@@ -276,9 +275,10 @@ __global__ __launch_bounds__(kDwThreads) void dedisperse_dm_wide_kernel(const fl
         // bookkeeping reads first (the compiler's own LDS operations: everything after them is one of the bodies' row reads;
         // LDS returns in order, so the bodies' counted waits also cover whatever of these is still in flight)
         // (behind the last channel these read the next table's first bytes: inside the LDS allocation, never used)
-        const int oA_next = offsA[f + 1], oB_next = offsB[f + 1];
+        const int oAB_next = offsAB[f + 1];
         const v2i tafter = tab[f + 3];
-        const int uA = __builtin_amdgcn_readfirstlane(oA), uB = __builtin_amdgcn_readfirstlane(oB);
+        const int uAB = __builtin_amdgcn_readfirstlane(oAB);
+        const int uA = uAB & 0xFF, uB = uAB >> 8;
         const int delta = uB - uA;                        // wave-uniform
         const unsigned pa = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)(win + slot + uA * kDwRowBytes + lane_col);
         const unsigned pb = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)(win + slot + uB * kDwRowBytes + lane_col);
@@ -292,8 +292,7 @@ __global__ __launch_bounds__(kDwThreads) void dedisperse_dm_wide_kernel(const fl
                      : "+{v[40:71]}"(accA), "+{v[72:103]}"(accB), "+{v[104:111]}"(ra), "+{v[112:119]}"(rb)
                      : [pa] "v"(pa), [pb] "v"(pb), [d] "s"(delta)
                      : "memory", "scc");
-        oA = oA_next;
-        oB = oB_next;
+        oAB = oAB_next;
         tnext = tafter;
         slot = slot + win_bytes == ring_bytes ? 0 : slot + win_bytes;
         slot2 = slot2 + win_bytes == ring_bytes ? 0 : slot2 + win_bytes;
