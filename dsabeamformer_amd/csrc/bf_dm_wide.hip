@@ -179,13 +179,23 @@ __global__ __launch_bounds__(kDwThreads) void dedisperse_dm_wide_kernel(const fl
         char* buf = win + slot_b;
         if (ty_ & 0x10000) {
             const unsigned soff0 = (unsigned)first * row_stride_b + col_b + wave_piece_b;
-#pragma unroll
-            for (int j = 0; j < kDwPairsPerWave; j++) {
+            // (nested, not four independent tests: a wave without a second piece -- the common case -- leaves after one more compare)
+            auto piece = [&](int j) {
                 const int pr = wave + kDwWaves * j;       // wave-uniform
-                if (kDwRowsPerDma * pr < nr) {
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(s_rsrc, (lds_ptr)(buf + kDwRowsPerDma * pr * kDwRowBytes), 16, (int)lane_off,
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(s_rsrc, (lds_ptr)(buf + kDwRowsPerDma * pr * kDwRowBytes), 16, (int)lane_off,
                                                          (int)(soff0 + (unsigned)(kDwRowsPerDma * kDwWaves * j) * row_stride_b), 0, 0);
-                    issued = j + 1;
+                issued = j + 1;
+            };
+            auto more = [&](int j) { return kDwRowsPerDma * (wave + kDwWaves * j) < nr; };
+            static_assert(kDwPairsPerWave == 4, "the nest below is written for four pieces per wave");
+            if (more(0)) {
+                piece(0);
+                if (more(1)) {
+                    piece(1);
+                    if (more(2)) {
+                        piece(2);
+                        if (more(3)) piece(3);
+                    }
                 }
             }
             return issued;
