@@ -276,12 +276,11 @@ __global__ __launch_bounds__(kDwThreads) void dedisperse_dm_wide_kernel(const fl
     v2i tnext = tab[min(2, n_freq - 1)];                  // the window the first iteration will fetch
     wait_dma_but(0);
     block_barrier();
-    int slot = 0, slot2 = (2 % kDwNbuf) * win_bytes;      // ring positions of channel f and of channel f + 2, as byte offsets into win
-    const int ring_bytes = kDwNbuf * win_bytes;
 #if DSABF_DW_PROBE
     unsigned long long pt_body = 0, pt_dma = 0, pt_bar = 0, pt0 = __builtin_amdgcn_s_memtime();
 #endif
-    for (int f = 0; f < n_freq; f++) {
+    // one channel: f's window sits at byte offset `slot` of the ring, window f + 2 goes to `slot2`
+    auto channel = [&](const int f, const int slot, const int slot2) {
         // bookkeeping reads first (the compiler's own LDS operations: everything after them is one of the bodies' row reads;
         // LDS returns in order, so the bodies' counted waits also cover whatever of these is still in flight)
         // (behind the last channel these read the next table's first bytes: inside the LDS allocation, never used)
@@ -304,8 +303,6 @@ __global__ __launch_bounds__(kDwThreads) void dedisperse_dm_wide_kernel(const fl
                      : "memory", "scc");
         oAB = oAB_next;
         tnext = tafter;
-        slot = slot + win_bytes == ring_bytes ? 0 : slot + win_bytes;
-        slot2 = slot2 + win_bytes == ring_bytes ? 0 : slot2 + win_bytes;
 #if DSABF_DW_PROBE
         const unsigned long long pt1 = __builtin_amdgcn_s_memtime();
 #endif
@@ -318,6 +315,20 @@ __global__ __launch_bounds__(kDwThreads) void dedisperse_dm_wide_kernel(const fl
         const unsigned long long pt3 = __builtin_amdgcn_s_memtime();
         pt_body += pt1 - pt0, pt_dma += pt2 - pt1, pt_bar += pt3 - pt2, pt0 = pt3;
 #endif
+    };
+    // A whole turn of the ring per trip: the ring positions are loop constants (no per-channel position arithmetic: every
+    // instruction a wave executes per channel is ~0.7 % of the kernel's time), three copies of the body.
+    static_assert(kDwNbuf == 3, "the loop below is unrolled over a ring of three windows");
+    const int pos1 = win_bytes, pos2 = 2 * win_bytes;
+    int f0 = 0;
+    for (; f0 + kDwNbuf <= n_freq; f0 += kDwNbuf) {
+        channel(f0, 0, pos2);
+        channel(f0 + 1, pos1, 0);
+        channel(f0 + 2, pos2, pos1);
+    }
+    if (f0 < n_freq) {
+        channel(f0, 0, pos2);
+        if (f0 + 1 < n_freq) channel(f0 + 1, pos1, 0);
     }
 #if DSABF_DW_PROBE   // diagnostic build only (results invalid): tile 0's waves leave their per-channel cycle averages in out[wave * 4 ...]
     if (v == 0 && lane == 0) {
