@@ -134,7 +134,10 @@ __global__ __launch_bounds__(kDwThreads) void dedisperse_dm_wide_kernel(const fl
         // the staging loop then needs no range test and no per-lane address)
         const int rows = hi - lo + kDwTb, rows_up = (rows + kDwRowsPerDma - 1) / kDwRowsPerDma * kDwRowsPerDma;
         const bool inside = (long long)t0 + lo >= 0 && (long long)t0 + lo + rows_up <= n_t && (bg + 1) * kDwBeams <= n_beams;   // (and every beam of the tile live)
-        tab[f] = v2i{lo, rows | (inside ? 0x10000 : 0)};
+        // .x: the group's smallest delay -- or, for an inside window, the byte offset of its first row at this channel and tile
+        // (what the staging loop's scalar offset starts from; 32 bits: the launcher keeps longer series away from this kernel)
+        const unsigned first_b = (unsigned)(t0 + lo) * (unsigned)((size_t)n_freq * n_beams * sizeof(float)) + (unsigned)f * (unsigned)n_beams * (unsigned)sizeof(float);
+        tab[f] = v2i{inside ? (int)first_b : lo, rows | (inside ? 0x10000 : 0)};
         fits &= (long long)hi - lo + kDwTb <= rows_cap && lo > -(1 << 30) && hi < (1 << 30);   // (and row arithmetic stays in int)
         for (int k = 0; k < kDwTrials; k++)               // a missing trial repeats the last one (computed, never stored)
             offs[((k >> 1) * n_freq + f) * 2 + (k & 1)] = (unsigned char)(delays[(size_t)(dm0 + min(k, nk - 1)) * n_freq + f] - lo);
@@ -172,13 +175,11 @@ __global__ __launch_bounds__(kDwThreads) void dedisperse_dm_wide_kernel(const fl
     // returns the number of DMA instructions THIS wave issued (what wait_dma_but has to leave in flight one iteration later)
     auto dma_window = [&](int f, int slot_b, v2i t) -> int { // t = tab[f], already in registers; slot_b = (f % kDwNbuf) * win_bytes
         int issued = 0;
-        const int ty_ = __builtin_amdgcn_readfirstlane(t.y);
+        const int ty_ = __builtin_amdgcn_readfirstlane(t.y), tx_ = __builtin_amdgcn_readfirstlane(t.x);
         const int nr = ty_ & 0xFFFF;
-        const int first = t0 + __builtin_amdgcn_readfirstlane(t.x);
-        const unsigned col_b = (unsigned)f * (unsigned)n_beams * (unsigned)sizeof(float);   // uniform
         char* buf = win + slot_b;
         if (ty_ & 0x10000) {
-            const unsigned soff0 = (unsigned)first * row_stride_b + col_b + wave_piece_b;
+            const unsigned soff0 = (unsigned)tx_ + wave_piece_b;
             // (nested, not four independent tests: a wave without a second piece -- the common case -- leaves after one more compare)
             auto piece = [&](int j) {
                 const int pr = wave + kDwWaves * j;       // wave-uniform
@@ -198,8 +199,9 @@ __global__ __launch_bounds__(kDwThreads) void dedisperse_dm_wide_kernel(const fl
                     }
                 }
             }
-            return issued;
-        }
+        } else {
+        const int first = t0 + tx_;
+        const unsigned col_b = (unsigned)f * (unsigned)n_beams * (unsigned)sizeof(float);   // uniform
 #pragma unroll
         for (int j = 0; j < kDwPairsPerWave; j++) {
             const int pr = wave + kDwWaves * j;           // wave-uniform
@@ -218,6 +220,7 @@ __global__ __launch_bounds__(kDwThreads) void dedisperse_dm_wide_kernel(const fl
                 __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(src), (lds_ptr)(buf + kDwRowsPerDma * pr * kDwRowBytes), 16, 0, 0);
                 issued = j + 1;
             }
+        }
         }
         return issued;
     };
