@@ -20,6 +20,13 @@
 //   * bounds: one fp32 add and one 4-byte LDS operand per (trial, time, beam, channel).  The adds: 64 lanes per clock and CU
 //     (v_pk_add_f32 issues at half rate: the same) = 1024 cycles per channel and tile; the operands: round 3 1024 cycles at
 //     256 B/clk/CU, now 19/32 of that.
+//   * what actually binds the kernel (round 4, late): INSTRUCTION ISSUE.  The 16 waves run their per-channel instruction
+//     streams in lock step between barriers, and every instruction a wave executes per channel costs ~0.7 % of the kernel's
+//     time (measured by adding some).  LDS, VALU and the DMA path are each 30-35 % busy.  So the loop around the asm body is
+//     kept as short as it gets -- 92 instructions per wave and channel, ~60 of them the adds, the row reads and their waits:
+//     windows staged by buffer-addressed LDS-DMA from a byte offset the table pass precomputed (no range test, no vector
+//     address), the count of issued DMAs kept instead of recomputed, a hand-written vmcnt switch, a wave's two offsets as one
+//     16-bit read, the loop unrolled over the ring's three positions.  0.249 ms (round 3) -> 0.192 ms.
 // The sum of one (trial, time, beam) still runs over ascending f in ONE register, one add per channel: the same bits as
 // dedisperse_dm_kernel and as the oracle (orc_dedisperse_dm).
 //
