@@ -888,7 +888,9 @@ def main():
                                      "kernel": "dsabf::dedisperse_dm_wide_kernel (+ dedisperse_dm_kernel for "
                                                "trial groups whose delays do not fit a window)",
                                      "note": "peak = 256 CUs x 64 fp32 adds (= 64 LDS operands of 4 bytes) per clock x 2.4 GHz; one "
-                                             "add and one LDS operand per (trial, time, beam, channel)"},
+                                             "add and one LDS operand per (trial, time, beam, channel).  What binds the kernel in practice is "
+                                             "instruction issue (92 instructions per wave and channel in lock step between barriers: "
+                                             "DESIGN.md 3.4), not this floor"},
                         "note": "not the headline; ascending-f fp32 sum per (trial, time, beam), bit-exact vs the oracle in both "
                                 "kernels; the delay law and the ladder are pinned by executing the reference's notebook "
                                 "(tests/golden/make_dispersion_golden.py)"})
