@@ -139,6 +139,12 @@ def test_dm_kernels(objects):
     ops = isa_report.disassembly(co, name)
     assert isa_report.count(ops, "ds_read2_b64") == 0     # the 8-byte-aligned pair read measured slower (profiles/r03_variants_log.txt)
     assert isa_report.count(ops, "scratch_") == 0
+    # The kernel is bound by instruction issue (every instruction per wave and channel ~0.7 % of its time): its loop
+    # must keep the scalar-only staging path (buffer-addressed LDS-DMA), the unrolling over the ring's three positions (five copies
+    # of the 160-add body, a barrier per copy) and its size -- a compiler that re-inflates the bookkeeping shows up here first.
+    assert isa_report.count(ops, "buffer_load_dwordx4") >= 15 and isa_report.count(ops, "v_pk_add_f32") == 5 * 160
+    assert isa_report.count(ops, "s_barrier") >= 8
+    assert len(ops) <= 4400 and sum(1 for o in ops if o.startswith("s_")) <= 2050, (len(ops), "instructions")
     co, ks = objects["bf_kernels"]
     name = [n for n in ks if "dedisperse_dm_kernel" in n][0]
     assert ks[name]["private_segment_fixed_size"] == 0 and ks[name]["vgpr_count"] <= 128
