@@ -21,15 +21,32 @@ Order of work (so that the GPU is busy for seconds around the timed region and n
 N > 1 (strong scaling, BASELINE.json configs[3]): rank r owns frequencies [r*256/N, (r+1)*256/N) of every gemm-unit; the
 only collective is the gather of the detected powers, through the C-ABI (bf_comm_create / bf_gather_detected: RCCL
 point-to-point over xGMI, include/dsabf.h).  `--gather` picks the headline mode (default alltoall = distributed owners);
-every mode -- none, root, alltoall, each in both layouts -- is then timed side by side under "gather_modes", so a scaling
-run separates kernel scaling from xGMI.
+every mode -- none, root, alltoall, each in both layouts and transports -- is then timed side by side under "gather_modes",
+so a scaling run separates kernel scaling from xGMI.
+
+N > 1 cannot fail softly:
+  * a process-level deadline (class Deadline) is armed at the top of main(), before torch is imported, before the process
+    group and before any RCCL call; every stage that can block names itself and has its own time limit.  When one expires
+    rank 0 prints ONE JSON line with what exists -- the stage, the rank, the kernel-only record if it was taken -- and the
+    process ends with a NON-ZERO status (a fresh exit, never a re-exec);
+  * the control plane (barrier, max-over-ranks, unique-id broadcast, checksum exchange) runs on gloo over 127.0.0.1: the
+    GPU fabric carries the data path only, so a fabric problem cannot take the measurement's own bookkeeping with it;
+  * kernel-only strong scaling (gather mode "none": no RCCL communicator exists yet) is measured FIRST and stored; only then
+    is the communicator created and the headline gather warmed up and timed.  If that hangs or fails, the line still carries
+    gather_modes.none, "gather_error" names the stage, value is null and the exit status is non-zero;
+  * every gather mode is VERIFIED after it is timed: each rank publishes position-weighted 64-bit checksums of its local
+    rows (a small all-gather on the control plane), each receiver recomputes them on what it holds:
+    gather_modes[k].verified.  A headline mode that delivered anything else ends the run non-zero.
 """
 from __future__ import annotations
 
 import argparse
+import glob
 import json
 import os
+import signal
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -66,9 +83,20 @@ def parse():
     ap.add_argument("--force-dist", action="store_true",
                     help="single process: still create the process group and a one-rank RCCL communicator and run the "
                          "gather path (plumbing check on a 1-GPU box)")
-    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
-                    help="torch.distributed backend for the barrier / max-over-ranks / id broadcast (gloo: tests that run "
-                         "several ranks on ONE GPU, with DSABF_BENCH_ONE_GPU=1 and a loopback DSABF_RCCL_LIB)")
+    ap.add_argument("--dist-backend", default="gloo", choices=["gloo", "nccl"],
+                    help="torch.distributed backend of the CONTROL PLANE only (barrier, max-over-ranks, id broadcast, checksum "
+                         "exchange).  gloo (default, loopback TCP): no RCCL traffic before the kernel-only record exists, and a "
+                         "fabric problem cannot hang the bookkeeping; nccl: torch's own RCCL communicator.  The data path -- "
+                         "the gather -- is RCCL point-to-point behind the C-ABI either way")
+    ap.add_argument("--deadline-seconds", type=float, default=1500.0,
+                    help="process-level limit from the top of main(): when it expires before the headline exists, rank 0 prints "
+                         "a diagnostic line (stage, rank) and every rank exits non-zero")
+    ap.add_argument("--stage-seconds", type=float, default=300.0,
+                    help="limit of each blocking stage before the headline (imports, process group, handle, kernel-only region)")
+    ap.add_argument("--gather-timeout", type=float, default=180.0,
+                    help="limit of each stage that runs RCCL: communicator creation, and the warm-up / timed region / "
+                         "verification of each gather mode")
+    ap.add_argument("--no-verify", action="store_true", help="skip the checksum verification of the gather modes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--budget-seconds", type=float, default=900.0,
                     help="wall-clock limit for everything AFTER the headline measurement (supplementary records, gather modes, "
@@ -157,6 +185,33 @@ def pmc_mfma_busy(vals):
     if "SQ_VALU_MFMA_BUSY_CYCLES" not in vals or "GRBM_GUI_ACTIVE" not in vals:
         return None
     return vals["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * vals["GRBM_GUI_ACTIVE"] / 8.0)
+
+
+def issue_model(vals, kernel_ms):
+    """What binds the fused kernel, from the committed PMC pass of this launch (docs/PERF_MODEL.md section 2):
+    a wave that issues MFMAs and the detect's VALU ops needs ~13 + 2.45 K cycles of its SIMD's issue per MFMA, K = VALU ops
+    per MFMA.  issue_occupancy = (MFMAs per SIMD x that) / the cycles the launch took: near 1 means the SIMDs' instruction
+    issue is the bound, not the matrix pipe (whose own busy fraction is mfma_busy_frac).  {} if the pass is not committed."""
+    need = ("SQ_INSTS_VALU", "SQ_INSTS_VALU_MFMA_I8", "GRBM_GUI_ACTIVE")
+    if not all(k in vals for k in need) or not vals["SQ_INSTS_VALU_MFMA_I8"]:
+        return {"bound_measured": None}
+    mfma = vals["SQ_INSTS_VALU_MFMA_I8"]
+    k = (vals["SQ_INSTS_VALU"] - mfma) / mfma
+    cyc_per_mfma = 13.0 + 2.45 * k
+    cycles = vals["GRBM_GUI_ACTIVE"] / 8.0                       # the counter sums the 8 XCDs
+    occupancy = (mfma / 1024.0) * cyc_per_mfma / cycles          # 1024 SIMDs
+    busy = pmc_mfma_busy(vals)
+    rec = {"valu_per_mfma": k, "issue_model_cycles_per_mfma": cyc_per_mfma, "issue_occupancy": occupancy,
+           "bound_measured": "simd-issue" if (occupancy > 0.8 and (busy is None or busy < 0.7)) else "mfma-pipe" if (busy or 0) >= 0.7 else "unclear",
+           "issue_model": "13 + 2.45 * valu_per_mfma cycles of a SIMD's issue per MFMA (docs/PERF_MODEL.md section 2); "
+                          "issue_occupancy = MFMAs per SIMD x that / launch cycles; bound = the algorithmic roof the fraction "
+                          "is quoted against, bound_measured = what the counters say limits the kernel"}
+    # the clock the chip held in the profiled pass (profiled passes clock a little lower than timed ones)
+    prof_ms = vals["_KERNEL_NS_GRBM_PASS"] * 1e-6 if vals.get("_KERNEL_NS_GRBM_PASS") else None
+    rec["clock_ghz_under_load"] = cycles / ((prof_ms or kernel_ms) * 1e-3) / 1e9
+    rec["clock_note"] = ("GRBM_GUI_ACTIVE / 8 XCDs / %s" % ("the kernel's average duration in the same rocprofv3 pass" if prof_ms else
+                                                            "this run's HIP-event kernel time (the counters are from the committed pass)"))
+    return rec
 
 
 def time_launches(torch, fn, n, stream):
@@ -259,19 +314,54 @@ def launcher_command(n, argv, port):
             "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
 
 
+METRIC_NAME = "beam-blocks/sec (256 beams x 256 freq x N_TIME)"
+
+
+def count_gpus():
+    """GPUs this process could open, WITHOUT loading the HIP runtime (torch.cuda.device_count() loads it; the parent of the
+    ranks must stay a process that never touched the GPU): KFD topology nodes with SIMDs whose render node is present and
+    accessible (a container that was handed one GPU of an 8-GPU host sees all eight topology nodes but one /dev/dri/renderD*),
+    cut to HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES when those are set.  DSABF_KFD_TOPOLOGY / DSABF_DRI_DIR: tests."""
+    base = os.environ.get("DSABF_KFD_TOPOLOGY", "/sys/class/kfd/kfd/topology/nodes")
+    dri = os.environ.get("DSABF_DRI_DIR", "/dev/dri")
+    n = 0
+    for path in sorted(glob.glob(os.path.join(base, "*", "properties"))):
+        props = {}
+        try:
+            for line in open(path):
+                k, _, v = line.strip().partition(" ")
+                props[k] = v
+        except OSError:
+            continue
+        try:
+            if int(props.get("simd_count", "0")) <= 0:
+                continue                                   # a CPU node
+            minor = int(props.get("drm_render_minor", "-1"))
+        except ValueError:
+            continue
+        if minor >= 0 and not os.access(os.path.join(dri, "renderD%d" % minor), os.R_OK | os.W_OK):
+            continue                                       # not handed to this container
+        n += 1
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip()]))
+    return n
+
+
 def self_launch(args):
-    """`python bench.py --gpus N` with N > 1 and no launcher around it: run torch.distributed.run as a child process and exit
-    with its status.  Nothing in this process has initialised the GPU (no torch.cuda call, no HIP call: only a device COUNT),
-    and the ranks are children, never an exec of this process.  stdout / stderr are inherited, so rank 0's one JSON line is
-    this command's one JSON line."""
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: run torch.distributed.run as a CHILD process and exit
+    with its status.  This process never initialises the GPU -- the device count comes from sysfs (count_gpus), torch is not
+    even imported -- and the ranks are children, never an exec of this process.  stdout / stderr are inherited, so rank 0's
+    one JSON line is this command's one JSON line.  The child runs in its own session under this process's deadline: if the
+    launcher itself does not come back (a rendezvous that never completes), its whole process group is killed, a diagnostic
+    line is printed and the status is non-zero."""
     import socket
     import subprocess
 
     one_gpu = os.environ.get("DSABF_BENCH_ONE_GPU") == "1"     # test mode: the ranks time-share GPU 0
     if not one_gpu:
-        import torch
-
-        have = torch.cuda.device_count()                        # counting devices does not initialise the GPU on this image
+        have = count_gpus()
         if have < args.gpus:
             sys.exit("bench.py --gpus %d: this node shows %d GPU(s)" % (args.gpus, have))
     port = os.environ.get("MASTER_PORT")
@@ -284,47 +374,170 @@ def self_launch(args):
     env.setdefault("OMP_NUM_THREADS", "1")                      # (what torchrun would set, without its warning)
     cmd = launcher_command(args.gpus, sys.argv[1:], port)
     print("bench.py: --gpus %d without a launcher: starting %s" % (args.gpus, " ".join(cmd[1:9])), file=sys.stderr, flush=True)
-    sys.exit(subprocess.call(cmd, env=env))
+    limit = args.deadline_seconds + float(os.environ.get("DSABF_LAUNCH_GRACE", "90"))   # the ranks' own deadlines fire first and say more
+    child = subprocess.Popen(cmd, env=env, start_new_session=True)
+    try:
+        sys.exit(child.wait(timeout=limit))
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(child.pid, signal.SIGKILL)                # the launcher and every rank it started (its own session)
+        except OSError:
+            pass
+        print(json.dumps({"metric": METRIC_NAME, "value": None, "unit": "beam-blocks/s", "n_gpus": args.gpus,
+                          "error": "the launcher did not return within %.0f s; its process group was killed" % limit,
+                          "stage": "torch.distributed.run (child)", "rank": None}), flush=True)
+        sys.exit(5)
 
 
-class Watchdog:
-    """Prints the JSON line exactly once: normally through finish(); if the budget expires first (a supplementary record or a
-    gather mode hangs), from a timer thread with whatever has been recorded, then ends the process with status 0."""
+class Deadline:
+    """Guarantees that the process ENDS, and that rank 0 prints exactly one JSON line, whatever blocks.
 
-    def __init__(self, out, seconds):
-        import threading
+    Before the headline exists (complete == False) an expiry is a FAILURE: rank 0 prints a diagnostic line -- the stage that
+    did not finish, the rank, the seconds, and `out` as far as it was recorded (the kernel-only record of an N > 1 run) with
+    value null -- and the process ends with fail_code (non-zero) through os._exit: a collective that never returns cannot
+    be caught as an exception, and atexit handlers of a hung runtime must not get a second chance to hang.
+    After the headline (complete == True) an expiry only cuts supplementary records short: the line is printed with what is
+    there plus "truncated" and the process ends with `exit_code` (0 unless a verification failed).
+    Two timers: the process-level one (total_seconds, armed in __init__) and the current stage's (stage())."""
 
-        self.out, self.lock, self.printed = out, threading.Lock(), False
-        self.timer = threading.Timer(seconds, self._expired)
-        self.timer.daemon = True
-        self.timer.start()
+    def __init__(self, rank=0, n_gpus=1, total_seconds=None, out=None, complete=False, fail_code=3):
+        self.rank, self.n_gpus, self.out, self.complete, self.fail_code = rank, n_gpus, out, complete, fail_code
+        self.exit_code = 0
+        self.t0 = time.time()
+        self.stage_name, self.stage_timer, self.stage_limit = "start", None, None
+        self.lock, self.printed = threading.Lock(), False
+        self.error_key = "error"            # "gather_error" once the kernel-only record exists
+        self.total = None
+        if total_seconds:
+            self.total = threading.Timer(total_seconds, self._expired, args=("the process-level deadline (%.0f s)" % total_seconds,))
+            self.total.daemon = True
+            self.total.start()
 
-    def _emit(self, note=None):
+    # -- stages ------------------------------------------------------------------------------------------------
+    def stage(self, name, seconds=None):
+        """Names what the process is about to do; `seconds` (optional) is that stage's own limit."""
+        with self.lock:
+            if self.stage_timer is not None:
+                self.stage_timer.cancel()
+                self.stage_timer = None
+            self.stage_name, self.stage_limit = name, seconds
+            if seconds:
+                self.stage_timer = threading.Timer(seconds, self._expired, args=("stage '%s' (%.0f s)" % (name, seconds),))
+                self.stage_timer.daemon = True
+                self.stage_timer.start()
+        if os.environ.get("DSABF_BENCH_TRACE") == "1":
+            print("bench.py[rank %d] +%.1f s: %s" % (self.rank, time.time() - self.t0, name), file=sys.stderr, flush=True)
+
+    def set_rank(self, rank, n_gpus):
+        self.rank, self.n_gpus = rank, n_gpus
+
+    def adopt(self, out, error_key="gather_error"):
+        """rank 0: the record so far (printed with value null if a later stage never finishes)."""
+        self.out, self.error_key = out, error_key
+
+    def headline_complete(self, budget_seconds=None):
+        """From here on an expiry truncates instead of failing; the process-level timer is re-armed with the budget."""
+        with self.lock:
+            self.complete = True
+            if self.total is not None:
+                self.total.cancel()
+                self.total = None
+            if budget_seconds:
+                self.total = threading.Timer(budget_seconds, self._expired, args=("the budget for supplementary records "
+                                                                                  "(--budget-seconds)",))
+                self.total.daemon = True
+                self.total.start()
+
+    # -- the one line -------------------------------------------------------------------------------------------
+    def _line(self, out):
+        try:
+            return json.dumps(out)
+        except Exception:   # a record half-written by the main thread
+            return json.dumps({k: v for k, v in out.items() if k in (
+                "metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "truncated", "error", "gather_error", "stage", "rank")})
+
+    def _emit(self, note=None, failure=None):
         with self.lock:
             if self.printed:
                 return
             self.printed = True
-            if self.out is not None:
-                if note:
-                    self.out["truncated"] = note
-                try:
-                    line = json.dumps(self.out)
-                except Exception:   # a record half-written by the main thread
-                    line = json.dumps({k: v for k, v in self.out.items() if k in (
-                        "metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-                        "vs_baseline", "dtype", "data", "config", "roofline", "truncated")})
-                print(line, flush=True)
+            if self.rank != 0:
+                if failure:
+                    print("bench.py[rank %d]: %s" % (self.rank, failure), file=sys.stderr, flush=True)
+                return
+            out = self.out
+            if failure:
+                if out is None:
+                    out = {"metric": METRIC_NAME, "value": None, "unit": "beam-blocks/s", "n_gpus": self.n_gpus}
+                out = dict(out)
+                out["value"] = None
+                out[self.error_key] = failure
+                out["stage"], out["rank"], out["elapsed_s"] = self.stage_name, self.rank, round(time.time() - self.t0, 1)
+            elif out is not None and note:
+                out["truncated"] = note
+            if out is not None:
+                print(self._line(out), flush=True)
 
-    def _expired(self):
-        self._emit("the budget for supplementary records (--budget-seconds) expired; the headline and roofline are complete")
-        os._exit(0)
+    def _expired(self, what):
+        if self.complete:
+            self._emit("%s expired in stage '%s'; the headline and roofline are complete" % (what, self.stage_name))
+            os._exit(self.exit_code)
+        self._emit(failure="%s expired: '%s' did not finish (+%.0f s since start)" % (what, self.stage_name, time.time() - self.t0))
+        os._exit(self.fail_code)
+
+    def fail(self, message, code=None):
+        """A failure the main thread noticed itself (an exception in a gather stage, a verification that failed before the
+        headline): the same line, the same non-zero end."""
+        self._emit(failure=message)
+        sys.stdout.flush()
+        os._exit(code or self.fail_code)
+
+    def terminated(self, signum):
+        """SIGTERM from the launcher (another rank failed): say what was there, end non-zero unless everything was done."""
+        if self.complete:
+            self._emit("terminated by signal %d in stage '%s'" % (signum, self.stage_name))
+            os._exit(self.exit_code if self.exit_code else 143)
+        self._emit(failure="terminated by signal %d (the launcher stops the other ranks when one fails) in stage '%s'"
+                           % (signum, self.stage_name))
+        os._exit(143)
 
     def finish(self):
-        self.timer.cancel()
+        with self.lock:
+            for t in (self.total, self.stage_timer):
+                if t is not None:
+                    t.cancel()
         self._emit()
 
     def cancel(self):
-        self.timer.cancel()
+        with self.lock:
+            for t in (self.total, self.stage_timer):
+                if t is not None:
+                    t.cancel()
+
+
+class Watchdog(Deadline):
+    """The post-headline form by itself: Watchdog(out, seconds) prints `out` exactly once -- through finish(), or, if the
+    budget expires first, from the timer thread with "truncated" -- and then ends the process with status 0."""
+
+    def __init__(self, out, seconds):
+        super().__init__(rank=0, total_seconds=seconds, out=out, complete=True)
+
+
+def watch_sigterm(deadline):
+    """SIGTERM is blocked in every thread and picked up by a thread of its own (sigwait): a Python-level handler would never
+    run while the main thread sits inside a C call that does not return -- which is exactly when the launcher sends it."""
+    try:
+        signal.pthread_sigmask(signal.SIG_BLOCK, {signal.SIGTERM})
+    except (AttributeError, ValueError, OSError):   # pragma: no cover
+        return
+
+    def wait():
+        signum = signal.sigwait({signal.SIGTERM})
+        deadline.terminated(signum)
+
+    t = threading.Thread(target=wait, daemon=True)
+    t.start()
 
 
 def main():
@@ -333,11 +546,22 @@ def main():
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args)          # never returns
-    import torch
-
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # ---- the deadline is armed HERE: before torch is imported, before the process group, before any RCCL call.  Ranks other
+    # than 0 give rank 0 a few seconds to print its line first (the launcher stops everybody when the first rank exits).
+    lag = 0.0 if rank == 0 else 5.0
+    try:
+        signal.pthread_sigmask(signal.SIG_BLOCK, {signal.SIGTERM})   # before any thread exists: see watch_sigterm
+    except (AttributeError, ValueError, OSError):   # pragma: no cover
+        pass
+    deadline = Deadline(rank, max(world, args.gpus), args.deadline_seconds + lag)
+    watch_sigterm(deadline)
+    stage_s, gather_s = args.stage_seconds + lag, args.gather_timeout + lag
+    deadline.stage("import torch", stage_s)
+    import torch
+
     if args.gpus != world:
         if world == 1 and args.gpus > 1:   # WORLD_SIZE=1 in the environment next to --gpus N: a launcher started ONE rank
             sys.exit("bench.py --gpus %d under a launcher with WORLD_SIZE=1: start it with --nproc-per-node %d, or call "
@@ -345,8 +569,9 @@ def main():
         args.gpus = world
     if os.environ.get("DSABF_BENCH_ONE_GPU") == "1":
         local = 0          # test mode: every rank time-shares GPU 0
+    deadline.stage("torch.cuda.set_device(%d)" % local, stage_s)
     torch.cuda.set_device(local)
-    dist_dev = "cuda" if args.dist_backend == "nccl" else "cpu"
+    backend = args.dist_backend
     dist = None
     if world > 1 or args.force_dist:
         import torch.distributed as dist
@@ -356,11 +581,19 @@ def main():
             os.environ.setdefault("MASTER_PORT", "29541")
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
-        if args.dist_backend == "nccl":
+        deadline.stage("control plane: init_process_group(%s)" % backend, stage_s)
+        if backend == "gloo":
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")    # the container's hostname may not resolve; loopback always does
+            try:
+                dist.init_process_group("gloo")
+            except Exception as e:   # pragma: no cover  (a gloo that cannot bind: fall back to torch's RCCL communicator)
+                print("bench.py[rank %d]: gloo control plane failed (%s); using nccl" % (rank, str(e)[:200]), file=sys.stderr, flush=True)
+                backend = "nccl"
+        if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-        else:
-            dist.init_process_group("gloo")
+    dist_dev = "cuda" if backend == "nccl" else "cpu"
 
+    deadline.stage("import dsabeamformer_amd (libdsabf.so)", stage_s)
     import dsabeamformer_amd as bfm
     from dsabeamformer_amd import api
 
@@ -373,6 +606,7 @@ def main():
         cfg.n_ant, cfg.n_beams = 100, 512
     cfg.detect_mode = DETECT[args.detect]
     n_ipo, n_time = cfg.n_pol * cfg.n_avg, n_out * cfg.n_pol * cfg.n_avg
+    deadline.stage("bf_create + bf_set_weights", stage_s)
     bf = bfm.Beamformer(cfg, device=local)
     bf.set_weights(product_weights(cfg, rank * n_freq))
 
@@ -380,6 +614,7 @@ def main():
     blocks_per_step = units * n_out                      # beam-blocks per step (whole job)
     in_bytes = units * n_freq * n_time * cfg.n_ant       # this rank's packed bytes per step
     out_floats = units * n_out * n_freq * cfg.n_beams    # this rank's detected floats per step
+    deadline.stage("synthetic input in HBM", stage_s)
     gen = torch.Generator(device="cuda").manual_seed(0xD5A + rank)
     d_in = [torch.randint(0, 256, (in_bytes,), dtype=torch.uint8, device="cuda", generator=gen)
             for _ in range(max(1, args.nbuf))]
@@ -393,35 +628,38 @@ def main():
     # ---- the gather (N > 1 or --force-dist): bf_comm / bf_gather_detected behind the C-ABI -------------------------------
     n_rows, row_floats = units * n_out, n_freq * cfg.n_beams
     # There is ONE gather path.  If the communicator cannot be created the run ends non-zero: a scaling line must never
-    # come from a second code path.
-    comm, rccl_info = None, None
-    if dist is not None:
-        idt = torch.zeros(128, dtype=torch.uint8, device=dist_dev)
-        if rank == 0:
-            idt.copy_(torch.frombuffer(bytearray(api.comm_unique_id()), dtype=torch.uint8))
-        dist.broadcast(idt, 0)
-        comm = api.Comm(rank, world, bytes(idt.cpu().numpy().tobytes()), device=local)
-        rccl_info = comm.info()      # ranks as the LIBRARY counts them, its version, the file it was loaded from
-        if rccl_info["ranks"] not in (world, -1):
-            sys.exit("bf_comm: the library reports %d ranks, the launcher %d" % (rccl_info["ranks"], world))
+    # come from a second code path.  The communicator is created AFTER the kernel-only region (see below).
+    comm_box = {"comm": None}
+    rccl_info = None
     side = torch.cuda.Stream() if dist is not None else None
 
     class GatherMode:
         """One way of bringing the shards together, double-buffered: the collective of step i runs on a side stream and
         overlaps the kernel of step i+1; the compute stream waits for it only before it overwrites that slot again."""
 
-        def __init__(self, mode, layout):
-            self.mode, self.layout = mode, layout
+        def __init__(self, mode, layout, transport="inplace"):
+            self.mode, self.layout, self.transport = mode, layout, transport
             self.root = {"root": 0, "alltoall": api.GATHER_ROOT_DISTRIBUTED}.get(mode)
             self.lay = api.GATHER_RANK_MAJOR if layout == "rank" else api.GATHER_FREQ_MAJOR
             self.kernel_done = [torch.cuda.Event() for _ in range(2)]
             self.gather_done = [None, None]
             self.full = [None, None]
+            self.stage = [None, None]
+            self.held = 0
             if mode == "none":
                 return
-            held = comm.rows_held(n_rows, self.root)
-            if held:
-                self.full = [torch.empty(held * world * row_floats, dtype=torch.float32, device="cuda") for _ in range(2)]
+            comm = comm_box["comm"]
+            self.held = comm.rows_held(n_rows, self.root)
+            if self.held:
+                self.full = [torch.empty(self.held * world * row_floats, dtype=torch.float32, device="cuda") for _ in range(2)]
+                if transport == "staged":
+                    self.stage = [torch.empty(self.held * world * row_floats, dtype=torch.float32, device="cuda") for _ in range(2)]
+
+        @property
+        def key(self):
+            if self.mode == "none":
+                return "none"
+            return "%s_%s_major" % (self.mode, self.layout) + ("_staged" if self.transport == "staged" else "")
 
         def before_kernel(self, slot):
             if self.gather_done[slot] is not None:
@@ -433,7 +671,11 @@ def main():
                 return
             self.kernel_done[slot].record(stream)
             side.wait_event(self.kernel_done[slot])
-            comm.gather(d_out[slot], n_rows, row_floats, self.root, self.lay, self.full[slot], side.cuda_stream)
+            comm = comm_box["comm"]
+            if self.transport == "staged":
+                comm.gather_staged(d_out[slot], n_rows, row_floats, self.root, self.full[slot], self.stage[slot], side.cuda_stream)
+            else:
+                comm.gather(d_out[slot], n_rows, row_floats, self.root, self.lay, self.full[slot], side.cuda_stream)
             ev = torch.cuda.Event()
             ev.record(side)
             self.gather_done[slot] = ev
@@ -442,8 +684,6 @@ def main():
             for slot in (0, 1):
                 self.before_kernel(slot)
             torch.cuda.synchronize()
-
-    headline_mode = GatherMode(args.gather if dist is not None else "none", args.layout)
 
     def step(i, gm, ev_pair=None):
         slot = i & 1
@@ -474,36 +714,73 @@ def main():
             elapsed = float(t.item())
         return elapsed, events
 
-    # ---- warm-up: W steps, then keep stepping until the chip has been busy for min-warm-seconds -------------------------
-    t_w = time.perf_counter()
-    for i in range(args.warmup):
-        step(i, headline_mode)
-    extra_warm = 0
-    while True:
-        headline_mode.drain()
-        go = torch.tensor([1.0 if time.perf_counter() - t_w < args.min_warm_seconds else 0.0], device=dist_dev)
-        if dist is not None:
-            dist.all_reduce(go, op=dist.ReduceOp.MAX)   # every rank takes the same number of extra steps
-        if go.item() == 0.0:
-            break
-        for i in range(32):
-            step(i, headline_mode)
-        extra_warm += 32
+    def warm_up(gm, n_steps, min_seconds):
+        """W steps, then more of the same -- the same number on every rank -- until the chip has been busy for min_seconds."""
+        t_w = time.perf_counter()
+        for i in range(n_steps):
+            step(i, gm)
+        extra = 0
+        while True:
+            gm.drain()
+            go = torch.tensor([1.0 if time.perf_counter() - t_w < min_seconds else 0.0], device=dist_dev)
+            if dist is not None:
+                dist.all_reduce(go, op=dist.ReduceOp.MAX)   # every rank takes the same number of extra steps
+            if go.item() == 0.0:
+                break
+            for i in range(32):
+                step(i, gm)
+            extra += 32
+        return extra
 
-    elapsed, events = timed_region(headline_mode, args.steps, True)
+    CS_MOD = 4093
 
-    if args.force_dist and world == 1 and headline_mode.mode != "none":
-        # one rank: the gathered tensor must be the kernel's output of that slot (both layouts are the identity)
-        for slot in (0, 1):
-            got = headline_mode.full[slot]
-            if got is not None and not torch.equal(got.reshape(-1), d_out[slot]):
-                sys.exit("gather plumbing check failed: slot %d differs from the kernel output" % slot)
+    def row_checksums(flat, rows, floats):
+        """Position-weighted 64-bit checksum of every row of a float32 array, on the device, exact integer arithmetic (the bit
+        patterns as int32 times weights 1 .. 4093: |sum| < 2^62 for rows of up to 2^19 floats)."""
+        x = flat.view(torch.int32).view(rows, floats)
+        wgt = (torch.arange(floats, device=flat.device, dtype=torch.int64) % CS_MOD) + 1
+        cs = torch.empty(rows, dtype=torch.int64, device=flat.device)
+        chunk = max(1, (32 << 20) // floats)
+        for r0 in range(0, rows, chunk):
+            cs[r0:r0 + chunk] = (x[r0:r0 + chunk].to(torch.int64) * wgt).sum(dim=1)
+        return cs
 
-    kern_ms = sorted(a.elapsed_time(b) for a, b in events)
-    kern_avg_ms = sum(kern_ms) / len(kern_ms)
+    def verify(gm):
+        """One more step of this mode, then: every rank publishes the checksums of its local rows (all-gather on the control
+        plane), every receiver recomputes them on what the gather delivered.  True on every rank iff every receiver agrees."""
+        step(0, gm)
+        gm.drain()
+        mine = row_checksums(d_out[0], n_rows, row_floats).to(dist_dev)
+        everyone = [torch.empty_like(mine) for _ in range(world)]
+        if world > 1:
+            dist.all_gather(everyone, mine)
+        else:
+            everyone = [mine]
+        sent = torch.stack(everyone).cpu()                       # [rank][row]
+        ok = 1
+        if gm.held:
+            first = comm_box["comm"].rank * gm.held if gm.root == api.GATHER_ROOT_DISTRIBUTED else 0
+            got = row_checksums(gm.full[0], gm.held * world, row_floats).cpu()
+            if gm.lay == api.GATHER_RANK_MAJOR:
+                got = got.view(world, gm.held)                   # [rank][row held]
+            else:
+                got = got.view(gm.held, world).t()               # [row held][rank] -> [rank][row held]
+            ok = int(torch.equal(got, sent[:, first:first + gm.held]))
+        flag = torch.tensor([ok], dtype=torch.int32, device=dist_dev)
+        if world > 1:
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return bool(flag.item())
 
-    out = None
-    if rank == 0:
+    info = bf.kernel_info(units)
+    paired = "PAIRED" in info["kernel"]
+    peak_cache = {}        # the micro-benchmarks behind roofline.peak_measured run once per process
+
+    def build_record(elapsed, events, extra_warm):
+        """rank 0: the JSON record of one timed region (elapsed = max over ranks; events = this rank's HIP-event pairs)."""
+        kern_ms = sorted(a.elapsed_time(b) for a, b in events)
+        kern_avg_ms = sum(kern_ms) / len(kern_ms)
+        if rank != 0:
+            return None
         total_blocks = args.steps * blocks_per_step
         value = total_blocks / elapsed
         # algorithmic work per beam-block (SURVEY.md 8d): ops = 8*B*A*n_ipo*F ; bytes = A*n_ipo*F + 4*B*F
@@ -512,8 +789,6 @@ def main():
         launch_ops = ops_per_block * blocks_per_step / world    # per launch (this rank's kernel)
         launch_bytes = bytes_per_block * blocks_per_step / world
         mfma_bound = args.workload != "c2"
-        info = bf.kernel_info(units)
-        paired = "PAIRED" in info["kernel"]
         # committed rocprofv3 PMC summaries of exactly this launch (tools/pmc.sh), if any
         pmc_name = {("c3", 128, True): "r04_c3_paired_pmc_summary.txt", ("c3", 128, False): "r04_c3_general_pmc_summary.txt",
                     ("c5", 16, True): "r04_c5_pmc_summary.txt", ("c5", 16, False): "r04_c5_general_pmc_summary.txt",
@@ -529,6 +804,8 @@ def main():
             # region, same HIP-event timing.  The chip does not hold 2.4 GHz under this load (DVFS), so this is what "100 %"
             # means here for a kernel that did nothing but MFMAs.
             try:
+                if "mfma" in peak_cache:
+                    raise StopIteration
                 d_sink = torch.empty(4 << 20, dtype=torch.uint8, device="cuda")
                 peak_ops = [0.0]
 
@@ -538,15 +815,19 @@ def main():
                     peak_fn(i)
                 torch.cuda.synchronize()
                 p_avg, _, p_min = time_launches(torch, peak_fn, 50, stream)
-                peak_measured = peak_ops[0] / (p_avg * 1e-3) / 1e12
-                roof.update({"peak_measured": peak_measured, "frac_of_measured_peak": achieved / peak_measured,
-                             "peak_measured_note": "back-to-back v_mfma_i32_16x16x64_i8, 2 accumulator chains per wave issued chain by chain, 4 waves "
-                                                   "per SIMD, operands = this workload's bytes (A = 16 * nibble, B = random "
-                                                   "int8), %.3f ms per launch of %.3g ops, measured after the timed region"
-                                                   % (p_avg, peak_ops[0])})
+                peak_cache["mfma"] = (peak_ops[0] / (p_avg * 1e-3) / 1e12,
+                                      "back-to-back v_mfma_i32_16x16x64_i8, 2 accumulator chains per wave issued chain by chain, 4 waves "
+                                      "per SIMD, operands = this workload's bytes (A = 16 * nibble, B = random "
+                                      "int8), %.3f ms per launch of %.3g ops, measured after the first timed region"
+                                      % (p_avg, peak_ops[0]))
+            except StopIteration:
+                pass
             except Exception as e:   # the headline never depends on the micro-benchmark
-                roof["peak_measured"] = None
-                roof["peak_measured_note"] = "micro-benchmark failed: %s" % e
+                peak_cache["mfma"] = (None, "micro-benchmark failed: %s" % e)
+            peak_measured, peak_note = peak_cache["mfma"]
+            roof.update({"peak_measured": peak_measured, "peak_measured_note": peak_note})
+            if peak_measured:
+                roof["frac_of_measured_peak"] = achieved / peak_measured
         else:
             achieved = launch_bytes / (kern_avg_ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -554,6 +835,8 @@ def main():
             # the measured counterpart of the nominal 8 TB/s: a pure streaming kernel on this box, after the timed region --
             # bf_expand_device (a1 alone: 1 byte in, 2 out per packed byte, whole 128-byte lines, nontemporal both ways)
             try:
+                if "hbm" in peak_cache:
+                    raise StopIteration
                 n_exp = 256 << 20      # 256 MiB in, 512 MiB out: well past the 256 MiB Infinity Cache
                 d_exp_in = torch.randint(0, 256, (n_exp,), dtype=torch.uint8, device="cuda")
                 d_exp = torch.empty(2 * n_exp, dtype=torch.uint8, device="cuda")
@@ -564,14 +847,18 @@ def main():
                     exp_fn(i)
                 torch.cuda.synchronize()
                 e_avg, _, _ = time_launches(torch, exp_fn, 30, stream)
-                peak_measured = 3 * n_exp / (e_avg * 1e-3) / 1e9
-                roof.update({"peak_measured": peak_measured, "frac_of_measured_peak": achieved / peak_measured,
-                             "peak_measured_note": "bf_expand_device streaming %d MiB in / %d MiB out: %.3f ms per launch, "
-                                                   "measured after the timed region" % (n_exp >> 20, n_exp >> 19, e_avg)})
+                peak_cache["hbm"] = (3 * n_exp / (e_avg * 1e-3) / 1e9,
+                                     "bf_expand_device streaming %d MiB in / %d MiB out: %.3f ms per launch, "
+                                     "measured after the first timed region" % (n_exp >> 20, n_exp >> 19, e_avg))
                 del d_exp, d_exp_in
+            except StopIteration:
+                pass
             except Exception as e:
-                roof["peak_measured"] = None
-                roof["peak_measured_note"] = "streaming micro-benchmark failed: %s" % e
+                peak_cache["hbm"] = (None, "streaming micro-benchmark failed: %s" % e)
+            peak_measured, peak_note = peak_cache["hbm"]
+            roof.update({"peak_measured": peak_measured, "peak_measured_note": peak_note})
+            if peak_measured:
+                roof["frac_of_measured_peak"] = achieved / peak_measured
         executed = launch_ops / 2 if paired else launch_ops
         roof.update({"kernel": info["kernel"],
                      "kernel_ms_avg": kern_avg_ms, "kernel_ms_median": kern_ms[len(kern_ms) // 2],
@@ -583,13 +870,15 @@ def main():
                      "pmc_source": ("profiles/" + pmc_name) if pmc else None,
                      # traffic and mfma_busy_frac are read from the committed rocprofv3 summary named above -- measured
                      # on an earlier box with the same kernel, NOT observed in this run (everything else in this object is)
-                     "from_committed_profile": ["traffic", "mfma_busy_frac"] if pmc else [],
+                     "from_committed_profile": (["traffic", "mfma_busy_frac"] + (["valu_per_mfma", "issue_occupancy", "bound_measured",
+                                                                                   "clock_ghz_under_load"] if mfma_bound else [])) if pmc else [],
                      "note": "int8 ops: 1 complex MAC = 8 ops.  frac = ALGORITHMIC ops / kernel time / peak; executed_frac = "
                              "the int8 ops the MFMA pipe really executes / time / peak (the conjugate-pair kernel forms two "
                              "beams from shared products: half the algorithmic ops, same bits); mfma_busy_frac = "
                              "SQ_VALU_MFMA_BUSY_CYCLES / SIMD cycles from the committed rocprofv3 PMC pass of this launch "
                              "(profiled passes clock lower); traffic = HBM bytes per launch from the same passes (FETCH_SIZE "
                              "doubled per the guide), null if this launch has no committed pass"})
+        roof.update(issue_model(pmc, kern_avg_ms) if mfma_bound else {})
         out = {
             "metric": "beam-blocks/sec (%d beams x %d freq x N_TIME)" % (cfg.n_beams, n_freq_total), "value": value,
             "unit": "beam-blocks/s",
@@ -607,6 +896,8 @@ def main():
                        "freq_per_gpu": n_freq,
                        "gather": ("%s, %s-major layout, bf_gather_detected (RCCL p2p behind the C-ABI)"
                                   % (args.gather, args.layout)) if dist is not None else "n/a",
+                       "control_plane": ("torch.distributed %s over 127.0.0.1: barrier, max-over-ranks, unique-id broadcast, "
+                                         "checksum exchange -- no detected power travels on it" % backend) if dist is not None else "n/a",
                        "detect_mode": args.detect,
                        "detect_reading": {"canonical": "x*x + y*y as two multiplies and an add: what g++ makes of "
                                                        "src/beamformer.cuh:151 and what the CPU oracle computes (bit-exact "
@@ -626,35 +917,118 @@ def main():
         }
         if rccl_info is not None:
             out["rccl"] = rccl_info
+        return out
 
-    # ---- from here on nothing may cost the headline: a watchdog prints the line with what is there when the budget expires
-    # (a collective that never returns cannot be caught as an exception) -------------------------------------------------
-    watchdog = Watchdog(out, args.budget_seconds + (0.0 if rank == 0 else 5.0))
+
+    # ---- kernel-only first: no RCCL communicator exists yet (at N = 1 this IS the headline) ------------------------------
+    none_mode = GatherMode("none", "rank")
+    deadline.stage("kernel-only warm-up", stage_s)
+    extra_warm = warm_up(none_mode, args.warmup, args.min_warm_seconds)
+    deadline.stage("kernel-only timed region", stage_s)
+    elapsed, events = timed_region(none_mode, args.steps, True)
+    deadline.stage("record of the kernel-only region", stage_s)
+    out = build_record(elapsed, events, extra_warm)
+    headline_mode = none_mode
+    gather_modes = {}
+
+    def mode_record(el, n_steps, ev=None):
+        rec = {"value": n_steps * blocks_per_step / el, "unit": "beam-blocks/s", "ms_per_step": el / n_steps * 1e3, "steps": n_steps}
+        if ev:
+            ms = [a.elapsed_time(b) for a, b in ev]
+            rec["kernel_ms_avg"] = sum(ms) / len(ms)
+        return rec
+
+    if dist is not None and args.gather != "none":
+        # ---- N > 1: the record so far is the kernel-only strong-scaling figure; the headline needs the gather ------------------
+        gather_modes["none"] = mode_record(elapsed, args.steps, events)
+        gather_modes["none"]["note"] = ("kernel-only strong scaling: measured first, before any RCCL communicator existed; "
+                                        "no collective at all")
+        if rank == 0:
+            out["gather_modes"] = gather_modes
+            out["kernel_only"] = {k: out[k] for k in ("value", "ms_per_step", "ms_per_block")}
+            out["kernel_only"]["roofline_frac"] = out["roofline"]["frac"]
+            deadline.adopt(out)         # printed with value null + gather_error if anything below never comes back
+
+        def gather_stage(name, fn):
+            """A stage that runs RCCL: its own time limit; an exception ends the run like an expiry does (line + non-zero)."""
+            deadline.stage(name, gather_s)
+            try:
+                return fn()
+            except Exception as e:
+                deadline.fail("%s failed: %s: %s" % (name, type(e).__name__, str(e)[:400]), code=4)
+
+        def make_comm():
+            idt = torch.zeros(128, dtype=torch.uint8, device=dist_dev)
+            if rank == 0:
+                idt.copy_(torch.frombuffer(bytearray(api.comm_unique_id()), dtype=torch.uint8))
+            dist.broadcast(idt, 0)
+            c = api.Comm(rank, world, bytes(idt.cpu().numpy().tobytes()), device=local)
+            inf = c.info()      # ranks as the LIBRARY counts them, its version, the file it was loaded from
+            if inf["ranks"] not in (world, -1):
+                raise RuntimeError("bf_comm: the library reports %d ranks, the launcher %d" % (inf["ranks"], world))
+            return c, inf
+
+        deadline.fail_code = 4
+        comm_box["comm"], rccl_info = gather_stage("RCCL communicator (bf_comm_unique_id, bf_comm_create)", make_comm)
+        headline_mode = GatherMode(args.gather, args.layout)
+        tag = "gather '%s'" % headline_mode.key
+        gather_stage(tag + ": warm-up", lambda: warm_up(headline_mode, args.warmup, 0.0))
+        elapsed, events = gather_stage(tag + ": timed region", lambda: timed_region(headline_mode, args.steps, True))
+        verified = None if args.no_verify else gather_stage(tag + ": verification", lambda: verify(headline_mode))
+        deadline.stage("record of the headline", stage_s)
+        out = build_record(elapsed, events, extra_warm)
+        gather_modes[headline_mode.key] = mode_record(elapsed, args.steps, events)
+        gather_modes[headline_mode.key].update({"verified": verified, "headline": True})
+        if rank == 0:
+            out["gather_modes"] = gather_modes
+            out["kernel_only"] = deadline.out["kernel_only"]
+            deadline.adopt(out)
+        if verified is False:
+            # the line still says everything that was measured; the number it would have carried is not a result
+            if rank == 0:
+                out["unverified_value"] = out["value"]
+            deadline.fail("the headline gather '%s' delivered other bits than the ranks sent (per-row checksums differ)"
+                          % headline_mode.key, code=6)
+
+    # ---- from here on nothing may cost the headline: the deadline now only truncates (prints the line with what is there) ----
+    deadline.headline_complete(args.budget_seconds + lag)
+    watchdog = deadline
+    deadline.stage("supplementary records")
 
     # ---- every gather mode side by side (N > 1) ----------------------------------------------------------------------------
-    if dist is not None and (world > 1 or args.force_dist) and not args.no_extras:
-        gather_modes = {} if out is None else out.setdefault("gather_modes", {})
+    if dist is not None and comm_box["comm"] is not None and not args.no_extras:
         n_side = max(5, min(args.steps, 50))
-        for mode, layout in (("none", "rank"), ("root", "rank"), ("root", "freq"), ("alltoall", "rank"), ("alltoall", "freq")):
-            key = mode if mode == "none" else "%s_%s_major" % (mode, layout)
+        for mode, layout, transport in (("root", "rank", "inplace"), ("root", "freq", "inplace"), ("root", "freq", "staged"),
+                                        ("alltoall", "rank", "inplace"), ("alltoall", "freq", "inplace"),
+                                        ("alltoall", "freq", "staged")):
+            gm = GatherMode(mode, layout, transport)
+            if gm.key in gather_modes:
+                continue
+            deadline.stage("gather '%s' (supplementary)" % gm.key, gather_s)
             try:   # a supplementary record must never cost the headline line
-                gm = GatherMode(mode, layout)
                 for i in range(4):
                     step(i, gm)
                 gm.drain()
                 el, _ = timed_region(gm, n_side, False)
-                gather_modes[key] = {"value": n_side * blocks_per_step / el, "unit": "beam-blocks/s",
-                                     "ms_per_step": el / n_side * 1e3, "steps": n_side}
-                del gm
+                gather_modes[gm.key] = mode_record(el, n_side)
+                if not args.no_verify:
+                    gather_modes[gm.key]["verified"] = verify(gm)
+                    if gather_modes[gm.key]["verified"] is False:
+                        deadline.exit_code = 6
             except Exception as e:  # pragma: no cover
-                gather_modes[key] = {"error": str(e)[:300]}
+                gather_modes[gm.key] = {"error": str(e)[:300]}
                 torch.cuda.synchronize()
+            del gm
+        deadline.stage("supplementary records")
 
     if rank == 0:
         if "gather_modes" in out:
             out["gather_modes"]["note"] = ("the same kernel and inputs, only the collective differs; rank-major = one message "
-                                           "per sender, freq-major = the reference's [o][f][b], one message per (row, sender); "
-                                           "root = everything to rank 0, alltoall = rank j owns rows j*n/N.. of the whole band")
+                                           "per sender, freq-major = the reference's [o][f][b], one message per (row, sender), "
+                                           "received in place; freq-major staged = the same result by bf_gather_detected_staged "
+                                           "(one message per sender + one device re-layout pass); root = everything to rank 0, "
+                                           "alltoall = rank j owns rows j*n/N.. of the whole band; verified = the receivers' "
+                                           "per-row checksums of what arrived equal the senders' (one extra step after the timing)")
 
         def variant(detect_mode, paired_env=None, wl=None, n_units=None, reps=None, calibrated=False, n_ant=None):
             """Kernel-time record of another variant / workload on this GPU (HIP events around every launch)."""
@@ -931,14 +1305,21 @@ def main():
             print("bench.py: GPU part done; timing the CPU baseline%s on the host cores (~%.0f s) ..."
                   % ("s" if world == 1 else "", secs + (15 if world == 1 else 2)), file=sys.stderr, flush=True)
             guarded("cpu_baseline", lambda: out.__setitem__("cpu_baseline", cpu_baselines(n_avg, n_out, secs, full=world == 1)))
+        deadline.stage("printing the line")
         watchdog.finish()
     else:
         watchdog.cancel()
+    # teardown can block too (a communicator whose peers are gone): under its own limit, after the line is out
+    deadline = Deadline(rank, world, 60.0 + lag, out=None, complete=True)
+    deadline.exit_code = watchdog.exit_code
     bf.close()
-    if comm is not None:
-        comm.close()
+    if comm_box["comm"] is not None:
+        comm_box["comm"].close()
     if dist is not None:
         dist.destroy_process_group()
+    deadline.cancel()
+    if watchdog.exit_code:
+        sys.exit(watchdog.exit_code)
 
 
 if __name__ == "__main__":

@@ -226,6 +226,11 @@ class Comm:
         check(self._lib.bf_gather_detected(self._c, _ptr(d_local), n_rows, row_floats, root, layout, _ptr(d_full),
                                            C.c_void_p(stream)))
 
+    def gather_staged(self, d_local, n_rows: int, row_floats: int, root: int, d_full, d_stage, stream: int = 0) -> None:
+        """bf_gather_detected_staged: freq-major result, rank-major on the wire + one device re-layout pass."""
+        check(self._lib.bf_gather_detected_staged(self._c, _ptr(d_local), n_rows, row_floats, root, _ptr(d_full), _ptr(d_stage),
+                                                  C.c_void_p(stream)))
+
     def close(self) -> None:
         if self._c:
             self._lib.bf_comm_destroy(self._c)

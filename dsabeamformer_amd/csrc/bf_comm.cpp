@@ -24,6 +24,7 @@
 #include <vector>
 
 #include "bf_host_internal.h"
+#include "bf_kernels.h"
 
 namespace {
 
@@ -97,6 +98,7 @@ int comm_fail(int code, const std::string& msg) { return dsabf::set_error(code, 
 
 struct bf_comm {
     int rank = 0, world = 1, device = 0;
+    int n_cus = 0;   // of `device`, asked for when the staged transport first needs it
     rccl_comm_t comm = nullptr;
 };
 
@@ -241,40 +243,32 @@ int bf_comm_info(const bf_comm* c, int* lib_ranks, int* version, char* lib_path,
 int bf_comm_rank(const bf_comm* c) { return c ? c->rank : BF_ERR_INVALID; }
 int bf_comm_world(const bf_comm* c) { return c ? c->world : BF_ERR_INVALID; }
 
-int bf_gather_detected(bf_comm* c, const float* d_local, size_t n_rows, size_t row_floats, int root, int layout,
-                       float* d_full, void* hip_stream)
+// The exchange itself.  Point-to-point messages follow the plan of `wire_layout` and are received into d_wire; the rank's own
+// rows are copied (no RCCL) to their place in d_self, which is laid out as `self_layout`.  In-place transport: both are the
+// caller's d_full in the layout it asked for.  Staged transport: the wire is rank-major into the staging area, the own rows go
+// straight to their freq-major place in d_full.
+static int gather_exchange(bf_comm* c, const float* d_local, size_t n_rows, size_t row_floats, int root, int wire_layout,
+                           float* d_wire, int self_layout, float* d_self, hipStream_t s)
 {
-    if (!c || !d_local) return comm_fail(BF_ERR_INVALID, "NULL argument");
-    if (root >= c->world || root < BF_GATHER_ROOT_DISTRIBUTED) return comm_fail(BF_ERR_INVALID, "root out of range");
-    if (root == BF_GATHER_ROOT_DISTRIBUTED && n_rows % (size_t)c->world)
-        return comm_fail(BF_ERR_INVALID, "distributed owners need n_rows divisible by the number of ranks");
-    if (layout != BF_GATHER_LAYOUT_FREQ_MAJOR && layout != BF_GATHER_LAYOUT_RANK_MAJOR)
-        return comm_fail(BF_ERR_INVALID, "unknown gather layout");
     const size_t held = bf_gather_rows_held(n_rows, c->world, c->rank, root);
     const bool receives = held > 0;
-    if (receives && !d_full) return comm_fail(BF_ERR_INVALID, "this rank receives: d_full must not be NULL");
-    if (n_rows == 0 || row_floats == 0) return BF_OK;
-    hipStream_t s = static_cast<hipStream_t>(hip_stream);
-    const size_t n = bf_gather_plan(layout, n_rows, row_floats, c->world, c->rank, root, nullptr, 0);
+    const size_t n = bf_gather_plan(wire_layout, n_rows, row_floats, c->world, c->rank, root, nullptr, 0);
     std::vector<bf_gather_msg> plan(n);
-    bf_gather_plan(layout, n_rows, row_floats, c->world, c->rank, root, plan.data(), n);
-    int prev = -1;
-    (void)hipGetDevice(&prev);
-    if (prev != c->device && hipSetDevice(c->device) != hipSuccess) return comm_fail(BF_ERR_DEVICE, "hipSetDevice failed");
+    bf_gather_plan(wire_layout, n_rows, row_floats, c->world, c->rank, root, plan.data(), n);
     int result = BF_OK;
     // own rows: a strided device-to-device copy (one call for the freq-major layout), not through RCCL -- unless
     // DSABF_GATHER_SELF_RCCL=1 asks for it (test switch: lets ONE GPU exercise the grouped ncclSend / ncclRecv path)
     const char* self_env = getenv("DSABF_GATHER_SELF_RCCL");
-    const bool self_rccl = c->comm && self_env && self_env[0] == '1';
+    const bool self_rccl = c->comm && self_env && self_env[0] == '1' && d_wire == d_self && wire_layout == self_layout;
     if (!self_rccl && receives) {
         const size_t first = root == BF_GATHER_ROOT_DISTRIBUTED ? (size_t)c->rank * held : 0;   // my own rows that I keep
-        const size_t off0 = bf_gather_offset(layout, held, row_floats, c->world, c->rank, 0);
+        const size_t off0 = bf_gather_offset(self_layout, held, row_floats, c->world, c->rank, 0);
         const float* src = d_local + first * row_floats;
         hipError_t e;
-        if (layout == BF_GATHER_LAYOUT_RANK_MAJOR)
-            e = hipMemcpyAsync(d_full + off0, src, held * row_floats * sizeof(float), hipMemcpyDeviceToDevice, s);
+        if (self_layout == BF_GATHER_LAYOUT_RANK_MAJOR)
+            e = hipMemcpyAsync(d_self + off0, src, held * row_floats * sizeof(float), hipMemcpyDeviceToDevice, s);
         else
-            e = hipMemcpy2DAsync(d_full + off0, (size_t)c->world * row_floats * sizeof(float), src, row_floats * sizeof(float),
+            e = hipMemcpy2DAsync(d_self + off0, (size_t)c->world * row_floats * sizeof(float), src, row_floats * sizeof(float),
                                  row_floats * sizeof(float), held, hipMemcpyDeviceToDevice, s);
         if (e != hipSuccess) result = comm_fail(BF_ERR_DEVICE, std::string("gather self-copy: ") + hipGetErrorString(e));
     }
@@ -282,7 +276,7 @@ int bf_gather_detected(bf_comm* c, const float* d_local, size_t n_rows, size_t r
         rccl_api& r = rccl();
         // One ncclGroup per range of rows, the SAME ranges on every rank (symmetric groups: each group is a complete
         // exchange of its rows), sized so that a group stays below ~2048 messages on the busiest rank.
-        const size_t rows_per_group = layout == BF_GATHER_LAYOUT_RANK_MAJOR ? n_rows : (2048 / (size_t)c->world ? 2048 / (size_t)c->world : 1);
+        const size_t rows_per_group = wire_layout == BF_GATHER_LAYOUT_RANK_MAJOR ? n_rows : (2048 / (size_t)c->world ? 2048 / (size_t)c->world : 1);
         size_t group_end_row = 0;
         bool open = false;
         auto close_group = [&]() {
@@ -313,7 +307,7 @@ int bf_gather_detected(bf_comm* c, const float* d_local, size_t n_rows, size_t r
             if (m.kind == BF_GATHER_SEND || m.kind == BF_GATHER_COPY)
                 rc = r.Send(d_local + m.local_offset, m.count, kNcclFloat32, m.peer, c->comm, s);
             if (rc == 0 && (m.kind == BF_GATHER_RECV || m.kind == BF_GATHER_COPY))
-                rc = r.Recv(d_full + m.full_offset, m.count, kNcclFloat32, m.peer, c->comm, s);
+                rc = r.Recv(d_wire + m.full_offset, m.count, kNcclFloat32, m.peer, c->comm, s);
             if (rc != 0) {
                 (void)close_group();
                 result = comm_fail(BF_ERR_DEVICE, std::string("ncclSend/Recv: ") + r.GetErrorString(rc));
@@ -324,6 +318,61 @@ int bf_gather_detected(bf_comm* c, const float* d_local, size_t n_rows, size_t r
             const int rc = close_group();
             if (rc != 0) result = comm_fail(BF_ERR_DEVICE, std::string("ncclGroupEnd: ") + r.GetErrorString(rc));
         }
+    }
+    return result;
+}
+
+static int gather_check(bf_comm* c, const float* d_local, size_t n_rows, int root)
+{
+    if (!c || !d_local) return comm_fail(BF_ERR_INVALID, "NULL argument");
+    if (root >= c->world || root < BF_GATHER_ROOT_DISTRIBUTED) return comm_fail(BF_ERR_INVALID, "root out of range");
+    if (root == BF_GATHER_ROOT_DISTRIBUTED && n_rows % (size_t)c->world)
+        return comm_fail(BF_ERR_INVALID, "distributed owners need n_rows divisible by the number of ranks");
+    return BF_OK;
+}
+
+int bf_gather_detected(bf_comm* c, const float* d_local, size_t n_rows, size_t row_floats, int root, int layout,
+                       float* d_full, void* hip_stream)
+{
+    if (int rc = gather_check(c, d_local, n_rows, root)) return rc;
+    if (layout != BF_GATHER_LAYOUT_FREQ_MAJOR && layout != BF_GATHER_LAYOUT_RANK_MAJOR)
+        return comm_fail(BF_ERR_INVALID, "unknown gather layout");
+    if (bf_gather_rows_held(n_rows, c->world, c->rank, root) > 0 && !d_full)
+        return comm_fail(BF_ERR_INVALID, "this rank receives: d_full must not be NULL");
+    if (n_rows == 0 || row_floats == 0) return BF_OK;
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    if (prev != c->device && hipSetDevice(c->device) != hipSuccess) return comm_fail(BF_ERR_DEVICE, "hipSetDevice failed");
+    const int result = gather_exchange(c, d_local, n_rows, row_floats, root, layout, d_full, layout, d_full, static_cast<hipStream_t>(hip_stream));
+    if (prev >= 0 && prev != c->device) (void)hipSetDevice(prev);
+    return result;
+}
+
+int bf_gather_detected_staged(bf_comm* c, const float* d_local, size_t n_rows, size_t row_floats, int root, float* d_full,
+                              float* d_stage, void* hip_stream)
+{
+    if (int rc = gather_check(c, d_local, n_rows, root)) return rc;
+    const size_t held = bf_gather_rows_held(n_rows, c->world, c->rank, root);
+    if (held > 0 && (!d_full || (!d_stage && c->world > 1)))
+        return comm_fail(BF_ERR_INVALID, "this rank receives: d_full and d_stage must not be NULL");
+    if (held > 0 && (row_floats % 4 || ((uintptr_t)d_full & 15) || ((uintptr_t)d_stage & 15)))
+        return comm_fail(BF_ERR_INVALID, "the staged transport moves 16-byte pieces: row_floats must be a multiple of 4, d_full and "
+                                         "d_stage 16-byte aligned");
+    if (n_rows == 0 || row_floats == 0) return BF_OK;
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    if (prev != c->device && hipSetDevice(c->device) != hipSuccess) return comm_fail(BF_ERR_DEVICE, "hipSetDevice failed");
+    int result = gather_exchange(c, d_local, n_rows, row_floats, root, BF_GATHER_LAYOUT_RANK_MAJOR, d_stage, BF_GATHER_LAYOUT_FREQ_MAJOR,
+                                 d_full, s);
+    if (result == BF_OK && held > 0 && c->world > 1) {
+        if (!c->n_cus) {
+            int n = 0;
+            if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess || n <= 0) n = 256;
+            c->n_cus = n;
+        }
+        const hipError_t e = dsabf::launch_gather_relayout(d_stage, d_full, held, c->world, row_floats, c->rank, c->n_cus, s);
+        if (e != hipSuccess) result = comm_fail(BF_ERR_DEVICE, std::string("gather re-layout launch: ") + hipGetErrorString(e));
     }
     if (prev >= 0 && prev != c->device) (void)hipSetDevice(prev);
     return result;

@@ -79,6 +79,10 @@ hipError_t launch_expand(const void* d_in, size_t nbytes, void* d_out, hipStream
 constexpr size_t kMfmaPeakSrcBytes = (size_t)(512 + 256) * 256 * 16;   // 3 MiB read as operands
 constexpr size_t kMfmaPeakSinkBytes = (size_t)4096 * 256 * sizeof(int);   // scratch for up to 1024 CUs
 hipError_t launch_mfma_peak(const void* d_src, void* d_sink, int iters, int n_cus, double* ops, hipStream_t s);
+// full[row][rank][row_floats] = stage[rank][row][row_floats] for every rank but skip_rank (-1: none); 16-byte aligned pointers,
+// row_floats a multiple of 4 (the staged transport of bf_gather_detected_staged)
+hipError_t launch_gather_relayout(const float* d_stage, float* d_full, size_t held, int world, size_t row_floats, int skip_rank,
+                                  int n_cus, hipStream_t s);
 hipError_t launch_dedisperse(const Geometry& g, const float* d_out_unit, float* d_ded, hipStream_t s);
 // ded[u][b] = ascending-f fp32 sum of output 0 of unit u, units `unit_stride` floats apart: one launch for a whole block
 hipError_t launch_dedisperse_units(const Geometry& g, const float* d_out_units, size_t unit_stride, int n_units, float* d_ded,

@@ -759,6 +759,41 @@ hipError_t launch_mfma_peak(const void* d_src, void* d_sink, int iters, int n_cu
     return hipGetLastError();
 }
 
+// The staged transport of the gather (bf_gather_detected_staged): the shards arrive sub-band-major,
+// stage[rank][row][row_floats] -- ONE message per sender -- and this pass puts them where the reference's [o][f][b] order has
+// them, full[row][rank][row_floats] (f = rank * n_freq_local + f_local).  Pure HBM traffic: every float is read once and
+// written once, in whole 16-byte pieces of 128-byte lines, nontemporal both ways (the data is not touched again here).
+// A workgroup moves whole (rank, row) blocks, consecutive workgroups consecutive rows of one rank: reads stream through
+// the stage linearly, writes land world * row_floats apart.  skip_rank: the receiver's own rows are copied straight from
+// its kernel output to their final place and never staged.
+__global__ __launch_bounds__(256) void gather_relayout_kernel(const v4i* __restrict__ stage, v4i* __restrict__ full, unsigned held,
+                                                              unsigned world, unsigned row_vec, int skip_rank)
+{
+    const size_t n_blocks = (size_t)held * world;
+    for (size_t blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
+        const unsigned r = (unsigned)(blk / held), h = (unsigned)(blk % held);
+        if ((int)r == skip_rank) continue;
+        const v4i* src = stage + blk * row_vec;
+        v4i* dst = full + ((size_t)h * world + r) * row_vec;
+        for (unsigned v = threadIdx.x; v < row_vec; v += 256) __builtin_nontemporal_store(__builtin_nontemporal_load(src + v), dst + v);
+    }
+}
+
+hipError_t launch_gather_relayout(const float* d_stage, float* d_full, size_t held, int world, size_t row_floats, int skip_rank,
+                                  int n_cus, hipStream_t s)
+{
+    if (!held || world <= 0 || !row_floats) return hipSuccess;
+    if (row_floats % 4 || ((uintptr_t)d_stage & 15) || ((uintptr_t)d_full & 15) || held >= (1u << 31) || row_floats / 4 >= (1u << 31))
+        return hipErrorInvalidValue;
+    clear_stale_error();
+    const size_t n_blocks = held * (size_t)world;
+    const size_t cap = (size_t)n_cus * 16;   // a few workgroups per CU keep enough 16-byte requests in flight to fill HBM
+    hipLaunchKernelGGL(gather_relayout_kernel, dim3((unsigned)(n_blocks < cap ? n_blocks : cap)), dim3(256), 0, s,
+                       reinterpret_cast<const v4i*>(d_stage), reinterpret_cast<v4i*>(d_full), (unsigned)held, (unsigned)world,
+                       (unsigned)(row_floats / 4), skip_rank);
+    return hipGetLastError();
+}
+
 hipError_t launch_dedisperse(const Geometry& g, const float* d_out_unit, float* d_ded, hipStream_t s)
 {
     clear_stale_error();

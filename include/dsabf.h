@@ -257,6 +257,17 @@ int bf_comm_world(const bf_comm *c);
 int bf_comm_info(const bf_comm *c, int *lib_ranks, int *version, char *lib_path, size_t n);
 int bf_gather_detected(bf_comm *c, const float *d_local, size_t n_rows, size_t row_floats, int root, int layout,
                        float *d_full, void *hip_stream);
+/* The same gather into BF_GATHER_LAYOUT_FREQ_MAJOR -- the reference's [o][f][b] over the whole band, src/beamformer.cuh:147 --
+ * by a second TRANSPORT.  bf_gather_detected receives every (row, sender) run at its final position: no extra pass over the
+ * data, but one point-to-point message per row and sender (14,336 messages of 32 KiB per rank for a 128-gemm-unit step of
+ * BASELINE configs[3] on 8 GPUs).  This entry point puts ONE message per sender on the wire (the rank-major plan, received
+ * into d_stage) and then moves the rows to their freq-major places with one device pass (every float read and written once,
+ * whole 128-byte lines, nontemporal); the receiver's own rows go straight from d_local to d_full.  d_stage: caller-owned,
+ * as large as d_full (rows held x world x row_floats floats; may be NULL on ranks that receive nothing, and when world == 1);
+ * row_floats a multiple of 4, both buffers 16-byte aligned.  Bit-identical d_full either way; which is faster is a property
+ * of the fabric and the message count (bench.py times both: gather_modes.*_freq_major[_staged]). */
+int bf_gather_detected_staged(bf_comm *c, const float *d_local, size_t n_rows, size_t row_floats, int root, float *d_full,
+                              float *d_stage, void *hip_stream);
 /* The layout arithmetic as plain host functions (no device, no RCCL): float offset of (rank, row) in the gathered array,
  * and the list of messages one rank issues (kind: send to peer, receive from peer, or copy its own rows). */
 size_t bf_gather_offset(int layout, size_t n_rows_held, size_t row_floats, int world, int rank, size_t row);

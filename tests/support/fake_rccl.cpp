@@ -156,6 +156,15 @@ int run_ops()
             std::this_thread::sleep_for(std::chrono::microseconds(50));
         }
     }
+    // FAKERCCL_CORRUPT=1: a fabric that delivers wrong bits -- one bit of the LAST message this group received is flipped
+    // (tests of bench.py's checksum verification: the gather must be caught, not believed)
+    if (const char* e = getenv("FAKERCCL_CORRUPT"))
+        if (e[0] == '1')
+            for (size_t k = g_ops.size(); k-- > 0;)
+                if (!g_ops[k].send && g_ops[k].bytes >= 8) {
+                    g_ops[k].host[g_ops[k].bytes / 2] ^= 0x10;
+                    break;
+                }
     for (op& o : g_ops)
         if (!o.send && hipMemcpy(o.dev, o.host.data(), o.bytes, hipMemcpyHostToDevice) != hipSuccess) return 1;
     g_ops.clear();
@@ -267,6 +276,10 @@ static int post(bool send, void* buf, size_t count, int dt, int peer, void* comm
 
 int ncclSend(const void* buf, size_t count, int dt, int peer, void* comm, hipStream_t s)
 {
+    // FAKERCCL_HANG_SEND=1: a fabric on which the first send never returns (tests of bench.py's deadline)
+    if (const char* e = getenv("FAKERCCL_HANG_SEND"))
+        if (e[0] == '1')
+            for (;;) std::this_thread::sleep_for(std::chrono::seconds(1));
     return post(true, const_cast<void*>(buf), count, dt, peer, comm, s);
 }
 int ncclRecv(void* buf, size_t count, int dt, int peer, void* comm, hipStream_t s) { return post(false, buf, count, dt, peer, comm, s); }

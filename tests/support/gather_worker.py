@@ -70,6 +70,14 @@ for root in (0, world - 1, api.GATHER_ROOT_ALL, api.GATHER_ROOT_DISTRIBUTED):
         torch.cuda.synchronize()
         if held:
             res["root%d_layout%d" % (root, layout)] = d_full.cpu().numpy()
+    # the staged transport of the freq-major layout: rank-major on the wire, one device re-layout pass (bf_gather_detected_staged)
+    held = comm.rows_held(n_rows, root)
+    d_full = torch.full((max(held, 1) * world * row_floats,), float("nan"), dtype=torch.float32, device="cuda")
+    d_stage = torch.full((max(held, 1) * world * row_floats,), float("nan"), dtype=torch.float32, device="cuda")
+    comm.gather_staged(d_local, n_rows, row_floats, root, d_full if held else None, d_stage if held else None, s)
+    torch.cuda.synchronize()
+    if held:
+        res["root%d_staged" % root] = d_full.cpu().numpy()
 # rank 0: DM-0 sum and a DM ladder over the WHOLE band, on the freq-major gathered series (rows = time samples)
 comm.gather(d_local, n_rows, row_floats, 0, api.GATHER_FREQ_MAJOR,
             d_band := (torch.empty(n_rows * world * row_floats, dtype=torch.float32, device="cuda") if rank == 0 else None), s)

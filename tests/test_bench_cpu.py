@@ -83,12 +83,18 @@ def test_multi_gpu_request_without_a_launcher_starts_the_launcher_itself(monkeyp
     # the hand-over itself, on this GPU-less box: the launcher is a subprocess, gets the flags, and its status comes back
     calls = {}
 
-    def fake_call(c, env=None):
-        calls["cmd"], calls["env"] = c, env
-        return 7
+    class FakeChild:
+        pid = 0
+
+        def __init__(self, c, env=None, start_new_session=False):
+            calls["cmd"], calls["env"], calls["session"] = c, env, start_new_session
+
+        def wait(self, timeout=None):
+            calls["timeout"] = timeout
+            return 7
 
     import subprocess as sp
-    monkeypatch.setattr(sp, "call", fake_call)
+    monkeypatch.setattr(sp, "Popen", FakeChild)
     monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2", "--steps", "3"])
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
         monkeypatch.delenv(k, raising=False)
@@ -100,14 +106,139 @@ def test_multi_gpu_request_without_a_launcher_starts_the_launcher_itself(monkeyp
         assert e.code == 7
     assert calls["cmd"][-4:] == ["--gpus", "2", "--steps", "3"] and calls["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
     assert int(calls["cmd"][calls["cmd"].index("--master-port") + 1]) > 0
+    assert calls["session"] is True and calls["timeout"] > 1500      # its own session, under the parent's deadline
 
 
-def test_multi_gpu_request_on_a_box_with_fewer_gpus_says_so():
-    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "DSABF_BENCH_ONE_GPU")}
+def _fake_topology(tmp_path, gpus, render_present):
+    """A KFD topology tree like /sys/class/kfd/kfd/topology/nodes: two CPU nodes, then `gpus` GPU nodes; render_present = the
+    GPU indices whose /dev/dri/renderD* exists (a container that was handed only some of the host's GPUs)."""
+    nodes, dri = tmp_path / "nodes", tmp_path / "dri"
+    dri.mkdir()
+    for i in range(2 + gpus):
+        d = nodes / str(i)
+        d.mkdir(parents=True)
+        if i < 2:
+            (d / "properties").write_text("cpu_cores_count 64\nsimd_count 0\ndrm_render_minor 0\n")
+        else:
+            (d / "properties").write_text("cpu_cores_count 0\nsimd_count 1024\ndrm_render_minor %d\n" % (128 + i - 2))
+            if i - 2 in render_present:
+                (dri / ("renderD%d" % (128 + i - 2))).write_text("")
+    return {"DSABF_KFD_TOPOLOGY": str(nodes), "DSABF_DRI_DIR": str(dri)}
+
+
+def test_gpu_count_comes_from_sysfs_not_from_the_hip_runtime(tmp_path, monkeypatch):
+    """VERDICT r04 item 1d / ADVICE: the parent of the ranks counts devices without loading HIP -- KFD topology nodes with
+    SIMDs whose render node this container can open, cut to HIP_VISIBLE_DEVICES."""
+    for k, v in _fake_topology(tmp_path, 8, {0, 1, 2, 3, 4, 5, 6, 7}).items():
+        monkeypatch.setenv(k, v)
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES", raising=False)
+    monkeypatch.delenv("ROCR_VISIBLE_DEVICES", raising=False)
+    assert bench.count_gpus() == 8
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,1")
+    assert bench.count_gpus() == 2
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES")
+    (tmp_path / "dri" / "renderD130").unlink()            # a GPU of the host that was not handed to this container
+    assert bench.count_gpus() == 7
+    monkeypatch.setenv("DSABF_KFD_TOPOLOGY", str(tmp_path / "nothing"))
+    assert bench.count_gpus() == 0
+    import inspect
+    assert "import torch" not in inspect.getsource(bench.self_launch) and "import torch" not in inspect.getsource(bench.count_gpus)
+
+
+def test_multi_gpu_request_on_a_box_with_fewer_gpus_says_so(tmp_path):
+    """`python bench.py --gpus 2` on a box that shows one GPU (an 8-GPU host, one render node in the container): a message, a
+    non-zero status, NO child process, no line -- whatever hardware the test itself runs on (the topology is a fixture)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "DSABF_BENCH_ONE_GPU",
+                                                             "HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES")}
+    env.update(_fake_topology(tmp_path, 8, {3}))
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
                        timeout=300, env=env)
-    assert r.returncode != 0 and "this node shows 0 GPU(s)" in (r.stderr + r.stdout)
+    assert r.returncode != 0 and "this node shows 1 GPU(s)" in (r.stderr + r.stdout)
+    assert "starting" not in r.stderr                                   # no launcher was started
     assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_a_launcher_that_never_returns_is_killed_and_reported(tmp_path):
+    """The parent's own deadline: the child (its own session) is killed as a process group, one diagnostic line, status 5."""
+    code = ("import sys; sys.path.insert(0, %r); import bench\n"
+            "bench.launcher_command = lambda n, argv, port: [sys.executable, '-c', 'import time; time.sleep(600)']\n"
+            "sys.argv = ['bench.py', '--gpus', '2', '--deadline-seconds', '1']\n"
+            "bench.main()\n" % ROOT)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.update(DSABF_BENCH_ONE_GPU="1", DSABF_LAUNCH_GRACE="1")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode == 5, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d["value"] is None and d["n_gpus"] == 2 and "did not return" in d["error"]
+
+
+def test_deadline_before_the_headline_is_a_failure_with_a_diagnostic_line():
+    """armed before anything can block; when a stage never finishes rank 0 prints ONE line naming the
+    stage and the process ends NON-ZERO (os._exit from the timer thread: the main thread is stuck by definition)."""
+    code = ("import sys, time; sys.path.insert(0, %r); import bench\n"
+            "d = bench.Deadline(rank=0, n_gpus=8, total_seconds=60.0)\n"
+            "d.stage('control plane: init_process_group(gloo)', 0.3)\n"
+            "time.sleep(30)\n"
+            "print('never reached')\n" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 3 and "never reached" not in r.stdout
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["value"] is None and d["n_gpus"] == 8 and d["rank"] == 0 and d["stage"].startswith("control plane")
+    assert "did not finish" in d["error"] and d["metric"].startswith("beam-blocks/sec")
+    # ranks other than 0 print no line (the launcher's stdout carries rank 0's only); they say why on stderr and end non-zero
+    r2 = subprocess.run([sys.executable, "-c", code.replace("rank=0", "rank=3")], capture_output=True, text=True, timeout=60)
+    assert r2.returncode == 3 and not [l for l in r2.stdout.splitlines() if l.startswith("{")] and "rank 3" in r2.stderr
+
+
+def test_deadline_after_the_kernel_only_record_keeps_it_and_names_the_gather():
+    """kernel-only scaling is recorded before any RCCL traffic; a gather stage that hangs leaves a line
+    with gather_modes.none, gather_error and value null; the exit status is the gather's failure code."""
+    code = ("import sys, time; sys.path.insert(0, %r); import bench\n"
+            "d = bench.Deadline(rank=0, n_gpus=2, total_seconds=60.0)\n"
+            "out = {'metric': 'm', 'value': 123.0, 'n_gpus': 2, 'gather_modes': {'none': {'value': 123.0}}, 'roofline': {'frac': 0.4}}\n"
+            "d.adopt(out); d.fail_code = 4\n"
+            "d.stage(\"gather 'alltoall_rank_major': warm-up\", 0.3)\n"
+            "time.sleep(30)\n" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 4
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d["value"] is None and d["gather_modes"]["none"]["value"] == 123.0 and "alltoall_rank_major" in d["gather_error"]
+    assert d["stage"].endswith("warm-up") and d["roofline"]["frac"] == 0.4
+
+
+def test_deadline_reports_a_sigterm_from_the_launcher():
+    """The launcher stops the other ranks with SIGTERM when one fails: rank 0 must still say what it had -- even while its main
+    thread sits in a call that never returns (sigwait on a thread of its own, not a Python-level handler)."""
+    code = ("import os, sys, time, signal; sys.path.insert(0, %r); import bench\n"
+            "signal.pthread_sigmask(signal.SIG_BLOCK, {signal.SIGTERM})\n"
+            "d = bench.Deadline(rank=0, n_gpus=2, total_seconds=60.0)\n"
+            "bench.watch_sigterm(d)\n"
+            "d.stage('RCCL communicator (bf_comm_create)', 50.0)\n"
+            "print('ready', flush=True)\n"
+            "time.sleep(30)\n" % ROOT)
+    p = subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert p.stdout.readline().strip() == "ready"
+    p.terminate()
+    out, _ = p.communicate(timeout=30)
+    assert p.returncode == 143
+    d = json.loads([l for l in out.splitlines() if l.startswith("{")][0])
+    assert "signal 15" in d["error"] and d["stage"].startswith("RCCL communicator")
+
+
+def test_issue_model_says_what_binds_the_kernel():
+    """from the committed PMC pass of the headline launch -- 17.2 VALU ops per MFMA, 13 + 2.45 K cycles of
+    issue per MFMA account for the launch's cycles (the SIMDs' instruction issue is the bound, the matrix pipe is 29 % busy),
+    and the clock the chip held."""
+    c3 = bench.pmc_summary("r04_c3_paired_pmc_summary.txt")
+    m = bench.issue_model(c3, 0.8896)
+    assert abs(m["valu_per_mfma"] - 17.2) < 0.1 and abs(m["issue_model_cycles_per_mfma"] - (13 + 2.45 * m["valu_per_mfma"])) < 1e-9
+    assert 0.9 < m["issue_occupancy"] < 1.05 and m["bound_measured"] == "simd-issue"
+    assert 1.9 < m["clock_ghz_under_load"] < 2.2
+    gen = bench.issue_model(bench.pmc_summary("r04_c3_general_pmc_summary.txt"), 0.9975)
+    assert 6.0 < gen["valu_per_mfma"] < 7.5 and gen["bound_measured"] in ("simd-issue", "unclear")
+    assert bench.issue_model({}, 1.0) == {"bound_measured": None}
 
 
 def test_committed_bench_lines_agree_with_the_committed_rocprof_kernel_stats():

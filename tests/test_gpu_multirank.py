@@ -68,6 +68,8 @@ def test_gather_detected_with_several_ranks_on_one_gpu(orc, fake_rccl, tmp_path,
             got_r = ranks[r]["root%d_layout1" % root].reshape(world, held, fl, B)  # sub-band-major
             assert np.array_equal(got_f, full[first:first + held]), (root, r)
             assert np.array_equal(got_r, shards[:, first:first + held]), (root, r)
+            # the staged transport (one message per sender + the device re-layout pass): the same [o][f][b], bit for bit
+            assert np.array_equal(ranks[r]["root%d_staged" % root].reshape(held, F, B), full[first:first + held]), (root, r)
     # dedispersion of the gathered band on rank 0 (bf_dedisperse_band_device / bf_dedisperse_dm_band_device): ascending f over
     # ALL channels = the bits a single GPU holding the whole band produces = the oracle's
     assert np.array_equal(ranks[0]["band_ded0"], orc.dedisperse(g, want[0]))
@@ -107,6 +109,7 @@ def test_gather_detected_8_ranks_at_the_true_config4_per_rank_shape(orc, fake_rc
             first = r * held if root == -2 else 0
             assert np.array_equal(ranks[r]["root%d_layout0" % root].reshape(held, F, B), full[first:first + held]), (root, r)
             assert np.array_equal(ranks[r]["root%d_layout1" % root].reshape(world, held, fl, B), shards[:, first:first + held]), (root, r)
+            assert np.array_equal(ranks[r]["root%d_staged" % root].reshape(held, F, B), full[first:first + held]), (root, r)
     assert np.array_equal(ranks[0]["band_ded0"], orc.dedisperse(g, want[0]))
     assert np.array_equal(ranks[0]["band_dm"], orc.dedisperse_dm(full, delays, n_rows - int(delays.max())))
 
@@ -168,8 +171,11 @@ def test_bench_with_two_ranks_on_one_gpu(fake_rccl, gather, n):
     # what the LIBRARY says about the communicator (bf_comm_info): as many ranks as the launcher started, and which file
     assert d["rccl"]["ranks"] == n and d["rccl"]["lib"].endswith("libfakerccl.so") and d["rccl"]["version"] == 0
     modes = d["gather_modes"]
-    for k in ("none", "root_rank_major", "root_freq_major", "alltoall_rank_major", "alltoall_freq_major"):
+    for k in ("none", "root_rank_major", "root_freq_major", "root_freq_major_staged", "alltoall_rank_major", "alltoall_freq_major",
+              "alltoall_freq_major_staged"):
         assert "error" not in modes[k] and modes[k]["value"] > 0, (k, modes[k])
+        assert k == "none" or modes[k]["verified"] is True, (k, modes[k])
+    assert modes["%s_rank_major" % gather]["headline"] is True and d["kernel_only"]["value"] == modes["none"]["value"]
 
 
 def test_bench_launches_its_own_ranks_when_called_plainly(fake_rccl):
@@ -198,6 +204,79 @@ def test_bench_launches_its_own_ranks_when_called_plainly(fake_rccl):
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["value"] > 0 and cb["unit"] == "beam-blocks/s" and cb["cores"] >= 1
     assert all("error" not in v for k, v in d["gather_modes"].items() if k != "note")
+
+
+def _plain_bench(env, *extra, timeout=600):
+    env = {k: v for k, v in env.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--units", "4",
+                           "--min-warm-seconds", "0.1", "--no-cpu-baseline", *extra], capture_output=True, text=True, timeout=timeout, env=env)
+
+
+def test_bench_with_a_send_that_never_returns_still_prints_the_kernel_only_record(fake_rccl):
+    """a fabric on which the first ncclSend never comes back (the stand-in sleeps forever in it).  The
+    kernel-only region was measured before any communicator existed, so the line carries gather_modes.none; the stage that hung
+    is named in gather_error; value is null; the command ends NON-ZERO -- all of it well inside a minute, not at the driver's
+    1800 s limit."""
+    import json
+    import time
+
+    env = dict(os.environ, DSABF_RCCL_LIB=fake_rccl, DSABF_BENCH_ONE_GPU="1", FAKERCCL_MAILBOX_MB="64", FAKERCCL_HANG_SEND="1")
+    t0 = time.time()
+    r = _plain_bench(env, "--gather-timeout", "8")
+    took = time.time() - t0
+    assert r.returncode != 0, (r.stdout + r.stderr)[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, (r.stdout + r.stderr)[-3000:]
+    d = json.loads(lines[0])
+    assert d["value"] is None and d["n_gpus"] == 2
+    assert d["gather_modes"]["none"]["value"] > 0 and d["kernel_only"]["value"] > 0 and 0 < d["kernel_only"]["roofline_frac"] < 1
+    assert "alltoall_rank_major" in d["gather_error"] and "did not finish" in d["gather_error"] and d["rank"] == 0
+    assert d["stage"].startswith("gather 'alltoall_rank_major'")
+    assert d["roofline"]["kernel_ms_avg"] > 0                     # the kernel-only region's own roofline record is in the line
+    assert took < 60, took
+
+
+def test_bench_catches_a_gather_that_delivers_wrong_bits(fake_rccl):
+    """every gather mode is verified after it is timed (per-row position-weighted checksums, published by
+    the senders on the control plane, recomputed by the receivers on what they hold).  A stand-in that flips ONE bit of one
+    received message: gather_modes[headline].verified is false, value is null, the command ends non-zero."""
+    import json
+
+    env = dict(os.environ, DSABF_RCCL_LIB=fake_rccl, DSABF_BENCH_ONE_GPU="1", FAKERCCL_MAILBOX_MB="64", FAKERCCL_CORRUPT="1")
+    r = _plain_bench(env)
+    assert r.returncode != 0, (r.stdout + r.stderr)[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, (r.stdout + r.stderr)[-3000:]
+    d = json.loads(lines[0])
+    assert d["gather_modes"]["alltoall_rank_major"]["verified"] is False and d["gather_modes"]["alltoall_rank_major"]["headline"] is True
+    assert d["value"] is None and d["unverified_value"] > 0 and "other bits" in d["gather_error"]
+    assert d["gather_modes"]["none"]["value"] > 0
+    # ... and the same run on an honest stand-in verifies every mode, both transports of the freq-major layout included
+    env.pop("FAKERCCL_CORRUPT")
+    r = _plain_bench(env)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    modes = {k: v for k, v in d["gather_modes"].items() if k not in ("note", "none")}
+    assert set(modes) == {"root_rank_major", "root_freq_major", "root_freq_major_staged", "alltoall_rank_major",
+                          "alltoall_freq_major", "alltoall_freq_major_staged"}
+    assert all(v["verified"] is True and v["value"] > 0 for v in modes.values()), modes
+    assert d["value"] > 0 and "gather_error" not in d and "gloo" in d["config"]["control_plane"]
+
+
+def test_plain_multi_gpu_request_on_this_one_gpu_box_is_refused_without_starting_anything():
+    """the parent counts GPUs from sysfs (no HIP, no torch): on a 1-GPU box `bench.py --gpus 2` says so,
+    ends non-zero and starts no child.  The sysfs count agrees with what the HIP runtime reports (asked in a child process)."""
+    import bench
+
+    n_hip = int(subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True,
+                               text=True, timeout=300).stdout.strip())
+    assert bench.count_gpus() == n_hip >= 1
+    if n_hip >= 2:
+        pytest.skip("this box has %d GPUs" % n_hip)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "DSABF_BENCH_ONE_GPU")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0 and "this node shows 1 GPU(s)" in r.stderr and "starting" not in r.stderr
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
 
 
 def test_bench_exits_nonzero_when_the_communicator_cannot_be_created():

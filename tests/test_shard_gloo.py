@@ -84,6 +84,22 @@ for layout in (0, 1):                                   # BF_GATHER_LAYOUT_FREQ_
             else:                                        # sub-band-major [rank][row][f_local][b]
                 assert np.array_equal(got.reshape(world, held, gl.n_freq, g.n_beams), shards[:, first:first + held] * np.float32(it)), (layout, root, rank)
         dist.barrier()
+# ---- the STAGED transport of the freq-major layout (bf_gather_detected_staged): the wire is the rank-major plan above; what the
+# device re-layout pass then does is full[bf_gather_offset(FREQ_MAJOR, rank, row)] = stage[bf_gather_offset(RANK_MAJOR, rank, row)]
+# for every (rank, row) -- walked here on the CPU with the product's own offset arithmetic
+for root in (0, world - 1, -1, -2):
+    src = local.reshape(-1).contiguous()
+    held, stage = gather(1, root, src)
+    if held:
+        first = rank * held if root == -2 else 0
+        relaid = torch.full_like(stage, float("nan"))
+        for r in range(world):
+            for row in range(held):
+                a = lib.bf_gather_offset(1, held, row_floats, world, r, row)
+                b = lib.bf_gather_offset(0, held, row_floats, world, r, row)
+                relaid[b:b + row_floats] = stage[a:a + row_floats]
+        assert np.array_equal(relaid.numpy().reshape(held, g.n_freq, g.n_beams), full[first:first + held]), (root, rank)
+    dist.barrier()
 # sub-band dedispersion: each rank sums its own channels (delays against the band-wide reference frequency), the
 # partials are added in rank order -> identical on every rank and equal to the banded oracle sum
 series = full                                                       # [t][F][B] detected series, t = og outputs

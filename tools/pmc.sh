@@ -22,6 +22,9 @@ for f in glob.glob(out + "/pass*/**/*counter_collection.csv", recursive=True):
         k = r["Kernel_Name"]
         if "fused" not in k and "expand_kernel" not in k: continue
         agg[k.split("(")[0][-60:]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        # the dispatch's own duration in the pass that counted the cycles: clock = GRBM_GUI_ACTIVE / 8 / this
+        if r["Counter_Name"] == "GRBM_GUI_ACTIVE" and r.get("Start_Timestamp") and r.get("End_Timestamp"):
+            agg[k.split("(")[0][-60:]]["_KERNEL_NS_GRBM_PASS"].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
 with open(out + "/summary.txt", "w") as fp:
     for k, d in agg.items():
         fp.write(k + "\n")
