@@ -928,6 +928,7 @@ def main():
     elapsed, events = timed_region(none_mode, args.steps, True)
     deadline.stage("record of the kernel-only region", stage_s)
     out = build_record(elapsed, events, extra_warm)
+    deadline.adopt(out, "error")          # rank 0: the record the one line is printed from (None on the other ranks)
     headline_mode = none_mode
     gather_modes = {}
 

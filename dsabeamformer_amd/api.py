@@ -134,6 +134,21 @@ class Beamformer:
     def enqueue_dedisperse(self, stream_idx: int, host_out_row=None) -> None:
         check(self._lib.bf_enqueue_dedisperse(self._h, stream_idx, _ptr(host_out_row)))
 
+    def queue_stream(self, stream_idx: int) -> int:
+        """bf_queue_stream: the hipStream_t of compute queue stream_idx (launches what is still only queued first)."""
+        p = C.c_void_p()
+        check(self._lib.bf_queue_stream(self._h, stream_idx, C.byref(p)))
+        return p.value or 0
+
+    def block_output_device(self, stream_idx: int) -> int:
+        """bf_block_output_device: device pointer of the queue's block buffer [n_gemms_per_block][output][freq][beam]."""
+        p = C.c_void_p()
+        check(self._lib.bf_block_output_device(self._h, stream_idx, C.byref(p)))
+        return p.value or 0
+
+    def enqueue_d2h(self, stream_idx: int, d_src, host_dst, n_floats: int) -> None:
+        check(self._lib.bf_enqueue_d2h(self._h, stream_idx, _ptr(d_src), _ptr(host_dst), n_floats))
+
     def record_analysis_event(self, event) -> None:
         check(self._lib.bf_record_analysis_event(self._h, _ptr(event)))
 

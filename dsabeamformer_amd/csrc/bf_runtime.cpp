@@ -5,6 +5,7 @@
 // detected-power buffer per compute queue.  There is no CPU fallback: without a gfx950 device every compute
 // entry point fails with BF_ERR_NO_DEVICE / BF_ERR_DEVICE.
 #include "../../include/dsabf.h"
+#include "../../include/dsabf_bench.h"
 
 #include <cstdlib>
 #include <hip/hip_runtime.h>
@@ -281,11 +282,16 @@ int bf_create(const bf_config* cfg, int device, bf_handle** out)
     return BF_OK;
 }
 
+static int flush_units(bf_handle* h);
+
 int bf_destroy(bf_handle* h)
 {
     if (!h) return BF_OK;
     DeviceScope dev_scope_(h->device);
-    h->pending.clear();   // gemm-units queued but never joined by an event or a sync: their results were never observable
+    // gemm-units queued but never joined by an event or a sync: launch them (as the literal pattern would have) so that their
+    // host copies land before the queues are drained below -- a destroy must not silently drop work that was accepted
+    if (!h->streams.empty() && h->streams[0] && h->flush_done) (void)flush_units(h);
+    h->pending.clear();
     for (auto s : h->streams)
         if (s) (void)hipStreamSynchronize(s);
     if (h->h2d) (void)hipStreamSynchronize(h->h2d);
@@ -317,8 +323,6 @@ int bf_get_config(const bf_handle* h, bf_config* cfg)
     *cfg = h->cfg;
     return BF_OK;
 }
-
-static int flush_units(bf_handle* h);
 
 static int finish_weights(bf_handle* h, const int8_t* d_w, hipStream_t s)
 {
@@ -588,6 +592,12 @@ static int flush_units(bf_handle* h)
     }
     HIP_TRY(hipEventRecord(h->flush_done, s));
     h->flush_recorded = true;
+    // The per-queue ordering guarantee of the literal pattern, kept: every caller-visible queue that had a unit in this flush
+    // waits for the flush's end.  Whatever the caller orders on streams[stream_idx] afterwards -- a raw hipStreamSynchronize on
+    // the stream bf_queue_stream handed out earlier, its own event, a bf_enqueue_d2h, RCCL chained on it -- is behind the
+    // unit's launch AND its host copy, exactly as when the unit itself ran there.
+    for (int st = 0; st < h->cfg.n_streams; st++)
+        if (reassigned[(size_t)st] && st != q) HIP_TRY(hipStreamWaitEvent(h->streams[st], h->flush_done, 0));
     for (const auto& u : units) {
         h->last_out[u.stream_idx] = blk + per_det * (size_t)u.time_slice;
         h->last_q[u.stream_idx] = q;
@@ -652,10 +662,12 @@ int bf_enqueue_block(bf_handle* h, int stream_idx, int slot, int first_unit, int
     const size_t per_det = bf_floats_per_detect(&h->cfg);
     if (h->d_out_blk.empty()) h->d_out_blk.assign((size_t)h->cfg.n_streams, nullptr);
     if (h->blk_ran.empty()) h->blk_ran.assign((size_t)h->cfg.n_streams, 0);
-    if (!h->d_out_blk[stream_idx])   // a caller rotates over the queues block after block: every queue's buffer NOW -- a hipMalloc
-        for (int q = 0; q < h->cfg.n_streams; q++)   // in the middle of a stream of blocks stalls the device (measured: 9.4 -> 10.9 us per beam-block)
-            if (!h->d_out_blk[q])
-                HIP_TRY(hipMalloc((void**)&h->d_out_blk[q], per_det * sizeof(float) * (size_t)h->cfg.n_gemms_per_block));
+    // This queue's block buffer, at first use.  A hipMalloc in the middle of a stream of blocks stalls the device (measured: 9.4 ->
+    // 10.9 us per beam-block), so a caller that rotates over queues reserves them BEFORE its loop with bf_block_output_device
+    // (run_observation does, for the queues it will use) -- the library does not guess and allocate all n_streams of them
+    // (8 x 128 MiB at the production geometry, six of them dead for a two-queue loop).
+    if (!h->d_out_blk[stream_idx])
+        HIP_TRY(hipMalloc((void**)&h->d_out_blk[stream_idx], per_det * sizeof(float) * (size_t)h->cfg.n_gemms_per_block));
     h->blk_ran[stream_idx] = 1;
     if (int rc = preserve_last_units(h, stream_idx, (size_t)first_unit, (size_t)first_unit + (size_t)n_units, nullptr)) return rc;
     const uint8_t* in = h->d_data + per_gemm * ((size_t)h->cfg.n_gemms_per_block * slot + first_unit);
@@ -691,10 +703,8 @@ int bf_enqueue_block_dedisperse(bf_handle* h, int stream_idx, int first_unit, in
     FLUSH_UNITS(h);
     const size_t per_det = bf_floats_per_detect(&h->cfg);
     if (h->d_ded_blk.empty()) h->d_ded_blk.assign((size_t)h->cfg.n_streams, nullptr);
-    if (!h->d_ded_blk[stream_idx])   // (all queues at once: see bf_enqueue_block)
-        for (int q = 0; q < h->cfg.n_streams; q++)
-            if (!h->d_ded_blk[q])
-                HIP_TRY(hipMalloc((void**)&h->d_ded_blk[q], (size_t)h->cfg.n_beams * sizeof(float) * (size_t)h->cfg.n_gemms_per_block));
+    if (!h->d_ded_blk[stream_idx])   // (n_gemms_per_block x n_beams floats: 32 KiB)
+        HIP_TRY(hipMalloc((void**)&h->d_ded_blk[stream_idx], (size_t)h->cfg.n_beams * sizeof(float) * (size_t)h->cfg.n_gemms_per_block));
     hipStream_t s = h->streams[stream_idx];
     float* ded = h->d_ded_blk[stream_idx] + (size_t)h->cfg.n_beams * first_unit;
     HIP_TRY(dsabf::launch_dedisperse_units(h->geom, h->d_out_blk[stream_idx] + per_det * (size_t)first_unit, per_det, n_units, ded, s));
@@ -769,7 +779,15 @@ int bf_enqueue_dedisperse(bf_handle* h, int stream_idx, float* host_out_row)
             return BF_OK;
         }
     FLUSH_UNITS(h);
-    hipStream_t s = h->streams[h->last_q[stream_idx]];
+    // d_ded[stream_idx] and the host row belong to queue stream_idx: every direct request runs THERE, in call order, behind the
+    // queue that produced (or moved) the unit's powers if that was another one -- two successive requests can then neither
+    // overwrite d_ded under a copy in flight nor land their rows out of order
+    hipStream_t s = h->streams[stream_idx];
+    const int lq = h->last_q[stream_idx];
+    if (lq != stream_idx) {
+        HIP_TRY(hipEventRecord(h->join[lq], h->streams[lq]));
+        HIP_TRY(hipStreamWaitEvent(s, h->join[lq], 0));
+    }
     float* ded = h->d_ded + (size_t)h->cfg.n_beams * stream_idx;
     HIP_TRY(dsabf::launch_dedisperse(h->geom, h->last_out[stream_idx], ded, s));
     if (host_out_row)

@@ -474,8 +474,9 @@ int run_observation(const bf_config& cfg, const observation_options& opt, block_
     if (upl <= 0 || upl > cfg.n_gemms_per_block || opt.comm) upl = cfg.n_gemms_per_block;   // 0 / sharded: the whole block
     while (cfg.n_gemms_per_block % upl) upl--;                    // whole launches only
     uint64_t launch_seq = 0;
+    const int n_queues_used = upl == cfg.n_gemms_per_block ? std::min(n_streams, 2) : n_streams;   // (the rotation below)
     if (block_launch)   // the per-queue block buffers are allocated on first use: do that here, not inside the timed loop
-        for (int q = 0; q < n_streams; q++) {
+        for (int q = 0; q < n_queues_used; q++) {
             float* unused = nullptr;
             if ((rc = bf_block_output_device(h, q, &unused)) != BF_OK) return rc;
             if (opt.comm && opt.rank == opt.gather_root && (rc = bf_block_gather_device(h, q, opt.world, &unused)) != BF_OK) return rc;
@@ -516,8 +517,7 @@ int run_observation(const bf_config& cfg, const observation_options& opt, block_
                     // whole blocks alternate between TWO queues (block i + 1's kernel under block i's copies, as in the DEBUG flow):
                     // more queues only put more concurrent host copies beside the H2D stream (9.6 -> 9.2 us per beam-block, and
                     // 11.6 -> 9.x with other streams alive in the process: tools/stream_queues.py); sub-block launches rotate over all
-                    const int n_rot = upl == n_units ? std::min(n_streams, 2) : n_streams;
-                    const int q = (int)(launch_seq++ % (uint64_t)n_rot);
+                    const int q = (int)(launch_seq++ % (uint64_t)n_queues_used);
                     for (int u = first; u < first + upl; u++) {
                         unit_dst[u] = &beam_out[(size_t)q * beam_out_stride];
                         if (opt.sink) {

@@ -80,9 +80,12 @@ typedef struct bf_config {
 typedef struct bf_handle bf_handle; /* owns device memory, 1 transfer queue + n_streams compute queues */
 typedef struct bf_event bf_event;
 
+/* Replace gpuErrchk / gpuBLASchk, src/beamformer.cuh:19-36 (print `GPUassert: <msg> <file> <line>` and exit): the message of
+ * the calling thread's most recent failure, and the library's identification string. */
 const char *bf_last_error(void);
 const char *bf_version(void);
 
+/* The reference's compile-time geometry as a value, src/beamformer.hh:45-152 (debug != 0: N_AVERAGING 1, :55-57). */
 int bf_config_default(bf_config *cfg, int debug);
 /* Derived sizes (src/beamformer.hh:117,120,144,147,137): */
 int bf_n_inputs_per_output(const bf_config *cfg);  /* N_INPUTS_PER_OUTPUT */
@@ -100,7 +103,7 @@ int bf_device_name(int device, char *buf, size_t buflen);
  * teardown :560-605.  d_B and d_C of the reference do not exist here (expand, GEMM and detect are fused). */
 int bf_create(const bf_config *cfg, int device, bf_handle **out);
 int bf_destroy(bf_handle *h);
-int bf_get_config(const bf_handle *h, bf_config *cfg);
+int bf_get_config(const bf_handle *h, bf_config *cfg); /* the geometry the handle was built for (the #defines of src/beamformer.hh:45-152) */
 
 /* Replaces the weight upload src/beamformer.cu:251,272.  `w` is a HOST array in the reference layout
  * [freq][ant][beam]{re,im} int8; the library re-lays it out once for the MFMA operand fragments.
@@ -109,7 +112,8 @@ int bf_get_config(const bf_handle *h, bf_config *cfg);
  * reference's -- the library notices (checked on the device, exactly) and runs a kernel that forms each such beam pair
  * from shared products: half the matrix-core work, identical results.  Nothing to configure. */
 int bf_set_weights(bf_handle *h, const int8_t *w);
-/* Same, from a DEVICE array (caller-owned HBM, e.g. weights computed on the GPU or a sharded slice). */
+/* Same (the cudaMemcpy of src/beamformer.cu:272 becomes a device-side read), from a DEVICE array: caller-owned HBM, e.g.
+ * weights computed on the GPU or a sharded slice. */
 int bf_set_weights_device(bf_handle *h, const int8_t *d_w, void *hip_stream);
 
 /* Replaces cudaHostAlloc/cudaFreeHost in src/test_data_generator.hh:35,40 and src/beamformer.cu:212,249,
@@ -153,11 +157,14 @@ int bf_record_transfer_event(bf_handle *h, bf_event *ev);
  * launches cannot fill the chip (0.28 of the int8 peak alone, 0.385 with 8 in flight; a block launch 0.49); same results.
  * The queued work is launched when a block's worth (n_gemms_per_block units) is queued and at every call that orders or
  * observes device work: bf_record_analysis_event (the reference calls it after each block, :525), bf_stream_sync,
- * bf_enqueue_block*, bf_enqueue_d2h, bf_queue_stream, bf_timer_stop.  Contract: a unit's results are complete when an event
- * of bf_record_analysis_event recorded after the call fires, or after bf_stream_sync -- which is all the reference's loop
- * relies on; `stream_idx` names the caller-visible queue (bf_enqueue_dedisperse refers to it), not necessarily the HIP
- * queue the coalesced launch runs on.  bf_set_switch(h, "coalesce", 0) / DSABF_COALESCE=0 at bf_create: the literal
- * pattern, one launch per call on queue stream_idx. */
+ * bf_enqueue_block*, bf_enqueue_d2h, bf_queue_stream, bf_timer_stop, bf_destroy.  Ordering contract -- the literal pattern's:
+ * once launched, a unit's kernel and host copy are ORDERED ON QUEUE stream_idx (that queue waits for the coalesced launch
+ * wherever it ran), so anything the caller puts on that queue afterwards -- bf_enqueue_d2h, a hipStreamSynchronize or an event
+ * of its own on the hipStream_t from bf_queue_stream, RCCL chained on it -- sees the unit complete; and a unit's results are
+ * complete when an event of bf_record_analysis_event recorded after the call fires, or after bf_stream_sync.  What is NOT the
+ * literal pattern: a hipStream_t obtained earlier says nothing about units that are still only queued (nothing has been
+ * launched for them yet) -- one of the calls above launches them.  DSABF_COALESCE=0 at bf_create (or the "coalesce" switch of
+ * dsabf_bench.h): the literal pattern itself, one launch per call on queue stream_idx. */
 int bf_enqueue_gemm_unit(bf_handle *h, int stream_idx, int slot, int time_slice, float *host_out);
 
 /* Block-granular form of the same: ONE kernel launch over the n_units consecutive gemm-units [first_unit, first_unit +
@@ -171,7 +178,7 @@ int bf_enqueue_block(bf_handle *h, int stream_idx, int slot, int first_unit, int
 /* Replaces K5, the DEBUG dedisperse, src/beamformer.cu:498-510: sums output 0 of the unit last enqueued on
  * `stream_idx` over frequency (ascending f, fp32) and copies the n_beams floats to host_out_row. */
 int bf_enqueue_dedisperse(bf_handle *h, int stream_idx, float *host_out_row);
-/* The same K5 for the gemm-units [first_unit, first_unit + n_units) of the block bf_enqueue_block last put on
+/* The same K5 (src/beamformer.cu:498-510) for the gemm-units [first_unit, first_unit + n_units) of the block bf_enqueue_block last put on
  * `stream_idx`, in ONE launch (units x beams threads; every beam's sum still runs over ascending f in one thread, so the
  * bits are those of n_units bf_enqueue_dedisperse calls).  host_rows, if not NULL, receives [n_units][n_beams] floats. */
 int bf_enqueue_block_dedisperse(bf_handle *h, int stream_idx, int first_unit, int n_units, float *host_rows);
@@ -192,7 +199,8 @@ int bf_timer_stop(bf_handle *h, float *ms);
 /* ---- Device-pointer entry points: operands already resident in HBM (caller-owned memory and queue). ----
  * These are what bench.py and the multi-GPU path call; `hip_stream` is a hipStream_t (NULL = default). */
 
-/* Fused a1+a2+a3 over n_units gemm-units: d_packed [n_units][freq][time][ant] -> d_out
+/* K1-K3 of src/beamformer.cu:464-481 (expand_input, cublasGemmStridedBatchedEx, detect_sum) without the copies around them.
+ * Fused a1+a2+a3 over n_units gemm-units: d_packed [n_units][freq][time][ant] -> d_out
  * [n_units][output][freq][beam].  One kernel launch.  Both pointers must be 16-byte aligned (16-byte loads; groups of
  * four beams are stored with one 16-byte store).  Like every entry point, the call leaves the caller's current HIP
  * device as it found it. */
@@ -206,11 +214,12 @@ int bf_expand_device(bf_handle *h, const void *d_in, size_t nbytes, void *d_out,
  * packed voltages -> complex float32 [freq][time][beam]{re,im} = (1/127) * W * V. */
 int bf_gemm_device(bf_handle *h, const void *d_packed_unit, float *d_c, void *hip_stream);
 
-/* a8 alone: d_out_unit [output][freq][beam] -> d_ded [beam] = sum over freq of output 0. */
+/* a8 alone (the cublasSgemv of src/beamformer.cu:498-504): d_out_unit [output][freq][beam] -> d_ded [beam] = sum over freq
+ * of output 0. */
 int bf_dedisperse_device(bf_handle *h, const float *d_out_unit, float *d_ded, void *hip_stream);
 
-/* Incoherent dedispersion beyond DM 0 (the reference stops at the DM-0 sum above and sketches
- * the delay law in sandbox/Dispersion Theory.ipynb).  d_series: n_t consecutive beam-blocks [t][freq][beam] (the
+/* Incoherent dedispersion beyond DM 0 (the reference stops at the DM-0 sum above,
+ * src/beamformer.cu:498-504, and sketches the delay law in sandbox/Dispersion Theory.ipynb).  d_series: n_t consecutive beam-blocks [t][freq][beam] (the
  * detected stream is exactly that); d_delays: int32 [n_dm][freq] sample delays (dsabf::dm_delays / bfh_dm_delays);
  * d_out [n_dm][n_t_out][beam] = sum over freq, ascending, fp32, of d_series[t + delay][freq][beam]; rows outside [0, n_t)
  * contribute nothing, so size n_t_out = n_t - (largest delay) for complete sums.  Groups of 32 consecutive trials whose
@@ -251,7 +260,7 @@ int bf_comm_create(int rank, int world, const void *id128, int device, bf_comm *
 int bf_comm_destroy(bf_comm *c);
 int bf_comm_rank(const bf_comm *c);
 int bf_comm_world(const bf_comm *c);
-/* Evidence for a scaling record: how many ranks the LIBRARY reports for the communicator (ncclCommCount; 0 = this bf_comm
+/* Evidence for a scaling record (the reference's 8 processes never meet, src/beamformer.cu:92-100): how many ranks the LIBRARY reports for the communicator (ncclCommCount; 0 = this bf_comm
  * has no RCCL communicator, -1 = the library cannot say), its version (ncclGetVersion, e.g. 22203; 0 = unknown) and the
  * file the point-to-point calls were resolved from.  Any pointer may be NULL. */
 int bf_comm_info(const bf_comm *c, int *lib_ranks, int *version, char *lib_path, size_t n);
@@ -268,8 +277,9 @@ int bf_gather_detected(bf_comm *c, const float *d_local, size_t n_rows, size_t r
  * of the fabric and the message count (bench.py times both: gather_modes.*_freq_major[_staged]). */
 int bf_gather_detected_staged(bf_comm *c, const float *d_local, size_t n_rows, size_t row_floats, int root, float *d_full,
                               float *d_stage, void *hip_stream);
-/* The layout arithmetic as plain host functions (no device, no RCCL): float offset of (rank, row) in the gathered array,
- * and the list of messages one rank issues (kind: send to peer, receive from peer, or copy its own rows). */
+/* The layout arithmetic as plain host functions (no device, no RCCL): float offset of (rank, row) in the gathered array --
+ * [o][f][b] of src/beamformer.cuh:147 with f running over the shards -- and the list of messages one rank issues (kind: send
+ * to peer, receive from peer, or copy its own rows). */
 size_t bf_gather_offset(int layout, size_t n_rows_held, size_t row_floats, int world, int rank, size_t row);
 size_t bf_gather_rows_held(size_t n_rows, int world, int rank, int root); /* rows `rank` ends up holding (0: it only sends) */
 #define BF_GATHER_SEND 0
@@ -284,51 +294,24 @@ typedef struct bf_gather_msg {
 size_t bf_gather_plan(int layout, size_t n_rows, size_t row_floats, int world, int rank, int root, bf_gather_msg *msgs,
                       size_t capacity); /* returns the number of messages (call with capacity 0 to size the array) */
 
-/* Device pointer of the per-queue block buffer bf_enqueue_block fills ([n_gemms_per_block][output][freq][beam]) and the
- * hipStream_t of compute queue `stream_idx`: what a caller needs to chain bf_gather_detected behind a block launch. */
+/* Device pointer of the per-queue block buffer bf_enqueue_block fills ([n_gemms_per_block][output][freq][beam]: the
+ * reference's d_dedispersed per stream, src/beamformer.cu:258,481) and the hipStream_t of compute queue `stream_idx`
+ * (stream[i], src/beamformer.cu:305-312): what a caller needs to chain bf_gather_detected behind a block launch. */
 int bf_block_output_device(bf_handle *h, int stream_idx, float **d_out);
 int bf_queue_stream(bf_handle *h, int stream_idx, void **hip_stream);
-/* A handle-owned device buffer for the gathered block of compute queue `stream_idx`: n_gemms_per_block * world *
+/* A handle-owned device buffer (allocated like src/beamformer.cu:249-266 allocates the per-stream ones) for the gathered block of compute queue `stream_idx`: n_gemms_per_block * world *
  * bf_floats_per_detect floats ([unit][output][world * n_freq][beam] with the freq-major layout); allocated on first use. */
 int bf_block_gather_device(bf_handle *h, int stream_idx, int world, float **d_full);
-/* Asynchronous device-to-host copy of n_floats on compute queue `stream_idx` (behind whatever was enqueued there). */
+/* Asynchronous device-to-host copy of n_floats on compute queue `stream_idx` (the cudaMemcpyAsync of src/beamformer.cu:485-488
+ * for a caller-chosen source): behind everything enqueued on that queue before the call, gemm-units included. */
 int bf_enqueue_d2h(bf_handle *h, int stream_idx, const float *d_src, float *host_dst, size_t n_floats);
 
-/* The two dedispersion entry points above on a gathered band: the same kernels over n_freq_total = world * n_freq
+/* The two dedispersion entry points above (src/beamformer.cu:498-504) on a gathered band: the same kernels over n_freq_total = world * n_freq
  * channels of a [row][n_freq_total][beam] array (BF_GATHER_LAYOUT_FREQ_MAJOR on the receiving rank) -- ascending f over the
  * WHOLE band, i.e. the bits one GPU holding all channels would produce. */
 int bf_dedisperse_band_device(bf_handle *h, const float *d_out_unit, int n_freq_total, float *d_ded, void *hip_stream);
 int bf_dedisperse_dm_band_device(bf_handle *h, const float *d_series, int n_t, int n_freq_total, const int32_t *d_delays,
                                  int n_dm, int n_t_out, float *d_out, void *hip_stream);
-
-/* The matrix pipe by itself, for roofline reports ("a back-to-back v_mfma micro-benchmark; report utilisation
- * against both nominal and measured peak"): one launch of `iters` x 16 independent v_mfma_i32_16x16x64_i8 per wave, 4 waves per
- * SIMD, nothing else in the loop.  Operands are read from the caller's buffer (>= 3 MiB; A = bytes & 0xF0 as the fused kernel
- * sees voltages, B = bytes as it sees weights): the clock the chip holds depends on the operand bits.  d_scratch: >= 4 MiB.
- * *ops = int8 ops the launch executes; the caller times it (HIP events on hip_stream). */
-int bf_mfma_peak_device(bf_handle *h, const void *d_operands, size_t operand_bytes, void *d_scratch, size_t scratch_bytes,
-                        int iters, double *ops, void *hip_stream);
-
-/* Introspection for benchmarks/roofline reports. */
-int bf_kernel_info(const bf_handle *h, int n_units, int *grid, int *block, int *lds_bytes, int *vgprs);
-/* Measurement / test switches of ONE handle (A/B runs inside one process).  They select among launches and kernels that
- * produce the same bits; none of them is needed in production.  The environment variables of the same meaning are read ONCE,
- * at bf_create (DSABF_TSPLIT, DSABF_LDS_PAD, DSABF_DM_WIDE) -- never in a launch path.
- *   "tsplit"   n >= 0   time splits per frequency of the fused launch (0: the library decides)
- *   "lds_pad"  bytes    extra dynamic LDS per workgroup (fewer resident workgroups per CU); clamped to what a CU has
- *   "dm_wide"  0 / 1    0: bf_dedisperse_dm*_device runs the per-thread-window kernel alone
- *   "paired"   0 / 1    0: the next bf_set_weights selects the general kernel even for conjugate-symmetric weights
- *   "coalesce" 0 / 1    0: bf_enqueue_gemm_unit launches one kernel per call (the reference's literal launch pattern) */
-int bf_set_switch(bf_handle *h, const char *name, int value);
-/* Counters of one handle: "fused_launches" = fused-kernel launches issued so far (what coalescing saves),
- * "queued_units" = gemm-units bf_enqueue_gemm_unit has queued and not launched yet. */
-int bf_get_counter(const bf_handle *h, const char *name, uint64_t *value);
-int bf_kernel_name(const bf_handle *h, char *buf, size_t buflen); /* which fused kernel this geometry runs */
-/* The same answers WITHOUT a handle or a device: which kernel and launch shape a configuration would run for n_units gemm-units
- * on a chip of n_cus compute units (MI355X: 256); paired != 0: as for a conjugate-symmetric weight set (honoured where a
- * conjugate-pair kernel exists).  Pure host arithmetic -- for planning, and so that the launch logic is testable anywhere. */
-int bf_launch_plan(const bf_config *cfg, int paired, int n_units, int n_cus, int *grid, int *block, int *lds_bytes, char *name,
-                   size_t name_len);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,49 @@
+/* dsabf_bench.h -- measurement and test instrumentation of libdsabf.so.  NOT part of the drop-in boundary.
+ *
+ * include/dsabf.h is what a maintainer of the reference binds: one entry point per cluster of CUDA / cuBLAS calls, each citing
+ * the call sites it replaces.  Everything here exists for benchmarks, roofline reports, A/B runs and tests: switches that pick
+ * among launches producing the same bits, counters, launch-shape introspection, the matrix pipe's micro-benchmark.  Nothing
+ * in this header is needed to run an observation, and none of it has a counterpart in the reference.
+ * (bench.py, tools/ and tests/ use it through dsabeamformer_amd/_lib.py.) */
+#ifndef DSABF_BENCH_H
+#define DSABF_BENCH_H
+
+#include "dsabf.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* The matrix pipe by itself, for roofline reports ("a back-to-back v_mfma micro-benchmark; report utilisation
+ * against both nominal and measured peak"): one launch of `iters` x 16 independent v_mfma_i32_16x16x64_i8 per wave, 4 waves per
+ * SIMD, nothing else in the loop.  Operands are read from the caller's buffer (>= 3 MiB; A = bytes & 0xF0 as the fused kernel
+ * sees voltages, B = bytes as it sees weights): the clock the chip holds depends on the operand bits.  d_scratch: >= 4 MiB.
+ * *ops = int8 ops the launch executes; the caller times it (HIP events on hip_stream). */
+int bf_mfma_peak_device(bf_handle *h, const void *d_operands, size_t operand_bytes, void *d_scratch, size_t scratch_bytes,
+                        int iters, double *ops, void *hip_stream);
+
+/* Introspection for benchmarks/roofline reports. */
+int bf_kernel_info(const bf_handle *h, int n_units, int *grid, int *block, int *lds_bytes, int *vgprs);
+/* Measurement / test switches of ONE handle (A/B runs inside one process).  They select among launches and kernels that
+ * produce the same bits; none of them is needed in production.  The environment variables of the same meaning are read ONCE,
+ * at bf_create (DSABF_TSPLIT, DSABF_LDS_PAD, DSABF_DM_WIDE) -- never in a launch path.
+ *   "tsplit"   n >= 0   time splits per frequency of the fused launch (0: the library decides)
+ *   "lds_pad"  bytes    extra dynamic LDS per workgroup (fewer resident workgroups per CU); clamped to what a CU has
+ *   "dm_wide"  0 / 1    0: bf_dedisperse_dm*_device runs the per-thread-window kernel alone
+ *   "paired"   0 / 1    0: the next bf_set_weights selects the general kernel even for conjugate-symmetric weights
+ *   "coalesce" 0 / 1    0: bf_enqueue_gemm_unit launches one kernel per call (the reference's literal launch pattern) */
+int bf_set_switch(bf_handle *h, const char *name, int value);
+/* Counters of one handle: "fused_launches" = fused-kernel launches issued so far (what coalescing saves),
+ * "queued_units" = gemm-units bf_enqueue_gemm_unit has queued and not launched yet. */
+int bf_get_counter(const bf_handle *h, const char *name, uint64_t *value);
+int bf_kernel_name(const bf_handle *h, char *buf, size_t buflen); /* which fused kernel this geometry runs */
+/* The same answers WITHOUT a handle or a device: which kernel and launch shape a configuration would run for n_units gemm-units
+ * on a chip of n_cus compute units (MI355X: 256); paired != 0: as for a conjugate-symmetric weight set (honoured where a
+ * conjugate-pair kernel exists).  Pure host arithmetic -- for planning, and so that the launch logic is testable anywhere. */
+int bf_launch_plan(const bf_config *cfg, int paired, int n_units, int n_cus, int *grid, int *block, int *lds_bytes, char *name,
+                   size_t name_len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DSABF_BENCH_H */

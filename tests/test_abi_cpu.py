@@ -18,13 +18,48 @@ def lib():
     return _lib.load()
 
 
-def _declared_symbols():
+HEADERS = ("dsabf.h", "dsabf_bench.h", "dsabf_host.h")
+
+
+def _declared_symbols(headers=HEADERS):
     names = set()
-    for hdr in ("dsabf.h", "dsabf_host.h"):
+    for hdr in headers:
         text = open(os.path.join(ROOT, "include", hdr)).read()
         text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
         names |= set(re.findall(r"\b(bfh?_[a-z0-9_]+)\s*\(", text))
     return sorted(names)
+
+
+CITATION = re.compile(r"(src/[\w.]+|README\.md|makefile|config/[\w.]+):\d+")
+
+
+def test_every_export_of_the_boundary_header_cites_the_reference_call_site_it_replaces():
+    """include/dsabf.h is the drop-in boundary and nothing else -- every function it declares must say,
+    in the comment block in front of it (shared by the declarations that follow one comment) or in a comment on its own line,
+    which lines of the reference it replaces (file:line).  The measurement knobs live in include/dsabf_bench.h, which includes
+    the boundary header, cites nothing and is named by no call-site map."""
+    text = open(os.path.join(ROOT, "include", "dsabf.h")).read()
+    pieces = re.split(r"(/\*.*?\*/)", text, flags=re.S)       # comment, code, comment, code, ...
+    last_comment, checked, prev_code = "", [], "\n"
+    for piece in pieces:
+        if piece.startswith("/*"):
+            if prev_code.rsplit("\n", 1)[-1].strip() == "":      # a block of its own (not trailing a declaration on its line)
+                last_comment = piece
+            continue
+        prev_code = piece
+        for m in re.finditer(r"\b(bf_[a-z0-9_]+)\s*\([^;{]*\)\s*;", piece, flags=re.S):
+            checked.append(m.group(1))
+            # the comment in front of this run of declarations; a trailing comment belongs to the declaration before it
+            tail = text[text.index(m.group(0)) + len(m.group(0)):].split("\n", 1)[0]
+            assert CITATION.search(last_comment) or CITATION.search(tail), \
+                "%s: neither the comment in front of it nor one on its line cites a reference call site" % m.group(1)
+    assert sorted(set(checked)) == _declared_symbols(("dsabf.h",)) and len(checked) >= 45
+    bench_only = set(_declared_symbols(("dsabf_bench.h",))) - set(_declared_symbols(("dsabf.h",)))
+    assert bench_only == {"bf_set_switch", "bf_get_counter", "bf_mfma_peak_device", "bf_launch_plan", "bf_kernel_info", "bf_kernel_name"}
+    assert not bench_only & set(checked)
+    integ = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    for name in bench_only:                                   # the call-site map binds the boundary, not the lab bench
+        assert name not in integ.split("## 2")[0] or "dsabf_bench.h" in integ, name
 
 
 def test_library_exports_every_declared_symbol(lib):
@@ -108,6 +143,9 @@ def test_headers_and_example_compile_as_plain_c(tmp_path):
 
     from conftest import ROOT
 
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I" + os.path.join(ROOT, "include"), "-x", "c",
+                        "-fsyntax-only", os.path.join(ROOT, "include", "dsabf_bench.h")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
     for name in ("minimal", "sharded"):     # single GPU; one rank of a frequency-sharded run (bf_comm_*, bf_gather_detected)
         obj = tmp_path / (name + ".o")
         r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I" + os.path.join(ROOT, "include"),

@@ -288,9 +288,14 @@ def test_bench_exits_nonzero_when_the_communicator_cannot_be_created():
                         "127.0.0.1", "--master-port", port, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
                         "--warmup", "1", "--units", "4", "--dist-backend", "gloo", "--min-warm-seconds", "0.1",
                         "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env)
+    import json
+
     assert r.returncode != 0
-    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]           # no line at all
-    assert "could not be loaded" in (r.stdout + r.stderr)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                   # round 5: the failure is a LINE -- with no headline in it
+    d = json.loads(lines[0])
+    assert d["value"] is None and "could not be loaded" in d["gather_error"] and d["stage"].startswith("RCCL communicator")
+    assert d["gather_modes"]["none"]["value"] > 0 and set(d["gather_modes"]) == {"none"}      # kernel-only: measured before RCCL
 
 
 @pytest.mark.parametrize("world", [1, 2, 4])
