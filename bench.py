@@ -1210,12 +1210,26 @@ def main():
                 out_b = chunks * pc.n_freq * pc.n_beams * 4
                 st[label] = {"ms_per_beam_block": r["ms"] / chunks, "input_gbs": in_b / (r["ms"] * 1e-3) / 1e9,
                              "output_gbs": out_b / (r["ms"] * 1e-3) / 1e9, "observation_ms": r["ms"], "blocks": n_blk}
+            # ... and with the DM stage in the loop: 64 trials of the notebook's ladder to DM 250 on every
+            # analysed block, the delay window carried over on the device, chunks [dm][t][b] copied to pinned host buffers
+            freq = [host.channel_frequency(0, c) for c in range(pc.n_freq)]
+            ladder = host.dm_trials(dm_max=250.0)
+            dms = ladder[:: max(1, len(ladder) // 64)][:64]
+            delays = host.dm_delays(dms, freq, freq[0], 0.131)
+            host.run_observation_junk_dm(pc, 8, delays, None, ring_blocks=4, device=local, burn_in=2)
+            r = host.run_observation_junk_dm(pc, n_blk, delays, None, ring_blocks=4, device=local, burn_in=4)
+            chunks = n_blk * pc.n_gemms_per_block * pc.n_out_per_gemm
+            st["block_launches_dm_stage"] = {"ms_per_beam_block": r["ms"] / chunks, "observation_ms": r["ms"], "blocks": n_blk,
+                                             "dm_trials": len(dms), "max_delay_rows": int(delays.max()), "dm_output_times": r["dm_times"],
+                                             "dm_output_gbs": r["dm_times"] * len(dms) * pc.n_beams * 4 / (r["ms"] * 1e-3) / 1e9}
             st["note"] = ("run_observation, production geometry (N_AVERAGING 16, 128 MiB blocks), in-memory junk source, "
                           "pinned host buffers: H2D of every block and D2H of every gemm-unit's detected powers included -- the "
                           "reference's 'Time per data chunk'; never the headline.  block_launches: the caller uses bf_enqueue_block; "
                           "reference_unit_launches: the caller keeps the reference's loop (one bf_enqueue_gemm_unit per gemm-unit "
                           "round-robin over 8 queues, src/beamformer.cu:454-519) and the library coalesces it into one launch per "
-                          "block; ..._literal: the same loop with DSABF_COALESCE=0, one launch per call.  Real-time budget: 0.131 ms per beam-block.  "
+                          "block; ..._literal: the same loop with DSABF_COALESCE=0, one launch per call; block_launches_dm_stage: block_launches + the "
+                          "DM-trial stage inside the loop (bf_dm_stream_push behind every block launch, 64 trials, window carried over on "
+                          "the device; bit-exact vs the oracle over the whole series in tests/test_gpu_round5.py).  Real-time budget: 0.131 ms per beam-block.  "
                           "PCIe-bound either way; interleaved sweep over the launch granularities: profiles/r02_streaming.txt (round 2)")
             out["streaming"] = st
 

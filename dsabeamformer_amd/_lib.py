@@ -89,6 +89,11 @@ SIGNATURES = {
     "bf_dedisperse_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bf_dedisperse_dm_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
                                           C.c_void_p]),
+    "bf_dm_stream_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "bf_dm_stream_destroy": (C.c_int, [C.c_void_p]),
+    "bf_dm_stream_max_delay": (C.c_int, [C.c_void_p]),
+    "bf_dm_stream_push": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_int), C.c_void_p]),
+    "bf_dm_stream_output_device": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "bf_comm_unique_id": (C.c_int, [C.c_void_p]),
     "bf_comm_create": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
     "bf_comm_destroy": (C.c_int, [C.c_void_p]),
@@ -104,6 +109,7 @@ SIGNATURES = {
     "bf_block_output_device": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
     "bf_queue_stream": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
     "bf_block_gather_device": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "bf_block_gather_stage_device": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "bf_enqueue_d2h": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]),
     "bf_dedisperse_band_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "bf_dedisperse_dm_band_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
@@ -163,6 +169,9 @@ SIGNATURES = {
     "bfh_run_observation_junk_to_file": (C.c_int, [C.POINTER(BfConfig), C.c_uint64, C.c_int, C.c_uint64, C.c_int, C.c_int,
                                                    C.c_int, C.c_int, C.c_char_p, C.POINTER(C.c_float),
                                                    C.POINTER(C.c_uint64), C.c_void_p]),
+    "bfh_run_observation_junk_dm": (C.c_int, [C.POINTER(BfConfig), C.c_uint64, C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int,
+                                              C.c_void_p, C.c_int, C.c_char_p, C.c_char_p, C.POINTER(C.c_float),
+                                              C.POINTER(C.c_uint64), C.c_void_p]),
     "bfh_run_observation_junk_to_ring": (C.c_int, [C.POINTER(BfConfig), C.c_uint64, C.c_int, C.c_uint64, C.c_int, C.c_int,
                                                    C.c_char_p, C.c_uint64, C.POINTER(C.c_float), C.POINTER(C.c_uint64),
                                                    C.c_void_p]),
@@ -183,6 +192,9 @@ SIGNATURES = {
     "bfh_shm_ring_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_char_p, C.c_size_t]),
     "bfh_shm_ring_write": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64]),
     "bfh_shm_ring_read": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "bfh_run_observation_shm_dm": (C.c_int, [C.POINTER(BfConfig), C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_void_p,
+                                             C.c_int, C.c_char_p, C.POINTER(C.c_float), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
+                                             C.POINTER(C.c_int)]),
     "bfh_run_observation_shm": (C.c_int, [C.POINTER(BfConfig), C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p,
                                           C.POINTER(C.c_float), C.POINTER(C.c_uint64), C.POINTER(C.c_int)]),
     "bfh_run_debug_observation": (C.c_int, [C.POINTER(BfConfig), C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p,

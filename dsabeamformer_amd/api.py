@@ -206,6 +206,47 @@ class Beamformer:
         self.close()
 
 
+class DmStream:
+    """bf_dm_stream: DM-trial dedispersion of the detected stream, block by block, with the delay window carried over on the
+    device (include/dsabf.h).  delays: int32 host array [n_dm][n_freq_total]."""
+
+    def __init__(self, bf: Beamformer, delays, n_freq_total: int, max_rows_per_push: int):
+        import numpy as np
+
+        self._lib = load()
+        self._s = C.c_void_p()
+        d = np.ascontiguousarray(delays, np.int32)
+        assert d.ndim == 2 and d.shape[1] == n_freq_total
+        self.n_dm, self.n_beams, self._bf = d.shape[0], bf.cfg.n_beams, bf
+        check(self._lib.bf_dm_stream_create(bf._h, _ptr(d), d.shape[0], n_freq_total, max_rows_per_push, C.byref(self._s)))
+
+    @property
+    def max_delay(self) -> int:
+        return self._lib.bf_dm_stream_max_delay(self._s)
+
+    def push(self, d_rows, n_rows: int, host_out=None, stream: int = 0):
+        """Returns (first_t, n_t_out) of the chunk this push emits ([n_dm][n_t_out][beam] into host_out, asynchronously)."""
+        first, n = C.c_uint64(), C.c_int()
+        check(self._lib.bf_dm_stream_push(self._s, _ptr(d_rows), n_rows, _ptr(host_out), C.byref(first), C.byref(n), C.c_void_p(stream)))
+        return int(first.value), int(n.value)
+
+    def output_device(self) -> int:
+        p = C.c_void_p()
+        check(self._lib.bf_dm_stream_output_device(self._s, C.byref(p)))
+        return p.value or 0
+
+    def close(self) -> None:
+        if self._s:
+            self._lib.bf_dm_stream_destroy(self._s)
+            self._s = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 # events / pinned memory as free functions (they are not tied to a handle in the C-ABI)
 GATHER_FREQ_MAJOR, GATHER_RANK_MAJOR = 0, 1
 GATHER_ROOT_ALL, GATHER_ROOT_DISTRIBUTED = -1, -2

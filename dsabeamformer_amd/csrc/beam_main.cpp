@@ -12,6 +12,13 @@
 //                                                   unique id there, the others wait for it.  beam_replicas -S starts
 //                                                   the `world` processes.  (The reference's own scaling -- 8 independent
 //                                                   sub-bands selected by -g, README.md:168 -- is beam_replicas without -S.)
+//   beam -j n_blocks -M dm_max [-N n_dm] [-T tsamp_ms] [-W dm_file]
+//                                                   the DM stage, where the reference's loop has its DM-0
+//                                                   collapse (src/beamformer.cu:492-511): the ladder of sandbox/Dispersion
+//                                                   Theory.ipynb from 0 to dm_max (at most n_dm of its trials, evenly picked),
+//                                                   every analysed block through a bf_dm_stream with the delay window carried
+//                                                   over on the device, chunks [dm][t][beam] to dm_file.  With -R: on the
+//                                                   gather root, over the gathered band.
 //
 // With the reference's `make debug` geometry (default) it generates synthetic point-source voltages on the CPU,
 // streams them through the observation loop and writes bin/data.py (dedispersed beam responses, one row per source)
@@ -46,9 +53,12 @@ int main(int argc, char* argv[])
     long junk_blocks = -1;
     int world = 1, rank = 0;
     std::string id_file;
+    double dm_max = 0.0, tsamp_ms = 0.131;   // (the notebook's sample time, cell 5)
+    int n_dm_cap = 0;
+    std::string dm_path;
 
     int arg = 0;
-    while ((arg = getopt(argc, argv, "s:g:p:d:o:D:a:c:k:K:j:w:R:r:I:uvh")) != -1) {  // src/beamformer.cu:41-43 (+ -o -D -a -v)
+    while ((arg = getopt(argc, argv, "s:g:p:d:o:D:a:c:k:K:j:w:R:r:I:M:N:T:W:uvh")) != -1) {  // src/beamformer.cu:41-43 (+ -o -D -a -v)
         switch (arg) {
             case 's': sources = optarg; break;                 // :77-89
             case 'g': opt.gpu = atoi(optarg); break;           // :92-100
@@ -63,6 +73,10 @@ int main(int argc, char* argv[])
             case 'R': world = atoi(optarg); break;
             case 'r': rank = atoi(optarg); break;
             case 'I': id_file = optarg; break;
+            case 'M': dm_max = atof(optarg); break;
+            case 'N': n_dm_cap = atoi(optarg); break;
+            case 'T': tsamp_ms = atof(optarg); break;
+            case 'W': dm_path = optarg; break;
             case 'u': per_unit = true; break;                   // the reference's launch pattern: one launch per gemm-unit
             case 'v': opt.verbose = true; cfg.verbose = 1; break;
             case 'c': core = atoi(optarg); break;              // :59-65
@@ -204,9 +218,42 @@ int main(int argc, char* argv[])
             }
         }
         oopt.sink = sink.get();
+        // -M: the DM stage.  Ladder and delay law of sandbox/Dispersion Theory.ipynb (cells 1-2 and 5) over the WHOLE sub-band this
+        // run covers (world x n_freq channels), referred to its highest frequency (channel 0): every delay is >= 0.
+        std::vector<int32_t> delays;
+        std::unique_ptr<dm_file_sink> dm_sink;
+        int n_dm = 0;
+        if (dm_max > 0.0) {
+            std::vector<double> dms = dm_trials(0.0, dm_max);
+            if (n_dm_cap > 0 && (int)dms.size() > n_dm_cap) {
+                std::vector<double> pick;
+                for (int i = 0; i < n_dm_cap; i++) pick.push_back(dms[(size_t)((double)i * (dms.size() - 1) / (n_dm_cap > 1 ? n_dm_cap - 1 : 1))]);
+                dms.swap(pick);
+            }
+            n_dm = (int)dms.size();
+            std::vector<float> freq((size_t)full_cfg.n_freq);
+            for (int c = 0; c < full_cfg.n_freq; c++) freq[(size_t)c] = channel_frequency_weights(opt.gpu, c);
+            delays.resize((size_t)n_dm * full_cfg.n_freq);
+            dm_delays(dms.data(), n_dm, freq.data(), full_cfg.n_freq, freq[0], tsamp_ms, delays.data());
+            int dmax = 0;
+            for (int32_t d : delays) dmax = d > dmax ? d : dmax;
+            std::cout << "DM stage: " << n_dm << " trials 0 .. " << dms.back() << " pc/cc, largest delay " << dmax << " samples of "
+                      << tsamp_ms << " ms" << std::endl;
+            oopt.dm_delays = delays.data();
+            oopt.n_dm = n_dm;
+            if (!dm_path.empty() && (!comm || rank == 0)) {
+                dm_sink.reset(new dm_file_sink(pcfg, full_cfg.n_freq, n_dm, dmax, dm_path.c_str(), opt.gpu));
+                if (!dm_sink->is_open()) {
+                    fprintf(stderr, "beam: could not open %s\n", dm_path.c_str());
+                    return EXIT_FAILURE;
+                }
+                oopt.dm_sink = dm_sink.get();
+            }
+        }
         observation_result ores;
         int orc = run_observation(pcfg, oopt, *src, pos.data(), dir.data(), &ores, std::cout);
         if (sink) std::cout << "Wrote " << sink->get_delivered() << " gemm-units of detected powers to " << sink_name << std::endl;
+        if (dm_sink) std::cout << "Wrote " << dm_sink->get_times_written() << " dedispersed samples x " << n_dm << " trials to " << dm_path << std::endl;
         bf_comm_destroy(comm);
         if (orc != BF_OK) {
             fprintf(stderr, "GPUassert: %s (%d)\n", bf_last_error(), orc);

@@ -290,7 +290,8 @@ int bfh_run_debug_observation2(const bf_config* cfg, int gpu, const char* positi
 }
 
 static int run_junk(const bf_config* cfg, uint64_t n_blocks, int ring_blocks, uint64_t seed, int gpu, int device,
-                    int burn_in, int verbose, detected_sink* sink, observation_result* res, void* ring_copy)
+                    int burn_in, int verbose, detected_sink* sink, observation_result* res, void* ring_copy,
+                    const int32_t* dm_delays = nullptr, int n_dm = 0, dm_chunk_sink* dm_sink = nullptr)
 {
     junk_block_source src(*cfg, n_blocks, ring_blocks, seed);
     if (!src.ok()) return BF_ERR_DEVICE;
@@ -304,6 +305,9 @@ static int run_junk(const bf_config* cfg, uint64_t n_blocks, int ring_blocks, ui
     opt.burn_in = burn_in;
     opt.verbose = verbose != 0;
     opt.sink = sink;
+    opt.dm_delays = dm_delays;
+    opt.n_dm = n_dm;
+    opt.dm_sink = dm_sink;
     std::ostringstream quiet;
     std::streambuf* keep = std::cout.rdbuf();
     if (!verbose) std::cout.rdbuf(quiet.rdbuf());  // "obs Complete" etc.
@@ -339,6 +343,31 @@ int bfh_run_observation_junk_to_file(const bf_config* cfg, uint64_t n_blocks, in
     if (rc != BF_OK) return rc;
     if (observation_ms) *observation_ms = res.observation_time_ms;
     if (gemms_written) *gemms_written = sink.get_delivered();
+    return BF_OK;
+}
+
+int bfh_run_observation_junk_dm(const bf_config* cfg, uint64_t n_blocks, int ring_blocks, uint64_t seed, int gpu, int device,
+                                int burn_in, int verbose, const int32_t* delays, int n_dm, const char* dm_path,
+                                const char* detected_path, float* observation_ms, uint64_t* dm_times, void* ring_copy)
+{
+    if (!cfg || !delays || n_dm <= 0) return BF_ERR_INVALID;
+    int dmax = 0;
+    for (size_t i = 0; i < (size_t)n_dm * cfg->n_freq; i++) dmax = delays[i] > dmax ? delays[i] : dmax;
+    std::unique_ptr<dm_file_sink> dms;
+    if (dm_path) {
+        dms.reset(new dm_file_sink(*cfg, cfg->n_freq, n_dm, dmax, dm_path, gpu));
+        if (!dms->is_open()) return BF_ERR_INVALID;
+    }
+    std::unique_ptr<file_sink> fs;
+    if (detected_path) {
+        fs.reset(new file_sink(*cfg, detected_path, gpu));
+        if (!fs->ok() || !fs->is_open()) return BF_ERR_INVALID;
+    }
+    observation_result res;
+    int rc = run_junk(cfg, n_blocks, ring_blocks, seed, gpu, device, burn_in, verbose, fs.get(), &res, ring_copy, delays, n_dm, dms.get());
+    if (rc != BF_OK) return rc;
+    if (observation_ms) *observation_ms = res.observation_time_ms;
+    if (dm_times) *dm_times = res.dm_times;
     return BF_OK;
 }
 
@@ -432,7 +461,22 @@ int bfh_shm_ring_read(bfh_shm_ring* r, void* out, uint64_t cap, uint64_t* bytes,
 int bfh_run_observation_shm(const bf_config* cfg, const char* name, int core, int gpu, int device, int verbose,
                             const char* path, float* observation_ms, uint64_t* gemms_written, int* pinned)
 {
+    return bfh_run_observation_shm_dm(cfg, name, core, gpu, device, verbose, path, nullptr, 0, nullptr, observation_ms, gemms_written,
+                                      nullptr, pinned);
+}
+
+int bfh_run_observation_shm_dm(const bf_config* cfg, const char* name, int core, int gpu, int device, int verbose, const char* path,
+                               const int32_t* delays, int n_dm, const char* dm_path, float* observation_ms, uint64_t* gemms_written,
+                               uint64_t* dm_times, int* pinned)
+{
     if (!cfg || !name) return BF_ERR_INVALID;
+    std::unique_ptr<dm_file_sink> dms;
+    if (delays && dm_path) {
+        int dmax = 0;
+        for (size_t i = 0; i < (size_t)n_dm * cfg->n_freq; i++) dmax = delays[i] > dmax ? delays[i] : dmax;
+        dms.reset(new dm_file_sink(*cfg, cfg->n_freq, n_dm, dmax, dm_path, gpu));
+        if (!dms->is_open()) return BF_ERR_INVALID;
+    }
     std::ostringstream quiet;
     std::ostream& log = verbose ? static_cast<std::ostream&>(std::cout) : quiet;
     shm_block_source src(name, core, /*pin=*/true, log);
@@ -453,12 +497,16 @@ int bfh_run_observation_shm(const bf_config* cfg, const char* name, int core, in
     opt.device = device;
     opt.verbose = verbose != 0;
     opt.sink = sink.get();
+    opt.dm_delays = delays;
+    opt.n_dm = delays ? n_dm : 0;
+    opt.dm_sink = dms.get();
     observation_result res;
     std::streambuf* keep = std::cout.rdbuf();
     if (!verbose) std::cout.rdbuf(quiet.rdbuf());
     int rc = run_observation(*cfg, opt, src, pos.data(), dir.data(), &res, log);
     std::cout.rdbuf(keep);
     if (rc != BF_OK) return rc;
+    if (dm_times) *dm_times = res.dm_times;
     if (observation_ms) *observation_ms = res.observation_time_ms;
     if (gemms_written) *gemms_written = sink ? sink->get_delivered() : res.blocks * cfg->n_gemms_per_block;
     return BF_OK;

@@ -62,6 +62,7 @@ struct bf_handle {
     std::vector<char> blk_ran;      // per compute queue: bf_enqueue_block has launched into d_out_blk[q]
     std::vector<float*> d_ded_blk;  // per compute queue, n_gemms_per_block x n_beams: bf_enqueue_block_dedisperse (lazy)
     std::vector<float*> d_full_blk; // per compute queue, the gathered block (world x as large): bf_block_gather_device (lazy)
+    std::vector<float*> d_stage_blk; // per compute queue, the staged transport's landing area: bf_block_gather_stage_device (lazy)
     int full_world = 0;
     hipStream_t h2d = nullptr;
     std::vector<hipStream_t> streams;
@@ -312,6 +313,7 @@ int bf_destroy(bf_handle* h)
     for (auto& sc : h->dm_scratch) (void)hipFree(sc.second);
     for (float* p : h->d_out_blk) (void)hipFree(p);
     for (float* p : h->d_full_blk) (void)hipFree(p);
+    for (float* p : h->d_stage_blk) (void)hipFree(p);
     for (float* p : h->d_ded_blk) (void)hipFree(p);
     delete h;
     return BF_OK;
@@ -744,6 +746,22 @@ int bf_block_gather_device(bf_handle* h, int stream_idx, int world, float** d_fu
     return BF_OK;
 }
 
+int bf_block_gather_stage_device(bf_handle* h, int stream_idx, int world, float** d_stage)
+{
+    if (!h || !d_stage) return fail(BF_ERR_INVALID, "NULL argument");
+    if (stream_idx < 0 || stream_idx >= h->cfg.n_streams) return fail(BF_ERR_INVALID, "stream %d out of range", stream_idx);
+    if (world < 1) return fail(BF_ERR_INVALID, "world must be positive");
+    if (h->full_world && h->full_world != world) return fail(BF_ERR_STATE, "the gather buffers were sized for world %d", h->full_world);
+    ON_DEVICE(h);
+    h->full_world = world;
+    if (h->d_stage_blk.empty()) h->d_stage_blk.assign((size_t)h->cfg.n_streams, nullptr);
+    if (!h->d_stage_blk[stream_idx])
+        HIP_TRY(hipMalloc((void**)&h->d_stage_blk[stream_idx],
+                          bf_floats_per_detect(&h->cfg) * sizeof(float) * (size_t)h->cfg.n_gemms_per_block * (size_t)world));
+    *d_stage = h->d_stage_blk[stream_idx];
+    return BF_OK;
+}
+
 int bf_enqueue_d2h(bf_handle* h, int stream_idx, const float* d_src, float* host_dst, size_t n_floats)
 {
     if (!h || !d_src || !host_dst) return fail(BF_ERR_INVALID, "NULL argument");
@@ -966,6 +984,136 @@ int bf_dedisperse_dm_band_device(bf_handle* h, const float* d_series, int n_t, i
     int* flags = nullptr;
     HIP_TRY(dm_scratch(h, as_stream(hip_stream), &flags));
     HIP_TRY(dsabf::launch_dedisperse_dm(g, d_series, n_t, d_delays, n_dm, n_t_out, d_out, flags, as_stream(hip_stream)));
+    return BF_OK;
+}
+
+// ---- DM-trial dedispersion as a stage of the observation loop (include/dsabf.h) ---------------------------
+// The detected stream arrives block by block; out[dm][t][b] needs rows t .. t + max_delay.  The stream keeps the last
+// max_delay rows of what it has seen in front of the rows of the next push (one device buffer, slid back to its start when its
+// end is reached), so every push runs the SAME kernels over [carry | new rows] that bf_dedisperse_dm_device runs over a
+// whole series -- and emits exactly the output times that became complete.  Every (trial, time, beam) sum still runs over
+// ascending f in one register from +0: the concatenated chunks are bit-identical to one call over the whole series.
+struct bf_dm_stream {
+    bf_handle* h = nullptr;
+    int n_dm = 0, n_freq = 0, max_delay = 0, max_rows = 0;
+    size_t row_floats = 0, cap_rows = 0;
+    size_t fill = 0;              // rows of d_buf in use: [fill - carry, fill) are the newest rows of the series
+    uint64_t pushed = 0;          // rows the stream has been given
+    float* d_buf = nullptr;       // cap_rows x [freq][beam]
+    float* d_out = nullptr;       // [n_dm][max_rows][beam]: the most recent push's chunk
+    int32_t* d_delays = nullptr;  // [n_dm][freq]
+    int* d_flags = nullptr;       // the wide kernel's scratch (dsabf::kDmScratchBytes), this stream's own
+    bool flags_zeroed = false;
+    hipEvent_t done = nullptr;    // end of the previous push (its host copy included): pushes are ordered, whatever queue they use
+    bool done_recorded = false;
+};
+
+int bf_dm_stream_create(bf_handle* h, const int32_t* delays, int n_dm, int n_freq_total, int max_rows_per_push, bf_dm_stream** out)
+{
+    if (!out) return fail(BF_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (!h || !delays) return fail(BF_ERR_INVALID, "NULL argument");
+    if (n_dm <= 0 || n_freq_total <= 0 || max_rows_per_push <= 0) return fail(BF_ERR_INVALID, "need n_dm, n_freq_total, max_rows_per_push > 0");
+    int dmax = 0;
+    for (size_t i = 0; i < (size_t)n_dm * n_freq_total; i++) {
+        if (delays[i] < 0) return fail(BF_ERR_INVALID, "a streamed dedispersion needs delays >= 0 (delay[%zu] = %d)", i, delays[i]);
+        if (delays[i] > dmax) dmax = delays[i];
+    }
+    ON_DEVICE(h);
+    bf_dm_stream* s = new (std::nothrow) bf_dm_stream();
+    if (!s) return fail(BF_ERR_DEVICE, "out of host memory");
+    s->h = h;
+    s->n_dm = n_dm;
+    s->n_freq = n_freq_total;
+    s->max_delay = dmax;
+    s->max_rows = max_rows_per_push;
+    s->row_floats = (size_t)n_freq_total * h->cfg.n_beams;
+    // room for the carry and a push twice over: when the end is reached the carry moves to the start without overlapping itself
+    s->cap_rows = 2 * ((size_t)dmax + (size_t)max_rows_per_push);
+    hipError_t e = hipMalloc((void**)&s->d_buf, s->cap_rows * s->row_floats * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void**)&s->d_out, (size_t)n_dm * max_rows_per_push * h->cfg.n_beams * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void**)&s->d_delays, (size_t)n_dm * n_freq_total * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMalloc((void**)&s->d_flags, dsabf::kDmScratchBytes);
+    if (e == hipSuccess) e = hipMemcpy(s->d_delays, delays, (size_t)n_dm * n_freq_total * sizeof(int32_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&s->done, hipEventDisableTiming);
+    if (e != hipSuccess) {
+        const int rc = fail(BF_ERR_DEVICE, "bf_dm_stream_create: %s", hipGetErrorString(e));
+        std::string keep = g_err;
+        bf_dm_stream_destroy(s);
+        g_err = keep;
+        return rc;
+    }
+    *out = s;
+    return BF_OK;
+}
+
+int bf_dm_stream_destroy(bf_dm_stream* s)
+{
+    if (!s) return BF_OK;
+    DeviceScope dev_scope_(s->h->device);
+    if (s->done) {
+        if (s->done_recorded) (void)hipEventSynchronize(s->done);
+        (void)hipEventDestroy(s->done);
+    }
+    (void)hipFree(s->d_buf);
+    (void)hipFree(s->d_out);
+    (void)hipFree(s->d_delays);
+    (void)hipFree(s->d_flags);
+    delete s;
+    return BF_OK;
+}
+
+int bf_dm_stream_max_delay(const bf_dm_stream* s) { return s ? s->max_delay : BF_ERR_INVALID; }
+
+int bf_dm_stream_output_device(bf_dm_stream* s, float** d_out)
+{
+    if (!s || !d_out) return fail(BF_ERR_INVALID, "NULL argument");
+    *d_out = s->d_out;
+    return BF_OK;
+}
+
+int bf_dm_stream_push(bf_dm_stream* s, const float* d_rows, int n_rows, float* host_out, uint64_t* first_t, int* n_t_out,
+                      void* hip_stream)
+{
+    if (!s || !d_rows) return fail(BF_ERR_INVALID, "NULL argument");
+    if (n_rows <= 0 || n_rows > s->max_rows) return fail(BF_ERR_INVALID, "n_rows must be 1 .. %d (max_rows_per_push)", s->max_rows);
+    bf_handle* h = s->h;
+    ON_DEVICE(h);
+    hipStream_t q = as_stream(hip_stream);
+    if (s->done_recorded) HIP_TRY(hipStreamWaitEvent(q, s->done, 0));   // behind the previous push, whatever queue that ran on
+    if (!s->flags_zeroed) {
+        HIP_TRY(hipMemsetAsync(s->d_flags, 0, dsabf::kDmScratchBytes, q));
+        s->flags_zeroed = true;
+    }
+    const size_t D = (size_t)s->max_delay;
+    const size_t carry = s->pushed < D ? (size_t)s->pushed : D;          // rows [fill - carry, fill) = series rows [pushed - carry, pushed)
+    if (s->fill + (size_t)n_rows > s->cap_rows) {                         // slide: fill - carry >= carry here (cap = 2 (D + max_rows))
+        if (carry)
+            HIP_TRY(hipMemcpyAsync(s->d_buf, s->d_buf + (s->fill - carry) * s->row_floats, carry * s->row_floats * sizeof(float),
+                                   hipMemcpyDeviceToDevice, q));
+        s->fill = carry;
+    }
+    HIP_TRY(hipMemcpyAsync(s->d_buf + s->fill * s->row_floats, d_rows, (size_t)n_rows * s->row_floats * sizeof(float),
+                           hipMemcpyDeviceToDevice, q));
+    s->fill += (size_t)n_rows;
+    const uint64_t emitted = s->pushed > D ? s->pushed - D : 0;          // output times [0, emitted) have been produced
+    const uint64_t after = s->pushed + (uint64_t)n_rows;
+    const uint64_t complete = after > D ? after - D : 0;                   // ... and [0, complete) can be now
+    const int n_out = (int)(complete - emitted);
+    const size_t n_t = carry + (size_t)n_rows;                            // the series the kernels see: starts at output time `emitted`
+    if (n_out > 0) {
+        dsabf::Geometry g = h->geom;
+        g.n_freq = s->n_freq;
+        HIP_TRY(dsabf::launch_dedisperse_dm(g, s->d_buf + (s->fill - n_t) * s->row_floats, (int)n_t, s->d_delays, s->n_dm, n_out, s->d_out,
+                                            s->d_flags, q));
+        if (host_out)
+            HIP_TRY(hipMemcpyAsync(host_out, s->d_out, (size_t)s->n_dm * n_out * h->cfg.n_beams * sizeof(float), hipMemcpyDeviceToHost, q));
+    }
+    HIP_TRY(hipEventRecord(s->done, q));
+    s->done_recorded = true;
+    s->pushed = after;
+    if (first_t) *first_t = emitted;
+    if (n_t_out) *n_t_out = n_out;
     return BF_OK;
 }
 

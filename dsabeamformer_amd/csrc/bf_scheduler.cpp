@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <fstream>
 #include <functional>
 #include <iostream>
@@ -411,6 +412,10 @@ int run_observation(const bf_config& cfg, const observation_options& opt, block_
         return set_error(BF_ERR_INVALID, "run_observation: the sharded gather needs block-granular launches");
     if (opt.comm && opt.sink && opt.rank != opt.gather_root)
         return set_error(BF_ERR_INVALID, "run_observation: only the gather root may have a sink");
+    if (opt.dm_delays && opt.n_dm <= 0) return set_error(BF_ERR_INVALID, "run_observation: dm_delays without n_dm");
+    if (opt.dm_sink && !opt.dm_delays) return set_error(BF_ERR_INVALID, "run_observation: a dm_sink needs dm_delays");
+    if (opt.comm && opt.dm_sink && opt.rank != opt.gather_root)
+        return set_error(BF_ERR_INVALID, "run_observation: only the gather root may have a dm_sink");
     source.read_headers();  // :334 (before the device exists here: the block-size check below needs no GPU)
     const size_t block_bytes = bf_bytes_per_block(&cfg);
     if (source.get_block_size() != block_bytes) {
@@ -430,10 +435,14 @@ int run_observation(const bf_config& cfg, const observation_options& opt, block_
     struct guard {
         bf_handle* h;
         void* pinned;
+        bf_dm_stream* dm = nullptr;
+        std::vector<void*> more_pinned;
         ~guard()
         {
             if (h) bf_stream_sync(h, -1);
+            bf_dm_stream_destroy(dm);   // (before its handle)
             bf_free_pinned(pinned);
+            for (void* p : more_pinned) bf_free_pinned(p);
             bf_destroy(h);
         }
     } g{h, nullptr};
@@ -475,11 +484,41 @@ int run_observation(const bf_config& cfg, const observation_options& opt, block_
     while (cfg.n_gemms_per_block % upl) upl--;                    // whole launches only
     uint64_t launch_seq = 0;
     const int n_queues_used = upl == cfg.n_gemms_per_block ? std::min(n_streams, 2) : n_streams;   // (the rotation below)
+    bool staged = opt.gather_staged;
+    if (const char* e = getenv("DSABF_GATHER_STAGED")) staged = e[0] == '1';
+    // ---- the DM stage: where the reference's loop has its frequency collapse, src/beamformer.cu:492-511 ----
+    const bool dm_here = opt.dm_delays && (!opt.comm || opt.rank == opt.gather_root);   // a sharded run dedisperses the gathered band
+    const int dm_rows = upl * cfg.n_out_per_gemm;                                       // beam-blocks per launch = rows per push
+    struct dm_chunk {
+        uint64_t block, first_t;
+        int n_t;
+        float* host;
+    };
+    std::deque<dm_chunk> dm_pending;            // pushed, not yet delivered (their block's analysis event has not fired)
+    std::vector<float*> dm_host;                // pinned chunk buffers, used round robin
+    uint64_t dm_seq = 0, dm_times = 0, dm_chunks = 0;
+    if (opt.dm_delays && !block_launch) return set_error(BF_ERR_INVALID, "run_observation: the DM stage needs block-granular launches");
+    if (dm_here) {
+        if ((rc = bf_dm_stream_create(h, opt.dm_delays, opt.n_dm, cfg.n_freq * (opt.comm ? opt.world : 1), dm_rows, &g.dm)) != BF_OK) {
+            log << "GPUassert: " << bf_last_error() << std::endl;
+            return rc;
+        }
+        // chunks in flight: the launches of MAX_TOTAL_SEP blocks queued + the one being delivered
+        const size_t n_buf = (size_t)(kMaxTotalSep + 2) * (size_t)(cfg.n_gemms_per_block / upl);
+        for (size_t i = 0; i < n_buf; i++) {
+            void* pb = nullptr;
+            if ((rc = bf_alloc_pinned(&pb, (size_t)opt.n_dm * dm_rows * cfg.n_beams * sizeof(float))) != BF_OK) return rc;
+            g.more_pinned.push_back(pb);
+            dm_host.push_back(static_cast<float*>(pb));
+        }
+    }
+
     if (block_launch)   // the per-queue block buffers are allocated on first use: do that here, not inside the timed loop
         for (int q = 0; q < n_queues_used; q++) {
             float* unused = nullptr;
             if ((rc = bf_block_output_device(h, q, &unused)) != BF_OK) return rc;
             if (opt.comm && opt.rank == opt.gather_root && (rc = bf_block_gather_device(h, q, opt.world, &unused)) != BF_OK) return rc;
+            if (opt.comm && staged && opt.rank == opt.gather_root && (rc = bf_block_gather_stage_device(h, q, opt.world, &unused)) != BF_OK) return rc;
         }
     bf_timer_start(h);  // :358
     while (!obs_state.check_observations_complete()) {  // :364
@@ -531,20 +570,38 @@ int run_observation(const bf_config& cfg, const observation_options& opt, block_
                     }
                     rc = bf_enqueue_block(h, q, (int)obs_state.get_next_gpu_analysis_block(), first, upl,
                                           opt.comm ? nullptr : &unit_dst[first]);
+                    float* d_rows = nullptr;     // where this launch's beam-blocks are on the device, [row][freq (over the band)][beam]
                     if (rc == BF_OK && opt.comm) {
                         // sharded (upl == n_units): bring the shards' powers together on the root, in [unit][o][f over the
                         // band][b], behind the launch on the same queue; only the root copies to the host
-                        float *d_blk = nullptr, *d_full = nullptr;
+                        float *d_blk = nullptr, *d_full = nullptr, *d_stage = nullptr;
                         void* qs = nullptr;
                         const size_t full_det = n_f_per_detect * (size_t)opt.world;
                         const bool root = opt.rank == opt.gather_root;
                         if ((rc = bf_block_output_device(h, q, &d_blk)) == BF_OK && (rc = bf_queue_stream(h, q, &qs)) == BF_OK &&
-                            (!root || (rc = bf_block_gather_device(h, q, opt.world, &d_full)) == BF_OK))
-                            rc = bf_gather_detected(opt.comm, d_blk, (size_t)n_units * cfg.n_out_per_gemm,
-                                                    (size_t)cfg.n_freq * cfg.n_beams, opt.gather_root,
-                                                    BF_GATHER_LAYOUT_FREQ_MAJOR, d_full, qs);
+                            (!root || (rc = bf_block_gather_device(h, q, opt.world, &d_full)) == BF_OK) &&
+                            (!root || !staged || (rc = bf_block_gather_stage_device(h, q, opt.world, &d_stage)) == BF_OK))
+                            rc = staged ? bf_gather_detected_staged(opt.comm, d_blk, (size_t)n_units * cfg.n_out_per_gemm,
+                                                                    (size_t)cfg.n_freq * cfg.n_beams, opt.gather_root, d_full, d_stage, qs)
+                                        : bf_gather_detected(opt.comm, d_blk, (size_t)n_units * cfg.n_out_per_gemm,
+                                                             (size_t)cfg.n_freq * cfg.n_beams, opt.gather_root,
+                                                             BF_GATHER_LAYOUT_FREQ_MAJOR, d_full, qs);
                         for (int u = 0; rc == BF_OK && root && u < n_units; u++)
                             rc = bf_enqueue_d2h(h, q, d_full + full_det * (size_t)u, unit_dst[u], full_det);
+                        d_rows = d_full;
+                    } else if (rc == BF_OK && dm_here) {
+                        if ((rc = bf_block_output_device(h, q, &d_rows)) == BF_OK) d_rows += n_f_per_detect * (size_t)first;
+                    }
+                    if (rc == BF_OK && dm_here) {
+                        // the DM stage, where the reference's loop collapses frequency (src/beamformer.cu:492-511): this launch's rows
+                        // into the stream on the launch's own queue; the chunk that becomes complete travels to a pinned buffer
+                        void* qs = nullptr;
+                        uint64_t first_t = 0;
+                        int n_t = 0;
+                        float* chunk = dm_host[(size_t)(dm_seq++ % dm_host.size())];
+                        if ((rc = bf_queue_stream(h, q, &qs)) == BF_OK)
+                            rc = bf_dm_stream_push(g.dm, d_rows, dm_rows, chunk, &first_t, &n_t, qs);
+                        if (rc == BF_OK && n_t > 0) dm_pending.push_back({(uint64_t)block_index, first_t, n_t, chunk});
                     }
                     if (rc != BF_OK) {
                         log << "GPUassert: " << bf_last_error() << std::endl;
@@ -580,6 +637,19 @@ int run_observation(const bf_config& cfg, const observation_options& opt, block_
             log << "GPUassert: event backend failed: " << bf_last_error() << std::endl;
             return obs_state.status();
         }
+        // the DM chunks of analysed blocks have landed too (their copies sit on the queues the analysis event joins)
+        while (!dm_pending.empty() && dm_pending.front().block < obs_state.get_blocks_analyzed()) {
+            const dm_chunk c = dm_pending.front();
+            dm_pending.pop_front();
+            dm_times += (uint64_t)c.n_t;
+            if (opt.dm_sink) {
+                dm_chunks++;
+                if (!opt.dm_sink->deliver(c.first_t, c.n_t, opt.n_dm, cfg.n_beams, c.host)) {
+                    log << "ERROR: DM sink failed at output time " << c.first_t << std::endl;
+                    return BF_ERR_STATE;
+                }
+            }
+        }
         if (opt.sink) {  // every D2H copy of an analysed block has landed: hand its gemm-units over, in order
             for (; sink_committed < obs_state.get_blocks_analyzed() * (uint64_t)cfg.n_gemms_per_block; sink_committed++)
                 if (!opt.sink->commit(sink_committed)) {
@@ -592,6 +662,7 @@ int run_observation(const bf_config& cfg, const observation_options& opt, block_
     bf_timer_stop(h, &ms);
     bf_stream_sync(h, -1);  // :560-562
     if (opt.sink) opt.sink->close();
+    if (opt.dm_sink) opt.dm_sink->close();
     const uint64_t blocks = obs_state.get_blocks_analyzed();
     const uint64_t chunks = obs_state.get_current_transfer_gemm() * cfg.n_out_per_gemm;  // :552
     const double rate = (double)source.get_block_size() * obs_state.get_blocks_transfer_queue() / ms / 1e6;  // :554
@@ -609,7 +680,12 @@ int run_observation(const bf_config& cfg, const observation_options& opt, block_
         res->gbytes_per_s = rate;
         res->beam_out.assign(beam_out, beam_out + beam_out_stride * n_streams);
         res->last_gemm = last_gemm;
+        res->dm_times = dm_times;
+        res->dm_chunks = dm_chunks;
     }
+    if (dm_here)
+        log << "DM stage: " << opt.n_dm << " trials, " << dm_times << " output times (largest delay " << bf_dm_stream_max_delay(g.dm)
+            << " samples carried over on the device)" << std::endl;
     return BF_OK;
 }
 

@@ -226,4 +226,59 @@ void ring_sink::finish()
     shm_ring::unlink(name.c_str());
 }
 
+// ---- DM-trial chunks ---------------------------------------------------------------------------------------------------
+dm_file_sink::dm_file_sink(const bf_config& cfg, int n_freq_total, int n_dm, int max_delay, const char* path, int gpu)
+{
+    fd = ::open(path, O_CREAT | O_TRUNC | O_WRONLY, 0644);
+    if (fd < 0) return;
+    char header[kHeaderBytes];
+    ::memset(header, 0, sizeof(header));
+    ::snprintf(header, sizeof(header),
+               "HDR_VERSION 1.0\nHDR_SIZE %zu\nINSTRUMENT DSA\nCONTENT dedispersed_power\nDTYPE float32\nENDIAN little\n"
+               "ORDER chunk(dm,time,beam)\nRECORD_HEADER_BYTES %zu\nN_DM %d\nN_BEAMS %d\nN_FREQUENCIES %d\nMAX_DELAY %d\n"
+               "N_OUTPUTS_PER_GEMM %d\nN_GEMMS_PER_BLOCK %d\nN_AVERAGING %d\nGPU %d\n",
+               kHeaderBytes, kRecordBytes, n_dm, cfg.n_beams, n_freq_total, max_delay, cfg.n_out_per_gemm, cfg.n_gemms_per_block,
+               cfg.n_avg, gpu);
+    if (!pwrite_all(fd, header, sizeof(header), 0) || ::lseek(fd, (off_t)kHeaderBytes, SEEK_SET) < 0) {
+        ::close(fd);
+        fd = -1;
+    }
+}
+
+dm_file_sink::~dm_file_sink() { close(); }
+
+static bool write_all(int fd, const char* p, size_t n)
+{
+    while (n) {
+        const ssize_t w = ::write(fd, p, n);
+        if (w <= 0) return false;
+        p += w;
+        n -= (size_t)w;
+    }
+    return true;
+}
+
+bool dm_file_sink::deliver(uint64_t first_t, int n_t, int n_dm, int n_beams, const float* data)
+{
+    if (fd < 0 || n_t <= 0) return fd >= 0;
+    if (first_t != written_t) return false;   // chunks follow each other without gaps
+    char rec[kRecordBytes];
+    ::memset(rec, 0, sizeof rec);
+    const uint32_t v[3] = {(uint32_t)n_t, (uint32_t)n_dm, (uint32_t)n_beams};
+    ::memcpy(rec, &first_t, 8);
+    ::memcpy(rec + 8, v, 12);
+    if (!write_all(fd, rec, sizeof rec) ||
+        !write_all(fd, reinterpret_cast<const char*>(data), (size_t)n_dm * n_t * n_beams * sizeof(float)))
+        return false;
+    written_t += (uint64_t)n_t;
+    chunks++;
+    return true;
+}
+
+void dm_file_sink::close()
+{
+    if (fd >= 0) ::close(fd);
+    fd = -1;
+}
+
 }  // namespace dsabf

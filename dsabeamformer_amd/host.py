@@ -262,6 +262,45 @@ def run_observation_junk_to_file(cfg: BfConfig, n_blocks: int, path: str, ring_b
     return {"ms": ms.value, "gemms_written": n.value, "ring": ring}
 
 
+def read_dm_file(path: str):
+    """Parse a dsabf::dm_file_sink file: returns (header dict, float32 array [n_dm][T][n_beams], list of (first_t, n_t) per
+    chunk).  The chunks ([dm][t][beam] each) are joined along t; they follow each other without gaps."""
+    raw = open(path, "rb").read()
+    text = raw[:DETECTED_HEADER_BYTES].split(b"\0", 1)[0].decode()
+    hdr = dict(line.split(None, 1) for line in text.splitlines() if line.strip())
+    at, rec = int(hdr["HDR_SIZE"]), int(hdr["RECORD_HEADER_BYTES"])
+    parts, chunks, next_t = [], [], 0
+    while at < len(raw):
+        first_t = int(np.frombuffer(raw, "<u8", 1, at)[0])
+        n_t, n_dm, n_beams = (int(v) for v in np.frombuffer(raw, "<u4", 3, at + 8))
+        assert first_t == next_t and n_dm == int(hdr["N_DM"]) and n_beams == int(hdr["N_BEAMS"])
+        at += rec
+        parts.append(np.frombuffer(raw, "<f4", n_dm * n_t * n_beams, at).reshape(n_dm, n_t, n_beams))
+        at += 4 * n_dm * n_t * n_beams
+        chunks.append((first_t, n_t))
+        next_t += n_t
+    data = np.concatenate(parts, axis=1) if parts else np.zeros((int(hdr["N_DM"]), 0, int(hdr["N_BEAMS"])), np.float32)
+    return hdr, data, chunks
+
+
+def run_observation_junk_dm(cfg: BfConfig, n_blocks: int, delays, dm_path: str | None, detected_path: str | None = None,
+                            ring_blocks: int = 4, seed: int = 0xD5A, gpu: int = 0, device: int = 0, burn_in: int = 0,
+                            verbose: bool = False):
+    """Production observation loop with the DM stage on: every analysed block's beam-blocks go through a bf_dm_stream
+    (delays: int32 [n_dm][cfg.n_freq]), the chunks to dm_path (read_dm_file), optionally the detected stream itself to
+    detected_path.  Returns dict(ms, dm_times, ring)."""
+    lib = load()
+    d = np.ascontiguousarray(delays, np.int32)
+    assert d.ndim == 2 and d.shape[1] == cfg.n_freq
+    n_time = cfg.n_out_per_gemm * cfg.n_pol * cfg.n_avg
+    ring = np.zeros((ring_blocks, cfg.n_gemms_per_block, cfg.n_freq, n_time, cfg.n_ant), np.uint8)
+    ms, n = C.c_float(), C.c_uint64()
+    check(lib.bfh_run_observation_junk_dm(C.byref(cfg), n_blocks, ring_blocks, seed, gpu, device, burn_in, 1 if verbose else 0,
+                                          _p(d), d.shape[0], dm_path.encode() if dm_path else None,
+                                          detected_path.encode() if detected_path else None, C.byref(ms), C.byref(n), _p(ring)))
+    return {"ms": ms.value, "dm_times": n.value, "ring": ring}
+
+
 def run_observation_junk_to_ring(cfg: BfConfig, n_blocks: int, out_ring: str, out_ring_blocks: int = 8,
                                  ring_blocks: int = 4, seed: int = 0xD5A, gpu: int = 0, device: int = 0):
     """Production observation loop with the detected stream handed to a consumer through the shared-memory ring
@@ -359,12 +398,17 @@ def shm_ring_unlink(name: str) -> None:
 
 
 def run_observation_shm(cfg: BfConfig, name: str, path: str | None = None, core: int = -1, gpu: int = 0, device: int = 0,
-                        verbose: bool = False):
-    """Production observation loop fed from the shared-memory ring `name`.  Returns dict(ms, gemms, pinned)."""
-    ms, n, pinned = C.c_float(), C.c_uint64(), C.c_int()
-    check(load().bfh_run_observation_shm(C.byref(cfg), name.encode(), core, gpu, device, 1 if verbose else 0,
-                                         path.encode() if path else None, C.byref(ms), C.byref(n), C.byref(pinned)))
-    return {"ms": ms.value, "gemms": n.value, "pinned": bool(pinned.value)}
+                        verbose: bool = False, delays=None, dm_path: str | None = None):
+    """Production observation loop fed from the shared-memory ring `name`; delays (int32 [n_dm][cfg.n_freq]): with the DM
+    stage on, chunks to dm_path.  Returns dict(ms, gemms, pinned, dm_times)."""
+    ms, n, nd, pinned = C.c_float(), C.c_uint64(), C.c_uint64(), C.c_int()
+    d = np.ascontiguousarray(delays, np.int32) if delays is not None else None
+    assert d is None or (d.ndim == 2 and d.shape[1] == cfg.n_freq)
+    check(load().bfh_run_observation_shm_dm(C.byref(cfg), name.encode(), core, gpu, device, 1 if verbose else 0,
+                                            path.encode() if path else None, _p(d) if d is not None else None,
+                                            d.shape[0] if d is not None else 0, dm_path.encode() if dm_path else None,
+                                            C.byref(ms), C.byref(n), C.byref(nd), C.byref(pinned)))
+    return {"ms": ms.value, "gemms": n.value, "pinned": bool(pinned.value), "dm_times": nd.value}
 
 
 def dm_trials(dm0: float = 0.0, dm_max: float = 2000.0, nchan: int = 2048, epsilon: float = 1.25,

@@ -230,6 +230,35 @@ int bf_dedisperse_device(bf_handle *h, const float *d_out_unit, float *d_ded, vo
 int bf_dedisperse_dm_device(bf_handle *h, const float *d_series, int n_t, const int32_t *d_delays, int n_dm, int n_t_out,
                             float *d_out, void *hip_stream);
 
+/* ---- DM-trial dedispersion as a STAGE of the observation loop ---------------------------------
+ * The reference collapses frequency INSIDE its loop, right behind each gemm-unit's detect (src/beamformer.cu:492-511: the
+ * cublasSgemv of :498-504 and the copy of :506-510) -- at DM 0 only.  A bf_dm_stream does the same for a ladder of DM trials on
+ * the detected stream as it is produced: the caller pushes the beam-blocks of every block it has beamformed ([row][freq][beam],
+ * rows in time order: exactly what bf_enqueue_block leaves in bf_block_output_device, or bf_gather_detected in the freq-major
+ * layout on the gather root), the stream keeps the last max_delay rows on the device in front of the next push, and every push
+ * emits the output times that have just become complete:
+ *   chunk [n_dm][n_t_out][beam], out[dm][t][b] = sum over f (ascending, fp32) of series[t + delay[dm][f]][f][b],
+ *   t = first_t .. first_t + n_t_out - 1 counted from the first row ever pushed.
+ * Chunks follow each other without gaps or overlap (first_t of a push = first_t + n_t_out of the one before); concatenated
+ * along t they are BIT-IDENTICAL to one bf_dedisperse_dm_device call over the whole series (same kernels, same ascending-f
+ * sum per output; the last max_delay times of a series are never complete, there as here).  n_t_out is 0 until max_delay rows
+ * have been seen, then equals n_rows.
+ *   delays: HOST int32 [n_dm][n_freq_total], all >= 0 (dsabf::dm_delays / bfh_dm_delays); n_freq_total = the channels of one
+ *   pushed row (cfg.n_freq, or world * cfg.n_freq on a gather root); max_rows_per_push: the largest n_rows of a push
+ *   (n_gemms_per_block * n_out_per_gemm for block launches).
+ * bf_dm_stream_push is asynchronous on `hip_stream` (the queue that produced d_rows: bf_queue_stream); successive pushes are
+ * ordered by the stream itself, whichever queues they are issued on.  host_out (optional, pinned, room for n_dm * n_rows *
+ * n_beams floats) receives the chunk; first_t / n_t_out are known to the host at once (pure arithmetic).  The device copy of
+ * the most recent chunk: bf_dm_stream_output_device.  Destroy the stream before its handle. */
+typedef struct bf_dm_stream bf_dm_stream;
+int bf_dm_stream_create(bf_handle *h, const int32_t *delays, int n_dm, int n_freq_total, int max_rows_per_push,
+                        bf_dm_stream **out);
+int bf_dm_stream_destroy(bf_dm_stream *s);
+int bf_dm_stream_max_delay(const bf_dm_stream *s);
+int bf_dm_stream_push(bf_dm_stream *s, const float *d_rows, int n_rows, float *host_out, uint64_t *first_t, int *n_t_out,
+                      void *hip_stream);
+int bf_dm_stream_output_device(bf_dm_stream *s, float **d_out);
+
 /* ---- Multi-GPU: frequency shards and the gather of their detected powers -------------------------------
  * The reference runs 8 independent processes, one sub-band per GPU (`-g`, src/beamformer.cu:92-100,233; README.md:168)
  * and never brings their outputs together.  Here a handle may own any contiguous range of frequencies (bf_config.n_freq
@@ -302,6 +331,7 @@ int bf_queue_stream(bf_handle *h, int stream_idx, void **hip_stream);
 /* A handle-owned device buffer (allocated like src/beamformer.cu:249-266 allocates the per-stream ones) for the gathered block of compute queue `stream_idx`: n_gemms_per_block * world *
  * bf_floats_per_detect floats ([unit][output][world * n_freq][beam] with the freq-major layout); allocated on first use. */
 int bf_block_gather_device(bf_handle *h, int stream_idx, int world, float **d_full);
+int bf_block_gather_stage_device(bf_handle *h, int stream_idx, int world, float **d_stage); /* same size: d_stage of bf_gather_detected_staged */
 /* Asynchronous device-to-host copy of n_floats on compute queue `stream_idx` (the cudaMemcpyAsync of src/beamformer.cu:485-488
  * for a caller-chosen source): behind everything enqueued on that queue before the call, gemm-units included. */
 int bf_enqueue_d2h(bf_handle *h, int stream_idx, const float *d_src, float *host_dst, size_t n_floats);

@@ -112,6 +112,15 @@ int bfh_run_observation_junk_to_ring(const bf_config *cfg, uint64_t n_blocks, in
                                      int device, const char *out_ring, uint64_t out_ring_blocks, float *observation_ms,
                                      uint64_t *gemms_written, void *ring_copy);
 
+/* Same loop with the DM stage on (SURVEY.md 8f-4 as a stage of the loop; where the reference collapses frequency,
+ * src/beamformer.cu:492-511): delays int32 [n_dm][cfg->n_freq] (bfh_dm_delays), every analysed block pushed into a bf_dm_stream
+ * behind its launch, the chunks written to dm_path (dsabf::dm_file_sink: 4096-byte header, then per chunk a 32-byte record
+ * {u64 first_t, u32 n_t, u32 n_dm, u32 n_beams} + float32 [dm][t][beam]; NULL: the stage runs, nothing is kept) and,
+ * optionally, the detected stream itself to detected_path.  dm_times (optional): output times produced. */
+int bfh_run_observation_junk_dm(const bf_config *cfg, uint64_t n_blocks, int ring_blocks, uint64_t seed, int gpu, int device,
+                                int burn_in, int verbose, const int32_t *delays, int n_dm, const char *dm_path,
+                                const char *detected_path, float *observation_ms, uint64_t *dm_times, void *ring_copy);
+
 /* The sink's ring on its own (tests; works without a device, the ring is then plain memory). */
 typedef struct bfh_sink bfh_sink;
 int bfh_file_sink_create(const bf_config *cfg, const char *path, int gpu, uint64_t slots, bfh_sink **out);
@@ -147,6 +156,11 @@ int bfh_shm_ring_read(bfh_shm_ring *r, void *out, uint64_t cap, uint64_t *bytes,
  * `path` if not NULL.  pinned (optional) receives whether the ring blocks could be page-locked. */
 int bfh_run_observation_shm(const bf_config *cfg, const char *name, int core, int gpu, int device, int verbose,
                             const char *path, float *observation_ms, uint64_t *gemms_written, int *pinned);
+
+/* The same with the DM stage on (as bfh_run_observation_junk_dm): delays int32 [n_dm][cfg->n_freq] or NULL, chunks to dm_path. */
+int bfh_run_observation_shm_dm(const bf_config *cfg, const char *name, int core, int gpu, int device, int verbose,
+                               const char *path, const int32_t *delays, int n_dm, const char *dm_path, float *observation_ms,
+                               uint64_t *gemms_written, uint64_t *dm_times, int *pinned);
 
 #ifdef __cplusplus
 }

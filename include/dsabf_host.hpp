@@ -454,6 +454,55 @@ public:
     memory_sink(const bf_config& cfg, uint64_t slots = 0) : detected_sink(cfg, slots ? slots : slots_for(cfg)) {}
 };
 
+// ---- DM-trial dedispersion of the detected stream, as a stage of the loop ------------------------
+// The reference collapses frequency inside its loop behind every gemm-unit (src/beamformer.cu:492-511, DM 0 only).  With
+// observation_options::dm_delays set, run_observation pushes every analysed block's beam-blocks into a bf_dm_stream
+// (include/dsabf.h) on the block's compute queue -- on the gather root, the gathered whole-band rows -- and hands the chunks
+// [n_dm][n_t][n_beams] that become complete to a dm_chunk_sink, in time order, once the block's analysis event has fired.
+struct dm_chunk_sink {
+    virtual ~dm_chunk_sink() {}
+    // out[dm][t][b] for t = first_t .. first_t + n_t - 1 (counted from the first beam-block of the observation)
+    virtual bool deliver(uint64_t first_t, int n_t, int n_dm, int n_beams, const float* data) = 0;
+    virtual void close() {}
+};
+
+// File: a 4096-byte ASCII header (`KEY value` lines, NUL padded; N_DM, N_BEAMS, N_FREQUENCIES, MAX_DELAY, the ladder's
+// delays are not repeated), then one record per chunk: 32 bytes {uint64 first_t; uint32 n_t, n_dm, n_beams; 12 bytes of
+// zeros} followed by n_dm * n_t * n_beams little-endian float32 in [dm][t][beam] order.
+class dm_file_sink : public dm_chunk_sink {
+    int fd = -1;
+    uint64_t written_t = 0, chunks = 0;
+
+public:
+    static constexpr size_t kHeaderBytes = 4096;
+    static constexpr size_t kRecordBytes = 32;
+    dm_file_sink(const bf_config& cfg, int n_freq_total, int n_dm, int max_delay, const char* path, int gpu);
+    ~dm_file_sink() override;
+    dm_file_sink(const dm_file_sink&) = delete;
+    dm_file_sink& operator=(const dm_file_sink&) = delete;
+    bool is_open() const { return fd >= 0; }
+    bool deliver(uint64_t first_t, int n_t, int n_dm, int n_beams, const float* data) override;
+    void close() override;
+    uint64_t get_times_written() const { return written_t; }
+    uint64_t get_chunks_written() const { return chunks; }
+};
+
+// Keeps the chunks in host memory, assembled as one [n_dm][T][n_beams] series on request (tests, small runs).
+class dm_memory_sink : public dm_chunk_sink {
+public:
+    struct chunk {
+        uint64_t first_t;
+        int n_t, n_dm, n_beams;
+        std::vector<float> data;
+    };
+    std::vector<chunk> chunks;
+    bool deliver(uint64_t first_t, int n_t, int n_dm, int n_beams, const float* data) override
+    {
+        chunks.push_back({first_t, n_t, n_dm, n_beams, std::vector<float>(data, data + (size_t)n_dm * n_t * n_beams)});
+        return true;
+    }
+};
+
 struct observation_options {
     int gpu = 0;          // -g
     int device = 0;
@@ -479,6 +528,16 @@ struct observation_options {
     // must then be built for the whole band: cfg.n_freq * world) -- the others pass sink = nullptr.  Needs block_launch.
     bf_comm* comm = nullptr;
     int gather_root = 0;
+    // Transport of that gather (both give the same [unit][o][f over the band][b] on the root): false = every (row, sender) run
+    // received in place (bf_gather_detected), true = one message per sender + one device re-layout pass
+    // (bf_gather_detected_staged).  DSABF_GATHER_STAGED=1 / 0 in the environment overrides (measurement switch).
+    bool gather_staged = false;
+    // DM-trial dedispersion of the detected stream (needs block_launch): int32 [n_dm][cfg.n_freq * world] sample delays, all >= 0
+    // (dm_delays()).  Every analysed block is pushed into a bf_dm_stream behind its launch -- on a sharded run by the gather
+    // root, on the gathered band -- and the chunks go to dm_sink (may be NULL: the stage still runs, e.g. for timing).
+    const int32_t* dm_delays = nullptr;
+    int n_dm = 0;
+    dm_chunk_sink* dm_sink = nullptr;
 };
 struct observation_result {
     float observation_time_ms = 0;
@@ -487,6 +546,8 @@ struct observation_result {
     double gbytes_per_s = 0;        // "Approximate datarate", src/beamformer.cu:554
     std::vector<float> beam_out;    // final contents of beam_out: [stream][N_F_PER_DETECT] (src/beamformer.cu:249,485-488)
     std::vector<long long> last_gemm;  // global gemm-unit index (block * N_GEMMS_PER_BLOCK + time_slice) behind each stream
+    uint64_t dm_times = 0;          // output times the DM stage produced (dm_delays set): rows analysed - the largest delay
+    uint64_t dm_chunks = 0;         // chunks handed to dm_sink
 };
 // The reference's production main() loop on top of the C-ABI.  pos/dir: antenna positions and beam directions.
 int run_observation(const bf_config& cfg, const observation_options& opt, block_source& source, const antenna* pos,

@@ -11,8 +11,46 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 CFG = os.path.join(GOLDEN, "config")
 
 
+# ---- the GPU suite runs on a budget (<= 300 s on a fresh driver box) -------------------------------------
+# The default `-m gpu` run keeps a spread of at most SWEEP_CAP cases of every parametrised GPU test (first, last and evenly
+# between, in collection order -- every kernel family, antenna class and config keeps its representatives; tests/README.md maps
+# SURVEY.md section 8's rows and BASELINE's configs to the tests that stay); DSABF_LONG_TESTS=1 runs every case (tools/
+# refresh_profiles_r05.sh does, and commits the tail under profiles/).  A test that must always run in full says
+# @pytest.mark.sweep_cap(n) with its own number.  CPU tests are never thinned.
+LONG = os.environ.get("DSABF_LONG_TESTS") == "1"
+SWEEP_CAP = 6
+
+
+def sweep(every, default):
+    """Parameter lists that are expensive per case: `default` in the budgeted run, `every` under DSABF_LONG_TESTS=1."""
+    return list(every) if LONG else list(default)
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "sweep_cap(n): cases of this parametrised GPU test kept in the budgeted run (default %d)" % SWEEP_CAP)
+
+
+def pytest_collection_modifyitems(config, items):
+    if LONG:
+        return
+    groups = {}
+    for it in items:
+        if it.get_closest_marker("gpu") is None:
+            continue
+        groups.setdefault((str(it.fspath), getattr(it, "originalname", None) or it.name), []).append(it)
+    drop = set()
+    for group in groups.values():
+        m = group[0].get_closest_marker("sweep_cap")
+        cap = int(m.args[0]) if m and m.args else SWEEP_CAP
+        if len(group) <= cap:
+            continue
+        keep = {round(i * (len(group) - 1) / max(cap - 1, 1)) for i in range(cap)}
+        drop.update(id(it) for k, it in enumerate(group) if k not in keep)
+    if drop:
+        gone = [it for it in items if id(it) in drop]
+        items[:] = [it for it in items if id(it) not in drop]
+        config.hook.pytest_deselected(items=gone)
 
 
 @pytest.fixture(scope="session")

@@ -10,7 +10,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN
+from conftest import GOLDEN, sweep
 
 pytestmark = pytest.mark.gpu
 
@@ -913,7 +913,7 @@ def test_wide_antenna_fast_detect_tolerance(torch, bfmod, orc):
     assert rel.max() <= 4 * g.n_ipo * 2.0 ** -24
 
 
-@pytest.mark.parametrize("gpu", [0, 5])
+@pytest.mark.parametrize("gpu", sweep([0, 5], [5]))
 def test_grid_configuration_debug_flow_bit_identical(bfmod, orc, gpu):
     """The reference's 2-D configuration end to end through the DEBUG flow (`beam -p grid_positions -d
     grid_beam_directions -s grid_source_directions_4096 -g <gpu>`): 8x8 antenna grid, 16x16 beam grid (conjugate-
@@ -940,7 +940,7 @@ def test_grid_configuration_debug_flow_bit_identical(bfmod, orc, gpu):
         assert np.array_equal(ded[batch * 1024 + 1023], orc.dedisperse(g, out[1023]))
 
 
-@pytest.mark.parametrize("paired", ["default", "0"])
+@pytest.mark.parametrize("paired", sweep(["default", "0"], ["default"]))
 def test_random_array_debug_flow_bit_identical(bfmod, orc, monkeypatch, paired):
     """The reference's remaining fixtures end to end through the DEBUG flow: config/random_positions.txt (uniform +-250 m, an
     array without any symmetry) with the 16x16 beam grid and the 61x61 source catalogue grid_source_directions_3721.txt --
@@ -970,8 +970,8 @@ def test_random_array_debug_flow_bit_identical(bfmod, orc, monkeypatch, paired):
             assert np.array_equal(ded[batch * 1024 + u], orc.dedisperse(g, out[u])), (batch, u)
 
 
-@pytest.mark.parametrize("mode", ["alltoall", "root"])
-@pytest.mark.parametrize("layout", ["rank", "freq"])
+@pytest.mark.parametrize("mode,layout", sweep([("alltoall", "rank"), ("root", "rank"), ("alltoall", "freq"), ("root", "freq")],
+                                               [("alltoall", "rank")]))
 def test_bench_rccl_gather_plumbing_on_one_gpu(mode, layout):
     """bench.py --force-dist: the multi-GPU path (process group, a one-rank RCCL communicator behind bf_comm_create,
     bf_gather_detected on its side stream, double buffering) with world size 1 -- what can be exercised of it on a 1-GPU

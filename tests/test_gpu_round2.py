@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import CFG, GOLDEN
+from conftest import CFG, GOLDEN, LONG
 
 pytestmark = pytest.mark.gpu
 
@@ -192,7 +192,7 @@ def test_run_time_antenna_classes_equal_the_compile_time_ones(torch, bfmod, orc,
 
 def test_geometry_fuzz_over_the_whole_contract(torch, bfmod, orc):
     rng = np.random.default_rng(20261003)
-    for case in range(40):
+    for case in range(40 if LONG else 12):     # (the budgeted run: the first 12 geometries of the same seeded walk)
         n_ant = 4 * int(rng.integers(1, 33))
         n_beams = 4 * int(rng.integers(1, 80))
         n_avg = int(rng.choice([1, 2, 4, 8, 16, 32]))
