@@ -1285,8 +1285,30 @@ def main():
                                 "(tests/golden/make_dispersion_golden.py)"})
             out["dedisperse_dm"] = rec
 
+        def extras_relayout():
+            # the device pass of the staged gather transport by itself, at the shape one receiver of BASELINE configs[3] sees in
+            # the distributed-owner gather: 8 ranks, 2048 / 8 = 256 rows held, 32 channels x 256 beams per row and sender
+            w8, held, rf = 8, (units * n_out) // 8, (256 // 8) * cfg.n_beams
+            d_st = torch.rand(w8 * held * rf, device="cuda")
+            d_fu = torch.empty(w8 * held * rf, device="cuda")
+            fn = lambda i: bf.gather_relayout(d_st, d_fu, held, w8, rf, 0, sptr)  # noqa: E731
+            for i in range(5):
+                fn(i)
+            torch.cuda.synchronize()
+            want = d_st.view(w8, held, rf).transpose(0, 1).reshape(-1)
+            ok = bool(torch.equal(d_fu.view(held, w8, rf)[:, 1:], want.view(held, w8, rf)[:, 1:]))
+            avg, med, mn = time_launches(torch, fn, 50, stream)
+            moved = 2.0 * (w8 - 1) * held * rf * 4
+            out["gather_relayout"] = {"kernel": "dsabf::gather_relayout_kernel", "ms_avg": avg, "ms_median": med, "bit_equal_to_a_transpose": ok,
+                                      "shape": "stage [8 ranks][%d rows][%d floats] -> full [row][rank][floats], own rank skipped" % (held, rf),
+                                      "roofline": {"bound": "hbm", "achieved": moved / (avg * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                   "frac": moved / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": moved},
+                                      "note": "bf_gather_detected_staged = one message per sender + this pass; every float read once and "
+                                              "written once, whole 128-byte lines, nontemporal; per step and receiver at N = 8"}
+
         if world == 1 and args.detect == "canonical" and args.workload in ("c3", "prod") and not args.no_extras:
             guarded("general_kernel", extras_variants)
+            guarded("gather_relayout", extras_relayout)
         def north_star_summary():
             """north_star: '>= 50 % int8 MFMA utilisation' -- which kernel / detect reading meets it in THIS run, one line each:
             algorithmic fraction of the nominal 5.0 POP/s from the records above (executed fraction = half for the pair kernel)."""

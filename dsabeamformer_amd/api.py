@@ -170,6 +170,11 @@ class Beamformer:
                                             C.byref(ops), C.c_void_p(stream)))
         return ops.value
 
+    def gather_relayout(self, d_stage, d_full, rows_held: int, world: int, row_floats: int, skip_rank: int, stream: int = 0) -> None:
+        """bf_gather_relayout_device (dsabf_bench.h): the staged transport's device pass by itself."""
+        check(self._lib.bf_gather_relayout_device(self._h, _ptr(d_stage), _ptr(d_full), rows_held, world, row_floats, skip_rank,
+                                                  C.c_void_p(stream)))
+
     def set_switch(self, name: str, value: int) -> None:
         """bf_set_switch: a measurement / test switch of this handle ("tsplit", "lds_pad", "dm_wide", "paired")."""
         check(self._lib.bf_set_switch(self._h, name.encode(), int(value)))

@@ -903,6 +903,17 @@ int bf_mfma_peak_device(bf_handle* h, const void* d_operands, size_t operand_byt
     return BF_OK;
 }
 
+int bf_gather_relayout_device(bf_handle* h, const float* d_stage, float* d_full, size_t rows_held, int world, size_t row_floats,
+                              int skip_rank, void* hip_stream)
+{
+    if (!h || !d_stage || !d_full) return fail(BF_ERR_INVALID, "NULL argument");
+    if (world < 1 || row_floats % 4 || ((uintptr_t)d_stage & 15) || ((uintptr_t)d_full & 15))
+        return fail(BF_ERR_INVALID, "need world >= 1, row_floats a multiple of 4 and 16-byte aligned pointers");
+    ON_DEVICE(h);
+    HIP_TRY(dsabf::launch_gather_relayout(d_stage, d_full, rows_held, world, row_floats, skip_rank, h->n_cus, as_stream(hip_stream)));
+    return BF_OK;
+}
+
 int bf_gemm_device(bf_handle* h, const void* d_packed_unit, float* d_c, void* hip_stream)
 {
     if (!h || !d_packed_unit || !d_c) return fail(BF_ERR_INVALID, "NULL argument");

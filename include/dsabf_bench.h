@@ -22,6 +22,12 @@ extern "C" {
 int bf_mfma_peak_device(bf_handle *h, const void *d_operands, size_t operand_bytes, void *d_scratch, size_t scratch_bytes,
                         int iters, double *ops, void *hip_stream);
 
+/* The device pass of the staged gather transport (bf_gather_detected_staged) by itself, for its roofline on ONE GPU:
+ * d_full[row][rank][row_floats] = d_stage[rank][row][row_floats] for every rank but skip_rank (-1: none).  HBM-bound: every
+ * float read once and written once.  16-byte aligned pointers, row_floats a multiple of 4. */
+int bf_gather_relayout_device(bf_handle *h, const float *d_stage, float *d_full, size_t rows_held, int world, size_t row_floats,
+                              int skip_rank, void *hip_stream);
+
 /* Introspection for benchmarks/roofline reports. */
 int bf_kernel_info(const bf_handle *h, int n_units, int *grid, int *block, int *lds_bytes, int *vgprs);
 /* Measurement / test switches of ONE handle (A/B runs inside one process).  They select among launches and kernels that

@@ -18,7 +18,7 @@ CFG = os.path.join(GOLDEN, "config")
 # refresh_profiles_r05.sh does, and commits the tail under profiles/).  A test that must always run in full says
 # @pytest.mark.sweep_cap(n) with its own number.  CPU tests are never thinned.
 LONG = os.environ.get("DSABF_LONG_TESTS") == "1"
-SWEEP_CAP = 6
+SWEEP_CAP = 4
 
 
 def sweep(every, default):

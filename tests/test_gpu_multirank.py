@@ -204,6 +204,13 @@ def test_bench_launches_its_own_ranks_when_called_plainly(fake_rccl):
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["value"] > 0 and cb["unit"] == "beam-blocks/s" and cb["cores"] >= 1
     assert all("error" not in v for k, v in d["gather_modes"].items() if k != "note")
+    # every mode is verified after it is timed (checksums of the senders' rows against what the receivers hold), both transports
+    # of the freq-major layout included
+    modes = {k: v for k, v in d["gather_modes"].items() if k not in ("note", "none")}
+    assert set(modes) == {"root_rank_major", "root_freq_major", "root_freq_major_staged", "alltoall_rank_major",
+                          "alltoall_freq_major", "alltoall_freq_major_staged"}
+    assert all(v["verified"] is True and v["value"] > 0 for v in modes.values()), modes
+    assert d["value"] > 0 and "gather_error" not in d and "gloo" in d["config"]["control_plane"]
 
 
 def _plain_bench(env, *extra, timeout=600):
@@ -222,7 +229,7 @@ def test_bench_with_a_send_that_never_returns_still_prints_the_kernel_only_recor
 
     env = dict(os.environ, DSABF_RCCL_LIB=fake_rccl, DSABF_BENCH_ONE_GPU="1", FAKERCCL_MAILBOX_MB="64", FAKERCCL_HANG_SEND="1")
     t0 = time.time()
-    r = _plain_bench(env, "--gather-timeout", "5")
+    r = _plain_bench(env, "--gather-timeout", "4")
     took = time.time() - t0
     assert r.returncode != 0, (r.stdout + r.stderr)[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -251,16 +258,7 @@ def test_bench_catches_a_gather_that_delivers_wrong_bits(fake_rccl):
     assert d["gather_modes"]["alltoall_rank_major"]["verified"] is False and d["gather_modes"]["alltoall_rank_major"]["headline"] is True
     assert d["value"] is None and d["unverified_value"] > 0 and "other bits" in d["gather_error"]
     assert d["gather_modes"]["none"]["value"] > 0
-    # ... and the same run on an honest stand-in verifies every mode, both transports of the freq-major layout included
-    env.pop("FAKERCCL_CORRUPT")
-    r = _plain_bench(env)
-    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
-    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
-    modes = {k: v for k, v in d["gather_modes"].items() if k not in ("note", "none")}
-    assert set(modes) == {"root_rank_major", "root_freq_major", "root_freq_major_staged", "alltoall_rank_major",
-                          "alltoall_freq_major", "alltoall_freq_major_staged"}
-    assert all(v["verified"] is True and v["value"] > 0 for v in modes.values()), modes
-    assert d["value"] > 0 and "gather_error" not in d and "gloo" in d["config"]["control_plane"]
+    # (the same command on an honest stand-in verifies every mode: test_bench_launches_its_own_ranks_when_called_plainly)
 
 
 def test_plain_multi_gpu_request_on_this_one_gpu_box_is_refused_without_starting_anything():

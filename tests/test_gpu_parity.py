@@ -934,10 +934,10 @@ def test_grid_configuration_debug_flow_bit_identical(bfmod, orc, gpu):
     w = orc.make_weights(g, pos, dirs, gpu)
     for batch in range(4):
         packed = orc.generate_test_data(g, pos, src, gpu, batch_counter=batch)
-        out = orc.beamform(g, w, packed)                                   # [1024 units][8][256][256]
-        for u in range(0, 1024, 37):                                       # every 37th source of the batch + the last
-            assert np.array_equal(ded[batch * 1024 + u], orc.dedisperse(g, out[u])), (batch, u)
-        assert np.array_equal(ded[batch * 1024 + 1023], orc.dedisperse(g, out[1023]))
+        picks = list(range(0, 1024, 37)) + [1023]                          # every 37th source of the batch + the last
+        out = orc.beamform(g, w, np.ascontiguousarray(packed[picks]))      # (the oracle beamforms the sampled units only)
+        for k, u in enumerate(picks):
+            assert np.array_equal(ded[batch * 1024 + u], orc.dedisperse(g, out[k])), (batch, u)
 
 
 @pytest.mark.parametrize("paired", sweep(["default", "0"], ["default"]))
@@ -964,10 +964,11 @@ def test_random_array_debug_flow_bit_identical(bfmod, orc, monkeypatch, paired):
     w = orc.make_weights(g, pos, dirs, 3)
     for batch in range(4):
         packed = orc.generate_test_data(g, pos, src, 3, batch_counter=batch)
-        out = orc.beamform(g, w, packed)                                   # [1024 units][8][256][256]
         n_here = min(1024, 3721 - batch * 1024)
-        for u in list(range(0, n_here, 41)) + [n_here - 1]:
-            assert np.array_equal(ded[batch * 1024 + u], orc.dedisperse(g, out[u])), (batch, u)
+        picks = list(range(0, n_here, 41)) + [n_here - 1]
+        out = orc.beamform(g, w, np.ascontiguousarray(packed[picks]))      # (the oracle beamforms the sampled units only)
+        for k, u in enumerate(picks):
+            assert np.array_equal(ded[batch * 1024 + u], orc.dedisperse(g, out[k])), (batch, u)
 
 
 @pytest.mark.parametrize("mode,layout", sweep([("alltoall", "rank"), ("root", "rank"), ("alltoall", "freq"), ("root", "freq")],
@@ -985,7 +986,7 @@ def test_bench_rccl_gather_plumbing_on_one_gpu(mode, layout):
 
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29600 + (os.getpid() % 300)))
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--force-dist", "--gather", mode, "--layout", layout,
-                        "--units", "16", "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--min-warm-seconds", "0.2"],
+                        "--units", "4", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--min-warm-seconds", "0.1"],
                        capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
