@@ -790,9 +790,9 @@ def main():
         launch_bytes = bytes_per_block * blocks_per_step / world
         mfma_bound = args.workload != "c2"
         # committed rocprofv3 PMC summaries of exactly this launch (tools/pmc.sh), if any
-        pmc_name = {("c3", 128, True): "r04_c3_paired_pmc_summary.txt", ("c3", 128, False): "r04_c3_general_pmc_summary.txt",
-                    ("c5", 16, True): "r04_c5_pmc_summary.txt", ("c5", 16, False): "r04_c5_general_pmc_summary.txt",
-                    ("c2", 128, True): "r04_c2_pmc_summary.txt"}.get(
+        pmc_name = {("c3", 128, True): "r05_c3_paired_pmc_summary.txt", ("c3", 128, False): "r05_c3_general_pmc_summary.txt",
+                    ("c5", 16, True): "r05_c5_pmc_summary.txt", ("c5", 16, False): "r05_c5_general_pmc_summary.txt",
+                    ("c2", 128, True): "r05_c2_pmc_summary.txt"}.get(
             (args.workload, units, paired))
         pmc = pmc_summary(pmc_name) if (pmc_name and world == 1 and args.detect == "canonical") else {}
         if mfma_bound:
@@ -1095,7 +1095,7 @@ def main():
             # supplementary, never the headline, same inputs:
             if paired:
                 g = variant(0, "0")
-                gp = pmc_summary("r04_c3_general_pmc_summary.txt") if args.workload == "c3" and units == 128 else {}
+                gp = pmc_summary("r05_c3_general_pmc_summary.txt") if args.workload == "c3" and units == 128 else {}
                 g.update({"mfma_busy_frac": pmc_mfma_busy(gp), "note": "DSABF_PAIRED=0: the kernel any weight set without the "
                           "conjugate symmetry runs; every algorithmic int8 op executes on the MFMA pipe; same bits"})
                 out["general_kernel"] = g
@@ -1135,7 +1135,7 @@ def main():
             s5 = variant(0, wl="c5", n_units=16, reps=30)
             s5["workload"] = ("C5 shard: one of 8 ranks of BASELINE configs[4] = 128 freq x 512 beams x 100 ant x 2 pol, "
                               "N_TIME 256, 16 gemm-units per launch; beam-blocks here are 512 beams x 128 freq")
-            s5["pmc_source"] = "profiles/r04_c5_pmc_summary.txt is the whole-band launch (16 gemm-units x 1024 freq), not this shard"
+            s5["pmc_source"] = "profiles/r05_c5_pmc_summary.txt is the whole-band launch (16 gemm-units x 1024 freq), not this shard"
             out["c5_shard"] = s5
             # the same C3 shape with 256 antennas (four k-steps: the deep classes of fused16_kernel) -- the
             # detect is amortised over 4 x the MACs.  The linear fan is conjugate-symmetric (pair kernel); the calibrated set is not.

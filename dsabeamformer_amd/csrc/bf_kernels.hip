@@ -775,7 +775,15 @@ __global__ __launch_bounds__(256) void gather_relayout_kernel(const v4i* __restr
         if ((int)r == skip_rank) continue;
         const v4i* src = stage + blk * row_vec;
         v4i* dst = full + ((size_t)h * world + r) * row_vec;
-        for (unsigned v = threadIdx.x; v < row_vec; v += 256) __builtin_nontemporal_store(__builtin_nontemporal_load(src + v), dst + v);
+        unsigned v = threadIdx.x;
+        for (; v + 3 * 256 < row_vec; v += 4 * 256) {     // four 16-byte loads in flight per lane before the first store
+            v4i x[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) x[i] = __builtin_nontemporal_load(src + v + i * 256);
+#pragma unroll
+            for (int i = 0; i < 4; i++) __builtin_nontemporal_store(x[i], dst + v + i * 256);
+        }
+        for (; v < row_vec; v += 256) __builtin_nontemporal_store(__builtin_nontemporal_load(src + v), dst + v);
     }
 }
 
@@ -787,7 +795,7 @@ hipError_t launch_gather_relayout(const float* d_stage, float* d_full, size_t he
         return hipErrorInvalidValue;
     clear_stale_error();
     const size_t n_blocks = held * (size_t)world;
-    const size_t cap = (size_t)n_cus * 16;   // a few workgroups per CU keep enough 16-byte requests in flight to fill HBM
+    const size_t cap = (size_t)n_cus * 32;   // enough workgroups per CU to keep the 16-byte requests that fill HBM in flight
     hipLaunchKernelGGL(gather_relayout_kernel, dim3((unsigned)(n_blocks < cap ? n_blocks : cap)), dim3(256), 0, s,
                        reinterpret_cast<const v4i*>(d_stage), reinterpret_cast<v4i*>(d_full), (unsigned)held, (unsigned)world,
                        (unsigned)(row_floats / 4), skip_rank);

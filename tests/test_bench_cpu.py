@@ -22,13 +22,13 @@ def test_defaults_are_the_contract(monkeypatch):
 
 
 def test_committed_pmc_summaries_give_the_quoted_traffic_and_mfma_busy():
-    """roofline.traffic / mfma_busy_frac come from profiles/r04_*_pmc_summary.txt: the files must parse, and the derived
+    """roofline.traffic / mfma_busy_frac come from profiles/r05_*_pmc_summary.txt: the files must parse, and the derived
     numbers must be what DESIGN.md section 4 quotes (traffic within 1 % of the algorithmic bytes for C3 and C2)."""
-    c3 = bench.pmc_summary("r04_c3_paired_pmc_summary.txt")
-    gen = bench.pmc_summary("r04_c3_general_pmc_summary.txt")
-    c5 = bench.pmc_summary("r04_c5_pmc_summary.txt")
-    c5g = bench.pmc_summary("r04_c5_general_pmc_summary.txt")
-    c2 = bench.pmc_summary("r04_c2_pmc_summary.txt")
+    c3 = bench.pmc_summary("r05_c3_paired_pmc_summary.txt")
+    gen = bench.pmc_summary("r05_c3_general_pmc_summary.txt")
+    c5 = bench.pmc_summary("r05_c5_pmc_summary.txt")
+    c5g = bench.pmc_summary("r05_c5_general_pmc_summary.txt")
+    c2 = bench.pmc_summary("r05_c2_pmc_summary.txt")
     assert c3 and gen and c5 and c5g and c2
     # the general kernel of the 100-antenna geometry keeps the matrix pipe busy more than half the time (22 % of that on the
     # zero weights behind antenna 99); round 3: 3-fragment image, 8-wave workgroups, iterative-maxocc scheduling: 58 -> 63 %
@@ -231,12 +231,12 @@ def test_issue_model_says_what_binds_the_kernel():
     """from the committed PMC pass of the headline launch -- 17.2 VALU ops per MFMA, 13 + 2.45 K cycles of
     issue per MFMA account for the launch's cycles (the SIMDs' instruction issue is the bound, the matrix pipe is 29 % busy),
     and the clock the chip held."""
-    c3 = bench.pmc_summary("r04_c3_paired_pmc_summary.txt")
-    m = bench.issue_model(c3, 0.8896)
+    c3 = bench.pmc_summary("r05_c3_paired_pmc_summary.txt")
+    m = bench.issue_model(c3, 0.9475)
     assert abs(m["valu_per_mfma"] - 17.2) < 0.1 and abs(m["issue_model_cycles_per_mfma"] - (13 + 2.45 * m["valu_per_mfma"])) < 1e-9
     assert 0.9 < m["issue_occupancy"] < 1.05 and m["bound_measured"] == "simd-issue"
     assert 1.9 < m["clock_ghz_under_load"] < 2.2
-    gen = bench.issue_model(bench.pmc_summary("r04_c3_general_pmc_summary.txt"), 0.9975)
+    gen = bench.issue_model(bench.pmc_summary("r05_c3_general_pmc_summary.txt"), 1.05)
     assert 6.0 < gen["valu_per_mfma"] < 7.5 and gen["bound_measured"] in ("simd-issue", "unclear")
     assert bench.issue_model({}, 1.0) == {"bound_measured": None}
 
@@ -247,9 +247,9 @@ def test_committed_bench_lines_agree_with_the_committed_rocprof_kernel_stats():
     for rocprof, a profiled one: 5 %; 8 % for the 50-us launches of C2), and roofline.frac must follow from it."""
     import csv
 
-    for wl, stats, units_blocks in (("c3", "r04_c3_paired_kernel_stats.csv", 2048), ("c5", "r04_c5_kernel_stats.csv", 128),
-                                    ("c2", "r04_c2_kernel_stats.csv", 1024)):
-        line = [l for l in open(os.path.join(ROOT, "profiles", "r04_%s_bench.json" % wl)) if l.startswith("{")][-1]
+    for wl, stats, units_blocks in (("c3", "r05_c3_paired_kernel_stats.csv", 2048), ("c5", "r05_c5_kernel_stats.csv", 128),
+                                    ("c2", "r05_c2_kernel_stats.csv", 1024)):
+        line = [l for l in open(os.path.join(ROOT, "profiles", "r05_%s_bench.json" % wl)) if l.startswith("{")][-1]
         d = json.loads(line)
         roof = d["roofline"]
         rows = [r for r in csv.DictReader(open(os.path.join(ROOT, "profiles", stats))) if "fused16_kernel" in r["Name"]]
@@ -262,7 +262,9 @@ def test_committed_bench_lines_agree_with_the_committed_rocprof_kernel_stats():
         scale = 1e12 if roof["bound"] == "mfma" else 1e9
         assert abs(per_launch / (roof["kernel_ms_avg"] * 1e-3) / scale / roof["peak"] / roof["frac"] - 1) < 1e-6
         assert roof["traffic"] is not None and roof["pmc_source"].startswith("profiles/r0")
-        assert set(roof["from_committed_profile"]) == {"traffic", "mfma_busy_frac"}     # labelled: not observed in that run
+        # labelled: not observed in that run (round 5 adds what binds the kernel, from the same committed passes)
+        assert {"traffic", "mfma_busy_frac"} <= set(roof["from_committed_profile"]) <= {"traffic", "mfma_busy_frac", "valu_per_mfma",
+                                                                                        "issue_occupancy", "bound_measured", "clock_ghz_under_load"}
         assert d["ms_per_step"] >= roof["kernel_ms_avg"] * 0.999          # the whole step cannot be shorter than its kernel
         # the measured peak beside the nominal one, from the same run (a pure MFMA loop / a pure streaming kernel)
         assert 0.6 * roof["peak"] < roof["peak_measured"] <= roof["peak"] * 1.02
