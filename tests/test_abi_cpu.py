@@ -147,7 +147,7 @@ def test_headers_and_example_compile_as_plain_c(tmp_path):
     r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I" + os.path.join(ROOT, "include"), "-x", "c",
                         "-fsyntax-only", os.path.join(ROOT, "include", "dsabf_bench.h")], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
-    for name in ("minimal", "sharded"):     # single GPU; one rank of a frequency-sharded run (bf_comm_*, bf_gather_detected)
+    for name in ("minimal", "sharded", "dm_stream"):     # single GPU; one rank of a frequency-sharded run; the DM stage of the loop
         obj = tmp_path / (name + ".o")
         r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I" + os.path.join(ROOT, "include"),
                             "-c", os.path.join(ROOT, "examples", name + ".c"), "-o", str(obj)], capture_output=True, text=True)

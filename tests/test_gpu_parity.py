@@ -1086,16 +1086,18 @@ def test_observation_detected_stream_to_output_ring(bfmod, orc):
             assert np.array_equal(got[blk * 8 + u], want[u]), (blk, u)
 
 
-def test_plain_c_example_runs(tmp_path):
-    """examples/minimal.c (C99, streaming entry points of the C-ABI) built with hipcc against libdsabf.so and run."""
+@pytest.mark.parametrize("name", ["minimal", "dm_stream"])
+def test_plain_c_example_runs(tmp_path, name):
+    """examples/minimal.c (C99, streaming entry points of the C-ABI) and examples/dm_stream.c (the DM stage behind block launches,
+    every emitted sum checked in C against the host's own ascending-f chain) built with hipcc against libdsabf.so and run."""
     import subprocess
 
     from conftest import ROOT
 
-    exe = str(tmp_path / "minimal")
+    exe = str(tmp_path / name)
     pkg = os.path.join(ROOT, "dsabeamformer_amd")
     b = subprocess.run(["/opt/rocm/bin/hipcc", "-x", "c", "-std=c99", "-I" + os.path.join(ROOT, "include"),
-                        os.path.join(ROOT, "examples", "minimal.c"), "-o", exe, "-L" + pkg, "-ldsabf",
+                        os.path.join(ROOT, "examples", name + ".c"), "-o", exe, "-L" + pkg, "-ldsabf",
                         "-Wl,-rpath," + pkg], capture_output=True, text=True, timeout=300)
     assert b.returncode == 0, b.stderr
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)

@@ -4,6 +4,8 @@ import os
 import numpy as np
 import pytest
 
+from conftest import LONG
+
 pytestmark = pytest.mark.gpu
 
 
@@ -322,3 +324,64 @@ def test_beam_cli_dm_stage_single_gpu_and_two_loopback_ranks(orc, tmp_path):
         hdr, got, chunks = host.read_dm_file(str(out))
         assert int(hdr["N_FREQUENCIES"]) == 256 and sum(n for _, n in chunks) == T - D
         assert np.array_equal(got, orc.dedisperse_dm(series, delays, T - D)), world
+
+
+@pytest.mark.skipif(not LONG, reason="DSABF_LONG_TESTS=1: builds a PSRDADA-branch beam on the box (~20 s) and moves 3.6 GB through shared memory")
+def test_beam_reads_a_psrdada_style_ring_through_the_dada_adapter(orc, tmp_path):
+    """`beam -k baXX -w det.bin` built with -DDSABF_WITH_PSRDADA: the reference's own command line (src/beamformer.cu:66-75,132)
+    taking the dada_block_source branch -- connect, lock_read, every ring block page-locked with hipHostRegister (the reference's
+    dada_cuda_dbregister), 25 burn-in reads, the observation loop fed from the ring, the short block that ends it -- against
+    tests/support/fake_psrdada (a functional stand-in for the libpsrdada calls; not PSRDADA).  Production geometry (128 MiB
+    blocks); sampled gemm-units of the detected stream against the oracle."""
+    import ctypes as C
+    import subprocess
+    import threading
+
+    from test_host_cpu import _build_fake_psrdada
+
+    import dsabeamformer_amd as bfm
+    from dsabeamformer_amd import host
+
+    lib_path, link = _build_fake_psrdada(tmp_path)
+    from conftest import ROOT
+
+    exe = link(str(tmp_path / "beam_dada"), os.path.join(ROOT, "dsabeamformer_amd", "csrc", "beam_main.cpp"))
+    fake = C.CDLL(lib_path)
+    fake.fakedada_create.restype = C.c_void_p
+    fake.fakedada_create.argtypes = [C.c_uint, C.c_uint64, C.c_uint64, C.c_char_p]
+    fake.fakedada_write.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+    fake.fakedada_destroy.argtypes = [C.c_void_p]
+    cfg = bfm.production_config()
+    n_time = cfg.n_out_per_gemm * cfg.n_pol * cfg.n_avg
+    block_bytes = cfg.n_gemms_per_block * cfg.n_freq * n_time * cfg.n_ant
+    key, n_an = 0xBA00 + os.getpid() % 200, 3
+    w = fake.fakedada_create(key, 4, block_bytes, b"HDR_SIZE 4096\n")
+    assert w
+    rng = np.random.default_rng(21)
+    distinct = [rng.integers(0, 256, size=block_bytes, dtype=np.uint8) for _ in range(3)]
+    rc = []
+
+    def writer():
+        for i in range(25 + n_an):                 # BURNIN reads first (src/beamformer.cu:348-355), then the analysed blocks
+            rc.append(fake.fakedada_write(w, distinct[i % 3].ctypes.data_as(C.c_void_p), block_bytes))
+        rc.append(fake.fakedada_write(w, None, 0))
+
+    t = threading.Thread(target=writer)
+    t.start()
+    det = tmp_path / "det.bin"
+    try:
+        r = subprocess.run([exe, "-k", "%x" % key, "-w", str(det)], capture_output=True, text=True, timeout=900)
+        t.join(timeout=60)
+    finally:
+        fake.fakedada_destroy(w)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert rc == [0] * (25 + n_an + 1)
+    assert ("block size is: %d" % block_bytes) in r.stdout and "Burning IN" in r.stdout and "could not pin" not in r.stdout
+    assert ("Wrote %d gemm-units" % (n_an * cfg.n_gemms_per_block)) in r.stdout
+    _, data = host.read_detected_file(str(det))
+    g = orc.Geom(n_beams=256, n_ant=64, n_freq=256, n_avg=16, n_out_per_gemm=8)
+    wts = orc.make_weights(g, orc.default_positions(64), orc.default_directions(256), 0)
+    for gemm in (0, 31, 45, n_an * 32 - 1):
+        blk, ts = divmod(gemm, 32)
+        unit = distinct[(25 + blk) % 3].reshape(32, 256, n_time, 64)[ts][None]
+        assert np.array_equal(data[gemm], orc.beamform(g, wts, unit)[0]), gemm
