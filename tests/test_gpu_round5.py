@@ -4,8 +4,6 @@ import os
 import numpy as np
 import pytest
 
-from conftest import LONG
-
 pytestmark = pytest.mark.gpu
 
 
@@ -326,7 +324,6 @@ def test_beam_cli_dm_stage_single_gpu_and_two_loopback_ranks(orc, tmp_path):
         assert np.array_equal(got, orc.dedisperse_dm(series, delays, T - D)), world
 
 
-@pytest.mark.skipif(not LONG, reason="DSABF_LONG_TESTS=1: builds a PSRDADA-branch beam on the box (~20 s) and moves 3.6 GB through shared memory")
 def test_beam_reads_a_psrdada_style_ring_through_the_dada_adapter(orc, tmp_path):
     """`beam -k baXX -w det.bin` built with -DDSABF_WITH_PSRDADA: the reference's own command line (src/beamformer.cu:66-75,132)
     taking the dada_block_source branch -- connect, lock_read, every ring block page-locked with hipHostRegister (the reference's
