@@ -229,7 +229,7 @@ def test_bench_with_a_send_that_never_returns_still_prints_the_kernel_only_recor
 
     env = dict(os.environ, DSABF_RCCL_LIB=fake_rccl, DSABF_BENCH_ONE_GPU="1", FAKERCCL_MAILBOX_MB="64", FAKERCCL_HANG_SEND="1")
     t0 = time.time()
-    r = _plain_bench(env, "--gather-timeout", "4")
+    r = _plain_bench(env, "--gather-timeout", "3")
     took = time.time() - t0
     assert r.returncode != 0, (r.stdout + r.stderr)[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]

@@ -10,7 +10,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, sweep
+from conftest import GOLDEN, LONG, sweep
 
 pytestmark = pytest.mark.gpu
 
@@ -986,7 +986,8 @@ def test_bench_rccl_gather_plumbing_on_one_gpu(mode, layout):
 
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29600 + (os.getpid() % 300)))
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--force-dist", "--gather", mode, "--layout", layout,
-                        "--units", "4", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--min-warm-seconds", "0.1"],
+                        "--units", "4", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--min-warm-seconds", "0.1"] +
+                       ([] if LONG else ["--no-extras"]),      # (the side-by-side modes: the multi-rank tests and the LONG run)
                        capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
@@ -994,7 +995,11 @@ def test_bench_rccl_gather_plumbing_on_one_gpu(mode, layout):
     assert d["n_gpus"] == 1 and d["config"]["gather"].startswith(mode) and "C-ABI" in d["config"]["gather"]
     assert "gather_note" not in d["config"]          # the C-ABI communicator was created (no torch.distributed fallback)
     assert d["value"] > 0 and d["roofline"]["frac"] > 0.05 and d["roofline"]["unit"] == "TOP/s"
-    assert set(d["gather_modes"]) >= {"none", "root_rank_major", "root_freq_major", "alltoall_rank_major", "alltoall_freq_major"}
+    key = "%s_%s_major" % (mode, layout)
+    assert d["gather_modes"][key]["verified"] is True and d["gather_modes"][key]["headline"] is True and d["gather_modes"]["none"]["value"] > 0
+    assert d["rccl"]["ranks"] == 1 and d["rccl"]["version"] > 0 and "rccl" in d["rccl"]["lib"]      # the real library, one rank
+    if LONG:
+        assert set(d["gather_modes"]) >= {"none", "root_rank_major", "root_freq_major", "alltoall_rank_major", "alltoall_freq_major"}
 
 
 def test_bench_watchdog_prints_the_headline_when_the_supplementary_records_overrun():

@@ -458,7 +458,7 @@ def test_beam_sharded_mode_and_replica_launcher_on_one_gpu(tmp_path):
     assert "Shard 0 of 1: channels 0 .. 255" in out and "Wrote 64 gemm-units" in out
     a, b = open(plain, "rb").read(), open(shard, "rb").read()
     assert len(a) == len(b) == 4096 + 64 * 8 * 256 * 256 * 4 and a == b
-    for extra, name in (([], "rep_{i}.bin"), (["-S"], "shd_{i}.bin")):
+    for extra, name in ((([], "rep_{i}.bin"), (["-S"], "shd_{i}.bin")) if LONG else ((["-S"], "shd_{i}.bin"),)):
         r = subprocess.run([build.REPLICAS, "-n", "1"] + extra + ["-j", "27", "-w", str(tmp_path / name)],
                            capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stdout + r.stderr
