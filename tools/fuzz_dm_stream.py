@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""Randomised bit-exact parity run of the DM stage of the loop (bf_dm_stream, include/dsabf.h): a detected series pushed in
+random pieces on alternating HIP streams, the delay window carried over on the device, against ONE oracle call over the whole
+series.  Random series length, channels, beams (any multiple of 4), trial counts, delay tables (fine / coarse / mixed / random /
+constant: the wide kernel, the per-thread kernel and both in one call), push sizes from 1 row to the whole series; both kernel
+selections.  GPU box, repo root:  SEED=1 CASES=300 python tools/fuzz_dm_stream.py > gpurun_out/r05p/r05_fuzz_dm_stream.txt"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, ".")
+import dsabeamformer_amd as bfm  # noqa: E402
+import oracle as orc  # noqa: E402
+from dsabeamformer_amd import api  # noqa: E402
+
+seed, cases = int(os.environ.get("SEED", "1")), int(os.environ.get("CASES", "200"))
+rng = np.random.default_rng(seed)
+streams = [torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.current_stream()]
+bad, kinds, pushes_total = 0, {}, 0
+for case in range(cases):
+    n_f = int(rng.choice([1, 3, 8, 17, 32, 64, 100, 128]))
+    n_b = 4 * int(rng.integers(1, 80))
+    n_dm = int(rng.integers(1, 100))
+    n_t = int(rng.integers(30, 400))
+    kind = str(rng.choice(["fine", "coarse", "mixed", "random", "constant"]))
+    slope = np.linspace(1.0, 0.0, n_f) ** 2 if n_f > 1 else np.ones(1)
+    if kind == "fine":
+        d = np.arange(n_dm)[:, None] * rng.uniform(0.2, 2.0) * slope[None, :]
+    elif kind == "coarse":
+        d = np.arange(n_dm)[:, None] * rng.uniform(3.0, 8.0) * slope[None, :]
+    elif kind == "mixed":
+        step = np.where(rng.random(n_dm) < 0.1, rng.uniform(5, 20), rng.uniform(0.2, 1.5))
+        d = np.cumsum(step)[:, None] * slope[None, :]
+    elif kind == "random":
+        d = rng.integers(0, 40, size=(n_dm, n_f)).astype(float)
+    else:
+        d = np.full((n_dm, n_f), float(rng.integers(0, 5)))
+    delays = np.ascontiguousarray(np.minimum(d, n_t - 2).astype(np.int32))     # (a streamed dedispersion needs delays >= 0)
+    D = int(delays.max())
+    max_rows = int(rng.choice([1, 7, 16, 32, 64, n_t]))
+    series = (rng.random((n_t, n_f, n_b), dtype=np.float32) * 1e3).astype(np.float32)
+    want = orc.dedisperse_dm(series, delays, n_t - D)
+    bf = bfm.Beamformer(bfm.debug_config(n_beams=n_b, n_freq=n_f))
+    d_series = torch.from_numpy(series).cuda()
+    row_bytes = n_f * n_b * 4
+    for mode in ("shared", "thread"):
+        bf.set_switch("dm_wide", 0 if mode == "thread" else 1)
+        dm = api.DmStream(bf, delays, n_f, max_rows)
+        host = torch.full((n_dm * max_rows * n_b,), float("nan"), dtype=torch.float32).pin_memory()
+        parts, at, pushed, k, ok = [], 0, 0, 0, True
+        while pushed < n_t:
+            n = min(int(rng.integers(1, max_rows + 1)), n_t - pushed)
+            st = streams[int(rng.integers(0, len(streams)))]
+            first, n_out = dm.push(d_series.data_ptr() + pushed * row_bytes, n, host, st.cuda_stream)
+            ok &= first == at and n_out == max(0, pushed + n - D) - max(0, pushed - D)
+            st.synchronize()
+            if n_out:
+                parts.append(host[:n_dm * n_out * n_b].numpy().reshape(n_dm, n_out, n_b).copy())
+            at += n_out
+            pushed += n
+            k += 1
+        pushes_total += k
+        got = np.concatenate(parts, axis=1) if parts else np.zeros((n_dm, 0, n_b), np.float32)
+        if not ok or got.shape != want.shape or not np.array_equal(got, want):
+            bad += 1
+            print("MISMATCH case %d mode %s kind %s n_t %d n_f %d n_b %d n_dm %d D %d max_rows %d" % (case, mode, kind, n_t, n_f, n_b, n_dm, D, max_rows))
+        dm.close()
+    kinds[kind] = kinds.get(kind, 0) + 1
+    bf.close()
+print("seed %d cases %d (x 2 kernel selections, %d pushes) mismatches %d kinds %s" % (seed, cases, pushes_total, bad, kinds))
+sys.exit(1 if bad else 0)

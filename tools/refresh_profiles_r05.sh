@@ -33,6 +33,7 @@ rm -rf $O/prof_c5g
 (cd $R && bash tools/pmc.sh r05p/pmc_c5g --workload c5 --units 16 > /dev/null 2>&1 && cp $O/pmc_c5g/summary.txt $O/r05_c5_general_pmc_summary.txt; rm -rf $O/pmc_c5g)
 unset DSABF_PAIRED
 cd $R
+SEED=51 CASES=300 python tools/fuzz_dm_stream.py > $O/r05_fuzz_dm_stream.txt 2>&1
 # the GPU suite: the budgeted default run with its durations, then every case
 python -m pytest tests -m gpu -q --durations=25 -p no:cacheprovider > $O/r05_gputest_durations.txt 2>&1
 DSABF_LONG_TESTS=1 python -m pytest tests -m gpu -q -p no:cacheprovider 2>&1 | tail -4 > $O/r05_gputest_long_tail.txt
