@@ -695,7 +695,13 @@ def main():
             ev_pair[1].record(stream)
         gm.after_kernel(slot)
 
+    closing = {}      # the last timed region's cost of the closing barrier (reported, not part of the step time)
+
     def timed_region(gm, n_steps, with_events):
+        """K steps between (barrier + synchronize) and (synchronize + barrier).  Every rank reads its clock when ITS K steps are
+        complete on the device (drain = synchronize: with a gather that includes what it had to receive); the job's time is the MAX
+        over ranks.  The closing barrier -- the MAX all-reduce itself, on the control plane -- is bookkeeping: its own latency
+        (a loopback TCP round of gloo, of the order of a whole step at N = 8) is measured beside it, not charged to the steps."""
         events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_steps)] if with_events else None
         if dist is not None:
             dist.barrier()
@@ -703,14 +709,13 @@ def main():
         t0 = time.perf_counter()
         for i in range(n_steps):
             step(i, gm, events[i] if events else None)
-        gm.drain()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+        gm.drain()                                   # torch.cuda.synchronize(): this rank's K steps are complete
         elapsed = time.perf_counter() - t0
         if dist is not None:
             t = torch.tensor([elapsed], dtype=torch.float64, device=dist_dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)  # the closing barrier: nobody leaves before everybody has finished
+            torch.cuda.synchronize()
+            closing["ms"] = (time.perf_counter() - t0 - elapsed) * 1e3
             elapsed = float(t.item())
         return elapsed, events
 
@@ -934,6 +939,8 @@ def main():
 
     def mode_record(el, n_steps, ev=None):
         rec = {"value": n_steps * blocks_per_step / el, "unit": "beam-blocks/s", "ms_per_step": el / n_steps * 1e3, "steps": n_steps}
+        if "ms" in closing:
+            rec["closing_barrier_ms"] = closing["ms"]      # rank 0's wait in the MAX all-reduce behind its own K steps
         if ev:
             ms = [a.elapsed_time(b) for a, b in ev]
             rec["kernel_ms_avg"] = sum(ms) / len(ms)
