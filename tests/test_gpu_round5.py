@@ -382,3 +382,35 @@ def test_beam_reads_a_psrdada_style_ring_through_the_dada_adapter(orc, tmp_path)
         blk, ts = divmod(gemm, 32)
         unit = distinct[(25 + blk) % 3].reshape(32, 256, n_time, 64)[ts][None]
         assert np.array_equal(data[gemm], orc.beamform(g, wts, unit)[0]), gemm
+
+
+def test_dm_stream_argument_errors(torch, bfmod):
+    """bf_dm_stream_*: return codes + bf_last_error instead of undefined behaviour -- negative delays (a streamed dedispersion
+    cannot look back before the first row), sizes out of range, NULL arguments."""
+    import ctypes as C
+
+    from dsabeamformer_amd import api
+    from dsabeamformer_amd._lib import DsabfError, load
+
+    bf = bfmod.Beamformer(bfmod.debug_config(n_beams=64, n_freq=8))
+    good = np.zeros((3, 8), np.int32)
+    for delays, n_f, rows, text in ((np.full((3, 8), -1, np.int32), 8, 4, "delays >= 0"), (good, 8, 0, "max_rows_per_push")):
+        with pytest.raises(DsabfError) as e:
+            api.DmStream(bf, delays, n_f, rows)
+        assert text in str(e.value), str(e.value)
+    lib = load()
+    s = C.c_void_p()
+    assert lib.bf_dm_stream_create(None, good.ctypes.data_as(C.c_void_p), 3, 8, 4, C.byref(s)) == -1 and not s.value
+    dm = api.DmStream(bf, good, 8, 4)
+    d_rows = torch.zeros(8 * 8 * 64, device="cuda")
+    for n in (0, 5):                                            # more rows than max_rows_per_push
+        with pytest.raises(DsabfError) as e:
+            dm.push(d_rows, n)
+        assert "n_rows must be 1 .. 4" in str(e.value)
+    assert lib.bf_dm_stream_push(dm._s, None, 1, None, None, None, None) == -1
+    first, n_out = dm.push(d_rows, 4)                           # all delays 0: every row is complete at once
+    assert (first, n_out) == (0, 4) and dm.max_delay == 0 and dm.output_device() != 0
+    torch.cuda.synchronize()
+    dm.close()
+    assert lib.bf_dm_stream_destroy(None) == 0 and lib.bf_dm_stream_max_delay(None) == -1
+    bf.close()
