@@ -301,8 +301,12 @@ def test_beam_cli_dm_stage_single_gpu_and_two_loopback_ranks(orc, tmp_path):
             assert r.returncode == 0, r.stdout + r.stderr
             outs = [r.stdout]
         else:
-            env = dict(os.environ, DSABF_RCCL_LIB=FAKE)
-            cmd = lambda rk: [build.BEAM] + common + ["-R", "2", "-r", str(rk), "-I", str(tmp_path / "id")] + (["-W", str(out)] if rk == 0 else [])  # noqa: E731
+            # (the shards' powers travel by the STAGED transport here -- one message per sender + the device re-layout pass inside
+            #  run_observation; the in-place transport: tests/test_gpu_multirank.py::test_beam_sharded_over_two_ranks_...) -- and
+            #  the root keeps the detected stream as well (-w): both sinks behind one loop
+            env = dict(os.environ, DSABF_RCCL_LIB=FAKE, DSABF_GATHER_STAGED="1")
+            det = tmp_path / "det_w2.bin"
+            cmd = lambda rk: [build.BEAM] + common + ["-R", "2", "-r", str(rk), "-I", str(tmp_path / "id")] + (["-W", str(out), "-w", str(det)] if rk == 0 else [])  # noqa: E731
             procs = [subprocess.Popen(cmd(rk), env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for rk in (0, 1)]
             outs = [p.communicate(timeout=900)[0] for p in procs]
             assert all(p.returncode == 0 for p in procs), "\n".join(outs)
@@ -322,6 +326,9 @@ def test_beam_cli_dm_stage_single_gpu_and_two_loopback_ranks(orc, tmp_path):
         hdr, got, chunks = host.read_dm_file(str(out))
         assert int(hdr["N_FREQUENCIES"]) == 256 and sum(n for _, n in chunks) == T - D
         assert np.array_equal(got, orc.dedisperse_dm(series, delays, T - D)), world
+        if world == 2:
+            raw = np.fromfile(det, np.float32, offset=4096).reshape(T, 256, 256)      # [gemm][o] = time rows of the whole band
+            assert np.array_equal(raw, series)
 
 
 def test_beam_reads_a_psrdada_style_ring_through_the_dada_adapter(orc, tmp_path):
