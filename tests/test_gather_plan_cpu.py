@@ -68,6 +68,23 @@ def test_simulated_gather_reproduces_the_full_band(world, layout, root):
             assert np.array_equal(buf.reshape(held, world * f_local, n_beams), full_ofb[first:first + held])
         else:
             assert np.array_equal(buf.reshape(world, held, f_local, n_beams), np.stack([x[first:first + held] for x in local]))
+    # ---- the STAGED transport of the freq-major layout (bf_gather_detected_staged, round 5): what arrived rank-major is moved by
+    # one device pass, full[bf_gather_offset(FREQ, rank, row)] = stage[bf_gather_offset(RANK, rank, row)] for every sender but the
+    # receiver itself, whose rows are copied straight from its own output -- the result is the reference's [o][f][b]
+    if layout == RANK_MAJOR:
+        for dst, stage in got.items():
+            held = lib.bf_gather_rows_held(n_rows, world, dst, root)
+            first = dst * held if root == -2 else 0
+            full = np.full(world * held * row_floats, np.nan, np.float32)
+            for r in range(world):
+                for row in range(held):
+                    to = lib.bf_gather_offset(FREQ_MAJOR, held, row_floats, world, r, row)
+                    if r == dst:                              # own rows: never staged
+                        full[to:to + row_floats] = local[dst][first + row].ravel()
+                    else:
+                        frm = lib.bf_gather_offset(RANK_MAJOR, held, row_floats, world, r, row)
+                        full[to:to + row_floats] = stage[frm:frm + row_floats]
+            assert np.array_equal(full.reshape(held, world * f_local, n_beams), full_ofb[first:first + held])
     # message counts: one per sender for the rank-major layout, one per (row, sender) for [o][f][b]
     r0 = root if root >= 0 else 0
     n_recv = len([m for m in plans[r0] if m[0] == RECV])
