@@ -33,6 +33,8 @@ def child(a):
         cfg.n_freq = a.n_freq          # e.g. 128: one rank's shard of BASELINE configs[4]
     if a.n_beams:
         cfg.n_beams = a.n_beams
+    if a.n_ant:
+        cfg.n_ant = a.n_ant            # e.g. 128 with --workload c5: the full two-k-step class
     if not a.paired:
         os.environ["DSABF_PAIRED"] = "0"
     bf = bfm.Beamformer(cfg)
@@ -73,6 +75,7 @@ def main():
     ap.add_argument("--units", type=int, default=0)
     ap.add_argument("--n-freq", type=int, default=0)
     ap.add_argument("--n-beams", type=int, default=0)
+    ap.add_argument("--n-ant", type=int, default=0)
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--launches", type=int, default=150)
     ap.add_argument("--warm", type=float, default=1.0)
@@ -94,7 +97,7 @@ def main():
     for r in range(a.rounds):
         for name, env in variants:
             cmd = [sys.executable, os.path.abspath(__file__), "--child", "--workload", a.workload, "--paired", str(a.paired),
-                   "--detect", a.detect, "--weights", a.weights, "--units", str(a.units), "--n-freq", str(a.n_freq), "--n-beams", str(a.n_beams), "--launches", str(a.launches),
+                   "--detect", a.detect, "--weights", a.weights, "--units", str(a.units), "--n-freq", str(a.n_freq), "--n-beams", str(a.n_beams), "--n-ant", str(a.n_ant), "--launches", str(a.launches),
                    "--warm", str(a.warm)]
             p = subprocess.run(cmd, env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
             try:
