@@ -937,8 +937,18 @@ def main():
     headline_mode = none_mode
     gather_modes = {}
 
-    def mode_record(el, n_steps, ev=None):
+    def mode_record(el, n_steps, ev=None, gm=None):
         rec = {"value": n_steps * blocks_per_step / el, "unit": "beam-blocks/s", "ms_per_step": el / n_steps * 1e3, "steps": n_steps}
+        if gm is not None and gm.mode != "none" and world > 1:
+            # what the fabric carries: a sender's bytes per step (root: everything it computed; alltoall: all but its own rows)
+            sent = out_floats * 4 * (1.0 if gm.mode == "root" else (world - 1) / world)
+            one_per_pair = gm.layout == "rank" or gm.transport == "staged"      # else: one message per (row, sender), in place
+            if gm.mode == "root":
+                msgs = 1 if one_per_pair else n_rows                            # a sender -> the root
+            else:
+                msgs = (world - 1) * (1 if one_per_pair else n_rows // world)   # a sender -> every other owner
+            rec.update({"bytes_sent_per_rank_per_step": sent, "send_gbs_per_rank": sent / (el / n_steps) / 1e9,
+                        "messages_sent_per_rank_per_step": msgs})
         if "ms" in closing:
             rec["closing_barrier_ms"] = closing["ms"]      # rank 0's wait in the MAX all-reduce behind its own K steps
         if ev:
@@ -985,7 +995,7 @@ def main():
         verified = None if args.no_verify else gather_stage(tag + ": verification", lambda: verify(headline_mode))
         deadline.stage("record of the headline", stage_s)
         out = build_record(elapsed, events, extra_warm)
-        gather_modes[headline_mode.key] = mode_record(elapsed, args.steps, events)
+        gather_modes[headline_mode.key] = mode_record(elapsed, args.steps, events, headline_mode)
         gather_modes[headline_mode.key].update({"verified": verified, "headline": True})
         if rank == 0:
             out["gather_modes"] = gather_modes
@@ -1018,7 +1028,7 @@ def main():
                     step(i, gm)
                 gm.drain()
                 el, _ = timed_region(gm, n_side, False)
-                gather_modes[gm.key] = mode_record(el, n_side)
+                gather_modes[gm.key] = mode_record(el, n_side, None, gm)
                 if not args.no_verify:
                     gather_modes[gm.key]["verified"] = verify(gm)
                     if gather_modes[gm.key]["verified"] is False:

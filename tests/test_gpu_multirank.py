@@ -176,6 +176,13 @@ def test_bench_with_two_ranks_on_one_gpu(fake_rccl, gather, n):
         assert "error" not in modes[k] and modes[k]["value"] > 0, (k, modes[k])
         assert k == "none" or modes[k]["verified"] is True, (k, modes[k])
     assert modes["%s_rank_major" % gather]["headline"] is True and d["kernel_only"]["value"] == modes["none"]["value"]
+    # what the fabric carries per sender and step: one message per (sender, receiver) pair for the rank-major wire and the staged
+    # transport, one per (row, sender) for the reference's layout received in place
+    n_rows = d["config"]["beam_blocks_per_step"]
+    assert modes["alltoall_freq_major"]["messages_sent_per_rank_per_step"] == (n - 1) * (n_rows // n)
+    assert modes["alltoall_freq_major_staged"]["messages_sent_per_rank_per_step"] == modes["alltoall_rank_major"]["messages_sent_per_rank_per_step"] == n - 1
+    assert modes["root_freq_major"]["messages_sent_per_rank_per_step"] == n_rows and modes["root_freq_major_staged"]["messages_sent_per_rank_per_step"] == 1
+    assert modes["alltoall_rank_major"]["bytes_sent_per_rank_per_step"] == n_rows * (256 // n) * 256 * 4 * (n - 1) / n
 
 
 def test_bench_launches_its_own_ranks_when_called_plainly(fake_rccl):
