@@ -3,7 +3,8 @@
 # Runs separate rocprofv3 --pmc passes (never combined with trace domains) and leaves CSVs under gpurun_out/<outdir>/.
 R=$PWD; OUT=$R/gpurun_out/$1; shift
 mkdir -p $OUT; export TMPDIR=/tmp; cd /tmp
-ARGS="--steps 6 --warmup 2 --no-cpu-baseline --no-extras $@"
+ARGS="${PMC_BENCH_ARGS:---steps 6 --warmup 2 --no-cpu-baseline --no-extras} $@"   # PMC_BENCH_ARGS: e.g. without --no-extras for the auxiliary kernels
+export PMC_FILTER="${PMC_FILTER:-fused|expand_kernel}"                            # kernels kept in the summary (regex on the name)
 i=0
 for C in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_VALU_MFMA_I8 SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY" \
          "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_VALU_MFMA_COEXEC_CYCLES SQ_INSTS_LDS SQ_INSTS_SALU" \
@@ -14,13 +15,14 @@ for C in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_VALU_MFMA_I8 SQ_V
 done
 cd $R
 python3 - "$OUT" <<'PY'
-import csv, glob, sys, collections
+import csv, glob, sys, collections, os, re
+keep = re.compile(os.environ.get("PMC_FILTER", "fused|expand_kernel"))
 out = sys.argv[1]
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(out + "/pass*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        if "fused" not in k and "expand_kernel" not in k: continue
+        if not keep.search(k): continue
         agg[k.split("(")[0][-60:]][r["Counter_Name"]].append(float(r["Counter_Value"]))
         # the dispatch's own duration in the pass that counted the cycles: clock = GRBM_GUI_ACTIVE / 8 / this
         if r["Counter_Name"] == "GRBM_GUI_ACTIVE" and r.get("Start_Timestamp") and r.get("End_Timestamp"):

@@ -32,6 +32,12 @@ find $O/prof_c5g -name "*kernel_stats.csv" | head -1 | xargs -I{} sh -c "grep -E
 rm -rf $O/prof_c5g
 (cd $R && bash tools/pmc.sh r05p/pmc_c5g --workload c5 --units 16 > /dev/null 2>&1 && cp $O/pmc_c5g/summary.txt $O/r05_c5_general_pmc_summary.txt; rm -rf $O/pmc_c5g)
 unset DSABF_PAIRED
+# the auxiliary kernels of the round: the staged transport's re-layout pass (and the DM kernels beside it), from a bench run WITH its
+# supplementary records: kernel trace + HBM traffic counters
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_aux -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/prof_aux.log 2>&1
+find $O/prof_aux -name "*kernel_stats.csv" | head -1 | xargs -I{} sh -c "grep -E 'Name|gather_relayout|dedisperse' {} > $O/r05_aux_kernel_stats.csv"
+rm -rf $O/prof_aux
+(cd $R && PMC_FILTER="gather_relayout" PMC_BENCH_ARGS="--steps 3 --warmup 1 --no-cpu-baseline" bash tools/pmc.sh r05p/pmc_aux > /dev/null 2>&1 && cp $O/pmc_aux/summary.txt $O/r05_relayout_pmc_summary.txt; rm -rf $O/pmc_aux)
 cd $R
 SEED=51 CASES=300 python tools/fuzz_dm_stream.py > $O/r05_fuzz_dm_stream.txt 2>&1
 # the GPU suite: the budgeted default run with its durations, then every case
