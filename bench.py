@@ -1306,14 +1306,15 @@ def main():
             # the device pass of the staged gather transport by itself, at the shape one receiver of BASELINE configs[3] sees in
             # the distributed-owner gather: 8 ranks, 2048 / 8 = 256 rows held, 32 channels x 256 beams per row and sender
             w8, held, rf = 8, (units * n_out) // 8, (256 // 8) * cfg.n_beams
-            d_st = torch.rand(w8 * held * rf, device="cuda")
-            d_fu = torch.empty(w8 * held * rf, device="cuda")
-            one = lambda i: bf.gather_relayout(d_st, d_fu, held, w8, rf, 0, sptr)  # noqa: E731
+            NB = 4         # distinct buffer pairs cycled (4 x 117 MB: the 256 MiB Infinity Cache cannot hold the stream)
+            d_sts = [torch.rand(w8 * held * rf, device="cuda") for _ in range(NB)]
+            d_fus = [torch.empty(w8 * held * rf, device="cuda") for _ in range(NB)]
+            d_st, d_fu = d_sts[0], d_fus[0]
             REP = 8        # launches between one pair of HIP events: a 20-us kernel would otherwise carry the events' own 2-3 us
 
             def fn(i):
-                for _ in range(REP):
-                    one(i)
+                for k in range(REP):
+                    bf.gather_relayout(d_sts[k % NB], d_fus[k % NB], held, w8, rf, 0, sptr)
             for i in range(5):
                 fn(i)
             torch.cuda.synchronize()
