@@ -18,7 +18,9 @@
 //                                                   Theory.ipynb from 0 to dm_max (at most n_dm of its trials, evenly picked),
 //                                                   every analysed block through a bf_dm_stream with the delay window carried
 //                                                   over on the device, chunks [dm][t][beam] to dm_file.  With -R: on the
-//                                                   gather root, over the gathered band.
+//                                                   gather root, over the gathered band.  With -R and -X: the shards' powers go to
+//                                                   EVERY rank (the one collective becomes an all-gather) and rank r dedisperses its
+//                                                   share of the ladder, writing dm_file.<r>: the DM work scales with the GPUs.
 //
 // With the reference's `make debug` geometry (default) it generates synthetic point-source voltages on the CPU,
 // streams them through the observation loop and writes bin/data.py (dedispersed beam responses, one row per source)
@@ -55,10 +57,11 @@ int main(int argc, char* argv[])
     std::string id_file;
     double dm_max = 0.0, tsamp_ms = 0.131;   // (the notebook's sample time, cell 5)
     int n_dm_cap = 0;
+    bool dm_split = false;
     std::string dm_path;
 
     int arg = 0;
-    while ((arg = getopt(argc, argv, "s:g:p:d:o:D:a:c:k:K:j:w:R:r:I:M:N:T:W:uvh")) != -1) {  // src/beamformer.cu:41-43 (+ -o -D -a -v)
+    while ((arg = getopt(argc, argv, "s:g:p:d:o:D:a:c:k:K:j:w:R:r:I:M:N:T:W:Xuvh")) != -1) {  // src/beamformer.cu:41-43 (+ -o -D -a -v)
         switch (arg) {
             case 's': sources = optarg; break;                 // :77-89
             case 'g': opt.gpu = atoi(optarg); break;           // :92-100
@@ -77,6 +80,7 @@ int main(int argc, char* argv[])
             case 'N': n_dm_cap = atoi(optarg); break;
             case 'T': tsamp_ms = atof(optarg); break;
             case 'W': dm_path = optarg; break;
+            case 'X': dm_split = true; break;
             case 'u': per_unit = true; break;                   // the reference's launch pattern: one launch per gemm-unit
             case 'v': opt.verbose = true; cfg.verbose = 1; break;
             case 'c': core = atoi(optarg); break;              // :59-65
@@ -241,8 +245,19 @@ int main(int argc, char* argv[])
                       << tsamp_ms << " ms" << std::endl;
             oopt.dm_delays = delays.data();
             oopt.n_dm = n_dm;
-            if (!dm_path.empty() && (!comm || rank == 0)) {
-                dm_sink.reset(new dm_file_sink(pcfg, full_cfg.n_freq, n_dm, dmax, dm_path.c_str(), opt.gpu));
+            int my_first = 0, my_count = n_dm;
+            if (dm_split && comm) {       // -X: every rank receives the band and takes its share of the trials
+                oopt.gather_root = BF_GATHER_ROOT_ALL;
+                oopt.dm_split_trials = true;
+                my_count = n_dm / world + (rank < n_dm % world ? 1 : 0);
+                my_first = rank * (n_dm / world) + (rank < n_dm % world ? rank : n_dm % world);
+                dmax = 0;
+                for (size_t i = (size_t)my_first * full_cfg.n_freq; i < (size_t)(my_first + my_count) * full_cfg.n_freq; i++) dmax = delays[i] > dmax ? delays[i] : dmax;
+                if (!dm_path.empty()) dm_path += "." + std::to_string(rank);
+                std::cout << "Shard " << rank << " dedisperses trials " << my_first << " .. " << my_first + my_count - 1 << std::endl;
+            }
+            if (!dm_path.empty() && my_count > 0 && (!comm || rank == 0 || oopt.dm_split_trials)) {
+                dm_sink.reset(new dm_file_sink(pcfg, full_cfg.n_freq, my_count, dmax, dm_path.c_str(), opt.gpu, my_first));
                 if (!dm_sink->is_open()) {
                     fprintf(stderr, "beam: could not open %s\n", dm_path.c_str());
                     return EXIT_FAILURE;
@@ -253,7 +268,7 @@ int main(int argc, char* argv[])
         observation_result ores;
         int orc = run_observation(pcfg, oopt, *src, pos.data(), dir.data(), &ores, std::cout);
         if (sink) std::cout << "Wrote " << sink->get_delivered() << " gemm-units of detected powers to " << sink_name << std::endl;
-        if (dm_sink) std::cout << "Wrote " << dm_sink->get_times_written() << " dedispersed samples x " << n_dm << " trials to " << dm_path << std::endl;
+        if (dm_sink) std::cout << "Wrote " << dm_sink->get_times_written() << " dedispersed samples x " << (oopt.dm_split_trials ? n_dm / world + (rank < n_dm % world ? 1 : 0) : n_dm) << " trials to " << dm_path << std::endl;
         bf_comm_destroy(comm);
         if (orc != BF_OK) {
             fprintf(stderr, "GPUassert: %s (%d)\n", bf_last_error(), orc);

@@ -404,18 +404,22 @@ int run_observation(const bf_config& cfg, const observation_options& opt, block_
 {
     const int n_streams = cfg.n_streams;
     if (cfg.n_gemms_per_block % n_streams) return BF_ERR_INVALID;
-    if (opt.world < 1 || opt.rank < 0 || opt.rank >= opt.world || opt.gather_root < 0 || opt.gather_root >= opt.world)
-        return set_error(BF_ERR_INVALID, "run_observation: need 0 <= rank, gather_root < world");
+    if (opt.world < 1 || opt.rank < 0 || opt.rank >= opt.world || opt.gather_root < BF_GATHER_ROOT_ALL || opt.gather_root >= opt.world)
+        return set_error(BF_ERR_INVALID, "run_observation: need 0 <= rank < world and gather_root a rank or BF_GATHER_ROOT_ALL");
+    // who holds the gathered band after every block: one rank, or (BF_GATHER_ROOT_ALL) every rank
+    const bool is_root = !opt.comm || opt.gather_root == BF_GATHER_ROOT_ALL || opt.rank == opt.gather_root;
     if (opt.comm && (bf_comm_rank(opt.comm) != opt.rank || bf_comm_world(opt.comm) != opt.world))
         return set_error(BF_ERR_INVALID, "run_observation: the communicator's rank / world differ from the options'");
     if (opt.comm && !opt.block_launch)
         return set_error(BF_ERR_INVALID, "run_observation: the sharded gather needs block-granular launches");
-    if (opt.comm && opt.sink && opt.rank != opt.gather_root)
+    if (opt.comm && opt.sink && !is_root)
         return set_error(BF_ERR_INVALID, "run_observation: only the gather root may have a sink");
     if (opt.dm_delays && opt.n_dm <= 0) return set_error(BF_ERR_INVALID, "run_observation: dm_delays without n_dm");
     if (opt.dm_sink && !opt.dm_delays) return set_error(BF_ERR_INVALID, "run_observation: a dm_sink needs dm_delays");
-    if (opt.comm && opt.dm_sink && opt.rank != opt.gather_root)
+    if (opt.comm && opt.dm_sink && !is_root)
         return set_error(BF_ERR_INVALID, "run_observation: only the gather root may have a dm_sink");
+    if (opt.dm_split_trials && (!opt.comm || opt.gather_root != BF_GATHER_ROOT_ALL))
+        return set_error(BF_ERR_INVALID, "run_observation: dm_split_trials needs a sharded run gathered to every rank (BF_GATHER_ROOT_ALL)");
     source.read_headers();  // :334 (before the device exists here: the block-size check below needs no GPU)
     const size_t block_bytes = bf_bytes_per_block(&cfg);
     if (source.get_block_size() != block_bytes) {
@@ -487,7 +491,17 @@ int run_observation(const bf_config& cfg, const observation_options& opt, block_
     bool staged = opt.gather_staged;
     if (const char* e = getenv("DSABF_GATHER_STAGED")) staged = e[0] == '1';
     // ---- the DM stage: where the reference's loop has its frequency collapse, src/beamformer.cu:492-511 ----
-    const bool dm_here = opt.dm_delays && (!opt.comm || opt.rank == opt.gather_root);   // a sharded run dedisperses the gathered band
+    const bool dm_here = opt.dm_delays && is_root;   // a sharded run dedisperses the gathered band
+    // dm_split_trials: every rank holds the whole band (one all-gather instead of a gather) and takes ITS share of the trial ladder --
+    // the DM work scales with the GPUs, the path still has ONE collective; rank r: trials [r n / R, (r + 1) n / R), the first n % R
+    // ranks one more
+    int dm_first = 0, dm_count = opt.n_dm;
+    if (opt.dm_split_trials) {
+        const int base_n = opt.n_dm / opt.world, extra = opt.n_dm % opt.world;
+        dm_count = base_n + (opt.rank < extra ? 1 : 0);
+        dm_first = opt.rank * base_n + std::min(opt.rank, extra);
+    }
+    const int n_freq_band = cfg.n_freq * (opt.comm ? opt.world : 1);
     const int dm_rows = upl * cfg.n_out_per_gemm;                                       // beam-blocks per launch = rows per push
     struct dm_chunk {
         uint64_t block, first_t;
@@ -498,8 +512,9 @@ int run_observation(const bf_config& cfg, const observation_options& opt, block_
     std::vector<float*> dm_host;                // pinned chunk buffers, used round robin
     uint64_t dm_seq = 0, dm_times = 0, dm_chunks = 0;
     if (opt.dm_delays && !block_launch) return set_error(BF_ERR_INVALID, "run_observation: the DM stage needs block-granular launches");
-    if (dm_here) {
-        if ((rc = bf_dm_stream_create(h, opt.dm_delays, opt.n_dm, cfg.n_freq * (opt.comm ? opt.world : 1), dm_rows, &g.dm)) != BF_OK) {
+    const bool dm_run = dm_here && dm_count > 0;      // (more ranks than trials: the surplus ranks only beamform)
+    if (dm_run) {
+        if ((rc = bf_dm_stream_create(h, opt.dm_delays + (size_t)dm_first * n_freq_band, dm_count, n_freq_band, dm_rows, &g.dm)) != BF_OK) {
             log << "GPUassert: " << bf_last_error() << std::endl;
             return rc;
         }
@@ -507,7 +522,7 @@ int run_observation(const bf_config& cfg, const observation_options& opt, block_
         const size_t n_buf = (size_t)(kMaxTotalSep + 2) * (size_t)(cfg.n_gemms_per_block / upl);
         for (size_t i = 0; i < n_buf; i++) {
             void* pb = nullptr;
-            if ((rc = bf_alloc_pinned(&pb, (size_t)opt.n_dm * dm_rows * cfg.n_beams * sizeof(float))) != BF_OK) return rc;
+            if ((rc = bf_alloc_pinned(&pb, (size_t)dm_count * dm_rows * cfg.n_beams * sizeof(float))) != BF_OK) return rc;
             g.more_pinned.push_back(pb);
             dm_host.push_back(static_cast<float*>(pb));
         }
@@ -517,8 +532,8 @@ int run_observation(const bf_config& cfg, const observation_options& opt, block_
         for (int q = 0; q < n_queues_used; q++) {
             float* unused = nullptr;
             if ((rc = bf_block_output_device(h, q, &unused)) != BF_OK) return rc;
-            if (opt.comm && opt.rank == opt.gather_root && (rc = bf_block_gather_device(h, q, opt.world, &unused)) != BF_OK) return rc;
-            if (opt.comm && staged && opt.rank == opt.gather_root && (rc = bf_block_gather_stage_device(h, q, opt.world, &unused)) != BF_OK) return rc;
+            if (opt.comm && is_root && (rc = bf_block_gather_device(h, q, opt.world, &unused)) != BF_OK) return rc;
+            if (opt.comm && staged && is_root && (rc = bf_block_gather_stage_device(h, q, opt.world, &unused)) != BF_OK) return rc;
         }
     bf_timer_start(h);  // :358
     while (!obs_state.check_observations_complete()) {  // :364
@@ -577,7 +592,7 @@ int run_observation(const bf_config& cfg, const observation_options& opt, block_
                         float *d_blk = nullptr, *d_full = nullptr, *d_stage = nullptr;
                         void* qs = nullptr;
                         const size_t full_det = n_f_per_detect * (size_t)opt.world;
-                        const bool root = opt.rank == opt.gather_root;
+                        const bool root = is_root;
                         if ((rc = bf_block_output_device(h, q, &d_blk)) == BF_OK && (rc = bf_queue_stream(h, q, &qs)) == BF_OK &&
                             (!root || (rc = bf_block_gather_device(h, q, opt.world, &d_full)) == BF_OK) &&
                             (!root || !staged || (rc = bf_block_gather_stage_device(h, q, opt.world, &d_stage)) == BF_OK))
@@ -589,10 +604,10 @@ int run_observation(const bf_config& cfg, const observation_options& opt, block_
                         for (int u = 0; rc == BF_OK && root && u < n_units; u++)
                             rc = bf_enqueue_d2h(h, q, d_full + full_det * (size_t)u, unit_dst[u], full_det);
                         d_rows = d_full;
-                    } else if (rc == BF_OK && dm_here) {
+                    } else if (rc == BF_OK && dm_run) {
                         if ((rc = bf_block_output_device(h, q, &d_rows)) == BF_OK) d_rows += n_f_per_detect * (size_t)first;
                     }
-                    if (rc == BF_OK && dm_here) {
+                    if (rc == BF_OK && dm_run) {
                         // the DM stage, where the reference's loop collapses frequency (src/beamformer.cu:492-511): this launch's rows
                         // into the stream on the launch's own queue; the chunk that becomes complete travels to a pinned buffer
                         void* qs = nullptr;
@@ -644,7 +659,7 @@ int run_observation(const bf_config& cfg, const observation_options& opt, block_
             dm_times += (uint64_t)c.n_t;
             if (opt.dm_sink) {
                 dm_chunks++;
-                if (!opt.dm_sink->deliver(c.first_t, c.n_t, opt.n_dm, cfg.n_beams, c.host)) {
+                if (!opt.dm_sink->deliver(c.first_t, c.n_t, dm_count, cfg.n_beams, c.host)) {
                     log << "ERROR: DM sink failed at output time " << c.first_t << std::endl;
                     return BF_ERR_STATE;
                 }
@@ -683,9 +698,9 @@ int run_observation(const bf_config& cfg, const observation_options& opt, block_
         res->dm_times = dm_times;
         res->dm_chunks = dm_chunks;
     }
-    if (dm_here)
-        log << "DM stage: " << opt.n_dm << " trials, " << dm_times << " output times (largest delay " << bf_dm_stream_max_delay(g.dm)
-            << " samples carried over on the device)" << std::endl;
+    if (dm_run)
+        log << "DM stage: trials " << dm_first << " .. " << dm_first + dm_count - 1 << " of " << opt.n_dm << ", " << dm_times
+            << " output times (largest delay " << bf_dm_stream_max_delay(g.dm) << " samples carried over on the device)" << std::endl;
     return BF_OK;
 }
 

@@ -227,7 +227,7 @@ void ring_sink::finish()
 }
 
 // ---- DM-trial chunks ---------------------------------------------------------------------------------------------------
-dm_file_sink::dm_file_sink(const bf_config& cfg, int n_freq_total, int n_dm, int max_delay, const char* path, int gpu)
+dm_file_sink::dm_file_sink(const bf_config& cfg, int n_freq_total, int n_dm, int max_delay, const char* path, int gpu, int first_trial)
 {
     fd = ::open(path, O_CREAT | O_TRUNC | O_WRONLY, 0644);
     if (fd < 0) return;
@@ -235,10 +235,10 @@ dm_file_sink::dm_file_sink(const bf_config& cfg, int n_freq_total, int n_dm, int
     ::memset(header, 0, sizeof(header));
     ::snprintf(header, sizeof(header),
                "HDR_VERSION 1.0\nHDR_SIZE %zu\nINSTRUMENT DSA\nCONTENT dedispersed_power\nDTYPE float32\nENDIAN little\n"
-               "ORDER chunk(dm,time,beam)\nRECORD_HEADER_BYTES %zu\nN_DM %d\nN_BEAMS %d\nN_FREQUENCIES %d\nMAX_DELAY %d\n"
+               "ORDER chunk(dm,time,beam)\nRECORD_HEADER_BYTES %zu\nN_DM %d\nDM_FIRST_TRIAL %d\nN_BEAMS %d\nN_FREQUENCIES %d\nMAX_DELAY %d\n"
                "N_OUTPUTS_PER_GEMM %d\nN_GEMMS_PER_BLOCK %d\nN_AVERAGING %d\nGPU %d\n",
-               kHeaderBytes, kRecordBytes, n_dm, cfg.n_beams, n_freq_total, max_delay, cfg.n_out_per_gemm, cfg.n_gemms_per_block,
-               cfg.n_avg, gpu);
+               kHeaderBytes, kRecordBytes, n_dm, first_trial, cfg.n_beams, n_freq_total, max_delay, cfg.n_out_per_gemm,
+               cfg.n_gemms_per_block, cfg.n_avg, gpu);
     if (!pwrite_all(fd, header, sizeof(header), 0) || ::lseek(fd, (off_t)kHeaderBytes, SEEK_SET) < 0) {
         ::close(fd);
         fd = -1;

@@ -476,7 +476,7 @@ class dm_file_sink : public dm_chunk_sink {
 public:
     static constexpr size_t kHeaderBytes = 4096;
     static constexpr size_t kRecordBytes = 32;
-    dm_file_sink(const bf_config& cfg, int n_freq_total, int n_dm, int max_delay, const char* path, int gpu);
+    dm_file_sink(const bf_config& cfg, int n_freq_total, int n_dm, int max_delay, const char* path, int gpu, int first_trial = 0);
     ~dm_file_sink() override;
     dm_file_sink(const dm_file_sink&) = delete;
     dm_file_sink& operator=(const dm_file_sink&) = delete;
@@ -523,7 +523,7 @@ struct observation_options {
     // is the LOCAL count).  The weights are generated for those channels; the input blocks are the rank's own slice.
     int world = 1, rank = 0;
     // Sharded run: the communicator of the frequency partition (bf_comm_create; rank / world above must agree with it).
-    // After every block the detected powers of all shards are gathered to rank `gather_root` in the reference's
+    // After every block the detected powers of all shards are gathered to rank `gather_root` (BF_GATHER_ROOT_ALL: to every rank) in the reference's
     // [unit][output][freq over the whole band][beam] layout; only that rank copies to the host / feeds `sink` (which
     // must then be built for the whole band: cfg.n_freq * world) -- the others pass sink = nullptr.  Needs block_launch.
     bf_comm* comm = nullptr;
@@ -538,6 +538,11 @@ struct observation_options {
     const int32_t* dm_delays = nullptr;
     int n_dm = 0;
     dm_chunk_sink* dm_sink = nullptr;
+    // Sharded runs only, with gather_root = BF_GATHER_ROOT_ALL (every rank receives the whole band: the ONE collective of the path
+    // becomes an all-gather): rank r dedisperses ITS share of the ladder -- trials [r n / R, (r + 1) n / R), the first n % R ranks
+    // one more -- so the DM work scales with the GPUs.  Every rank may then have a dm_sink of its own; a chunk carries the rank's
+    // trials only (dm_file_sink records the first one as DM_FIRST_TRIAL).
+    bool dm_split_trials = false;
 };
 struct observation_result {
     float observation_time_ms = 0;

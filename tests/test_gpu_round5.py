@@ -272,7 +272,7 @@ def test_beam_cli_dm_stage_single_gpu_and_two_loopback_ranks(orc, tmp_path):
     """`beam -j 27 -M 40 -N 6 -T 0.02 -W dm.bin` (25 burn-in reads + 2 analysed blocks of the production geometry) on one GPU,
     and the same sub-band as `-R 2` shard processes (loopback stand-in for RCCL p2p): the gather root dedisperses the GATHERED
     band.  Each file is bit-equal to orc.dedisperse_dm over the whole detected series the run produced, ascending f over all
-    256 channels -- one GPU or two."""
+    256 channels -- one GPU or two.  With -X the band goes to every rank and the TRIALS are split across the shards."""
     from test_gpu_multirank import FAKE, SUPPORT  # noqa: F401  (built by that module's fixture; build here if it has not run)
     import subprocess
 
@@ -329,6 +329,23 @@ def test_beam_cli_dm_stage_single_gpu_and_two_loopback_ranks(orc, tmp_path):
         if world == 2:
             raw = np.fromfile(det, np.float32, offset=4096).reshape(T, 256, 256)      # [gemm][o] = time rows of the whole band
             assert np.array_equal(raw, series)
+            # ---- -X: the same two shards, the powers gathered to EVERY rank (one all-gather), the ladder split: rank r dedisperses
+            # trials [3 r, 3 r + 3) of the six and writes dm_x.bin.<r>; each file is the oracle's over ITS trials (a rank's window is
+            # its own trials' largest delay, so the low-DM rank completes more output times)
+            outx = tmp_path / "dm_x.bin"
+            cmdx = lambda rk: [build.BEAM] + common + ["-R", "2", "-r", str(rk), "-I", str(tmp_path / "idx"), "-X", "-W", str(outx)]  # noqa: E731
+            procs = [subprocess.Popen(cmdx(rk), env=dict(os.environ, DSABF_RCCL_LIB=FAKE), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+                     for rk in (0, 1)]
+            outs = [p.communicate(timeout=900)[0] for p in procs]
+            assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+            for rk in (0, 1):
+                assert ("Shard %d dedisperses trials %d .. %d" % (rk, 3 * rk, 3 * rk + 2)) in outs[rk]
+                mine = np.ascontiguousarray(delays[3 * rk:3 * rk + 3])
+                d_r = int(mine.max())
+                hdr, got, chunks = host.read_dm_file(str(outx) + ".%d" % rk)
+                assert int(hdr["N_DM"]) == 3 and int(hdr["DM_FIRST_TRIAL"]) == 3 * rk and int(hdr["MAX_DELAY"]) == d_r
+                assert np.array_equal(got, orc.dedisperse_dm(series, mine, T - d_r)), rk
+            assert int(delays[:3].max()) < D                       # (rank 0's window really is the shorter one)
 
 
 def test_beam_reads_a_psrdada_style_ring_through_the_dada_adapter(orc, tmp_path):
