@@ -226,7 +226,7 @@ int main(int argc, char* argv[])
         // run covers (world x n_freq channels), referred to its highest frequency (channel 0): every delay is >= 0.
         std::vector<int32_t> delays;
         std::unique_ptr<dm_file_sink> dm_sink;
-        int n_dm = 0;
+        int n_dm = 0, my_trials = 0;
         if (dm_max > 0.0) {
             std::vector<double> dms = dm_trials(0.0, dm_max);
             if (n_dm_cap > 0 && (int)dms.size() > n_dm_cap) {
@@ -249,13 +249,13 @@ int main(int argc, char* argv[])
             if (dm_split && comm) {       // -X: every rank receives the band and takes its share of the trials
                 oopt.gather_root = BF_GATHER_ROOT_ALL;
                 oopt.dm_split_trials = true;
-                my_count = n_dm / world + (rank < n_dm % world ? 1 : 0);
-                my_first = rank * (n_dm / world) + (rank < n_dm % world ? rank : n_dm % world);
+                dm_trial_share(n_dm, world, rank, &my_first, &my_count);
                 dmax = 0;
                 for (size_t i = (size_t)my_first * full_cfg.n_freq; i < (size_t)(my_first + my_count) * full_cfg.n_freq; i++) dmax = delays[i] > dmax ? delays[i] : dmax;
                 if (!dm_path.empty()) dm_path += "." + std::to_string(rank);
                 std::cout << "Shard " << rank << " dedisperses trials " << my_first << " .. " << my_first + my_count - 1 << std::endl;
             }
+            my_trials = my_count;
             if (!dm_path.empty() && my_count > 0 && (!comm || rank == 0 || oopt.dm_split_trials)) {
                 dm_sink.reset(new dm_file_sink(pcfg, full_cfg.n_freq, my_count, dmax, dm_path.c_str(), opt.gpu, my_first));
                 if (!dm_sink->is_open()) {
@@ -268,7 +268,7 @@ int main(int argc, char* argv[])
         observation_result ores;
         int orc = run_observation(pcfg, oopt, *src, pos.data(), dir.data(), &ores, std::cout);
         if (sink) std::cout << "Wrote " << sink->get_delivered() << " gemm-units of detected powers to " << sink_name << std::endl;
-        if (dm_sink) std::cout << "Wrote " << dm_sink->get_times_written() << " dedispersed samples x " << (oopt.dm_split_trials ? n_dm / world + (rank < n_dm % world ? 1 : 0) : n_dm) << " trials to " << dm_path << std::endl;
+        if (dm_sink) std::cout << "Wrote " << dm_sink->get_times_written() << " dedispersed samples x " << my_trials << " trials to " << dm_path << std::endl;
         bf_comm_destroy(comm);
         if (orc != BF_OK) {
             fprintf(stderr, "GPUassert: %s (%d)\n", bf_last_error(), orc);

@@ -389,6 +389,13 @@ int bfh_dm_delays(const double* dms, int n_dm, const float* freq_ghz, int n_freq
     return BF_OK;
 }
 
+int bfh_dm_trial_share(int n_dm, int world, int rank, int* first, int* count)
+{
+    if (n_dm < 0 || world < 1 || rank < 0 || rank >= world) return BF_ERR_INVALID;
+    dm_trial_share(n_dm, world, rank, first, count);
+    return BF_OK;
+}
+
 int bfh_junk_fill(const bf_config* cfg, int ring_blocks, uint64_t seed, void* out)
 {
     if (!cfg || !out || ring_blocks < 1) return BF_ERR_INVALID;

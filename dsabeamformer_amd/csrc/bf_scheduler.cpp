@@ -186,6 +186,13 @@ std::ostream& operator<<(std::ostream& out, const observation_loop_state& a)
                << "current_gemm: " << a.most_recent_gemm << ", transfers_complete: " << a.transfers_complete;
 }
 
+void dm_trial_share(int n_dm, int world, int rank, int* first, int* count)
+{
+    const int base = world > 0 ? n_dm / world : 0, extra = world > 0 ? n_dm % world : 0;
+    if (count) *count = (rank >= 0 && rank < world) ? base + (rank < extra ? 1 : 0) : 0;
+    if (first) *first = rank * base + std::min(std::max(rank, 0), extra);
+}
+
 // ---- the DEBUG main() flow (src/beamformer.cu:12-621 with -DDEBUG) ----------------------------------------------------
 int run_debug_observation(const bf_config& cfg, const debug_run_options& opt, debug_run_result* res,
                           std::vector<float>* dedispersed_result, std::ostream& log)
@@ -496,11 +503,7 @@ int run_observation(const bf_config& cfg, const observation_options& opt, block_
     // the DM work scales with the GPUs, the path still has ONE collective; rank r: trials [r n / R, (r + 1) n / R), the first n % R
     // ranks one more
     int dm_first = 0, dm_count = opt.n_dm;
-    if (opt.dm_split_trials) {
-        const int base_n = opt.n_dm / opt.world, extra = opt.n_dm % opt.world;
-        dm_count = base_n + (opt.rank < extra ? 1 : 0);
-        dm_first = opt.rank * base_n + std::min(opt.rank, extra);
-    }
+    if (opt.dm_split_trials) dm_trial_share(opt.n_dm, opt.world, opt.rank, &dm_first, &dm_count);
     const int n_freq_band = cfg.n_freq * (opt.comm ? opt.world : 1);
     const int dm_rows = upl * cfg.n_out_per_gemm;                                       // beam-blocks per launch = rows per push
     struct dm_chunk {

@@ -136,6 +136,9 @@ int bfh_dm_trials(double dm0, double dm_max, int nchan, double epsilon, double n
 int bfh_dm_delays(const double *dms, int n_dm, const float *freq_ghz, int n_freq, double f_ref_ghz, double tsamp_ms,
                   int32_t *out);
 
+/* dsabf::dm_trial_share: which trials rank `rank` of `world` dedisperses when a sharded run splits the ladder. */
+int bfh_dm_trial_share(int n_dm, int world, int rank, int *first, int *count);
+
 /* The junk source's bytes: ring_blocks blocks of cfg's block size into `out` (dsabf::junk_fill). */
 int bfh_junk_fill(const bf_config *cfg, int ring_blocks, uint64_t seed, void *out);
 

@@ -261,6 +261,10 @@ std::vector<double> dm_trials(double dm0 = 0.0, double dm_max = 2000.0, int ncha
 void dm_delays(const double* dms, int n_dm, const float* freq_ghz, int n_freq, double f_ref_ghz, double tsamp_ms,
                int32_t* out);
 
+// dm_split_trials (observation_options): rank r of R takes trials [first, first + count) of an n_dm-trial ladder -- n_dm / R each,
+// the first n_dm % R ranks one more; count may be 0 (more ranks than trials).
+void dm_trial_share(int n_dm, int world, int rank, int* first, int* count);
+
 // Fills `ring_blocks` consecutive blocks of cfg's block size at `ring` with the junk source's bytes (64-bit xorshift*,
 // every nibble code in both halves; depends only on seed, ring_blocks and the block size).
 void junk_fill(const bf_config& cfg, int ring_blocks, uint64_t seed, char* ring);

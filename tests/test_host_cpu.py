@@ -677,3 +677,23 @@ def test_psrdada_adapter_runs_against_a_stand_in_library(tmp_path):
     # a key nobody created: the reference's message, ok() false (the reference exits)
     r = subprocess.run([exe, "%x" % (key + 7), str(bufsz)], capture_output=True, text=True, timeout=120)
     assert r.returncode == 2 and "Error: could not connect to dada buffer" in r.stdout
+
+
+def test_dm_trial_share_covers_the_ladder_once():
+    """dm_split_trials: the ranks' shares are contiguous, disjoint, cover every trial, differ by at most one."""
+    import ctypes as C
+
+    from dsabeamformer_amd._lib import load
+
+    lib = load()
+    for n_dm in (0, 1, 5, 6, 64, 97):
+        for world in (1, 2, 3, 8):
+            at, counts = 0, []
+            for r in range(world):
+                f, c = C.c_int(), C.c_int()
+                assert lib.bfh_dm_trial_share(n_dm, world, r, C.byref(f), C.byref(c)) == 0
+                assert f.value == at and c.value >= 0
+                at += c.value
+                counts.append(c.value)
+            assert at == n_dm and max(counts) - min(counts) <= 1 and counts == sorted(counts, reverse=True)
+    assert lib.bfh_dm_trial_share(4, 2, 2, None, None) != 0
