@@ -57,7 +57,7 @@ int main(int argc, char **argv)
     int n_freq_total;
 
     if (argc < 4) {
-        fprintf(stderr, "usage: %s <rank> <world> <id-file> [device]\n", argv[0]);
+        fprintf(stderr, "usage: %s <rank> <world> <id-file> [device [staged]]\n", argv[0]);
         return 2;
     }
     rank = atoi(argv[1]);
@@ -118,7 +118,14 @@ int main(int argc, char **argv)
     CHECK(bf_block_output_device(h, 0, &d_local));
     CHECK(bf_queue_stream(h, 0, &stream));
     if (rank == 0) CHECK(bf_block_gather_device(h, 0, world, &d_full));
-    CHECK(bf_gather_detected(comm, d_local, n_rows, row_floats, /*root=*/0, BF_GATHER_LAYOUT_FREQ_MAJOR, d_full, stream));
+    if (argc > 5 && !strcmp(argv[5], "staged")) {
+        /* the same [o][f][b] by the second transport: ONE message per sender into a staging area, then one device re-layout pass */
+        float *d_stage = NULL;
+        if (rank == 0) CHECK(bf_block_gather_stage_device(h, 0, world, &d_stage));
+        CHECK(bf_gather_detected_staged(comm, d_local, n_rows, row_floats, /*root=*/0, d_full, d_stage, stream));
+    } else {
+        CHECK(bf_gather_detected(comm, d_local, n_rows, row_floats, /*root=*/0, BF_GATHER_LAYOUT_FREQ_MAJOR, d_full, stream));
+    }
 
     if (rank == 0) {
         const size_t full_floats = n_rows * (size_t)world * row_floats;
