@@ -808,6 +808,13 @@ int bf_enqueue_dedisperse(bf_handle* h, int stream_idx, float* host_out_row)
     }
     float* ded = h->d_ded + (size_t)h->cfg.n_beams * stream_idx;
     HIP_TRY(dsabf::launch_dedisperse(h->geom, h->last_out[stream_idx], ded, s));
+    if (lq != stream_idx) {
+        // ... and the producer queue waits for this read: the next launch that overwrites the unit's place in ITS block buffer (a later
+        // flush on queue lq, for a queue whose latest unit is being replaced: preserve_last_units skips those) must not start under
+        // it.  (Found by tools/fuzz_calls.py, seed 2118: unit, flush on queue A, late DM-0 on its own queue, next flush on A.)
+        HIP_TRY(hipEventRecord(h->join[stream_idx], s));
+        HIP_TRY(hipStreamWaitEvent(h->streams[lq], h->join[stream_idx], 0));
+    }
     if (host_out_row)
         HIP_TRY(hipMemcpyAsync(host_out_row, ded, (size_t)h->cfg.n_beams * sizeof(float), hipMemcpyDeviceToHost, s));
     return BF_OK;

@@ -61,7 +61,10 @@ for s in range(seed0, seed0 + cases):
     try:
         t.test_random_call_sequences_leave_every_host_buffer_with_its_own_units_bits(torch, bfm, orc, s)
     except AssertionError as e:
-        if "> 10" in str(e) or "assert" in str(e) and "len(" in str(e):
+        import traceback
+
+        where = traceback.extract_tb(sys.exc_info()[2])[-1].line or ""
+        if "len(expect_out) > 10" in where:
             continue                 # (a walk with too few host buffers: not a parity failure)
         bad += 1
         print("seed", s, "FAILED:", str(e)[:200], flush=True)
