@@ -4,6 +4,8 @@ import os
 import numpy as np
 import pytest
 
+from conftest import sweep
+
 pytestmark = pytest.mark.gpu
 
 
@@ -438,3 +440,41 @@ def test_dm_stream_argument_errors(torch, bfmod):
     dm.close()
     assert lib.bf_dm_stream_destroy(None) == 0 and lib.bf_dm_stream_max_delay(None) == -1
     bf.close()
+
+
+@pytest.mark.parametrize("seed", sweep(range(12), [4, 10]))
+def test_production_loop_with_the_dm_stage_under_random_launch_patterns(bfmod, orc, tmp_path, monkeypatch, seed):
+    """run_observation with the DM stage AND the detected-stream sink under random block sizes, queue counts, sub-block launches
+    (every launch is a push, on its own queue: the stream orders them), ladders whose window is shorter or much longer than a
+    block, both kernel selections: the detected stream and the streamed [dm][t][b] are the oracle's over the whole observation."""
+    from dsabeamformer_amd import host
+
+    rng = np.random.default_rng(5200 + seed)
+    n_u = int(rng.choice([4, 8, 16]))
+    n_st = int(rng.choice([s for s in (1, 2, 4, 8) if s <= n_u]))
+    n_blocks, ring_blocks = int(rng.integers(3, 9)), int(rng.integers(2, 5))
+    if rng.integers(2):
+        monkeypatch.setenv("DSABF_UNITS_PER_LAUNCH", str(int(rng.choice([1, 2, n_u // 2]))))
+    monkeypatch.setenv("DSABF_DM_WIDE", str(int(rng.integers(2))))
+    n_freq, n_out = int(rng.choice([4, 8, 12])), int(rng.choice([2, 4]))
+    cfg = bfmod.production_config(n_freq=n_freq, n_avg=int(rng.choice([16, 8])), n_out_per_gemm=n_out)
+    cfg.n_beams, cfg.n_gemms_per_block, cfg.n_streams = 64, n_u, n_st
+    T = n_blocks * n_u * n_out
+    n_dm = int(rng.integers(1, 50))
+    d_max = int(rng.integers(0, max(1, min(T - 2, 3 * n_u * n_out))))                  # up to three blocks of window
+    if rng.integers(3) == 0:
+        delays = rng.integers(0, d_max + 1, size=(n_dm, n_freq)).astype(np.int32)       # no ladder at all (per-thread kernel)
+    else:
+        delays = _pulse_delays(n_dm, n_freq, d_max)
+    D = int(delays.max())
+    det, dmf = str(tmp_path / "det.bin"), str(tmp_path / "dm.bin")
+    r = host.run_observation_junk_dm(cfg, n_blocks, delays, dmf, detected_path=det, ring_blocks=ring_blocks, seed=2000 + seed, gpu=1)
+    assert r["dm_times"] == T - D, (seed, T, D)
+    g = orc.Geom(n_beams=64, n_ant=64, n_freq=n_freq, n_avg=cfg.n_avg, n_out_per_gemm=n_out)
+    w = orc.make_weights(g, orc.default_positions(64), orc.default_directions(64), 1)
+    series = np.concatenate([orc.beamform(g, w, r["ring"][b % ring_blocks]).reshape(n_u * n_out, n_freq, 64) for b in range(n_blocks)])
+    _, data = host.read_detected_file(det)
+    assert np.array_equal(data.reshape(series.shape), series), seed
+    hdr, got, chunks = host.read_dm_file(dmf)
+    assert sum(n for _, n in chunks) == T - D and int(hdr["MAX_DELAY"]) == D
+    assert np.array_equal(got, orc.dedisperse_dm(series, delays, T - D)), (seed, n_u, n_st, n_dm, D)

@@ -44,6 +44,36 @@ if os.environ.get("FUZZ") == "loops":      # run_observation to a file sink unde
                 env.undo()
     print("observation loops, seeds %d..%d: %d runs, %d parity failures" % (seed0, seed0 + cases - 1, cases, bad))
     sys.exit(0)
+if os.environ.get("FUZZ") == "dmloops":    # run_observation with the DM stage + detected sink under random launch patterns (round 5)
+    import pathlib
+    import tempfile
+
+    import test_gpu_round5 as t5
+
+    class Env5:
+        def __init__(self):
+            self.set = []
+
+        def setenv(self, k, v):
+            os.environ[k] = v
+            self.set.append(k)
+
+        def undo(self):
+            for k in self.set:
+                os.environ.pop(k, None)
+
+    for s in range(seed0, seed0 + cases):
+        env = Env5()
+        with tempfile.TemporaryDirectory() as d:
+            try:
+                t5.test_production_loop_with_the_dm_stage_under_random_launch_patterns(bfm, orc, pathlib.Path(d), env, s)
+            except AssertionError as e:
+                bad += 1
+                print("seed", s, "FAILED:", str(e)[:200], flush=True)
+            finally:
+                env.undo()
+    print("observation loops with the DM stage, seeds %d..%d: %d runs, %d parity failures" % (seed0, seed0 + cases - 1, cases, bad))
+    sys.exit(0)
 if os.environ.get("FUZZ") == "debug":      # the DEBUG flow end to end on random catalogues / geometries / launch patterns
     import pathlib
     import tempfile
