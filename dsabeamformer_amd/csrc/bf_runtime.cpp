@@ -64,6 +64,7 @@ struct bf_handle {
     std::vector<float*> d_full_blk; // per compute queue, the gathered block (world x as large): bf_block_gather_device (lazy)
     std::vector<float*> d_stage_blk; // per compute queue, the staged transport's landing area: bf_block_gather_stage_device (lazy)
     int full_world = 0;
+    std::vector<struct bf_dm_stream*> dm_streams;   // DM stages created on this handle: bf_destroy releases their device memory
     hipStream_t h2d = nullptr;
     std::vector<hipStream_t> streams;
     std::vector<hipEvent_t> join;  // one per compute queue, for bf_record_analysis_event
@@ -284,6 +285,7 @@ int bf_create(const bf_config* cfg, int device, bf_handle** out)
 }
 
 static int flush_units(bf_handle* h);
+static void dm_stream_release(struct bf_dm_stream* s);
 
 int bf_destroy(bf_handle* h)
 {
@@ -310,6 +312,7 @@ int bf_destroy(bf_handle* h)
     (void)hipFree(h->d_data);
     (void)hipFree(h->d_out);
     (void)hipFree(h->d_ded);
+    for (auto* ds : h->dm_streams) dm_stream_release(ds);   // a DM stage that outlives its handle is left empty, not dangling
     for (auto& sc : h->dm_scratch) (void)hipFree(sc.second);
     for (float* p : h->d_out_blk) (void)hipFree(p);
     for (float* p : h->d_full_blk) (void)hipFree(p);
@@ -951,7 +954,8 @@ static hipError_t dm_scratch(bf_handle* h, hipStream_t s, int** out)
     if (h->dm_scratch.size() >= 64) {   // a caller that keeps creating streams: nothing of ours may still be in flight
         hipError_t e = hipDeviceSynchronize();
         if (e != hipSuccess) return e;
-        for (auto& sc : h->dm_scratch) (void)hipFree(sc.second);
+        for (auto* ds : h->dm_streams) dm_stream_release(ds);   // a DM stage that outlives its handle is left empty, not dangling
+    for (auto& sc : h->dm_scratch) (void)hipFree(sc.second);
         h->dm_scratch.clear();
     }
     int* p = nullptr;
@@ -1054,6 +1058,7 @@ int bf_dm_stream_create(bf_handle* h, const int32_t* delays, int n_dm, int n_fre
     if (e == hipSuccess) e = hipMalloc((void**)&s->d_flags, dsabf::kDmScratchBytes);
     if (e == hipSuccess) e = hipMemcpy(s->d_delays, delays, (size_t)n_dm * n_freq_total * sizeof(int32_t), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&s->done, hipEventDisableTiming);
+    h->dm_streams.push_back(s);
     if (e != hipSuccess) {
         const int rc = fail(BF_ERR_DEVICE, "bf_dm_stream_create: %s", hipGetErrorString(e));
         std::string keep = g_err;
@@ -1065,10 +1070,9 @@ int bf_dm_stream_create(bf_handle* h, const int32_t* delays, int n_dm, int n_fre
     return BF_OK;
 }
 
-int bf_dm_stream_destroy(bf_dm_stream* s)
+// device side of a DM stage (its handle's device must be current); the object itself stays, detached from the handle
+static void dm_stream_release(bf_dm_stream* s)
 {
-    if (!s) return BF_OK;
-    DeviceScope dev_scope_(s->h->device);
     if (s->done) {
         if (s->done_recorded) (void)hipEventSynchronize(s->done);
         (void)hipEventDestroy(s->done);
@@ -1077,6 +1081,26 @@ int bf_dm_stream_destroy(bf_dm_stream* s)
     (void)hipFree(s->d_out);
     (void)hipFree(s->d_delays);
     (void)hipFree(s->d_flags);
+    s->done = nullptr;
+    s->d_buf = s->d_out = nullptr;
+    s->d_delays = nullptr;
+    s->d_flags = nullptr;
+    s->h = nullptr;
+}
+
+int bf_dm_stream_destroy(bf_dm_stream* s)
+{
+    if (!s) return BF_OK;
+    if (s->h) {   // (NULL: the handle went first and took the device memory with it)
+        bf_handle* h = s->h;
+        DeviceScope dev_scope_(h->device);
+        for (size_t i = 0; i < h->dm_streams.size(); i++)
+            if (h->dm_streams[i] == s) {
+                h->dm_streams.erase(h->dm_streams.begin() + (long)i);
+                break;
+            }
+        dm_stream_release(s);
+    }
     delete s;
     return BF_OK;
 }
@@ -1086,6 +1110,7 @@ int bf_dm_stream_max_delay(const bf_dm_stream* s) { return s ? s->max_delay : BF
 int bf_dm_stream_output_device(bf_dm_stream* s, float** d_out)
 {
     if (!s || !d_out) return fail(BF_ERR_INVALID, "NULL argument");
+    if (!s->h) return fail(BF_ERR_STATE, "the handle of this DM stage has been destroyed");
     *d_out = s->d_out;
     return BF_OK;
 }
@@ -1095,6 +1120,7 @@ int bf_dm_stream_push(bf_dm_stream* s, const float* d_rows, int n_rows, float* h
 {
     if (!s || !d_rows) return fail(BF_ERR_INVALID, "NULL argument");
     if (n_rows <= 0 || n_rows > s->max_rows) return fail(BF_ERR_INVALID, "n_rows must be 1 .. %d (max_rows_per_push)", s->max_rows);
+    if (!s->h) return fail(BF_ERR_STATE, "the handle of this DM stage has been destroyed");
     bf_handle* h = s->h;
     ON_DEVICE(h);
     hipStream_t q = as_stream(hip_stream);
@@ -1103,17 +1129,19 @@ int bf_dm_stream_push(bf_dm_stream* s, const float* d_rows, int n_rows, float* h
         HIP_TRY(hipMemsetAsync(s->d_flags, 0, dsabf::kDmScratchBytes, q));
         s->flags_zeroed = true;
     }
+    // (the stream's bookkeeping -- fill, pushed -- is committed at the end: a call that fails on the way leaves it as it found it)
     const size_t D = (size_t)s->max_delay;
     const size_t carry = s->pushed < D ? (size_t)s->pushed : D;          // rows [fill - carry, fill) = series rows [pushed - carry, pushed)
-    if (s->fill + (size_t)n_rows > s->cap_rows) {                         // slide: fill - carry >= carry here (cap = 2 (D + max_rows))
+    size_t fill = s->fill;
+    if (fill + (size_t)n_rows > s->cap_rows) {                            // slide: fill - carry >= carry here (cap = 2 (D + max_rows))
         if (carry)
-            HIP_TRY(hipMemcpyAsync(s->d_buf, s->d_buf + (s->fill - carry) * s->row_floats, carry * s->row_floats * sizeof(float),
+            HIP_TRY(hipMemcpyAsync(s->d_buf, s->d_buf + (fill - carry) * s->row_floats, carry * s->row_floats * sizeof(float),
                                    hipMemcpyDeviceToDevice, q));
-        s->fill = carry;
+        fill = carry;
     }
-    HIP_TRY(hipMemcpyAsync(s->d_buf + s->fill * s->row_floats, d_rows, (size_t)n_rows * s->row_floats * sizeof(float),
+    HIP_TRY(hipMemcpyAsync(s->d_buf + fill * s->row_floats, d_rows, (size_t)n_rows * s->row_floats * sizeof(float),
                            hipMemcpyDeviceToDevice, q));
-    s->fill += (size_t)n_rows;
+    fill += (size_t)n_rows;
     const uint64_t emitted = s->pushed > D ? s->pushed - D : 0;          // output times [0, emitted) have been produced
     const uint64_t after = s->pushed + (uint64_t)n_rows;
     const uint64_t complete = after > D ? after - D : 0;                   // ... and [0, complete) can be now
@@ -1122,13 +1150,14 @@ int bf_dm_stream_push(bf_dm_stream* s, const float* d_rows, int n_rows, float* h
     if (n_out > 0) {
         dsabf::Geometry g = h->geom;
         g.n_freq = s->n_freq;
-        HIP_TRY(dsabf::launch_dedisperse_dm(g, s->d_buf + (s->fill - n_t) * s->row_floats, (int)n_t, s->d_delays, s->n_dm, n_out, s->d_out,
+        HIP_TRY(dsabf::launch_dedisperse_dm(g, s->d_buf + (fill - n_t) * s->row_floats, (int)n_t, s->d_delays, s->n_dm, n_out, s->d_out,
                                             s->d_flags, q));
         if (host_out)
             HIP_TRY(hipMemcpyAsync(host_out, s->d_out, (size_t)s->n_dm * n_out * h->cfg.n_beams * sizeof(float), hipMemcpyDeviceToHost, q));
     }
     HIP_TRY(hipEventRecord(s->done, q));
     s->done_recorded = true;
+    s->fill = fill;
     s->pushed = after;
     if (first_t) *first_t = emitted;
     if (n_t_out) *n_t_out = n_out;

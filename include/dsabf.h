@@ -249,7 +249,8 @@ int bf_dedisperse_dm_device(bf_handle *h, const float *d_series, int n_t, const 
  * bf_dm_stream_push is asynchronous on `hip_stream` (the queue that produced d_rows: bf_queue_stream); successive pushes are
  * ordered by the stream itself, whichever queues they are issued on.  host_out (optional, pinned, room for n_dm * n_rows *
  * n_beams floats) receives the chunk; first_t / n_t_out are known to the host at once (pure arithmetic).  The device copy of
- * the most recent chunk: bf_dm_stream_output_device.  Destroy the stream before its handle. */
+ * the most recent chunk: bf_dm_stream_output_device.  Destroy the stream before its handle (a handle that goes first releases the
+ * stage's device memory; the stage then only answers BF_ERR_STATE and can still be destroyed). */
 typedef struct bf_dm_stream bf_dm_stream;
 int bf_dm_stream_create(bf_handle *h, const int32_t *delays, int n_dm, int n_freq_total, int max_rows_per_push,
                         bf_dm_stream **out);

@@ -439,7 +439,13 @@ def test_dm_stream_argument_errors(torch, bfmod):
     torch.cuda.synchronize()
     dm.close()
     assert lib.bf_dm_stream_destroy(None) == 0 and lib.bf_dm_stream_max_delay(None) == -1
+    # a handle that is destroyed first takes the stage's device memory with it: the stage answers BF_ERR_STATE, and can still be destroyed
+    orphan = api.DmStream(bf, good, 8, 4)
     bf.close()
+    with pytest.raises(DsabfError) as e:
+        orphan.push(d_rows, 4)
+    assert e.value.code == -4 and "has been destroyed" in str(e.value)
+    orphan.close()
 
 
 @pytest.mark.parametrize("seed", sweep(range(12), [4, 10]))
