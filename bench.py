@@ -975,6 +975,12 @@ def main():
             except Exception as e:
                 deadline.fail("%s failed: %s: %s" % (name, type(e).__name__, str(e)[:400]), code=4)
 
+        if rank == 0:       # which library is about to be asked for a communicator: known to the line even if it never answers
+            try:
+                out["rccl"] = dict(api.comm_library_info(), ranks=None, note="bound, no communicator yet")
+            except Exception as e:
+                out["rccl"] = {"error": str(e)[:300]}
+
         def make_comm():
             idt = torch.zeros(128, dtype=torch.uint8, device=dist_dev)
             if rank == 0:

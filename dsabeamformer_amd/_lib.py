@@ -99,6 +99,7 @@ SIGNATURES = {
     "bf_comm_destroy": (C.c_int, [C.c_void_p]),
     "bf_comm_rank": (C.c_int, [C.c_void_p]),
     "bf_comm_world": (C.c_int, [C.c_void_p]),
+    "bf_comm_library_info": (C.c_int, [C.POINTER(C.c_int), C.c_char_p, C.c_size_t]),
     "bf_comm_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, C.c_size_t]),
     "bf_gather_detected": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "bf_gather_detected_staged": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),

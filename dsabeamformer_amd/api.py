@@ -264,6 +264,13 @@ def comm_unique_id() -> bytes:
     return buf.raw
 
 
+def comm_library_info() -> dict:
+    """Which librccl bf_comm_create would bind, and its version -- before any communicator exists (bf_comm_library_info)."""
+    v, path = C.c_int(), C.create_string_buffer(512)
+    check(load().bf_comm_library_info(C.byref(v), path, 512))
+    return {"version": v.value, "lib": path.value.decode(errors="replace")}
+
+
 class Comm:
     """bf_comm: this rank's place in the frequency partition + the RCCL communicator behind bf_gather_detected."""
 

@@ -240,6 +240,20 @@ int bf_comm_info(const bf_comm* c, int* lib_ranks, int* version, char* lib_path,
     return BF_OK;
 }
 
+// The same evidence BEFORE a communicator exists (a diagnostic line must be able to name the library whose ncclCommInitRank never
+// came back): binds librccl as bf_comm_create would -- dlopen only, no device, no network -- and reports its version and file.
+int bf_comm_library_info(int* version, char* lib_path, size_t n)
+{
+    if (version) *version = 0;
+    if (lib_path && n) lib_path[0] = 0;
+    rccl_api& r = rccl();
+    if (!r.error.empty()) return comm_fail(BF_ERR_DEVICE, r.error);
+    if (version && r.GetVersion) (void)r.GetVersion(version);
+    Dl_info di{};
+    if (lib_path && n && dladdr(reinterpret_cast<void*>(r.Send), &di) && di.dli_fname) snprintf(lib_path, n, "%s", di.dli_fname);
+    return BF_OK;
+}
+
 int bf_comm_rank(const bf_comm* c) { return c ? c->rank : BF_ERR_INVALID; }
 int bf_comm_world(const bf_comm* c) { return c ? c->world : BF_ERR_INVALID; }
 

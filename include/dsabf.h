@@ -294,6 +294,7 @@ int bf_comm_world(const bf_comm *c);
  * has no RCCL communicator, -1 = the library cannot say), its version (ncclGetVersion, e.g. 22203; 0 = unknown) and the
  * file the point-to-point calls were resolved from.  Any pointer may be NULL. */
 int bf_comm_info(const bf_comm *c, int *lib_ranks, int *version, char *lib_path, size_t n);
+int bf_comm_library_info(int *version, char *lib_path, size_t n); /* the same two answers BEFORE a communicator exists (dlopen only) */
 int bf_gather_detected(bf_comm *c, const float *d_local, size_t n_rows, size_t row_floats, int root, int layout,
                        float *d_full, void *hip_stream);
 /* The same gather into BF_GATHER_LAYOUT_FREQ_MAJOR -- the reference's [o][f][b] over the whole band, src/beamformer.cuh:147 --

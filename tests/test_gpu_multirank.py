@@ -246,6 +246,7 @@ def test_bench_with_a_send_that_never_returns_still_prints_the_kernel_only_recor
     assert d["gather_modes"]["none"]["value"] > 0 and d["kernel_only"]["value"] > 0 and 0 < d["kernel_only"]["roofline_frac"] < 1
     assert "alltoall_rank_major" in d["gather_error"] and "did not finish" in d["gather_error"] and d["rank"] == 0
     assert d["stage"].startswith("gather 'alltoall_rank_major'")
+    assert d["rccl"]["lib"].endswith("libfakerccl.so")            # the diagnostic names the library that never answered
     assert d["roofline"]["kernel_ms_avg"] > 0                     # the kernel-only region's own roofline record is in the line
     assert took < 60, took
 
@@ -301,6 +302,7 @@ def test_bench_exits_nonzero_when_the_communicator_cannot_be_created():
     d = json.loads(lines[0])
     assert d["value"] is None and "could not be loaded" in d["gather_error"] and d["stage"].startswith("RCCL communicator")
     assert d["gather_modes"]["none"]["value"] > 0 and set(d["gather_modes"]) == {"none"}      # kernel-only: measured before RCCL
+    assert "could not be loaded" in d["rccl"]["error"]
 
 
 @pytest.mark.parametrize("world", sweep([1, 2, 4], [2]))
