@@ -152,6 +152,30 @@ def test_dm_kernels(objects):
     assert ks[name]["vgpr_count"] <= 32 and ks[name]["private_segment_fixed_size"] == 0
 
 
+def test_gather_relayout_kernel_streams_whole_16_byte_pieces(objects):
+    """The staged gather transport's device pass (round 5) is an HBM-bound copy: its loop must be 16-byte nontemporal loads and
+    stores, four loads in flight before the first store, nothing spilled -- a compiler that splits the pieces or serialises
+    load -> store shows up here, not as 0.4 of the HBM roofline on the first multi-GPU node."""
+    co, ks = objects["bf_kernels"]
+    name = [n for n in ks if "gather_relayout_kernel" in n][0]
+    k = ks[name]
+    assert k["private_segment_fixed_size"] == 0 and k["vgpr_count"] <= 64
+    import subprocess
+
+    txt = subprocess.check_output([os.path.join(isa_report.LLVM, "llvm-objdump"), "-d", "--no-show-raw-insn", "--disassemble-symbols=" + name, co],
+                                  text=True)
+    ops = [l.strip() for l in txt.splitlines() if l.startswith("\t")]
+    loads = [o for o in ops if o.startswith("global_load_dwordx4")]
+    stores = [o for o in ops if o.startswith("global_store_dwordx4")]
+    assert len(loads) >= 5 and len(stores) >= 5                    # the unrolled body (4 + 4) and the tail loop (1 + 1)
+    assert all(" nt" in o for o in loads + stores), (loads[:2], stores[:2])
+    assert not [o for o in ops if o.startswith(("global_load_dword ", "global_store_dword ", "global_load_dwordx2", "global_store_dwordx2"))]
+    # four loads issued back to back before the first store of the unrolled body
+    first_store = next(i for i, o in enumerate(ops) if o.startswith("global_store_dwordx4"))
+    before = [o for o in ops[:first_store] if o.startswith("global_load_dwordx4")]
+    assert len(before) >= 4
+
+
 def test_generated_dm_body_is_what_the_generator_writes():
     """csrc/bf_dm_wide_body.inc is generated (tools/gen_dm_body.py) and committed: the two must not drift apart."""
     import gen_dm_body
