@@ -12,7 +12,7 @@
 //                                                   unique id there, the others wait for it.  beam_replicas -S starts
 //                                                   the `world` processes.  (The reference's own scaling -- 8 independent
 //                                                   sub-bands selected by -g, README.md:168 -- is beam_replicas without -S.)
-//   beam -j n_blocks -M dm_max [-N n_dm] [-T tsamp_ms] [-W dm_file]
+//   beam -j n_blocks -M dm_max [-N n_dm] [-T tsamp_ms] [-W dm_file | -Q dm_ring]
 //                                                   the DM stage, where the reference's loop has its DM-0
 //                                                   collapse (src/beamformer.cu:492-511): the ladder of sandbox/Dispersion
 //                                                   Theory.ipynb from 0 to dm_max (at most n_dm of its trials, evenly picked),
@@ -58,10 +58,10 @@ int main(int argc, char* argv[])
     double dm_max = 0.0, tsamp_ms = 0.131;   // (the notebook's sample time, cell 5)
     int n_dm_cap = 0;
     bool dm_split = false;
-    std::string dm_path;
+    std::string dm_path, dm_ring;   // -W file / -Q shared-memory ring for the DM chunks
 
     int arg = 0;
-    while ((arg = getopt(argc, argv, "s:g:p:d:o:D:a:c:k:K:j:w:R:r:I:M:N:T:W:Xuvh")) != -1) {  // src/beamformer.cu:41-43 (+ -o -D -a -v)
+    while ((arg = getopt(argc, argv, "s:g:p:d:o:D:a:c:k:K:j:w:R:r:I:M:N:T:W:Q:Xuvh")) != -1) {  // src/beamformer.cu:41-43 (+ -o -D -a -v)
         switch (arg) {
             case 's': sources = optarg; break;                 // :77-89
             case 'g': opt.gpu = atoi(optarg); break;           // :92-100
@@ -81,6 +81,7 @@ int main(int argc, char* argv[])
             case 'T': tsamp_ms = atof(optarg); break;
             case 'W': dm_path = optarg; break;
             case 'X': dm_split = true; break;
+            case 'Q': dm_ring = optarg; break;
             case 'u': per_unit = true; break;                   // the reference's launch pattern: one launch per gemm-unit
             case 'v': opt.verbose = true; cfg.verbose = 1; break;
             case 'c': core = atoi(optarg); break;              // :59-65
@@ -226,6 +227,7 @@ int main(int argc, char* argv[])
         // run covers (world x n_freq channels), referred to its highest frequency (channel 0): every delay is >= 0.
         std::vector<int32_t> delays;
         std::unique_ptr<dm_file_sink> dm_sink;
+        std::unique_ptr<dm_ring_sink> dm_rsink;
         int n_dm = 0, my_trials = 0;
         if (dm_max > 0.0) {
             std::vector<double> dms = dm_trials(0.0, dm_max);
@@ -263,6 +265,16 @@ int main(int argc, char* argv[])
                     return EXIT_FAILURE;
                 }
                 oopt.dm_sink = dm_sink.get();
+            } else if (!dm_ring.empty() && my_count > 0 && (!comm || rank == 0 || oopt.dm_split_trials)) {
+                // -Q: hand the chunks to another process (the downstream search) through a shared-memory ring
+                if (oopt.dm_split_trials) dm_ring += "." + std::to_string(rank);
+                dm_rsink.reset(new dm_ring_sink(pcfg, full_cfg.n_freq, my_count, dmax, pcfg.n_gemms_per_block * pcfg.n_out_per_gemm,
+                                                dm_ring.c_str(), 4, opt.gpu, my_first));
+                if (!dm_rsink->is_open()) {
+                    fprintf(stderr, "beam: could not create ring %s\n", dm_ring.c_str());
+                    return EXIT_FAILURE;
+                }
+                oopt.dm_sink = dm_rsink.get();
             }
         }
         observation_result ores;

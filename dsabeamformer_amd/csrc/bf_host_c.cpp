@@ -353,10 +353,22 @@ int bfh_run_observation_junk_dm(const bf_config* cfg, uint64_t n_blocks, int rin
     if (!cfg || !delays || n_dm <= 0) return BF_ERR_INVALID;
     int dmax = 0;
     for (size_t i = 0; i < (size_t)n_dm * cfg->n_freq; i++) dmax = delays[i] > dmax ? delays[i] : dmax;
-    std::unique_ptr<dm_file_sink> dms;
-    if (dm_path) {
-        dms.reset(new dm_file_sink(*cfg, cfg->n_freq, n_dm, dmax, dm_path, gpu));
-        if (!dms->is_open()) return BF_ERR_INVALID;
+    std::unique_ptr<dm_chunk_sink> dms;
+    if (dm_path && !std::strncmp(dm_path, "ring:", 5)) {   // "ring:<name>[:<blocks>]": the chunks to another process (dm_ring_sink)
+        std::string nm(dm_path + 5);
+        uint64_t blocks = 4;
+        const size_t colon = nm.find(':');
+        if (colon != std::string::npos) {
+            blocks = std::strtoull(nm.c_str() + colon + 1, nullptr, 10);
+            nm.resize(colon);
+        }
+        dm_ring_sink* rs = new dm_ring_sink(*cfg, cfg->n_freq, n_dm, dmax, cfg->n_gemms_per_block * cfg->n_out_per_gemm, nm.c_str(), blocks, gpu);
+        dms.reset(rs);
+        if (!rs->is_open()) return BF_ERR_INVALID;
+    } else if (dm_path) {
+        dm_file_sink* fs2 = new dm_file_sink(*cfg, cfg->n_freq, n_dm, dmax, dm_path, gpu);
+        dms.reset(fs2);
+        if (!fs2->is_open()) return BF_ERR_INVALID;
     }
     std::unique_ptr<file_sink> fs;
     if (detected_path) {

@@ -281,4 +281,47 @@ void dm_file_sink::close()
     fd = -1;
 }
 
+dm_ring_sink::dm_ring_sink(const bf_config& cfg, int n_freq_total, int n_dm, int max_delay, int max_rows, const char* ring_name,
+                           uint64_t ring_blocks, int gpu, int first_trial)
+    : name(ring_name ? ring_name : "")
+{
+    block_bytes = dm_file_sink::kRecordBytes + (size_t)n_dm * max_rows * cfg.n_beams * sizeof(float);
+    char header[kRingHeaderBytes];
+    ::snprintf(header, sizeof(header),
+               "HDR_VERSION 1.0\nHDR_SIZE %zu\nINSTRUMENT DSA\nCONTENT dedispersed_power\nDTYPE float32\nENDIAN little\n"
+               "ORDER chunk(dm,time,beam)\nRECORD_HEADER_BYTES %zu\nN_DM %d\nDM_FIRST_TRIAL %d\nN_BEAMS %d\nN_FREQUENCIES %d\nMAX_DELAY %d\n"
+               "MAX_TIMES_PER_CHUNK %d\nGPU %d\n",
+               kRingHeaderBytes, dm_file_sink::kRecordBytes, n_dm, first_trial, cfg.n_beams, n_freq_total, max_delay, max_rows, gpu);
+    out = shm_ring::create(name.c_str(), ring_blocks, block_bytes, header);
+}
+
+dm_ring_sink::~dm_ring_sink() { close(); }
+
+bool dm_ring_sink::deliver(uint64_t first_t, int n_t, int n_dm, int n_beams, const float* data)
+{
+    if (!out) return false;
+    const size_t payload = (size_t)n_dm * n_t * n_beams * sizeof(float);
+    if (n_t <= 0 || dm_file_sink::kRecordBytes + payload > block_bytes) return n_t <= 0;
+    char* b = out->open_block_write();   // blocks while the consumer is behind by a whole ring
+    if (!b) return false;
+    ::memset(b, 0, dm_file_sink::kRecordBytes);
+    const uint32_t v[3] = {(uint32_t)n_t, (uint32_t)n_dm, (uint32_t)n_beams};
+    ::memcpy(b, &first_t, 8);
+    ::memcpy(b + 8, v, 12);
+    ::memcpy(b + dm_file_sink::kRecordBytes, data, payload);
+    out->close_block_write(block_bytes);   // always a whole block: a short one means end of data
+    chunks++;
+    return true;
+}
+
+void dm_ring_sink::close()
+{
+    if (!out) return;
+    if (out->open_block_write()) out->close_block_write(0);   // short block: end of data
+    for (int waited = 0; out->get_blocks_read() < out->get_blocks_written() && waited < 10000; waited += 5) ::usleep(5000);
+    delete out;
+    out = nullptr;
+    shm_ring::unlink(name.c_str());
+}
+
 }  // namespace dsabf

@@ -115,7 +115,8 @@ int bfh_run_observation_junk_to_ring(const bf_config *cfg, uint64_t n_blocks, in
 /* Same loop with the DM stage on (SURVEY.md 8f-4 as a stage of the loop; where the reference collapses frequency,
  * src/beamformer.cu:492-511): delays int32 [n_dm][cfg->n_freq] (bfh_dm_delays), every analysed block pushed into a bf_dm_stream
  * behind its launch, the chunks written to dm_path (dsabf::dm_file_sink: 4096-byte header, then per chunk a 32-byte record
- * {u64 first_t, u32 n_t, u32 n_dm, u32 n_beams} + float32 [dm][t][beam]; NULL: the stage runs, nothing is kept) and,
+ * {u64 first_t, u32 n_t, u32 n_dm, u32 n_beams} + float32 [dm][t][beam]; "ring:<name>[:<blocks>]": the same records, one per block of a
+ * shared-memory ring the call creates, to another process (dsabf::dm_ring_sink); NULL: the stage runs, nothing is kept) and,
  * optionally, the detected stream itself to detected_path.  dm_times (optional): output times produced. */
 int bfh_run_observation_junk_dm(const bf_config *cfg, uint64_t n_blocks, int ring_blocks, uint64_t seed, int gpu, int device,
                                 int burn_in, int verbose, const int32_t *delays, int n_dm, const char *dm_path,

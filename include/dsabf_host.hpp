@@ -491,6 +491,28 @@ public:
     uint64_t get_chunks_written() const { return chunks; }
 };
 
+// Hands every chunk to another process through a shared-memory ring (the downstream search's input): one ring block per chunk --
+// the 32-byte record {uint64 first_t; uint32 n_t, n_dm, n_beams; zeros} followed by [dm][n_t][beam] float32, padded to the block
+// size (32 + n_dm * max_rows * n_beams * 4 bytes: chunks emitted before the delay window has filled hold fewer times) -- then a
+// short block.  The sink creates the ring; like any PSRDADA writer the loop blocks while the consumer is a whole ring behind.
+class dm_ring_sink : public dm_chunk_sink {
+    shm_ring* out = nullptr;
+    std::string name;
+    size_t block_bytes = 0;
+    uint64_t chunks = 0;
+
+public:
+    dm_ring_sink(const bf_config& cfg, int n_freq_total, int n_dm, int max_delay, int max_rows, const char* ring_name, uint64_t ring_blocks,
+                 int gpu, int first_trial = 0);
+    ~dm_ring_sink() override;
+    dm_ring_sink(const dm_ring_sink&) = delete;
+    dm_ring_sink& operator=(const dm_ring_sink&) = delete;
+    bool is_open() const { return out != nullptr; }
+    bool deliver(uint64_t first_t, int n_t, int n_dm, int n_beams, const float* data) override;
+    void close() override;
+    uint64_t get_chunks_written() const { return chunks; }
+};
+
 // Keeps the chunks in host memory, assembled as one [n_dm][T][n_beams] series on request (tests, small runs).
 class dm_memory_sink : public dm_chunk_sink {
 public:

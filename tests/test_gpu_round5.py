@@ -484,3 +484,54 @@ def test_production_loop_with_the_dm_stage_under_random_launch_patterns(bfmod, o
     hdr, got, chunks = host.read_dm_file(dmf)
     assert sum(n for _, n in chunks) == T - D and int(hdr["MAX_DELAY"]) == D
     assert np.array_equal(got, orc.dedisperse_dm(series, delays, T - D)), (seed, n_u, n_st, n_dm, D)
+
+
+def test_dm_chunks_to_another_process_through_a_shared_memory_ring(bfmod, orc):
+    """dsabf::dm_ring_sink (`beam -Q ring`): the DM stage's chunks handed to a consumer -- the downstream search -- through a
+    shared-memory ring the loop creates, one block per chunk (record header + [dm][t][beam], whole blocks; a short block ends the
+    data).  A 2-block ring for 7 chunks and a consumer that dawdles: the loop waits, nothing is dropped; joined along t the
+    chunks are the oracle's over the whole detected series."""
+    import threading
+    import time
+
+    from dsabeamformer_amd import host
+
+    cfg = bfmod.production_config(n_freq=8, n_out_per_gemm=2)
+    cfg.n_beams, cfg.n_gemms_per_block, cfg.n_streams = 64, 4, 2
+    n_blocks, ring_blocks, n_dm = 8, 3, 10
+    rows = cfg.n_gemms_per_block * cfg.n_out_per_gemm
+    delays = _pulse_delays(n_dm, cfg.n_freq, 11)                    # longer than a block of 8 rows: the first block completes nothing
+    D, T = int(delays.max()), n_blocks * rows
+    name = "dsabf_dmout_%d" % os.getpid()
+    got, err = [], []
+
+    def consumer():
+        try:
+            ring = host.ShmRing(name, timeout_ms=20000)
+            assert ring.block_size == 32 + n_dm * rows * 64 * 4 and "dedispersed_power" in ring.header
+            assert "MAX_DELAY %d" % D in ring.header and "MAX_TIMES_PER_CHUNK %d" % rows in ring.header
+            while True:
+                data, bid = ring.read()
+                if data.size < ring.block_size:
+                    break
+                first_t = int(data[:8].view("<u8")[0])
+                n_t, nd, nb = (int(v) for v in data[8:20].view("<u4"))
+                assert (nd, nb) == (n_dm, 64) and first_t == sum(p.shape[1] for p in got)
+                got.append(data[32:32 + 4 * nd * n_t * nb].view(np.float32).reshape(nd, n_t, nb).copy())
+                if bid == 2:
+                    time.sleep(0.3)    # let the 2-block ring fill: the loop must wait for the consumer, not drop a chunk
+            ring.detach()
+        except Exception as e:  # noqa: BLE001
+            err.append(e)
+
+    t = threading.Thread(target=consumer)
+    t.start()
+    r = host.run_observation_junk_dm(cfg, n_blocks, delays, "ring:%s:2" % name, ring_blocks=ring_blocks, seed=77, gpu=1)
+    t.join(timeout=60)
+    assert not err, err
+    assert r["dm_times"] == T - D and not os.path.exists("/dev/shm/" + name)      # drained, then removed by the sink
+    g = orc.Geom(n_beams=64, n_ant=64, n_freq=8, n_avg=16, n_out_per_gemm=2)
+    w = orc.make_weights(g, orc.default_positions(64), orc.default_directions(64), 1)
+    series = np.concatenate([orc.beamform(g, w, r["ring"][b % ring_blocks]).reshape(rows, 8, 64) for b in range(n_blocks)])
+    assert [p.shape[1] for p in got] == [2 * rows - D] + [rows] * (n_blocks - 2)
+    assert np.array_equal(np.concatenate(got, axis=1), orc.dedisperse_dm(series, delays, T - D))
