@@ -241,8 +241,8 @@ int bf_dedisperse_dm_device(bf_handle *h, const float *d_series, int n_t, const 
  *   t = first_t .. first_t + n_t_out - 1 counted from the first row ever pushed.
  * Chunks follow each other without gaps or overlap (first_t of a push = first_t + n_t_out of the one before); concatenated
  * along t they are BIT-IDENTICAL to one bf_dedisperse_dm_device call over the whole series (same kernels, same ascending-f
- * sum per output; the last max_delay times of a series are never complete, there as here).  n_t_out is 0 until max_delay rows
- * have been seen, then equals n_rows.
+ * sum per output; the last max_delay times of a series are never complete, there as here).  n_t_out is 0 until more than
+ * max_delay rows have been seen; the first chunk holds the times beyond them, every later one n_rows.
  *   delays: HOST int32 [n_dm][n_freq_total], all >= 0 (dsabf::dm_delays / bfh_dm_delays); n_freq_total = the channels of one
  *   pushed row (cfg.n_freq, or world * cfg.n_freq on a gather root); max_rows_per_push: the largest n_rows of a push
  *   (n_gemms_per_block * n_out_per_gemm for block launches).
