@@ -186,6 +186,9 @@ SIGNATURES = {
                                 C.c_double, C.POINTER(C.c_double), C.c_int]),
     "bfh_dm_delays": (C.c_int, [C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_float), C.c_int, C.c_double, C.c_double,
                                 C.POINTER(C.c_int32)]),
+    "bfh_dm_sink_create": (C.c_int, [C.POINTER(BfConfig), C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "bfh_dm_sink_deliver": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "bfh_dm_sink_destroy": (C.c_int, [C.c_void_p]),
     "bfh_dm_trial_share": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "bfh_junk_fill": (C.c_int, [C.POINTER(BfConfig), C.c_int, C.c_uint64, C.c_void_p]),
     "bfh_shm_ring_create": (C.c_int, [C.c_char_p, C.c_uint64, C.c_uint64, C.c_char_p, C.POINTER(C.c_void_p)]),

@@ -586,4 +586,51 @@ int bfh_sink_destroy(bfh_sink* s)
     return BF_OK;
 }
 
+// the DM chunk sinks on their own (tests; no device needed)
+struct bfh_dm_sink {
+    dm_chunk_sink* s;
+};
+int bfh_dm_sink_create(const bf_config* cfg, const char* target, int n_freq_total, int n_dm, int max_delay, int max_rows, int first_trial,
+                       bfh_dm_sink** out)
+{
+    if (!cfg || !target || !out || n_dm <= 0 || max_rows <= 0) return BF_ERR_INVALID;
+    *out = nullptr;
+    if (!std::strncmp(target, "ring:", 5)) {
+        std::string nm(target + 5);
+        uint64_t blocks = 4;
+        const size_t colon = nm.find(':');
+        if (colon != std::string::npos) {
+            blocks = std::strtoull(nm.c_str() + colon + 1, nullptr, 10);
+            nm.resize(colon);
+        }
+        dm_ring_sink* r = new dm_ring_sink(*cfg, n_freq_total, n_dm, max_delay, max_rows, nm.c_str(), blocks, 0, first_trial);
+        if (!r->is_open()) {
+            delete r;
+            return BF_ERR_INVALID;
+        }
+        *out = new bfh_dm_sink{r};
+        return BF_OK;
+    }
+    dm_file_sink* f = new dm_file_sink(*cfg, n_freq_total, n_dm, max_delay, target, 0, first_trial);
+    if (!f->is_open()) {
+        delete f;
+        return BF_ERR_INVALID;
+    }
+    *out = new bfh_dm_sink{f};
+    return BF_OK;
+}
+int bfh_dm_sink_deliver(bfh_dm_sink* s, uint64_t first_t, int n_t, int n_dm, int n_beams, const float* data)
+{
+    if (!s || !data) return BF_ERR_INVALID;
+    return s->s->deliver(first_t, n_t, n_dm, n_beams, data) ? BF_OK : BF_ERR_STATE;
+}
+int bfh_dm_sink_destroy(bfh_dm_sink* s)
+{
+    if (!s) return BF_OK;
+    s->s->close();
+    delete s->s;
+    delete s;
+    return BF_OK;
+}
+
 }  // extern "C"

@@ -130,6 +130,15 @@ int bfh_sink_commit(bfh_sink *s, uint64_t gemm_index);                 /* in ord
 int bfh_sink_close(bfh_sink *s);
 int bfh_sink_destroy(bfh_sink *s);
 
+/* The DM-chunk sinks on their own (tests; no device): target = a file path (dsabf::dm_file_sink) or "ring:<name>[:<blocks>]"
+ * (dsabf::dm_ring_sink, which creates the ring; destroy waits until a consumer has drained it).  Chunks must follow each other
+ * without gaps (first_t = the times delivered so far), else BF_ERR_STATE. */
+typedef struct bfh_dm_sink bfh_dm_sink;
+int bfh_dm_sink_create(const bf_config *cfg, const char *target, int n_freq_total, int n_dm, int max_delay, int max_rows,
+                       int first_trial, bfh_dm_sink **out);
+int bfh_dm_sink_deliver(bfh_dm_sink *s, uint64_t first_t, int n_t, int n_dm, int n_beams, const float *data);
+int bfh_dm_sink_destroy(bfh_dm_sink *s);
+
 /* DM trial ladder and per-channel sample delays (sandbox/Dispersion Theory.ipynb cells 1-2 and 5; dsabf::dm_trials,
  * dsabf::dm_delays).  bfh_dm_trials returns the number of trials written (<= cap). */
 int bfh_dm_trials(double dm0, double dm_max, int nchan, double epsilon, double nu_ghz, double chan_bw_mhz, double ti_us,

@@ -697,3 +697,66 @@ def test_dm_trial_share_covers_the_ladder_once():
                 counts.append(c.value)
             assert at == n_dm and max(counts) - min(counts) <= 1 and counts == sorted(counts, reverse=True)
     assert lib.bfh_dm_trial_share(4, 2, 2, None, None) != 0
+
+
+def test_dm_chunk_sinks_file_and_ring_without_a_device(tmp_path):
+    """The DM stage's sinks (round 5) on their own: the file of chunk records read back by host.read_dm_file (header keys, record
+    framing, chunks joined along t, a gap refused), and the shared-memory ring to another process (whole blocks, the record in
+    front of the payload, back-pressure on a 2-block ring, the short block that ends the data, the ring removed afterwards)."""
+    import ctypes as C
+    import threading
+
+    from dsabeamformer_amd import api, host
+    from dsabeamformer_amd._lib import load
+
+    lib = load()
+    cfg = api.production_config(n_freq=8, n_out_per_gemm=2)
+    cfg.n_beams, cfg.n_gemms_per_block = 12, 4
+    n_dm, rows, D = 5, 8, 3
+    rng = np.random.default_rng(8)
+    sizes = [5, 8, 8, 1]
+    chunks = [rng.random((n_dm, n, 12), dtype=np.float32) for n in sizes]
+    # ---- file ----
+    path = str(tmp_path / "dm.bin")
+    s = C.c_void_p()
+    assert lib.bfh_dm_sink_create(C.byref(cfg), path.encode(), 8, n_dm, D, rows, 2, C.byref(s)) == 0
+    at = 0
+    for c in chunks:
+        assert lib.bfh_dm_sink_deliver(s, at, c.shape[1], n_dm, 12, c.ctypes.data_as(C.c_void_p)) == 0
+        at += c.shape[1]
+    assert lib.bfh_dm_sink_deliver(s, at + 1, 1, n_dm, 12, chunks[0].ctypes.data_as(C.c_void_p)) != 0      # a gap: refused
+    assert lib.bfh_dm_sink_destroy(s) == 0
+    hdr, data, recs = host.read_dm_file(path)
+    assert (int(hdr["N_DM"]), int(hdr["DM_FIRST_TRIAL"]), int(hdr["MAX_DELAY"]), int(hdr["N_FREQUENCIES"]), int(hdr["N_BEAMS"])) == (5, 2, 3, 8, 12)
+    assert recs == [(0, 5), (5, 8), (13, 8), (21, 1)] and np.array_equal(data, np.concatenate(chunks, axis=1))
+    assert lib.bfh_dm_sink_create(C.byref(cfg), b"/nonexistent/dir/dm.bin", 8, n_dm, D, rows, 0, C.byref(s)) != 0
+    # ---- ring ----
+    name = "dsabf_dmsink_%d" % os.getpid()
+    got, err = [], []
+
+    def consumer():
+        try:
+            ring = host.ShmRing(name, timeout_ms=20000)
+            assert ring.block_size == 32 + n_dm * rows * 12 * 4 and "DM_FIRST_TRIAL 0" in ring.header
+            while True:
+                blk, bid = ring.read()
+                if blk.size < ring.block_size:
+                    break
+                first_t, (n_t, nd, nb) = int(blk[:8].view("<u8")[0]), (int(v) for v in blk[8:20].view("<u4"))
+                got.append((first_t, blk[32:32 + 4 * nd * n_t * nb].view(np.float32).reshape(nd, n_t, nb).copy()))
+            ring.detach()
+        except Exception as e:  # noqa: BLE001
+            err.append(e)
+
+    assert lib.bfh_dm_sink_create(C.byref(cfg), ("ring:%s:2" % name).encode(), 8, n_dm, D, rows, 0, C.byref(s)) == 0
+    t = threading.Thread(target=consumer)
+    t.start()
+    at = 0
+    for c in chunks:
+        assert lib.bfh_dm_sink_deliver(s, at, c.shape[1], n_dm, 12, c.ctypes.data_as(C.c_void_p)) == 0   # (4 chunks, 2 blocks: waits)
+        at += c.shape[1]
+    assert lib.bfh_dm_sink_destroy(s) == 0          # the short block, the drain, the unlink
+    t.join(timeout=30)
+    assert not err, err
+    assert [f for f, _ in got] == [0, 5, 13, 21] and all(np.array_equal(g, c) for (_, g), c in zip(got, chunks))
+    assert not os.path.exists("/dev/shm/" + name)
