@@ -376,6 +376,24 @@ def self_launch(args):
     print("bench.py: --gpus %d without a launcher: starting %s" % (args.gpus, " ".join(cmd[1:9])), file=sys.stderr, flush=True)
     limit = args.deadline_seconds + float(os.environ.get("DSABF_LAUNCH_GRACE", "90"))   # the ranks' own deadlines fire first and say more
     child = subprocess.Popen(cmd, env=env, start_new_session=True)
+
+    def pass_on(signum, _frame):
+        """The ranks live in a session of their own: a signal that ends THIS process must end them too (first SIGTERM -- their
+        sigwait threads print what they have -- then, if the launcher lingers, SIGKILL), or they would keep the GPUs."""
+        for sig, wait_s in ((signal.SIGTERM, 15.0), (signal.SIGKILL, 5.0)):
+            try:
+                os.killpg(child.pid, sig)
+            except OSError:
+                break
+            try:
+                child.wait(timeout=wait_s)
+                break
+            except subprocess.TimeoutExpired:
+                continue
+        os._exit(128 + signum)
+
+    for sig in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
+        signal.signal(sig, pass_on)
     try:
         sys.exit(child.wait(timeout=limit))
     except subprocess.TimeoutExpired:

@@ -270,3 +270,38 @@ def test_committed_bench_lines_agree_with_the_committed_rocprof_kernel_stats():
         assert 0.6 * roof["peak"] < roof["peak_measured"] <= roof["peak"] * 1.02
         assert abs(roof["achieved"] / roof["peak_measured"] / roof["frac_of_measured_peak"] - 1) < 1e-9
         assert roof["frac"] < roof["frac_of_measured_peak"] < 1.05
+
+
+def test_a_signal_to_the_parent_ends_the_ranks_too(tmp_path):
+    """The launcher and its ranks run in a session of their own (so that the parent's deadline can kill them as a group): a
+    SIGTERM to the parent must therefore be passed on, or the ranks would outlive it and keep the GPUs."""
+    import signal
+    import time
+
+    marker = tmp_path / "child.pid"
+    child_code = "import os, time; open(%r, 'w').write(str(os.getpid())); time.sleep(600)" % str(marker)
+    code = ("import sys; sys.path.insert(0, %r); import bench\n"
+            "bench.launcher_command = lambda n, argv, port: [sys.executable, '-c', %r]\n"
+            "sys.argv = ['bench.py', '--gpus', '2']\n"
+            "bench.main()\n" % (ROOT, child_code))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.update(DSABF_BENCH_ONE_GPU="1")
+    p = subprocess.Popen([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    t0 = time.time()
+    while not marker.exists() and time.time() - t0 < 60:
+        time.sleep(0.05)
+    assert marker.exists()
+    time.sleep(0.2)
+    pid = int(marker.read_text())
+    p.send_signal(signal.SIGTERM)
+    p.communicate(timeout=60)
+    assert p.returncode == 128 + signal.SIGTERM
+    for _ in range(100):                       # the child is gone (ESRCH), not orphaned
+        try:
+            os.kill(pid, 0)
+        except OSError:
+            break
+        time.sleep(0.05)
+    else:
+        os.kill(pid, signal.SIGKILL)
+        raise AssertionError("the launcher's child outlived its parent")
