@@ -47,7 +47,12 @@ event_backend* make_hip_event_backend(bf_handle* h) { return new hip_backend(h);
 // ---- observation_loop_state (src/observation_loop.hh:54-176) -------------------------------------------------------
 observation_loop_state::observation_loop_state(uint64_t max_tsep, uint64_t max_totsep, const bf_config& cfg,
                                                event_backend* backend, bool debug)
-    : maximum_transfer_seperation(max_tsep), maximum_total_seperation(max_totsep), debug_mode(debug),
+    // The device ring has n_blocks_on_gpu slots and block j lives in slot j % n_blocks_on_gpu until its analysis has COMPLETED: a
+    // transfer may run at most n_blocks_on_gpu blocks ahead of blocks_analyzed, or it overwrites voltages a kernel is still reading.
+    // The reference never meets the case (N_BLOCKS_ON_GPU 8 > MAX_TOTAL_SEP 4, both compile-time: src/beamformer.hh:85,124); with
+    // a run-time ring the separations are held to its size (found by the random DEBUG-flow fuzz, round 5: 2 slots, 1 run in 400).
+    : maximum_transfer_seperation(std::min<uint64_t>(max_tsep, (uint64_t)std::max(cfg.n_blocks_on_gpu, 1))),
+      maximum_total_seperation(std::min<uint64_t>(max_totsep, (uint64_t)std::max(cfg.n_blocks_on_gpu, 1))), debug_mode(debug),
       verbose(cfg.verbose != 0), n_gemms_per_block(cfg.n_gemms_per_block), n_blocks_on_gpu(cfg.n_blocks_on_gpu),
       n_events(5 * cfg.n_blocks_on_gpu), ev(backend)
 {

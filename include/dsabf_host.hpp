@@ -126,6 +126,8 @@ struct event_backend {
 };
 event_backend* make_hip_event_backend(bf_handle* h);  // caller deletes
 
+// (One difference from the reference, where both are compile-time and N_BLOCKS_ON_GPU 8 > MAX_TOTAL_SEP 4: the two separations
+// are held to the ring's size, cfg.n_blocks_on_gpu -- a transfer must never overwrite a slot whose block is still being analysed.)
 class observation_loop_state {
 private:
     uint64_t blocks_analyzed = 0;

@@ -760,3 +760,46 @@ def test_dm_chunk_sinks_file_and_ring_without_a_device(tmp_path):
     assert not err, err
     assert [f for f, _ in got] == [0, 5, 13, 21] and all(np.array_equal(g, c) for (_, g), c in zip(got, chunks))
     assert not os.path.exists("/dev/shm/" + name)
+
+
+@pytest.mark.parametrize("ring", [1, 2, 3, 4, 8])
+def test_a_transfer_never_overwrites_a_ring_slot_that_is_still_being_analysed(host, bfm, ring):
+    """Round 5, found by the random DEBUG-flow fuzz (2 ring slots, 1 run in 400 wrong): block j lives in slot j % n_blocks_on_gpu
+    until its analysis has COMPLETED, so a transfer may be at most n_blocks_on_gpu blocks ahead of blocks_analyzed.  The
+    reference's separations (MAX_TOTAL_SEP 4, MAX_TRANSFER_SEP 2) only guarantee that for its own ring of 8; with a run-time
+    ring the scheduler holds them to the ring's size.  Slow analyses, instant transfers: every H2D must find its slot free."""
+    cfg = bfm.debug_config(n_blocks_on_gpu=ring)
+    obs = make_obs(host, cfg, debug=True)
+    n_src = 32 * 20
+    obs.set_n_pt_sources(n_src)
+    busy = {}                    # slot -> block whose voltages it holds and whose analysis has not completed
+    analysed_upto = 0
+    pend_a, it = [], 0
+    while not obs.check_observations_complete():
+        it += 1
+        assert it < 20000
+        c = obs.counters()
+        assert c["TQ"] - c["A"] <= min(4, ring) and c["TQ"] - c["T"] <= min(2, ring)
+        if obs.check_ready_for_transfer():
+            slot = obs.get_next_gpu_transfer_block()
+            assert slot == c["TQ"] % ring
+            assert slot not in busy, "block %d would overwrite slot %d under block %d" % (c["TQ"], slot, busy.get(slot, -1))
+            busy[slot] = c["TQ"]
+            obs.generate_transfer_event()
+            obs.check_transfers_complete()
+        obs.fake_complete(10, 0)                         # transfers land at once
+        obs.check_transfer_events()
+        if obs.check_ready_for_analysis():
+            for ts in range(32):
+                obs.get_current_analysis_gemm(ts)
+            obs.generate_analysis_event()
+            pend_a.append(it)
+        if pend_a and it - pend_a[0] >= 7:               # an analysis takes 7 iterations
+            obs.fake_complete(0, 1)
+            pend_a.pop(0)
+        obs.check_analysis_events()
+        while analysed_upto < obs.counters()["A"]:       # completed analyses free their slots
+            assert busy.pop(analysed_upto % ring) == analysed_upto
+            analysed_upto += 1
+    assert obs.counters()["A"] == 20 and not busy
+    obs.close()
