@@ -40,7 +40,7 @@ rm -rf $O/prof_aux
 (cd $R && PMC_FILTER="gather_relayout" PMC_BENCH_ARGS="--steps 3 --warmup 1 --no-cpu-baseline" bash tools/pmc.sh r05p/pmc_aux > /dev/null 2>&1 && cp $O/pmc_aux/summary.txt $O/r05_relayout_pmc_summary.txt; rm -rf $O/pmc_aux)
 cd $R
 SEED=51 CASES=300 python tools/fuzz_dm_stream.py > $O/r05_fuzz_dm_stream.txt 2>&1
-(SEED=2000 CASES=1200 python tools/fuzz_calls.py; SEED=10000 CASES=300 python tools/fuzz_calls.py; FUZZ=loops SEED=3000 CASES=150 python tools/fuzz_calls.py; FUZZ=debug SEED=4000 CASES=150 python tools/fuzz_calls.py; FUZZ=dmloops SEED=6000 CASES=200 python tools/fuzz_calls.py) 2>&1 | grep -v "obs Complete\|amdgpu.ids" > $O/r05_fuzz_calls.txt
+(SEED=2000 CASES=1200 python tools/fuzz_calls.py; SEED=10000 CASES=300 python tools/fuzz_calls.py; FUZZ=loops SEED=3000 CASES=150 python tools/fuzz_calls.py; FUZZ=debug SEED=4000 CASES=400 python tools/fuzz_calls.py; FUZZ=dmloops SEED=6000 CASES=200 python tools/fuzz_calls.py) 2>&1 | grep -v "obs Complete\|amdgpu.ids" > $O/r05_fuzz_calls.txt
 # the GPU suite: the budgeted default run with its durations, then every case
 python -m pytest tests -m gpu -q --durations=25 -p no:cacheprovider > $O/r05_gputest_durations.txt 2>&1
 DSABF_LONG_TESTS=1 python -m pytest tests -m gpu -q -p no:cacheprovider 2>&1 | tail -4 > $O/r05_gputest_long_tail.txt
