@@ -1,7 +1,7 @@
 // beam_main.cpp -- the `beam` driver: command line and lifecycle of the reference's main() (src/beamformer.cu:12-157,
 // 539-571; usage() src/beamformer.hh:222-243) on top of libdsabf.so.
 //
-//   beam [-g gpu] [-p position_file] [-d direction_file] [-s source_file] [-o data.py] [-D device] [-a n_avg] [-u] [-v] [-h]
+//   beam [-g gpu] [-p position_file] [-d direction_file] [-s source_file] [-o data.py] [-D device] [-a n_avg] [-u] [-v] [-h | -H]
 //        (-u: the reference's launch pattern, one launch + copy per gemm-unit, instead of one per block; same data.py)
 //   beam -j n_blocks [-g gpu] [-p ...] [-d ...]     production geometry, observation loop fed by the in-memory
 //                                                   dada_junkdb stand-in (soak / data-rate run, makefile:28-29)
@@ -61,7 +61,7 @@ int main(int argc, char* argv[])
     std::string dm_path, dm_ring;   // -W file / -Q shared-memory ring for the DM chunks
 
     int arg = 0;
-    while ((arg = getopt(argc, argv, "s:g:p:d:o:D:a:c:k:K:j:w:R:r:I:M:N:T:W:Q:Xuvh")) != -1) {  // src/beamformer.cu:41-43 (+ -o -D -a -v)
+    while ((arg = getopt(argc, argv, "s:g:p:d:o:D:a:c:k:K:j:w:R:r:I:M:N:T:W:Q:XuvhH")) != -1) {  // src/beamformer.cu:41-43 (+ -o -D -a -v)
         switch (arg) {
             case 's': sources = optarg; break;                 // :77-89
             case 'g': opt.gpu = atoi(optarg); break;           // :92-100
@@ -87,6 +87,24 @@ int main(int argc, char* argv[])
             case 'c': core = atoi(optarg); break;              // :59-65
             case 'k': ring_key = optarg; break;                // :66-75 (a shared-memory ring name instead of a hex key)
             case 'h': usage(true, std::cout); return EXIT_SUCCESS;  // :123-125
+            case 'H':   // the reference's text, then what this build adds to its command line
+                usage(true, std::cout);
+                std::cout << "extensions of this build (no counterpart in the reference):\n"
+                             " -o file                 where the DEBUG run writes its table [bin/data.py]\n"
+                             " -D device               HIP device index [0]\n"
+                             " -a n_avg                N_AVERAGING of the DEBUG geometry [1]\n"
+                             " -u                      the reference's launch pattern: one launch + copy per gemm-unit\n"
+                             " -v                      verbose (the reference's -DVERBOSE)\n"
+                             " -j n_blocks             observation mode: production geometry, in-memory dada_junkdb source\n"
+                             " -k name | hexkey        observation mode: blocks from a shared-memory ring (hex key: PSRDADA builds)\n"
+                             " -c core                 bind to a CPU core (with -k)\n"
+                             " -w file | -K ring       keep the detected stream: file, or shared-memory ring to another process\n"
+                             " -R world -r rank -I id  one frequency shard of a sub-band; powers gathered to rank 0 (RCCL)\n"
+                             " -M dm_max [-N n_dm] [-T tsamp_ms]   the DM-trial stage inside the loop (notebook ladder 0 .. dm_max)\n"
+                             " -W file | -Q ring       its chunks [dm][t][beam]: file of records, or shared-memory ring\n"
+                             " -X                      with -R: gather to every shard, shard r dedisperses its share of the trials\n"
+                             " -H                      this text\n";
+                return EXIT_SUCCESS;
             default: usage(true, std::cerr); return EXIT_FAILURE;
         }
     }

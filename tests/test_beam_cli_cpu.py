@@ -33,3 +33,13 @@ def test_fails_loudly_without_a_gpu():
     _build()
     r = subprocess.run([BEAM], capture_output=True, text=True, timeout=60)
     assert r.returncode != 0 and "GPUassert" in r.stderr  # no CPU fallback
+
+
+def test_extended_usage_lists_what_this_build_adds():
+    """`beam -h` is the reference's text, byte for byte; `beam -H` appends the options this build adds (observation sources and
+    sinks, sharding, the DM stage), so that nobody has to read the driver's source to find them."""
+    r = subprocess.run([BEAM, "-H"], capture_output=True, text=True, timeout=60)
+    h = subprocess.run([BEAM, "-h"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and r.stdout.startswith(h.stdout) and "extensions of this build" in r.stdout
+    for flag in ("-j n_blocks", "-R world -r rank -I id", "-M dm_max", "-W file | -Q ring", "-X ", "-w file | -K ring"):
+        assert flag in r.stdout, flag
