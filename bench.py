@@ -660,6 +660,7 @@ def main():
             self.root = {"root": 0, "alltoall": api.GATHER_ROOT_DISTRIBUTED}.get(mode)
             self.lay = api.GATHER_RANK_MAJOR if layout == "rank" else api.GATHER_FREQ_MAJOR
             self.kernel_done = [torch.cuda.Event() for _ in range(2)]
+            self.gather_ev = [torch.cuda.Event() for _ in range(2)]     # created once: the step loop creates nothing
             self.gather_done = [None, None]
             self.full = [None, None]
             self.stage = [None, None]
@@ -694,9 +695,8 @@ def main():
                 comm.gather_staged(d_out[slot], n_rows, row_floats, self.root, self.full[slot], self.stage[slot], side.cuda_stream)
             else:
                 comm.gather(d_out[slot], n_rows, row_floats, self.root, self.lay, self.full[slot], side.cuda_stream)
-            ev = torch.cuda.Event()
-            ev.record(side)
-            self.gather_done[slot] = ev
+            self.gather_ev[slot].record(side)
+            self.gather_done[slot] = self.gather_ev[slot]
 
         def drain(self):
             for slot in (0, 1):
@@ -727,6 +727,7 @@ def main():
         t0 = time.perf_counter()
         for i in range(n_steps):
             step(i, gm, events[i] if events else None)
+        closing["enqueue_ms"] = (time.perf_counter() - t0) * 1e3 / n_steps     # host time to SUBMIT a step (kernel + gather calls)
         gm.drain()                                   # torch.cuda.synchronize(): this rank's K steps are complete
         elapsed = time.perf_counter() - t0
         if dist is not None:
@@ -969,6 +970,10 @@ def main():
                         "messages_sent_per_rank_per_step": msgs})
         if "ms" in closing:
             rec["closing_barrier_ms"] = closing["ms"]      # rank 0's wait in the MAX all-reduce behind its own K steps
+        if "enqueue_ms" in closing:
+            # rank 0's host time to submit one step: if it approaches ms_per_step the region was bound by the launching thread
+            # (python + ctypes + the RCCL group call), not by the GPUs or the fabric
+            rec["host_submit_ms_per_step"] = closing["enqueue_ms"]
         if ev:
             ms = [a.elapsed_time(b) for a, b in ev]
             rec["kernel_ms_avg"] = sum(ms) / len(ms)
