@@ -941,6 +941,8 @@ def main():
         }
         if rccl_info is not None:
             out["rccl"] = rccl_info
+        if "enqueue_ms" in closing:     # the host's time to submit one step of the region this record was built from
+            out["host_submit_ms_per_step"] = closing["enqueue_ms"]
         return out
 
 
