@@ -174,6 +174,9 @@ SIGNATURES = {
     "bfh_run_observation_junk_dm": (C.c_int, [C.POINTER(BfConfig), C.c_uint64, C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int,
                                               C.c_void_p, C.c_int, C.c_char_p, C.c_char_p, C.POINTER(C.c_float),
                                               C.POINTER(C.c_uint64), C.c_void_p]),
+    "bfh_run_observation_junk_sharded": (C.c_int, [C.POINTER(BfConfig), C.c_uint64, C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int,
+                                                   C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.c_char_p,
+                                                   C.POINTER(C.c_float), C.POINTER(C.c_uint64), C.c_void_p]),
     "bfh_run_observation_junk_to_ring": (C.c_int, [C.POINTER(BfConfig), C.c_uint64, C.c_int, C.c_uint64, C.c_int, C.c_int,
                                                    C.c_char_p, C.c_uint64, C.POINTER(C.c_float), C.POINTER(C.c_uint64),
                                                    C.c_void_p]),

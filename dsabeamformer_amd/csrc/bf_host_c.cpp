@@ -383,6 +383,71 @@ int bfh_run_observation_junk_dm(const bf_config* cfg, uint64_t n_blocks, int rin
     return BF_OK;
 }
 
+// One frequency shard of a sharded observation (what `beam -R world -r rank` runs), with any geometry: communicator from the id,
+// the junk source (every shard reads the same bytes with its local geometry), the gather after every block in either transport,
+// to one root or to every rank, the DM stage on the root(s) or split by trials, file sinks where this rank holds the band.
+int bfh_run_observation_junk_sharded(const bf_config* cfg, uint64_t n_blocks, int ring_blocks, uint64_t seed, int gpu, int device, int rank,
+                                     int world, const void* id128, int gather_root, int staged, const int32_t* delays, int n_dm,
+                                     int split_trials, const char* detected_path, const char* dm_path, float* observation_ms,
+                                     uint64_t* dm_times, void* ring_copy)
+{
+    if (!cfg || world < 1 || rank < 0 || rank >= world) return BF_ERR_INVALID;
+    bf_comm* comm = nullptr;
+    int rc = bf_comm_create(rank, world, id128, device, &comm);
+    if (rc != BF_OK) return rc;
+    struct comm_guard {
+        bf_comm* c;
+        ~comm_guard() { bf_comm_destroy(c); }
+    } cg{comm};
+    const bool holds_band = gather_root == BF_GATHER_ROOT_ALL || gather_root == rank;
+    bf_config full = *cfg;
+    full.n_freq = cfg->n_freq * world;
+    std::unique_ptr<file_sink> fs;
+    if (detected_path && holds_band) {
+        fs.reset(new file_sink(full, detected_path, gpu));
+        if (!fs->ok() || !fs->is_open()) return BF_ERR_INVALID;
+    }
+    int first = 0, count = n_dm;
+    if (split_trials) dm_trial_share(n_dm, world, rank, &first, &count);
+    std::unique_ptr<dm_file_sink> dms;
+    if (delays && dm_path && holds_band && count > 0) {
+        int dmax = 0;
+        for (size_t i = (size_t)first * full.n_freq; i < (size_t)(first + count) * full.n_freq; i++) dmax = delays[i] > dmax ? delays[i] : dmax;
+        dms.reset(new dm_file_sink(*cfg, full.n_freq, count, dmax, dm_path, gpu, first));
+        if (!dms->is_open()) return BF_ERR_INVALID;
+    }
+    junk_block_source src(*cfg, n_blocks, ring_blocks, seed);
+    if (!src.ok()) return BF_ERR_DEVICE;
+    std::vector<antenna> pos((size_t)cfg->n_ant);
+    std::vector<beam_direction> dir((size_t)cfg->n_beams);
+    default_positions(cfg->n_ant, pos.data());
+    default_directions(cfg->n_beams, dir.data());
+    observation_options opt;
+    opt.gpu = gpu;
+    opt.device = device;
+    opt.world = world;
+    opt.rank = rank;
+    opt.comm = comm;
+    opt.gather_root = gather_root;
+    opt.gather_staged = staged != 0;
+    opt.sink = fs.get();
+    opt.dm_delays = delays;
+    opt.n_dm = delays ? n_dm : 0;
+    opt.dm_split_trials = split_trials != 0;
+    opt.dm_sink = dms.get();
+    observation_result res;
+    std::ostringstream quiet;
+    std::streambuf* keep = std::cout.rdbuf();
+    std::cout.rdbuf(quiet.rdbuf());
+    rc = run_observation(*cfg, opt, src, pos.data(), dir.data(), &res, quiet);
+    std::cout.rdbuf(keep);
+    if (rc != BF_OK) return rc;
+    if (ring_copy) std::memcpy(ring_copy, src.ring_data(), (size_t)src.get_block_size() * src.get_ring_blocks());
+    if (observation_ms) *observation_ms = res.observation_time_ms;
+    if (dm_times) *dm_times = res.dm_times;
+    return BF_OK;
+}
+
 int bfh_dm_trials(double dm0, double dm_max, int nchan, double epsilon, double nu_ghz, double chan_bw_mhz, double ti_us,
                   double tscat_us, double tsamp_us, double* out, int cap)
 {

@@ -301,6 +301,32 @@ def run_observation_junk_dm(cfg: BfConfig, n_blocks: int, delays, dm_path: str |
     return {"ms": ms.value, "dm_times": n.value, "ring": ring}
 
 
+def dm_trial_share(n_dm: int, world: int, rank: int):
+    """dsabf::dm_trial_share: (first, count) of the DM trials rank `rank` of `world` dedisperses when the ladder is split."""
+    f, c = C.c_int(), C.c_int()
+    check(load().bfh_dm_trial_share(n_dm, world, rank, C.byref(f), C.byref(c)))
+    return f.value, c.value
+
+
+def run_observation_junk_sharded(cfg: BfConfig, n_blocks: int, rank: int, world: int, unique_id: bytes | None, gather_root: int = 0,
+                                 staged: bool = False, delays=None, split_trials: bool = False, detected_path: str | None = None,
+                                 dm_path: str | None = None, ring_blocks: int = 4, seed: int = 0xD5A, gpu: int = 0, device: int = 0):
+    """One frequency shard of a sharded observation (bfh_run_observation_junk_sharded): cfg is the shard's geometry, unique_id the
+    128 bytes rank 0 drew (api.comm_unique_id).  Returns dict(ms, dm_times, ring)."""
+    lib = load()
+    d = np.ascontiguousarray(delays, np.int32) if delays is not None else None
+    assert d is None or (d.ndim == 2 and d.shape[1] == cfg.n_freq * world)
+    n_time = cfg.n_out_per_gemm * cfg.n_pol * cfg.n_avg
+    ring = np.zeros((ring_blocks, cfg.n_gemms_per_block, cfg.n_freq, n_time, cfg.n_ant), np.uint8)
+    idbuf = C.create_string_buffer(unique_id, 128) if unique_id is not None else None
+    ms, n = C.c_float(), C.c_uint64()
+    check(lib.bfh_run_observation_junk_sharded(C.byref(cfg), n_blocks, ring_blocks, seed, gpu, device, rank, world, idbuf, gather_root,
+                                               1 if staged else 0, _p(d) if d is not None else None, d.shape[0] if d is not None else 0,
+                                               1 if split_trials else 0, detected_path.encode() if detected_path else None,
+                                               dm_path.encode() if dm_path else None, C.byref(ms), C.byref(n), _p(ring)))
+    return {"ms": ms.value, "dm_times": n.value, "ring": ring}
+
+
 def run_observation_junk_to_ring(cfg: BfConfig, n_blocks: int, out_ring: str, out_ring_blocks: int = 8,
                                  ring_blocks: int = 4, seed: int = 0xD5A, gpu: int = 0, device: int = 0):
     """Production observation loop with the detected stream handed to a consumer through the shared-memory ring

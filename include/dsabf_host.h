@@ -122,6 +122,17 @@ int bfh_run_observation_junk_dm(const bf_config *cfg, uint64_t n_blocks, int rin
                                 int burn_in, int verbose, const int32_t *delays, int n_dm, const char *dm_path,
                                 const char *detected_path, float *observation_ms, uint64_t *dm_times, void *ring_copy);
 
+/* One frequency SHARD of a sharded observation with any geometry (`beam -R world -r rank` is the production-geometry form): cfg is
+ * the shard's (n_freq = the local count), id128 the bytes of bf_comm_unique_id from rank 0; after every block the shards' powers are
+ * gathered to gather_root (a rank, or BF_GATHER_ROOT_ALL) in the reference's [o][f][b] over the band -- staged != 0: by
+ * bf_gather_detected_staged.  delays (optional): int32 [n_dm][world * cfg->n_freq], the DM stage on the rank(s) that hold the band;
+ * split_trials != 0 (needs BF_GATHER_ROOT_ALL): each rank takes its dm_trial_share.  detected_path / dm_path: files, written only
+ * by ranks that hold the band.  Every shard must be given the same n_blocks. */
+int bfh_run_observation_junk_sharded(const bf_config *cfg, uint64_t n_blocks, int ring_blocks, uint64_t seed, int gpu, int device,
+                                     int rank, int world, const void *id128, int gather_root, int staged, const int32_t *delays,
+                                     int n_dm, int split_trials, const char *detected_path, const char *dm_path,
+                                     float *observation_ms, uint64_t *dm_times, void *ring_copy);
+
 /* The sink's ring on its own (tests; works without a device, the ring is then plain memory). */
 typedef struct bfh_sink bfh_sink;
 int bfh_file_sink_create(const bf_config *cfg, const char *path, int gpu, uint64_t slots, bfh_sink **out);

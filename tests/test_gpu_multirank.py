@@ -332,3 +332,78 @@ def test_plain_c_sharded_example(fake_rccl, tmp_path, world):
         seen.append(peaks[0])
     assert seen[0] == seen[1]                   # the same band either way
     (tmp_path / ("peak%d.txt" % world)).write_text(seen[0])
+
+
+# (soak: DSABF_LONG_TESTS=1 DSABF_SHARD_SEEDS=16:200 walks other seeds)
+@pytest.mark.parametrize("seed", sweep(range(*(int(v) for v in os.environ.get("DSABF_SHARD_SEEDS", "0:16").split(":"))), [1, 6]))
+def test_sharded_observation_loop_under_random_shapes(orc, fake_rccl, tmp_path, seed):
+    """dsabf::run_observation with a communicator, every shard its own process (bfh_run_observation_junk_sharded): random world
+    size (2 .. 4), shard geometry, block size, queue count, sub-block launches, ring, transport (in place / staged), receiver
+    (one root, the last rank, every rank) and DM stage (none / on the rank(s) that hold the band / split by trials).  Every
+    rank that holds the band wrote the oracle's [gemm][o][world * f][b] -- every shard's channels from ITS weights -- and the
+    DM files, joined along the trials, are the oracle's [dm][t][b] over the whole observation."""
+    import json
+
+    from dsabeamformer_amd import host
+
+    rng = np.random.default_rng(7100 + seed)
+    world = int(rng.integers(2, 5))
+    n_u = int(rng.choice([4, 8]))
+    n_st = int(rng.choice([s for s in (1, 2, 4) if s <= n_u]))
+    fl, n_out, n_avg, B = int(rng.choice([4, 8])), int(rng.choice([2, 4])), int(rng.choice([16, 8])), int(rng.choice([64, 128]))
+    n_blocks, ring_blocks = int(rng.integers(3, 7)), int(rng.integers(2, 5))
+    gather_root = int(rng.choice([0, world - 1, -1]))
+    dm_kind = ["none", "holders", "split"][int(rng.integers(3))]
+    if dm_kind == "split":
+        gather_root = -1
+    T, F = n_blocks * n_u * n_out, fl * world
+    n_dm = 0 if dm_kind == "none" else int(rng.integers(1, 14))         # fewer trials than ranks happens: a rank with no share
+    delays = None
+    if n_dm:
+        d_max = int(rng.integers(0, max(1, min(T - 2, 2 * n_u * n_out))))
+        delays = np.ascontiguousarray((np.arange(n_dm)[:, None] * np.linspace(d_max / max(n_dm - 1, 1), 0.0, F)[None, :]).astype(np.int32))
+        np.save(tmp_path / "delays.npy", delays)
+    env_in = {}
+    if rng.integers(2):
+        env_in["DSABF_UNITS_PER_LAUNCH"] = int(rng.choice([1, 2, n_u // 2]))
+    prob = dict(world=world, n_beams=B, n_freq_local=fl, n_avg=n_avg, n_out=n_out, n_units=n_u, n_streams=n_st, n_blocks=n_blocks,
+                ring_blocks=ring_blocks, gather_root=gather_root, staged=bool(rng.integers(2)), n_dm=n_dm, split=dm_kind == "split",
+                seed=3000 + seed, gpu=int(rng.integers(0, 3)), env=env_in)
+    json.dump(prob, open(tmp_path / "problem.json", "w"))
+    env = dict(os.environ, DSABF_RCCL_LIB=fake_rccl, FAKERCCL_MAILBOX_MB="8")
+    procs = [subprocess.Popen([sys.executable, os.path.join(SUPPORT, "shard_loop_worker.py"), str(r), str(tmp_path)],
+                              env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), (prob, "\n".join(outs))
+    ranks = [np.load(tmp_path / ("rank%d.npz" % r)) for r in range(world)]
+    g = orc.Geom(n_beams=B, n_ant=64, n_freq=fl, n_avg=n_avg, n_out_per_gemm=n_out)
+    pos, dirs = host.default_positions(64), host.default_directions(B)
+    band = []
+    for r in range(world):     # every shard read the same junk bytes with its local geometry; its weights are its own channels
+        w = host.make_weights(pos, dirs, fl, chan0=fl * r, gpu=prob["gpu"])
+        ring = ranks[r]["ring"]
+        band.append(np.concatenate([orc.beamform(g, w, ring[b % ring_blocks]).reshape(n_u * n_out, fl, B) for b in range(n_blocks)]))
+    series = np.concatenate(band, axis=1)                              # [T][F][B]
+    holders = list(range(world)) if gather_root < 0 else [gather_root]
+    for r in range(world):
+        assert os.path.exists(tmp_path / ("det.%d" % r)) == (r in holders), (prob, r)
+    for r in holders:
+        hdr, data = host.read_detected_file(str(tmp_path / ("det.%d" % r)))
+        assert int(hdr["N_FREQUENCIES"]) == F, (prob, r)
+        assert np.array_equal(data.reshape(series.shape), series), (prob, r)
+    if n_dm:
+        D = int(delays.max())
+        want = orc.dedisperse_dm(series, delays, T - D)
+        for r in holders:
+            first, count = host.dm_trial_share(n_dm, world, r) if prob["split"] else (0, n_dm)
+            path = tmp_path / ("dm.%d" % r)
+            if count == 0:
+                assert not os.path.exists(path) and int(ranks[r]["dm_times"]) == 0, (prob, r)
+                continue
+            d_r = int(delays[first:first + count].max())               # a rank's window is its OWN trials' largest delay
+            hdr, got, chunks = host.read_dm_file(str(path))
+            assert int(hdr["DM_FIRST_TRIAL"]) == first and int(hdr["N_DM"]) == count and int(hdr["MAX_DELAY"]) == d_r, (prob, r)
+            assert int(ranks[r]["dm_times"]) == T - d_r == got.shape[1], (prob, r)
+            assert np.array_equal(got[:, :T - D], want[first:first + count]), (prob, r)
+            if d_r < D:       # the rank's shorter window gives it more output times than the whole ladder's: check those too
+                assert np.array_equal(got, orc.dedisperse_dm(series, delays[first:first + count], T - d_r)), (prob, r)
