@@ -1079,7 +1079,7 @@ def main():
                                            "alltoall = rank j owns rows j*n/N.. of the whole band; verified = the receivers' "
                                            "per-row checksums of what arrived equal the senders' (one extra step after the timing)")
 
-        def variant(detect_mode, paired_env=None, wl=None, n_units=None, reps=None, calibrated=False, n_ant=None):
+        def variant(detect_mode, paired_env=None, wl=None, n_units=None, reps=None, calibrated=False, n_ant=None, n_freq_rank=None):
             """Kernel-time record of another variant / workload on this GPU (HIP events around every launch)."""
             old = os.environ.get("DSABF_PAIRED")
             if paired_env is not None:
@@ -1091,6 +1091,8 @@ def main():
                     c2.n_ant, c2.n_beams, c2.n_freq = 100, 512, 128
                 if n_ant:
                     c2.n_ant = n_ant
+                if n_freq_rank:
+                    c2.n_freq = n_freq_rank
                 b2 = bfm.Beamformer(c2, device=local)
                 w2 = product_weights(c2, 0)
                 b2.set_weights(calibrated_weights(w2) if calibrated else w2)
@@ -1179,6 +1181,16 @@ def main():
                                      "roofline": {"bound": "hbm", "achieved": d["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                                   "frac": d["gbs"] / HBM_PEAK_GBS},
                                      "note": "not the headline; bit-exact parity on this geometry is what tests/ check"}
+            # one rank's share of BASELINE configs[3] (C4): 32 of the 256 channels, the headline step's 128 gemm-units -- what ONE
+            # GPU of an 8-GPU run launches, alone on this chip.  8 x its rate over the whole band's = the kernel-only strong
+            # scaling the partition itself allows at N = 8 (launch shape and tail effects; no fabric, no host): the figure the
+            # driver's N = 8 run is to be read against while no 8-GPU node has run the bench
+            if world == 1 and args.workload == "c3":
+                s4 = variant(0, n_freq_rank=32, reps=60)
+                s4["workload"] = ("C4 shard: one of 8 ranks of BASELINE configs[3] = 32 freq x 256 beams x 64 ant x 2 pol, N_TIME 512, "
+                                  "%d gemm-units per launch; beam-blocks here are 256 beams x 32 freq" % units)
+                s4["kernel_only_scaling_at_8_ranks_by_launch_shape"] = out["roofline"]["kernel_ms_avg"] / (8 * s4["kernel_ms_avg"])
+                out["c4_shard"] = s4
             # one rank's share of BASELINE configs[4]: 128 of 1024 freq x 512 beams x 100 ant, n_ipo 32, 16 gemm-units
             s5 = variant(0, wl="c5", n_units=16, reps=30)
             s5["workload"] = ("C5 shard: one of 8 ranks of BASELINE configs[4] = 128 freq x 512 beams x 100 ant x 2 pol, "
