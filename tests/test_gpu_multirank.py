@@ -229,8 +229,8 @@ def _plain_bench(env, *extra, timeout=600):
 def test_bench_with_a_send_that_never_returns_still_prints_the_kernel_only_record(fake_rccl):
     """a fabric on which the first ncclSend never comes back (the stand-in sleeps forever in it).  The
     kernel-only region was measured before any communicator existed, so the line carries gather_modes.none; the stage that hung
-    is named in gather_error; value is null; the command ends NON-ZERO -- all of it well inside a minute, not at the driver's
-    1800 s limit."""
+    is named in gather_error; value is null; the command ends NON-ZERO -- in seconds (6 s here; the bound below leaves room for a
+    cold, slow box), not at the driver's 1800 s limit."""
     import json
     import time
 
@@ -248,7 +248,7 @@ def test_bench_with_a_send_that_never_returns_still_prints_the_kernel_only_recor
     assert d["stage"].startswith("gather 'alltoall_rank_major'")
     assert d["rccl"]["lib"].endswith("libfakerccl.so")            # the diagnostic names the library that never answered
     assert d["roofline"]["kernel_ms_avg"] > 0                     # the kernel-only region's own roofline record is in the line
-    assert took < 60, took
+    assert took < 150, took
 
 
 def test_bench_catches_a_gather_that_delivers_wrong_bits(fake_rccl):
