@@ -235,7 +235,7 @@ def test_issue_model_says_what_binds_the_kernel():
     m = bench.issue_model(c3, 0.9475)
     assert abs(m["valu_per_mfma"] - 17.2) < 0.1 and abs(m["issue_model_cycles_per_mfma"] - (13 + 2.45 * m["valu_per_mfma"])) < 1e-9
     assert 0.9 < m["issue_occupancy"] < 1.05 and m["bound_measured"] == "simd-issue"
-    assert 1.9 < m["clock_ghz_under_load"] < 2.2
+    assert 1.9 < m["clock_ghz_under_load"] < 2.45      # (2.04 ... 2.20 by box; nominal 2.4)
     gen = bench.issue_model(bench.pmc_summary("r05_c3_general_pmc_summary.txt"), 1.05)
     assert 6.0 < gen["valu_per_mfma"] < 7.5 and gen["bound_measured"] in ("simd-issue", "unclear")
     assert bench.issue_model({}, 1.0) == {"bound_measured": None}
