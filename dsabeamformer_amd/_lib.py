@@ -118,6 +118,7 @@ SIGNATURES = {
     "bf_gather_relayout_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_size_t, C.c_int, C.c_void_p]),
     "bf_set_switch": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "bf_get_counter": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_uint64)]),
+    "bf_rtw_plan": (C.c_int, [C.POINTER(BfConfig), C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "bf_kernel_info": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
                                  C.POINTER(C.c_int)]),
     "bf_kernel_name": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t]),

@@ -746,6 +746,7 @@ __global__ __launch_bounds__(64 * WAVES, (fused_min_waves<AIN, NIPO, WRITE_C, NS
                         if (rt_en[r]) {
                             rt_m = 0;
                             rt_o[r] = rt_oq++;
+                            rt_en[r] = rt_o[r] < (unsigned)a.rt_kout;   // (a "window" of padding rows behind the stream's last one is nobody's)
                         }
                     }
                 }

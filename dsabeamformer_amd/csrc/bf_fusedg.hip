@@ -25,12 +25,13 @@
 //     of the float 1.5 * 2^23 + n, then ONE fma for fl(n / 127)) holds for every supported antenna count.
 //   * An accumulator's two MFMAs of a plane are issued back to back (the second continues the first inside the matrix unit):
 //     what the pipe charges for is every accumulator that enters and leaves it (profiles/r04_ubench_chains.txt).
-//   * Any n_ipo.  A lane group's 32 rows of a chunk are one STREAM: `kout` whole accumulation windows back to back
-//     (kout = 32 / n_ipo windows of n_ipo samples when they fit, else one window over cpg = ceil(n_ipo / 32) chunks), so a
-//     window never straddles two lane groups and its sum is one lane's sequential fp32 chain in time order, as the reference
-//     sums it (src/beamformer.cuh:150-152).  Rows behind the last whole window of a run are padding (zero voltages, never
-//     stored): efficiency kout * n_ipo / 32, e.g. 30/32 for n_ipo = 6 or 10, 24/32 for 12 or 24 (the power-of-two windows of
-//     fused16_kernel have none).  Window starts and ends are wave-uniform, so they cost scalar branches, not lane masks.
+//   * Any n_ipo.  A lane group's rows are one STREAM: `kout` whole accumulation windows back to back over cpg = ceil(kout *
+//     n_ipo / 32) chunks of 32 rows, so a window never straddles two lane groups and its sum is one lane's sequential fp32 chain
+//     in time order, as the reference sums it (src/beamformer.cuh:150-152).  Rows behind the stream's last window are padding
+//     (zero voltages, never stored): efficiency kout * n_ipo / (32 cpg).  A small launch takes what fits one chunk (30/32 for
+//     n_ipo = 6 or 10, 24/32 for 12 or 24); one that fills the chip the kout with the least padding that still does -- whole
+//     chunks (4 windows of 24 = 3 chunks) -- rtw_kout, bf_kernels.hip (round 5; the power-of-two windows have none either
+//     way).  Window starts and ends are wave-uniform, so they cost scalar branches, not lane masks.
 #include "bf_fused16.hpp"
 
 #include <cstdio>
@@ -387,8 +388,8 @@ __global__ __launch_bounds__(kGThreads, 2) void fusedg_kernel(GenArgs a)
                         if (++m == a.L) {
                             m = 0;
                             const unsigned o = sigma * (unsigned)a.kout + oq;     // this lane's output (over the whole launch)
-                            oq++;
-                            if ((unsigned long long)o * (unsigned)a.L < a.S) {
+                            // (a "window" of padding rows behind the stream's last one is nobody's)
+                            if (oq++ < (unsigned)a.kout && (unsigned long long)o * (unsigned)a.L < a.S) {
                                 float x[kGNT];
 #pragma unroll
                                 for (int t = 0; t < kGNT; t++) x[t] = FAST ? sum[t] * (kAlpha * kAlpha) : sum[t];
@@ -494,15 +495,15 @@ LaunchShape generic_launch_shape(const Geometry& g, int n_units, int n_cus)
 {
     LaunchShape ls{};
     const int L = g.n_ipo;
-    const int kout = L <= 32 ? 32 / L : 1;
+    const long long S = (long long)n_units * g.n_time;
+    ls.n_bgroups = (g.n_beams + 16 * kGNT * kGWaves - 1) / (16 * kGNT * kGWaves);
+    const long long base = (long long)g.n_freq * ls.n_bgroups;
+    const int kout = ls.rt_kout = rtw_kout(g, S, base, n_cus);   // (the stream with the least padding that still fills the chip)
     const long long Ls = (long long)kout * L;
     const int cpg = (int)((Ls + 31) / 32);
-    const long long S = (long long)n_units * g.n_time;
     const long long n_streams = (S + Ls - 1) / Ls;
     const long long groups = (n_streams + 3) / 4;
     ls.chunks_total = (int)(groups * cpg);
-    ls.n_bgroups = (g.n_beams + 16 * kGNT * kGWaves - 1) / (16 * kGNT * kGWaves);
-    const long long base = (long long)g.n_freq * ls.n_bgroups;
     // two 4-wave workgroups are resident per CU (128 accumulator registers per wave): two rounds of them fill the chip's tail,
     // but a workgroup should keep >= 2 chunk groups (the prologue and the B fragments of k-step 0 are paid per workgroup)
     long long want = (4LL * n_cus + base - 1) / base;
@@ -546,7 +547,7 @@ hipError_t launch_fused_generic(const Geometry& g, const void* d_image, const vo
     a.ks = generic_ksteps(g);
     a.T = g.n_time;
     a.L = g.n_ipo;
-    a.kout = g.n_ipo <= 32 ? 32 / g.n_ipo : 1;
+    a.kout = ls.rt_kout;
     a.Ls = a.kout * a.L;
     a.cpg = (a.Ls + 31) / 32;
     a.S = (unsigned)((long long)n_units * g.n_time);

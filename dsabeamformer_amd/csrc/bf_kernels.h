@@ -28,6 +28,7 @@ struct Geometry {
     bool plain_col_tiles = false;                       // DSABF_COL_TILES=4: 4 output slots per wave everywhere
     bool runtime_ant = false;                           // DSABF_RUNTIME_ANT=1: the run-time antenna classes everywhere
     // ... and three that only pick among launches of the same kernels; bf_set_switch changes them per handle for A/B runs
+    int rtw_kout = 0;                                   // windows per stream of the run-time-window launch (0: fused_launch_shape decides)
     int tsplit = 0;                                     // DSABF_TSPLIT=n: time splits per frequency (0: fused_launch_shape decides)
     int lds_pad = 0;                                    // DSABF_LDS_PAD=bytes: extra dynamic LDS (fewer resident workgroups); clamped
     bool dm_wide = true;                                // DSABF_DM_WIDE=0: the per-thread-window DM kernel alone
@@ -51,6 +52,7 @@ bool fused_supported(const Geometry& g, const char** why);
 
 struct LaunchShape {
     int grid, block, lds_bytes, n_tsplit, chunks_total;
+    int rt_kout;     // run-time-window class: whole windows per lane-group stream (0 otherwise)
     int n_bgroups;   // workgroups along the beam axis: ceil(n_beams / (64 * waves per workgroup))
 };
 // Waves per workgroup of the fused kernel for this geometry: 4, or 8 (two k-steps, n_ipo >= 16, an even number of 256-beam
@@ -59,6 +61,9 @@ int fused_wg_waves(const Geometry& g, bool write_c = false);
 // 16-beam output slots per wave: 4, or 8 (conjugate-pair kernel, two k-steps, n_ipo >= 16, n_beams a multiple of 512).
 int fused_col_tiles(const Geometry& g, bool paired);
 LaunchShape fused_launch_shape(const Geometry& g, int n_units, int n_cus, bool write_c = false);
+// Whole windows per lane-group stream of a launch with run-time window boundaries (fused16_kernel<NIPO = 0>, fusedg_kernel): S samples
+// per frequency, base = workgroups per time split (bf_kernels.hip).
+int rtw_kout(const Geometry& g, long long S, long long base, int n_cus);
 
 // Reference-layout weights [f][a][b]{re,im} (device) -> fragment image (device).  Sets *d_bad to non-zero if
 // any imaginary part is -128 (its negation does not fit int8).  With d_pair_image (pairing_supported geometries) also

@@ -553,6 +553,26 @@ int fused_wg_waves(const Geometry& g, bool write_c)
     return (can && !g.plain_wg_waves) ? kWavesWide16 : kWaves16;
 }
 
+// Run-time window: a lane group's stream is kout whole windows = kout * L rows over cpg = ceil(kout L / 32) chunks of 32; the rows
+// between the stream's end and 32 cpg are padding the MFMAs multiply all the same (L = 24 alone in a chunk: a quarter of the
+// launch; L = 40 alone in two: three eighths).  kout * L a multiple of 32 wastes nothing (kout = 32 / gcd(L, 32) always is one),
+// but a group of 4 streams is also the unit the launch is split by: the kout with the fewest chunks in total among those that
+// still leave 8 groups per CU for the chip, the smallest such; a small launch keeps what fits one chunk.
+int rtw_kout(const Geometry& g, long long S, long long base, int n_cus)
+{
+    const int L = g.n_ipo;
+    if (g.rtw_kout > 0) return g.rtw_kout;
+    const long long W = (S + L - 1) / L;   // windows per frequency
+    auto groups = [&](int k) { return (W + 4LL * k - 1) / (4LL * k); };
+    auto chunks = [&](int k) { return groups(k) * (((long long)k * L + 31) / 32); };
+    int gcd = 32;
+    while (L % gcd) gcd >>= 1;
+    int best = L <= 32 ? 32 / L : 1;       // what fits one chunk (one window over ceil(L / 32) chunks): the finest split there is
+    for (int k = best + 1; k <= 32 / gcd; k++)
+        if (base * groups(k) >= 8LL * n_cus && chunks(k) < chunks(best)) best = k;
+    return best;
+}
+
 LaunchShape fused_launch_shape(const Geometry& g, int n_units, int n_cus, bool write_c)
 {
     if (use_generic(g)) return generic_launch_shape(g, n_units, n_cus);
@@ -564,7 +584,7 @@ LaunchShape fused_launch_shape(const Geometry& g, int n_units, int n_cus, bool w
     long long rows;
     int cpg = 1;  // chunks per output group: a workgroup's chunk range must cover whole groups
     if (rtw_class(g)) {                                  // run-time window: streams of kout whole windows, 32 rows per chunk
-        const int kout = g.n_ipo <= 32 ? 32 / g.n_ipo : 1;
+        const int kout = ls.rt_kout = rtw_kout(g, S, (long long)g.n_freq * ls.n_bgroups, n_cus);
         const long long Ls = (long long)kout * g.n_ipo;
         cpg = (int)((Ls + 31) / 32);
         const long long groups = ((S + Ls - 1) / Ls + 3) / 4;
@@ -643,7 +663,7 @@ static FusedArgs make_args(const Geometry& g, const void* d_image, const void* d
     a.interleave = interleaved(g, g.paired);
     if (rtw_class(g)) {
         a.rt_L = g.n_ipo;
-        a.rt_kout = g.n_ipo <= 32 ? 32 / g.n_ipo : 1;
+        a.rt_kout = ls.rt_kout;
         a.rt_Ls = a.rt_kout * a.rt_L;
         a.rt_cpg = (a.rt_Ls + 31) / 32;
     }

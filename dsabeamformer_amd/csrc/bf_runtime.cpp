@@ -1171,6 +1171,9 @@ int bf_set_switch(bf_handle* h, const char* name, int value)
     if (!strcmp(name, "tsplit")) {
         if (value < 0) return fail(BF_ERR_INVALID, "tsplit must be >= 0 (0: the library decides)");
         h->geom.tsplit = value;
+    } else if (!strcmp(name, "rtw_kout")) {
+        if (value < 0 || value > 16) return fail(BF_ERR_INVALID, "rtw_kout must be 0 .. 16 (0: the library decides)");
+        h->geom.rtw_kout = value;
     } else if (!strcmp(name, "lds_pad")) {
         if (value < 0 || value > dsabf::kLdsPerCuBytes) return fail(BF_ERR_INVALID, "lds_pad must be 0 .. %d bytes", dsabf::kLdsPerCuBytes);
         h->geom.lds_pad = value;
@@ -1182,7 +1185,7 @@ int bf_set_switch(bf_handle* h, const char* name, int value)
     } else if (!strcmp(name, "paired")) {
         h->force_general = value == 0;   // takes effect at the next bf_set_weights (the kernel is chosen per weight set)
     } else {
-        return fail(BF_ERR_INVALID, "unknown switch \"%s\" (tsplit, lds_pad, dm_wide, paired, coalesce)", name);
+        return fail(BF_ERR_INVALID, "unknown switch \"%s\" (tsplit, rtw_kout, lds_pad, dm_wide, paired, coalesce)", name);
     }
     return BF_OK;
 }
@@ -1224,6 +1227,19 @@ int bf_launch_plan(const bf_config* cfg, int paired, int n_units, int n_cus, int
     if (block) *block = ls.block;
     if (lds_bytes) *lds_bytes = ls.lds_bytes;
     if (name && name_len) dsabf::fused_kernel_name(g, name, name_len);
+    return BF_OK;
+}
+
+int bf_rtw_plan(const bf_config* cfg, int n_units, int n_cus, int* windows_per_stream, int* chunks_total)
+{
+    if (int rc = check_cfg(cfg)) return rc;
+    const dsabf::Geometry g = make_geom(*cfg);
+    const char* why = nullptr;
+    if (!dsabf::fused_supported(g, &why)) return fail(BF_ERR_INVALID, "unsupported geometry: %s", why);
+    if (n_units <= 0 || n_cus <= 0) return fail(BF_ERR_INVALID, "need n_units > 0 and n_cus > 0");
+    const dsabf::LaunchShape ls = dsabf::fused_launch_shape(g, n_units, n_cus);
+    if (windows_per_stream) *windows_per_stream = ls.rt_kout;
+    if (chunks_total) *chunks_total = ls.chunks_total;
     return BF_OK;
 }
 

@@ -30,10 +30,16 @@ int bf_gather_relayout_device(bf_handle *h, const float *d_stage, float *d_full,
 
 /* Introspection for benchmarks/roofline reports. */
 int bf_kernel_info(const bf_handle *h, int n_units, int *grid, int *block, int *lds_bytes, int *vgprs);
+/* Accumulation windows without a compile-time instantiation (n_pol * n_avg not 2 .. 64 a power of two): how the launch of n_units
+ * gemm-units lays a frequency's samples out -- windows_per_stream whole windows per lane-group stream (0: this geometry does not
+ * run the run-time-window class), chunks_total 128-row chunks per frequency, padding included.  No GPU needed. */
+int bf_rtw_plan(const bf_config *cfg, int n_units, int n_cus, int *windows_per_stream, int *chunks_total);
 /* Measurement / test switches of ONE handle (A/B runs inside one process).  They select among launches and kernels that
  * produce the same bits; none of them is needed in production.  The environment variables of the same meaning are read ONCE,
  * at bf_create (DSABF_TSPLIT, DSABF_LDS_PAD, DSABF_DM_WIDE) -- never in a launch path.
  *   "tsplit"   n >= 0   time splits per frequency of the fused launch (0: the library decides)
+ *   "rtw_kout" 0 .. 16  whole windows per lane-group stream of a run-time-window launch (accumulation windows without a
+ *                       compile-time instantiation; 0: the library picks the one with the least padding that still fills the chip)
  *   "lds_pad"  bytes    extra dynamic LDS per workgroup (fewer resident workgroups per CU); clamped to what a CU has
  *   "dm_wide"  0 / 1    0: bf_dedisperse_dm*_device runs the per-thread-window kernel alone
  *   "paired"   0 / 1    0: the next bf_set_weights selects the general kernel even for conjugate-symmetric weights

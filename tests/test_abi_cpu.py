@@ -55,7 +55,7 @@ def test_every_export_of_the_boundary_header_cites_the_reference_call_site_it_re
                 "%s: neither the comment in front of it nor one on its line cites a reference call site" % m.group(1)
     assert sorted(set(checked)) == _declared_symbols(("dsabf.h",)) and len(checked) >= 45
     bench_only = set(_declared_symbols(("dsabf_bench.h",))) - set(_declared_symbols(("dsabf.h",)))
-    assert bench_only == {"bf_set_switch", "bf_get_counter", "bf_mfma_peak_device", "bf_launch_plan", "bf_kernel_info", "bf_kernel_name",
+    assert bench_only == {"bf_set_switch", "bf_get_counter", "bf_mfma_peak_device", "bf_launch_plan", "bf_kernel_info", "bf_rtw_plan", "bf_kernel_name",
                           "bf_gather_relayout_device"}
     assert not bench_only & set(checked)
     integ = open(os.path.join(ROOT, "INTEGRATION.md")).read()

@@ -535,3 +535,79 @@ def test_dm_chunks_to_another_process_through_a_shared_memory_ring(bfmod, orc):
     series = np.concatenate([orc.beamform(g, w, r["ring"][b % ring_blocks]).reshape(rows, 8, 64) for b in range(n_blocks)])
     assert [p.shape[1] for p in got] == [2 * rows - D] + [rows] * (n_blocks - 2)
     assert np.array_equal(np.concatenate(got, axis=1), orc.dedisperse_dm(series, delays, T - D))
+
+
+# ---- run-time accumulation windows (src/beamformer.hh:55-60: any N_AVERAGING): the stream length of the launch -------------------
+def _small_cfg(bfmod, g, **over):
+    cfg = bfmod.debug_config(n_beams=g.n_beams, n_ant=g.n_ant, n_freq=g.n_freq, n_pol=g.n_pol, n_avg=g.n_avg, n_out_per_gemm=g.n_out_per_gemm)
+    for k, v in over.items():
+        setattr(cfg, k, v)
+    return cfg
+
+
+@pytest.mark.parametrize("n_avg,n_ant", [(3, 64), (5, 64), (6, 100), (9, 64), (12, 64), (12, 100), (20, 64), (48, 64), (37, 36), (12, 132), (5, 192),
+                                         (20, 260)])
+def test_run_time_window_streams_of_any_length_bit_exact(torch, bfmod, orc, n_avg, n_ant):
+    """A lane group's stream of a run-time-window launch is kout whole windows over ceil(kout L / 32) chunks; the library picks the
+    kout with the least padding that still fills the chip (a big launch of L = 24 runs 4 windows over 3 chunks instead of 1 window in
+    1 chunk, a quarter of it padding).  Every kout gives the oracle's bits -- windows that cross chunk boundaries inside a stream,
+    ragged last streams, several chunk groups per workgroup, general and conjugate-pair weights, both bit-exact readings -- and
+    the library's own choice for a launch that fills the chip is one without padding."""
+    g = orc.Geom(n_beams=64, n_ant=n_ant, n_freq=2, n_avg=n_avg, n_out_per_gemm=5)
+    L = g.n_ipo
+    rng = np.random.default_rng(31 * n_avg + n_ant)
+    w = rng.integers(-127, 128, size=(g.n_freq, g.n_ant, g.n_beams, 2), dtype=np.int8)
+    if n_avg % 2:
+        w[:, :, 32:, 0] = w[:, :, :32, 0][:, :, ::-1]
+        w[:, :, 32:, 1] = -w[:, :, :32, 1][:, :, ::-1]
+    n_units = 41                                         # 205 windows: several groups of 4 streams even at 16 windows per stream
+    packed = rng.integers(0, 256, size=(n_units, g.n_freq, g.n_time, g.n_ant), dtype=np.uint8)
+    import math
+    k_full = 32 // math.gcd(L, 32)                      # the shortest stream that is whole chunks
+    for mode, contract in ((0, orc.CONTRACT_NONE), (2, orc.CONTRACT_NVCC)):
+        with orc.detect_contract(contract):
+            want = orc.beamform(g, w, packed).reshape(-1)
+        bf = bfmod.Beamformer(_small_cfg(bfmod, g, detect_mode=mode))
+        bf.set_weights(w)
+        name = bf.kernel_info(n_units)["kernel"]           # up to 128 antennas fused16_kernel's run-time-window class, beyond fusedg_kernel
+        assert ("NIPO=%d(run-time)" % L in name) if n_ant <= 128 else ("fusedg_kernel" in name and "NIPO=%d" % L in name), name
+        for kout in sorted({0, 1, 2, 3, 5, k_full, min(16, k_full + 1), 16}):
+            bf.set_switch("rtw_kout", kout)
+            for tsplit in (0, 2):
+                bf.set_switch("tsplit", tsplit)
+                d_in = torch.from_numpy(packed).cuda()
+                d_out = torch.full((want.size,), float("nan"), dtype=torch.float32, device="cuda")
+                bf.beamform(d_in, n_units, d_out, torch.cuda.current_stream().cuda_stream)
+                torch.cuda.synchronize()
+                assert np.array_equal(d_out.cpu().numpy(), want), (mode, kout, tsplit)
+        with pytest.raises(bfmod.DsabfError):
+            bf.set_switch("rtw_kout", 17)
+        bf.close()
+
+
+@pytest.mark.parametrize("n_avg,kout,rows", [(12, 4, 12288), (20, 4, 20480), (9, 3, 11008)])
+def test_run_time_window_launch_that_fills_the_chip_takes_whole_chunk_streams(torch, bfmod, orc, n_avg, kout, rows):
+    """The library's own choice at a size where it matters (64 channels x 512 windows): bf_rtw_plan says kout windows per stream --
+    L = 24 and 40: whole chunks, not one padding row; L = 18: 16 windows per stream would leave too few groups for the chip, 3 (54
+    of 64 rows) it is -- and the launch gives the oracle's bits over the whole output."""
+    import ctypes as C
+
+    from dsabeamformer_amd._lib import load
+
+    g = orc.Geom(n_beams=64, n_ant=64, n_freq=64, n_avg=n_avg, n_out_per_gemm=16)
+    cfg = _small_cfg(bfmod, g)
+    n_units = 32
+    k, chunks = C.c_int(), C.c_int()
+    bf = bfmod.Beamformer(cfg)
+    assert load().bf_rtw_plan(C.byref(cfg), n_units, 256, C.byref(k), C.byref(chunks)) == 0
+    assert k.value == kout and chunks.value * 128 == rows >= n_units * g.n_time, (k.value, chunks.value)
+    rng = np.random.default_rng(n_avg)
+    w = rng.integers(-127, 128, size=(g.n_freq, g.n_ant, g.n_beams, 2), dtype=np.int8)
+    bf.set_weights(w)
+    packed = rng.integers(0, 256, size=(n_units, g.n_freq, g.n_time, g.n_ant), dtype=np.uint8)
+    want = orc.beamform(g, w, packed).reshape(-1)
+    d_out = torch.full((want.size,), float("nan"), dtype=torch.float32, device="cuda")
+    bf.beamform(torch.from_numpy(packed).cuda(), n_units, d_out, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(d_out.cpu().numpy(), want)
+    bf.close()

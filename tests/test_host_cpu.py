@@ -803,3 +803,39 @@ def test_a_transfer_never_overwrites_a_ring_slot_that_is_still_being_analysed(ho
             analysed_upto += 1
     assert obs.counters()["A"] == 20 and not busy
     obs.close()
+
+
+def test_run_time_window_plan_pads_nothing_when_the_launch_fills_the_chip():
+    """bf_rtw_plan (include/dsabf_bench.h; no GPU): accumulation windows without a compile-time instantiation run streams of kout
+    whole windows over ceil(kout L / 32) chunks.  A launch that fills the chip takes a kout whose streams are whole chunks -- no
+    padding rows for the MFMAs -- unless a shorter stream costs no more; a one-unit launch keeps what fits one chunk (the finest
+    split); compile-time windows are not this class."""
+    import math
+
+    import ctypes as C
+
+    import dsabeamformer_amd as bfm
+    from dsabeamformer_amd._lib import load
+
+    lib = load()
+
+    def plan(n_avg, n_units, n_ant=64):
+        cfg = bfm.production_config(n_ant=n_ant, n_avg=n_avg, n_out_per_gemm=16)
+        k, c = C.c_int(), C.c_int()
+        assert lib.bf_rtw_plan(C.byref(cfg), n_units, 256, C.byref(k), C.byref(c)) == 0
+        return k.value, c.value
+
+    assert plan(16, 32)[0] == 0 and plan(1, 32)[0] == 0                       # n_ipo 32, 2: compile-time windows
+    for n_avg in (3, 5, 6, 7, 9, 10, 12, 13, 20, 24, 37, 48, 100):
+        L = 2 * n_avg
+        k, chunks = plan(n_avg, 32)
+        rows = 32 * 16 * L                                                    # samples per frequency of the launch
+        k_full = 32 // math.gcd(L, 32)
+        assert 1 <= k <= 16 and chunks * 128 >= rows
+        if 32 * 16 >= 4 * k_full * 8:                                         # enough windows for whole-chunk streams, 8 groups at least
+            assert chunks * 128 <= rows * 1.04 + 128 * (k * L // 32 + 1), (n_avg, k, chunks)     # at most a ragged last group of padding
+        k1, c1 = plan(n_avg, 1)
+        assert k1 == (32 // L if L <= 32 else 1), (n_avg, k1)                # a small launch: one chunk's worth
+    assert plan(12, 32) == (4, 32 * 16 // 16 * 3)                             # L = 24: 4 windows = 96 rows = 3 chunks, 32 groups of 4 streams
+    assert plan(12, 32, n_ant=100)[0] == 4
+    assert lib.bf_rtw_plan(None, 1, 256, None, None) != 0
