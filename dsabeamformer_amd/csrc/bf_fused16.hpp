@@ -570,7 +570,9 @@ __global__ __launch_bounds__(64 * WAVES, (fused_min_waves<AIN, NIPO, WRITE_C, NS
                                 const float xx = x * x;
                                 pp = xx + yy;
                             }
-                            sum[sl] = rt_st[r] ? pp : sum[sl] + pp;
+                            // (a window's first sample: 0 * sum + pp = pp, any other: 1 * sum + pp in ONE rounding = sum + pp -- the
+                            //  select folded into the add; the sums are finite and >= +0)
+                            sum[sl] = __builtin_fmaf(sum[sl], rt_st[r] ? 0.0f : 1.0f, pp);
                             if (rt_en[r]) rt_x[r][sl] = sum[sl];
                         }
                     }

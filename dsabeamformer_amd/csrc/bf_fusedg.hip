@@ -382,7 +382,7 @@ __global__ __launch_bounds__(kGThreads, 2) void fusedg_kernel(GenArgs a)
                                 s0 = __builtin_fmaf(dr, dr, s0);
                                 sum[t] = __builtin_fmaf(di, di, s0);
                             } else {
-                                sum[t] = start ? pw[t][r] : sum[t] + pw[t][r];
+                                sum[t] = __builtin_fmaf(sum[t], start ? 0.0f : 1.0f, pw[t][r]);   // (0 * sum + p = p; 1 * sum + p in one rounding)
                             }
                         }
                         if (++m == a.L) {
