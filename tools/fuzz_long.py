@@ -63,6 +63,10 @@ for case in range(N):
     bf = bfm.Beamformer(bfm.debug_config(n_beams=g.n_beams, n_ant=g.n_ant, n_freq=g.n_freq, n_pol=g.n_pol, n_avg=g.n_avg,
                                           n_out_per_gemm=g.n_out_per_gemm, detect_mode=mode))
     bf.set_weights(w)
+    kout = 0
+    if os.environ.get("FUZZ_GENERIC") == "1":   # round 5: any stream length of the run-time-window launches (0: the library's choice)
+        kout = int(rng.integers(0, 17))
+        bf.set_switch("rtw_kout", kout)
     info = bf.kernel_info(n_units)
     name = info["kernel"]
     generic = "fusedg_kernel" in name
@@ -79,7 +83,7 @@ for case in range(N):
     ok = np.array_equal(d_out.cpu().numpy().reshape(want.shape), want)
     if not ok:
         bad += 1
-        print("MISMATCH", case, g, n_units, paired, mode, os.environ["DSABF_TSPLIT"])
+        print("MISMATCH", case, g, n_units, paired, mode, os.environ["DSABF_TSPLIT"], "rtw_kout", kout)
     bf.close()
 print("seed", os.environ.get("SEED", "1"), "cases", N, "mismatches", bad, "distinct (antenna class, n_ipo, paired, mode, launch) combinations", len(classes),
       "cases on 8-wave workgroups", sum(v for k, v in classes.items() if k[4] == "waves8"),
