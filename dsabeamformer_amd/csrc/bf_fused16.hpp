@@ -45,6 +45,8 @@ constexpr int kAntK2P16 = -3;  // 65..128 antennas, n_ant % 16 == 0: two k-steps
 constexpr int kAntK2P4 = -4;   // 65..128 antennas, n_ant % 4 == 0
 constexpr int kAntK4P16 = -5;  // 193..256 antennas, n_ant % 16 == 0: four k-steps (the "deep" classes, round 4)
 constexpr int kAntK3P16 = -6;  // 129..192 antennas, n_ant % 16 == 0: three k-steps
+constexpr int kAntK4P4 = -7;   // 193..256 antennas, n_ant % 4 == 0: four k-steps, 4-byte staging pieces (round 5)
+constexpr int kAntK3P4 = -8;   // 129..192 antennas, n_ant % 4 == 0
 
 constexpr unsigned kMagicBits = 0x4B400000u;        // float 12582912 = 1.5 * 2^23
 constexpr float kMagic = 12582912.0f;
@@ -166,7 +168,7 @@ template <int AIN>
 constexpr int ant_ksteps()
 {
     if (AIN > 0) return (AIN + 63) / 64;
-    return AIN == kAntK4P16 ? 4 : AIN == kAntK3P16 ? 3 : (AIN == kAntK2P16 || AIN == kAntK2P4) ? 2 : 1;
+    return (AIN == kAntK4P16 || AIN == kAntK4P4) ? 4 : (AIN == kAntK3P16 || AIN == kAntK3P4) ? 3 : (AIN == kAntK2P16 || AIN == kAntK2P4) ? 2 : 1;
 }
 template <int AIN>
 constexpr bool ant_two_ksteps() { return ant_ksteps<AIN>() == 2; }
@@ -212,8 +214,8 @@ __global__ __launch_bounds__(64 * WAVES, (fused_min_waves<AIN, NIPO, WRITE_C, NS
     static_assert(!FAST || ((NIPO >= 16 || RTW) && !WRITE_C), "the fast detect exists for n_ipo >= 16 only");
     static_assert(!RTW || (WAVES == kWaves16 && NS == kColTiles16 && !ant_deep<AIN>()), "run-time windows: the plain launch shape");
     static_assert(!(PAIRED && WRITE_C), "the stage-parity path always runs the general kernel");
-    static_assert(AIN >= kAntK3P16 && AIN != 0 && (AIN < 0 || AIN % 4 == 0) && AIN <= 256, "antenna class");
-    static_assert(!ant_deep<AIN>() || (WAVES == 8 && NIPO >= 16 && !WRITE_C && (AIN < 0 || AIN % 16 == 0)), "deep classes: 8 waves, long windows, 16-byte rows");
+    static_assert(AIN >= kAntK3P4 && AIN != 0 && (AIN < 0 || AIN % 4 == 0) && AIN <= 256, "antenna class");
+    static_assert(!ant_deep<AIN>() || (WAVES == 8 && NIPO >= 16 && !WRITE_C), "deep classes: 8 waves, long windows");
 #ifndef DSABF_DEEP_OFFSET
 #define DSABF_DEEP_OFFSET 1   // 0: the deep classes stage sign-extended nibbles (9 VALU per dword, and the pipe holds a lower clock on them:
 #endif                        //    profiles/r04_ubench_encoding.txt) instead of offset nibbles v + 8 with the correction in the accumulator seeds
@@ -226,7 +228,7 @@ __global__ __launch_bounds__(64 * WAVES, (fused_min_waves<AIN, NIPO, WRITE_C, NS
     constexpr int KS = ant_ksteps<AIN>();                // k-steps of 64 antennas
     constexpr int PLANE = kRowsPerChunk * RB;            // LDS bytes of one k-step's chunk image
     constexpr int BUF = KS * PLANE;
-    constexpr bool DW = RT ? (AIN == kAntK1P4 || AIN == kAntK2P4) : (AIN % 16) != 0;  // rows only dword-aligned: 4-byte pieces
+    constexpr bool DW = RT ? (AIN == kAntK1P4 || AIN == kAntK2P4 || AIN == kAntK3P4 || AIN == kAntK4P4) : (AIN % 16) != 0;  // rows only dword-aligned: 4-byte pieces
     constexpr int PB = DW ? 4 : 16;                      // bytes per staging piece
     constexpr int AMAX = RT ? 64 * KS : AIN;             // most antennas this instantiation can meet
     const int A = RT ? a.n_ant : AIN;                    // antennas per time sample (constant-folded unless RT)
@@ -422,8 +424,17 @@ __global__ __launch_bounds__(64 * WAVES, (fused_min_waves<AIN, NIPO, WRITE_C, NS
             if (!piece_live(k)) continue;
             if constexpr (DW) {
                 const unsigned w = (unsigned)stage[k];
-                *reinterpret_cast<int*>(buf + lds_re[k]) = (int)(w & 0xF0F0F0F0u);
-                *reinterpret_cast<int*>(buf + (lds_re[k] ^ 64)) = (int)((w << 4) & 0xF0F0F0F0u);
+                if constexpr (OFFSET_NIB) {          // (the deep classes' encodings: see the 16-byte pieces below)
+                    const unsigned x = w ^ 0x88888888u;
+                    *reinterpret_cast<int*>(buf + lds_re[k]) = (int)((x >> 4) & 0x0F0F0F0Fu);
+                    *reinterpret_cast<int*>(buf + (lds_re[k] ^ 64)) = (int)(x & 0x0F0F0F0Fu);
+                } else if constexpr (TRUE_NIB) {
+                    *reinterpret_cast<int*>(buf + lds_re[k]) = (int)(((((w >> 4) & 0x0F0F0F0Fu) ^ 0x88888888u) - 0x08080808u) ^ 0x80808080u);
+                    *reinterpret_cast<int*>(buf + (lds_re[k] ^ 64)) = (int)((((w & 0x0F0F0F0Fu) ^ 0x88888888u) - 0x08080808u) ^ 0x80808080u);
+                } else {
+                    *reinterpret_cast<int*>(buf + lds_re[k]) = (int)(w & 0xF0F0F0F0u);
+                    *reinterpret_cast<int*>(buf + (lds_re[k] ^ 64)) = (int)((w << 4) & 0xF0F0F0F0u);
+                }
             } else {
                 v4i re, im;
 #pragma unroll
@@ -933,7 +944,10 @@ FusedVariant fused16_variant_deep(int n_ipo, int mode, bool paired, int ns)
     switch (n_ipo) {
         case 16: return fused16_variant_deep_nipo<AIN, 16>(mode, paired, ns);
         case 32: return fused16_variant_deep_nipo<AIN, 32>(mode, paired, ns);
-        case 64: return fused16_variant_deep_nipo<AIN, 64>(mode, paired, ns);
+        case 64:   // (the dword-staged classes would spill at this window -- 12 / 16 staging pieces per thread -- and lose to fusedg_kernel:
+                   //  profiles/r05_deep_p4_perf.txt; deep_class() leaves them there)
+            if constexpr (AIN == kAntK3P4 || AIN == kAntK4P4) return FusedVariant{};
+            else return fused16_variant_deep_nipo<AIN, 64>(mode, paired, ns);
         default: return FusedVariant{};
     }
 }
@@ -942,6 +956,8 @@ FusedVariant fused16_variant_a192(int n_ipo, int mode, bool paired, int ns);
 FusedVariant fused16_variant_a256(int n_ipo, int mode, bool paired, int ns);
 FusedVariant fused16_variant_k4p16(int n_ipo, int mode, bool paired, int ns);
 FusedVariant fused16_variant_k3p16(int n_ipo, int mode, bool paired, int ns);
+FusedVariant fused16_variant_k4p4(int n_ipo, int mode, bool paired, int ns);
+FusedVariant fused16_variant_k3p4(int n_ipo, int mode, bool paired, int ns);
 
 // One definition per antenna class, each in its own translation unit (bf_fused16_*.hip).
 FusedVariant fused16_variant_a64(int n_ipo, bool write_c, int mode, bool paired);

@@ -383,7 +383,9 @@ int ksteps16(const Geometry& g) { return (g.n_ant + 63) / 64; }
 // 16 / 32 / 64 samples.  (The stage-parity launch and every other geometry beyond 128 antennas run fusedg_kernel.)
 bool deep_class(const Geometry& g)
 {
-    return !g.force_generic && !g.no_deep && g.n_ant > 128 && g.n_ant <= 256 && g.n_ant % 16 == 0 && (g.n_ipo == 16 || g.n_ipo == 32 || g.n_ipo == 64);
+    // (rows that are only dword-aligned -- 132, 140, ... antennas -- from round 5 on, in windows of 16 and 32 samples)
+    return !g.force_generic && !g.no_deep && g.n_ant > 128 && g.n_ant <= 256 && g.n_ant % 4 == 0 &&
+           (g.n_ipo == 16 || g.n_ipo == 32 || (g.n_ipo == 64 && g.n_ant % 16 == 0));
 }
 // MFMA column tiles per wave the beams are dealt to round-robin (beam_of_tile), 0 = tile t is beams 16 t ...: interleaved when every
 // wave owns whole groups of 16 * NS beams.  paired: the layout of the conjugate-pair image / kernel (NS / 2 pair tiles per wave).
@@ -415,6 +417,7 @@ FusedVariant select_variant(const Geometry& g, bool write_c)
         const int ns = fused_col_tiles(g, paired);
         if (!g.runtime_ant && g.n_ant == 192) return fused16_variant_a192(g.n_ipo, mode, paired, ns);
         if (!g.runtime_ant && g.n_ant == 256) return fused16_variant_a256(g.n_ipo, mode, paired, ns);
+        if (g.n_ant % 16) return g.n_ant > 192 ? fused16_variant_k4p4(g.n_ipo, mode, paired, ns) : fused16_variant_k3p4(g.n_ipo, mode, paired, ns);
         return g.n_ant > 192 ? fused16_variant_k4p16(g.n_ipo, mode, paired, ns) : fused16_variant_k3p16(g.n_ipo, mode, paired, ns);
     }
     if ((!nipo_supported(g.n_ipo) && !rtw_class(g)) || g.n_ant <= 0 || g.n_ant > 128 || g.n_ant % 4) return FusedVariant{};

@@ -403,7 +403,7 @@ def test_any_antenna_count_beyond_128_bit_exact(torch, bfmod, orc, n_ant, n_avg)
     bf = bfmod.Beamformer(_cfg_of(bfmod, g))
     bf.set_weights(w)
     name = bf.kernel_info(3)["kernel"]
-    deep = n_ant <= 256 and n_ant % 16 == 0 and n_avg == 16          # the three / four k-step classes of fused16_kernel
+    deep = n_ant <= 256 and n_avg == 16          # the three / four k-step classes of fused16_kernel (any multiple of 4: round 5)
     assert ("fused16_kernel<ANT=%d" % n_ant in name and "WAVES=8" in name) if deep else \
         ("fusedg_kernel" in name and ("%d k-steps" % -(-n_ant // 64)) in name), name
     want = orc.beamform(g, w, packed)
@@ -570,10 +570,10 @@ def test_debug_flow_with_random_catalogues_geometries_and_launch_patterns(bfmod,
 
 
 # ---- the deep classes of fused16_kernel: three / four k-steps, weights stationary (129 ... 256 antennas) -----------------------
-@pytest.mark.parametrize("n_ant", [144, 192, 208, 256])
+@pytest.mark.parametrize("n_ant", [144, 192, 208, 256, 132, 188, 196, 252])      # (the last four: rows only dword-aligned, round 5)
 @pytest.mark.parametrize("n_avg,paired", [(16, False), (8, False), (32, False), (16, True), (32, True), (16, 256), (8, 96)])
 def test_deep_classes_bit_exact_and_equal_to_the_generic_kernel(torch, bfmod, orc, monkeypatch, n_ant, n_avg, paired):
-    """129 ... 256 antennas in 16-byte rows with windows of 16 / 32 / 64 samples run fused16_kernel with three or four k-steps:
+    """129 ... 256 antennas with windows of 16 / 32 / 64 samples (rows that are only dword-aligned: 16 / 32) run fused16_kernel with three or four k-steps:
     8-wave workgroups, two output slots per wave (general) or two pair tiles (conjugate-symmetric weights, beams in groups
     of 512), true-nibble operands.  Bit-exact vs the oracle in both bit-exact readings, within tolerance in the fast one, and
     the same bits as fusedg_kernel (DSABF_DEEP=0) on the same handle geometry; several chunks per workgroup, a ragged tail."""
@@ -598,7 +598,10 @@ def test_deep_classes_bit_exact_and_equal_to_the_generic_kernel(torch, bfmod, or
         bf = bfmod.Beamformer(_cfg_of(bfmod, g, detect_mode=mode))
         bf.set_weights(w)
         name = bf.kernel_info(5)["kernel"]
-        assert "fused16_kernel<ANT=%d" % n_ant in name and ("PAIRED" in name) == paired and "WAVES=8" in name, name
+        if n_ant % 16 and g.n_ipo == 64:   # dword-aligned rows in windows of 64: the deep class would spill; fusedg_kernel keeps them
+            assert "fusedg_kernel" in name, name
+        else:
+            assert "fused16_kernel<ANT=%d" % n_ant in name and ("PAIRED" in name) == paired and "WAVES=8" in name, name
         out = _beamform(torch, bf, packed, 5 * g.out_per_gemm)
         bf.close()
         if contract is not None:

@@ -89,6 +89,12 @@ def test_spills_stay_where_they_are_known(objects):
             if "fused16_kernel" not in name:
                 continue
             sc = k["private_segment_fixed_size"]
+            if unit in ("bf_fused16_k3p4", "bf_fused16_k4p4"):
+                # the dword-staged deep classes (round 5: 132, 140, ... antennas; 12 / 16 staging pieces per thread beside 3 / 4 k-steps
+                # of weight fragments): three k-steps fit, four carry up to 432 bytes and still beat fusedg_kernel by 17 ... 96 %
+                # (profiles/r05_deep_p4_perf.txt); bounded on their own so that growth shows
+                assert sc <= (0 if unit == "bf_fused16_k3p4" else 448), (unit, name, sc)
+                continue
             worst = max(worst, sc)
             rtw = re.search(r"fused16_kernelIL[in0-9]+ELi0E", name) is not None   # run-time-window instantiations: not hot, may carry a few dwords
             if sc and unit in clean_units and not rtw:
