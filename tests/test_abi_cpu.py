@@ -113,7 +113,8 @@ def test_error_convention_without_gpu(lib):
     # which kernel a geometry runs is host arithmetic (bf_launch_plan): the reference's whole contract has one
     name = C.create_string_buffer(200)
     for n_ant, n_avg, expect in ((64, 16, b"fused16_kernel"), (100, 16, b"fused16_kernel"), (64, 3, b"fused16_kernel<ANT=64,NIPO=6(run-time)>"),
-                                 (132, 16, b"fusedg_kernel<ANT=132 (3 k-steps, 4-byte staging)"), (320, 16, b"(5 k-steps, 16-byte staging)"),
+                                 (132, 16, b"fused16_kernel<ANT=132(run-time),NIPO=32,WAVES=8>"), (132, 32, b"fusedg_kernel<ANT=132 (3 k-steps, 4-byte staging)"),
+                                 (324, 16, b"(6 k-steps, 4-byte staging)"), (320, 16, b"(5 k-steps, 16-byte staging)"),
                                  (256, 16, b"fused16_kernel<ANT=256,NIPO=32,WAVES=8>"), (144, 8, b"fused16_kernel<ANT=144(run-time),NIPO=16,WAVES=8>")):
         cfg.n_ant, cfg.n_avg = n_ant, n_avg
         assert lib.bf_launch_plan(C.byref(cfg), 0, 4, 256, None, None, None, name, 200) == 0
