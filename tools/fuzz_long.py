@@ -35,7 +35,7 @@ for case in range(N):
         n_out = int(rng.integers(1, 9))
         n_beams = 32 * int(rng.integers(1, 13)) if rng.integers(2) else 4 * int(rng.integers(1, 100))
     if os.environ.get("FUZZ_DEEP") == "1":      # round 4: the three / four k-step classes of fused16_kernel (129 ... 256 antennas)
-        n_ant = 16 * int(rng.integers(9, 17))
+        n_ant = 4 * int(rng.integers(33, 65))        # (any multiple of 4: rows that are only dword-aligned since round 5)
         n_pol, n_avg = 2, int(rng.choice([8, 16, 32]))
         n_ipo = 2 * n_avg
         n_out = int(rng.integers(1, 6))

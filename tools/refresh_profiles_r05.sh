@@ -41,6 +41,11 @@ rm -rf $O/prof_aux
 cd $R
 SEED=51 CASES=300 python tools/fuzz_dm_stream.py > $O/r05_fuzz_dm_stream.txt 2>&1
 (SEED=2000 CASES=1200 python tools/fuzz_calls.py; SEED=10000 CASES=300 python tools/fuzz_calls.py; FUZZ=loops SEED=3000 CASES=150 python tools/fuzz_calls.py; FUZZ=debug SEED=4000 CASES=400 python tools/fuzz_calls.py; FUZZ=dmloops SEED=6000 CASES=200 python tools/fuzz_calls.py) 2>&1 | grep -v "obs Complete\|amdgpu.ids" > $O/r05_fuzz_calls.txt
+# the in-contract geometries outside the BASELINE configs: run-time windows, dword-aligned rows beyond 128 antennas
+python tools/rtw_perf.py 2>&1 | grep -v amdgpu.ids > $O/r05_rtw_perf.txt
+python tools/deep_p4_perf.py 2>&1 | grep -v amdgpu.ids > $O/r05_deep_p4_perf.txt
+python tools/generic_perf.py 2>&1 | grep -v amdgpu.ids > $O/r05_generic_perf.txt
+(FUZZ_GENERIC=1 SEED=501 CASES=600 python tools/fuzz_long.py; FUZZ_GENERIC=1 SEED=502 CASES=600 python tools/fuzz_long.py; SEED=503 CASES=300 python tools/fuzz_long.py) 2>&1 | grep -v amdgpu.ids > $O/r05_fuzz_geometry.txt
 # the GPU suite: the budgeted default run with its durations, then every case
 python -m pytest tests -m gpu -q --durations=25 -p no:cacheprovider > $O/r05_gputest_durations.txt 2>&1
 DSABF_LONG_TESTS=1 python -m pytest tests -m gpu -q -p no:cacheprovider 2>&1 | tail -4 > $O/r05_gputest_long_tail.txt
