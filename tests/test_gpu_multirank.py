@@ -335,7 +335,7 @@ def test_plain_c_sharded_example(fake_rccl, tmp_path, world):
 
 
 # (soak: DSABF_LONG_TESTS=1 DSABF_SHARD_SEEDS=16:200 walks other seeds)
-@pytest.mark.parametrize("seed", sweep(range(*(int(v) for v in os.environ.get("DSABF_SHARD_SEEDS", "0:16").split(":"))), [1, 6]))
+@pytest.mark.parametrize("seed", sweep(range(*(int(v) for v in os.environ.get("DSABF_SHARD_SEEDS", "0:16").split(":"))), [6]))
 def test_sharded_observation_loop_under_random_shapes(orc, fake_rccl, tmp_path, seed):
     """dsabf::run_observation with a communicator, every shard its own process (bfh_run_observation_junk_sharded): random world
     size (2 .. 4), shard geometry, block size, queue count, sub-block launches, ring, transport (in place / staged), receiver

@@ -242,7 +242,7 @@ def test_coalescing_handles_any_enqueue_order(torch, bfmod, orc):
 
 # (the 48x walks: a queue's last unit overwritten in the block buffer before its late DM-0 request; 2118, round 5: ... UNDER a late
 #  DM-0 read that ran on another HIP queue than the flush that overwrote it)
-@pytest.mark.parametrize("seed", sweep([1, 2, 3, 4, 5, 6, 484, 486, 489, 498, 2118], [3, 486, 498, 2118]))
+@pytest.mark.parametrize("seed", sweep([1, 2, 3, 4, 5, 6, 484, 486, 489, 498, 2118], [486, 2118]))
 def test_random_call_sequences_leave_every_host_buffer_with_its_own_units_bits(torch, bfmod, orc, seed):
     """Randomised walk over the streaming entry points -- per-unit enqueues (with and without a host destination), DM-0 requests,
     block launches, analysis events, queue and device syncs, the coalesce switch flipped mid-stream -- with a private host
@@ -337,7 +337,7 @@ def test_random_call_sequences_leave_every_host_buffer_with_its_own_units_bits(t
     bf.close()
 
 
-@pytest.mark.parametrize("seed", sweep(range(12), [3, 9]))
+@pytest.mark.parametrize("seed", sweep(range(12), [9]))
 def test_production_loop_to_file_under_random_launch_patterns(bfmod, orc, tmp_path, monkeypatch, seed):
     """run_observation with a file sink under random block / queue counts and every launch pattern it offers (whole blocks,
     sub-block launches, the reference's per-unit loop coalesced or literal): the detected stream in the file is the oracle's,
