@@ -1172,7 +1172,7 @@ int bf_set_switch(bf_handle* h, const char* name, int value)
         if (value < 0) return fail(BF_ERR_INVALID, "tsplit must be >= 0 (0: the library decides)");
         h->geom.tsplit = value;
     } else if (!strcmp(name, "rtw_kout")) {
-        if (value < 0 || value > 16) return fail(BF_ERR_INVALID, "rtw_kout must be 0 .. 16 (0: the library decides)");
+        if (value < 0 || value > 32) return fail(BF_ERR_INVALID, "rtw_kout must be 0 .. 32 (0: the library decides)");
         h->geom.rtw_kout = value;
     } else if (!strcmp(name, "lds_pad")) {
         if (value < 0 || value > dsabf::kLdsPerCuBytes) return fail(BF_ERR_INVALID, "lds_pad must be 0 .. %d bytes", dsabf::kLdsPerCuBytes);

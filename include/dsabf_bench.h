@@ -38,7 +38,7 @@ int bf_rtw_plan(const bf_config *cfg, int n_units, int n_cus, int *windows_per_s
  * produce the same bits; none of them is needed in production.  The environment variables of the same meaning are read ONCE,
  * at bf_create (DSABF_TSPLIT, DSABF_LDS_PAD, DSABF_DM_WIDE) -- never in a launch path.
  *   "tsplit"   n >= 0   time splits per frequency of the fused launch (0: the library decides)
- *   "rtw_kout" 0 .. 16  whole windows per lane-group stream of a run-time-window launch (accumulation windows without a
+ *   "rtw_kout" 0 .. 32  whole windows per lane-group stream of a run-time-window launch (accumulation windows without a
  *                       compile-time instantiation; 0: the library picks the one with the least padding that still fills the chip)
  *   "lds_pad"  bytes    extra dynamic LDS per workgroup (fewer resident workgroups per CU); clamped to what a CU has
  *   "dm_wide"  0 / 1    0: bf_dedisperse_dm*_device runs the per-thread-window kernel alone

@@ -581,8 +581,30 @@ def test_run_time_window_streams_of_any_length_bit_exact(torch, bfmod, orc, n_av
                 torch.cuda.synchronize()
                 assert np.array_equal(d_out.cpu().numpy(), want), (mode, kout, tsplit)
         with pytest.raises(bfmod.DsabfError):
-            bf.set_switch("rtw_kout", 17)
+            bf.set_switch("rtw_kout", 33)
         bf.close()
+
+
+@pytest.mark.parametrize("n_avg", [5, 7, 19, 33])
+def test_run_time_window_streams_of_odd_windows_one_polarisation(torch, bfmod, orc, n_avg):
+    """N_POL = 1 (src/beamformer.hh:50) makes the window odd: whole-chunk streams are then 32 windows long.  Every stream length the
+    library may pick (1 ... 32) gives the oracle's bits."""
+    g = orc.Geom(n_beams=64, n_ant=64, n_freq=2, n_pol=1, n_avg=n_avg, n_out_per_gemm=9)
+    rng = np.random.default_rng(n_avg)
+    w = rng.integers(-127, 128, size=(g.n_freq, g.n_ant, g.n_beams, 2), dtype=np.int8)
+    n_units = 31
+    packed = rng.integers(0, 256, size=(n_units, g.n_freq, g.n_time, g.n_ant), dtype=np.uint8)
+    want = orc.beamform(g, w, packed).reshape(-1)
+    bf = bfmod.Beamformer(_small_cfg(bfmod, g))
+    bf.set_weights(w)
+    assert "NIPO=%d(run-time)" % n_avg in bf.kernel_info(n_units)["kernel"]
+    for kout in (0, 1, 6, 17, 25, 31, 32):
+        bf.set_switch("rtw_kout", kout)
+        d_out = torch.full((want.size,), float("nan"), dtype=torch.float32, device="cuda")
+        bf.beamform(torch.from_numpy(packed).cuda(), n_units, d_out, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert np.array_equal(d_out.cpu().numpy(), want), kout
+    bf.close()
 
 
 @pytest.mark.parametrize("n_avg,kout,rows", [(12, 4, 12288), (20, 4, 20480), (9, 3, 11008)])

@@ -65,7 +65,7 @@ for case in range(N):
     bf.set_weights(w)
     kout = 0
     if os.environ.get("FUZZ_GENERIC") == "1":   # round 5: any stream length of the run-time-window launches (0: the library's choice)
-        kout = int(rng.integers(0, 17))
+        kout = int(rng.integers(0, 33))
         bf.set_switch("rtw_kout", kout)
     info = bf.kernel_info(n_units)
     name = info["kernel"]
