@@ -970,6 +970,14 @@ def main():
                 msgs = (world - 1) * (1 if one_per_pair else n_rows // world)   # a sender -> every other owner
             rec.update({"bytes_sent_per_rank_per_step": sent, "send_gbs_per_rank": sent / (el / n_steps) / 1e9,
                         "messages_sent_per_rank_per_step": msgs})
+            # a model to read the figure with (docs/DESIGN_r03_sections.md 5): the busiest link of the step -- alltoall: every pair of
+            # GPUs exchanges 1 / world^2 of the step's powers in each direction; root: the root's links take a whole shard each, IN --
+            # at 50 and 75 GB/s per direction and link (what RCCL point-to-point holds of an xGMI link's 76.8).  The step cannot be
+            # faster than max(kernel, this); send_gbs_per_rank / (world - 1) is the per-link rate it really ran at
+            per_link = out_floats * 4 * (1.0 if gm.mode == "root" else 1.0 / world)
+            rec["link_model"] = {"bytes_on_the_busiest_link_per_step": per_link, "ms_at_50_gbs": per_link / 50e9 * 1e3,
+                                 "ms_at_75_gbs": per_link / 75e9 * 1e3,
+                                 "measured_gbs_per_link": (sent / (world - 1) if gm.mode != "root" else per_link) / (el / n_steps) / 1e9}
         if "ms" in closing:
             rec["closing_barrier_ms"] = closing["ms"]      # rank 0's wait in the MAX all-reduce behind its own K steps
         if "enqueue_ms" in closing:

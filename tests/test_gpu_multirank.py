@@ -183,6 +183,11 @@ def test_bench_with_two_ranks_on_one_gpu(fake_rccl, gather, n):
     assert modes["alltoall_freq_major_staged"]["messages_sent_per_rank_per_step"] == modes["alltoall_rank_major"]["messages_sent_per_rank_per_step"] == n - 1
     assert modes["root_freq_major"]["messages_sent_per_rank_per_step"] == n_rows and modes["root_freq_major_staged"]["messages_sent_per_rank_per_step"] == 1
     assert modes["alltoall_rank_major"]["bytes_sent_per_rank_per_step"] == n_rows * (256 // n) * 256 * 4 * (n - 1) / n
+    # the link model beside it: alltoall loads every link with 1 / n of a rank's powers per direction, root the root's with all of them
+    shard = n_rows * (256 // n) * 256 * 4
+    lm_a, lm_r = modes["alltoall_rank_major"]["link_model"], modes["root_rank_major"]["link_model"]
+    assert lm_a["bytes_on_the_busiest_link_per_step"] == shard / n and lm_r["bytes_on_the_busiest_link_per_step"] == shard
+    assert abs(lm_a["ms_at_75_gbs"] - shard / n / 75e9 * 1e3) < 1e-9 and lm_a["measured_gbs_per_link"] > 0 and "link_model" not in modes["none"]
 
 
 def test_bench_launches_its_own_ranks_when_called_plainly(fake_rccl):
