@@ -407,6 +407,26 @@ def self_launch(args):
         sys.exit(5)
 
 
+LINE_OUT = None     # where the ONE JSON line goes once main() has claimed stdout for it
+
+
+def claim_stdout():
+    """Only the JSON line may reach stdout.  Native libraries print there too -- gloo writes "[Gloo] Rank 0 is connected to 7 peer
+    ranks" once per rank at N > 1 -- so fd 1 is pointed at stderr for everything else (python's prints included) and the line is
+    written to a duplicate of the real stdout."""
+    global LINE_OUT
+    if LINE_OUT is None:
+        sys.stdout.flush()
+        LINE_OUT = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
+
+
+def print_line(text):
+    out = LINE_OUT or sys.stdout
+    out.write(text + "\n")
+    out.flush()
+
+
 class Deadline:
     """Guarantees that the process ENDS, and that rank 0 prints exactly one JSON line, whatever blocks.
 
@@ -495,7 +515,7 @@ class Deadline:
             elif out is not None and note:
                 out["truncated"] = note
             if out is not None:
-                print(self._line(out), flush=True)
+                print_line(self._line(out))
 
     def _expired(self, what):
         if self.complete:
@@ -564,6 +584,7 @@ def main():
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args)          # never returns
+    claim_stdout()                 # (every rank: what gloo, RCCL or anybody else prints goes to stderr from here on)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))

@@ -204,6 +204,9 @@ def test_bench_launches_its_own_ranks_when_called_plainly(fake_rccl):
                        capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, (r.stdout + r.stderr)[-4000:]
     assert "without a launcher: starting -m torch.distributed.run" in r.stderr
+    # stdout is the JSON line and nothing else: what the ranks' native libraries print there (gloo's "[Gloo] Rank 0 is connected to
+    # 1 peer ranks", one per rank) goes to stderr (bench.claim_stdout) -- a driver that parses the command's stdout sees one line
+    assert r.stdout.count("\n") == 1 and r.stdout.startswith("{"), r.stdout[:600]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
     d = json.loads(lines[0])
