@@ -114,7 +114,8 @@ def test_gather_detected_8_ranks_at_the_true_config4_per_rank_shape(orc, fake_rc
     assert np.array_equal(ranks[0]["band_dm"], orc.dedisperse_dm(full, delays, n_rows - int(delays.max())))
 
 
-def test_beam_sharded_over_two_ranks_gathers_the_whole_band(orc, fake_rccl, tmp_path):
+@pytest.mark.sweep_cap(0)   # DSABF_LONG_TESTS=1 only: the budgeted run keeps `beam -R 2` through test_gpu_round5::test_beam_cli_dm_stage_… (staged
+def test_beam_sharded_over_two_ranks_gathers_the_whole_band(orc, fake_rccl, tmp_path):   # transport, -w checked) and the sharded-loop walk (in place)
     """`beam -j 28 -R 2 -r i -I id` (25 burn-in reads + 3 analysed blocks): two shard processes, the detected powers of both gathered to shard 0 after every
     block (bf_gather_detected on the block's compute queue inside run_observation), shard 0 alone writes -w: the file
     holds [gemm][o][256 freq][beam] = shard 0's channels 0..127 next to shard 1's 128..255, bit for bit the oracle's."""
