@@ -416,9 +416,13 @@ def claim_stdout():
     written to a duplicate of the real stdout."""
     global LINE_OUT
     if LINE_OUT is None:
-        sys.stdout.flush()
-        LINE_OUT = os.fdopen(os.dup(1), "w")
-        os.dup2(2, 1)
+        try:
+            sys.stdout.flush()
+            keep = os.dup(1)
+            os.dup2(2, 1)
+            LINE_OUT = os.fdopen(keep, "w")
+        except OSError:          # no stderr (or no stdout) to work with: leave the descriptors as they are
+            LINE_OUT = None
 
 
 def print_line(text):

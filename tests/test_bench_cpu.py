@@ -305,3 +305,17 @@ def test_a_signal_to_the_parent_ends_the_ranks_too(tmp_path):
     else:
         os.kill(pid, signal.SIGKILL)
         raise AssertionError("the launcher's child outlived its parent")
+
+
+def test_stdout_is_reserved_for_the_line():
+    """bench.claim_stdout(): after it, what python prints and what native code writes to fd 1 (gloo's connection notes at N > 1)
+    lands on stderr; the line -- print_line -- is the only thing on the real stdout.  A closed stderr does not break it."""
+    import subprocess
+
+    code = ("import os, sys; sys.path.insert(0, %r); import bench; bench.claim_stdout(); print('python noise'); "
+            "os.write(1, b'native noise\\n'); bench.print_line('{\"ok\": 1}')" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout == '{"ok": 1}\n' and "native noise" in r.stderr and "python noise" in r.stderr
+    code = ("import os, sys; sys.path.insert(0, %r); import bench; os.close(2); bench.claim_stdout(); bench.print_line('{\"ok\": 1}')" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout == '{"ok": 1}\n'
