@@ -1290,8 +1290,9 @@ def main():
             n_blk = 64
             st = {}
             host.run_observation_junk(pc, 8, ring_blocks=4, device=local, burn_in=2)   # one-off costs outside the records
-            for label, env in (("block_launches", {}), ("reference_unit_launches", {"DSABF_UNIT_LAUNCH": "1"}),
-                               ("reference_unit_launches_literal", {"DSABF_UNIT_LAUNCH": "1", "DSABF_COALESCE": "0"})):
+            # (DSABF_UNIT_LAUNCH is a measurement switch: the library reads it only beside DSABF_LAB=1, set for these two records alone)
+            for label, env in (("block_launches", {}), ("reference_unit_launches", {"DSABF_LAB": "1", "DSABF_UNIT_LAUNCH": "1"}),
+                               ("reference_unit_launches_literal", {"DSABF_LAB": "1", "DSABF_UNIT_LAUNCH": "1", "DSABF_COALESCE": "0"})):
                 os.environ.update(env)
                 try:
                     r = host.run_observation_junk(pc, n_blk, ring_blocks=4, device=local, burn_in=4)

@@ -6,4 +6,4 @@ thin ctypes harness used by the tests, ``bench.py`` and the multi-GPU launcher; 
 and has no CPU fallback.
 """
 from ._lib import BfConfig, DsabfError, load  # noqa: F401
-from .api import Beamformer, debug_config, launch_plan, production_config  # noqa: F401
+from .api import Beamformer, debug_config, launch_plan, production_config, variant_key  # noqa: F401

@@ -126,6 +126,8 @@ SIGNATURES = {
                                     C.c_void_p]),
     "bf_launch_plan": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
                                C.c_char_p, C.c_size_t]),
+    "bf_variant_key": (C.c_int, [C.POINTER(BfConfig), C.c_int, C.c_int, C.c_char_p, C.c_size_t]),
+    "bf_handle_variant_key": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_size_t]),
     # ---- include/dsabf_host.h ----
     "bfh_default_positions": (C.c_int, [C.c_int, C.c_void_p]),
     "bfh_default_directions": (C.c_int, [C.c_int, C.c_void_p]),

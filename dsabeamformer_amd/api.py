@@ -37,6 +37,14 @@ def launch_plan(cfg: BfConfig, paired: bool, n_units: int = 1, n_cus: int = 256)
     return {"kernel": name.value.decode(), "grid": g.value, "block": b.value, "lds_bytes": l.value}
 
 
+def variant_key(cfg: BfConfig, paired: bool, write_c: bool = False) -> str:
+    """The compiled kernel instantiation ``cfg`` selects, as its demangled symbol spells the template arguments
+    (bf_variant_key: host arithmetic; the census of tests/test_census_cpu.py)."""
+    buf = C.create_string_buffer(120)
+    check(load().bf_variant_key(C.byref(cfg), int(paired), int(write_c), buf, 120))
+    return buf.value.decode()
+
+
 def _ptr(x) -> C.c_void_p:
     """Accept ints, ctypes pointers, numpy arrays (host) and torch tensors (device or host)."""
     if x is None:
@@ -192,6 +200,12 @@ class Beamformer:
         check(self._lib.bf_kernel_name(self._h, name, 160))
         return {"kernel": name.value.decode(), "grid": g.value, "block": b.value, "lds_bytes": l.value,
                 "vgprs": v.value}
+
+    def variant_key(self, write_c: bool = False) -> str:
+        """The instantiation this handle launches (after set_weights decided general / conjugate-pair)."""
+        buf = C.create_string_buffer(120)
+        check(self._lib.bf_handle_variant_key(self._h, int(write_c), buf, 120))
+        return buf.value.decode()
 
     def close(self) -> None:
         if self._h:

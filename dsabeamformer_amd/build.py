@@ -29,7 +29,8 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 # neutral or worse with either (C3 +-0.5 ... +1.1 %, the 8-slot pair kernel +0.2 ... +0.5 %) and keeps max-ilp.
 # Round 4: the deep classes (three / four k-steps, 8-wave workgroups; bf_fused16_{a192,a256,k3p16,k4p16}.hip) with iterative-ilp: general
 # kernel -6.3 % at 256 antennas (iterative-maxocc -3.8 %), conjugate-pair kernel -3.1 % (profiles/r04_deep_sched.txt).
-SCHED_BY_SUFFIX = {"_w8.hip": "iterative-maxocc", "_w8p.hip": "iterative-ilp", "_a192.hip": "iterative-ilp", "_a256.hip": "iterative-ilp",
+# Round 6: the compile-time classes a192 / a256 were folded into k3p16 / k4p16 (profiles/r06_class_fold_ab.txt), which already had the strategy.
+SCHED_BY_SUFFIX = {"_w8.hip": "iterative-maxocc", "_w8p.hip": "iterative-ilp",
                    "_k3p16.hip": "iterative-ilp", "_k4p16.hip": "iterative-ilp", "_k3p4.hip": "iterative-ilp", "_k4p4.hip": "iterative-ilp"}
 
 

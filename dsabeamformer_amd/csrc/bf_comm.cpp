@@ -272,7 +272,7 @@ static int gather_exchange(bf_comm* c, const float* d_local, size_t n_rows, size
     int result = BF_OK;
     // own rows: a strided device-to-device copy (one call for the freq-major layout), not through RCCL -- unless
     // DSABF_GATHER_SELF_RCCL=1 asks for it (test switch: lets ONE GPU exercise the grouped ncclSend / ncclRecv path)
-    const char* self_env = getenv("DSABF_GATHER_SELF_RCCL");
+    const char* self_env = dsabf::lab_getenv("DSABF_GATHER_SELF_RCCL");
     const bool self_rccl = c->comm && self_env && self_env[0] == '1' && d_wire == d_self && wire_layout == self_layout;
     if (!self_rccl && receives) {
         const size_t first = root == BF_GATHER_ROOT_DISTRIBUTED ? (size_t)c->rank * held : 0;   // my own rows that I keep

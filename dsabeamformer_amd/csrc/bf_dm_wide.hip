@@ -52,15 +52,12 @@ typedef int v2i __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 
 #ifndef DSABF_DW_PROBE
-#define DSABF_DW_PROBE 0   // diagnostic build: s_memtime around the phases of a channel (tools/dm_probe.py)
-#endif
-#ifndef DSABF_DW_TB
-#define DSABF_DW_TB 16
-#endif
-constexpr int kDwTb = DSABF_DW_TB;   // output times per tile; x beams per lane = 64 accumulator registers
+#define DSABF_DW_PROBE 0   // the one compile-time switch of this file: a diagnostic build tools/dm_probe.py makes BESIDE the product
+#endif                     // (s_memtime around the phases of a channel; results invalid)
+constexpr int kDwTb = 16;   // output times per tile; x beams per lane = 64 accumulator registers
 constexpr int kDwBpl = 64 / kDwTb;   // beams per lane: 4 (ds_read_b128) or 2 (ds_read_b64), both 256 B/clk/CU
 static_assert(kDwTb == 16 || kDwTb == 32, "16 times x 4 beams or 32 times x 2 beams per lane");
-constexpr int kDwWaves = DSABF_DW_WAVES;   // waves per workgroup, two trials each
+constexpr int kDwWaves = kDwWavesPerWg;   // waves per workgroup, two trials each
 constexpr int kDwThreads = 64 * kDwWaves;
 constexpr int kDwBeams = 32 * kDwBpl; // beams per tile: a half-wave across
 constexpr int kDwRowBytes = kDwBeams * 4;

@@ -9,22 +9,13 @@
 #include <atomic>
 #include <type_traits>
 
-#ifndef DSABF_PAIR_MFMA
-#define DSABF_PAIR_MFMA 4 // MFMAs per conjugate pair tile: 4 (+-P2, +-P4 on the VALU), 5 (real part chained on the MFMA), 6
-#endif
 #ifndef DSABF_CLOCKPROBE
-#define DSABF_CLOCKPROBE 0 // diagnostic build only (tools/clock_probe.sh): every workgroup overwrites out[blockIdx.x] with its
-#endif                     // in-kernel shader clock in GHz (s_memtime / s_memrealtime around the chunk loop); results invalid
-#ifndef DSABF_FASTADDR
-#define DSABF_FASTADDR 1  // scalar chunk addressing in fused16_kernel when gemm-units are a multiple of the chunk span
-#endif
-#ifndef DSABF_GEN3
-#define DSABF_GEN3 1      // general weight image holds 3 fragments per tile (Wr, -Wi, Wi) instead of 4 (Wr, -Wi, Wi, Wr again)
-#endif
-#ifndef DSABF_OCC16
-#define DSABF_OCC16 3     // default register budget of the one-k-step variants (168 VGPRs: 3 waves per SIMD); fused_min_waves()
-                          // raises it to 4 where 128 registers suffice
-#endif
+#define DSABF_CLOCKPROBE 0 // the ONE compile-time switch left in this kernel: a diagnostic build that tools/clock_probe.sh makes beside
+#endif                     // the product (-DDSABF_CLOCKPROBE=1: every workgroup overwrites out[blockIdx.x] with its in-kernel shader clock
+                           // in GHz, s_memtime / s_memrealtime around the chunk loop; results invalid).  The experiment arms of rounds
+                           // 1-5 (5 / 6 MFMAs per conjugate-pair tile, the 4-fragment general image, vector chunk addressing,
+                           // sign-extended nibbles in the deep classes, the timing ablations, -DDSABF_WAVES / _NS / _OCC16 builds) were
+                           // measured, lost, and are gone: profiles/r0[1-5]_variants_log.txt, docs/LOG_r06.md.
 
 namespace dsabf {
 
@@ -47,6 +38,10 @@ constexpr int kAntK4P16 = -5;  // 193..256 antennas, n_ant % 16 == 0: four k-ste
 constexpr int kAntK3P16 = -6;  // 129..192 antennas, n_ant % 16 == 0: three k-steps
 constexpr int kAntK4P4 = -7;   // 193..256 antennas, n_ant % 4 == 0: four k-steps, 4-byte staging pieces (round 5)
 constexpr int kAntK3P4 = -8;   // 129..192 antennas, n_ant % 4 == 0
+
+// Weight fragments per tile in the two images (weight_relayout16_kernel / weight_relayout16p_kernel, bf_kernels.hip):
+constexpr int kGeneralComps = 3;   // Wr, -Wi, Wi: the real row multiplies (Vr | Vi) by (Wr | -Wi), the imaginary row by (Wi | Wr) -- Wr serves both
+constexpr int kPairComps = 2;      // Wr, Wi: the conjugate-pair kernel forms +-P2, +-P4 on the VALU
 
 constexpr unsigned kMagicBits = 0x4B400000u;        // float 12582912 = 1.5 * 2^23
 constexpr float kMagic = 12582912.0f;
@@ -147,10 +142,10 @@ __device__ __forceinline__ int swz16(int chunk, int row)  // 8 chunks of 16 B pe
     return chunk ^ ((((row >> 1) & 1) | (((row / LR) & 3) << 1)) ^ ((row & 1) << 2));
 }
 
-constexpr int kWaves16 = DSABF_WAVES;        // waves per workgroup of fused16_kernel
+constexpr int kWaves16 = 4;                  // waves per workgroup of fused16_kernel
 constexpr int kThreads16 = 64 * kWaves16;
 constexpr int kWavesWide16 = 8;              // ... of the two-k-step classes where the beam count allows (fused_wg_waves)
-constexpr int kColTiles16 = DSABF_NS;        // 16-beam column tiles (output slots) per wave
+constexpr int kColTiles16 = 4;               // 16-beam column tiles (output slots) per wave
 constexpr int kColTilesWide16 = 8;           // ... of the two-k-step conjugate-pair kernels where the beams allow (fused_col_tiles)
 
 // PAIRED: the steering weights of beam B-1-b are the complex conjugates of those of beam b for every (frequency,
@@ -190,8 +185,8 @@ template <int AIN, int NIPO, bool WRITE_C, int NS = kColTiles16>
 constexpr int fused_min_waves()
 {
     if (NS == 8 || ant_ksteps<AIN>() >= 2) return 2;
-    if (DSABF_OCC16 == 3 && (AIN == 64 || AIN == kAntK1P16) && (NIPO == 8 || NIPO == 16 || NIPO == 32) && !WRITE_C) return 4;
-    return DSABF_OCC16;
+    if (AIN == kAntK1P16 && (NIPO == 8 || NIPO == 16 || NIPO == 32) && !WRITE_C) return 4;
+    return 3;   // 168 VGPRs
 }
 
 //
@@ -216,13 +211,12 @@ __global__ __launch_bounds__(64 * WAVES, (fused_min_waves<AIN, NIPO, WRITE_C, NS
     static_assert(!(PAIRED && WRITE_C), "the stage-parity path always runs the general kernel");
     static_assert(AIN >= kAntK3P4 && AIN != 0 && (AIN < 0 || AIN % 4 == 0) && AIN <= 256, "antenna class");
     static_assert(!ant_deep<AIN>() || (WAVES == 8 && NIPO >= 16 && !WRITE_C), "deep classes: 8 waves, long windows");
-#ifndef DSABF_DEEP_OFFSET
-#define DSABF_DEEP_OFFSET 1   // 0: the deep classes stage sign-extended nibbles (9 VALU per dword, and the pipe holds a lower clock on them:
-#endif                        //    profiles/r04_ubench_encoding.txt) instead of offset nibbles v + 8 with the correction in the accumulator seeds
-    constexpr bool TRUE_NIB = ant_deep<AIN>();           // operands count in units of the nibble value itself, not 16 x
-    constexpr bool OFFSET_NIB = TRUE_NIB && DSABF_DEEP_OFFSET != 0;   // ... as v + 8 in [0, 15]
-    constexpr float kA = TRUE_NIB ? kAlpha : kAlpha16;   // accumulator unit -> alpha
-    constexpr float kNKA = TRUE_NIB ? kNegMagicAlpha : kNegMagicAlpha16;
+    // the deep classes' operands count in units of the nibble value itself, not 16 x, staged as OFFSET nibbles v + 8 in [0, 15] with
+    // the correction in the accumulator seeds (sign-extended nibbles cost 9 VALU per dword and the pipe holds a lower clock on them:
+    // profiles/r04_ubench_encoding.txt)
+    constexpr bool OFFSET_NIB = ant_deep<AIN>();
+    constexpr float kA = OFFSET_NIB ? kAlpha : kAlpha16;   // accumulator unit -> alpha
+    constexpr float kNKA = OFFSET_NIB ? kNegMagicAlpha : kNegMagicAlpha16;
     constexpr bool RT = AIN < 0;                         // antenna count known only at run time
     constexpr int RB = 128;
     constexpr int KS = ant_ksteps<AIN>();                // k-steps of 64 antennas
@@ -260,9 +254,9 @@ __global__ __launch_bounds__(64 * WAVES, (fused_min_waves<AIN, NIPO, WRITE_C, NS
 
     // ---- which beams this lane produces, and the weight fragments ------------------------------------------
     int slot_beam[NS];                                    // beam index of output slot s (>= n_beams: none)
-    constexpr int NPC = DSABF_PAIR_MFMA >= 5 ? 3 : 2;     // paired fragments per tile: Wr, Wi (, -Wi)
-    constexpr int NGC = DSABF_GEN3 ? 3 : 4;               // general fragments per tile: Wr, -Wi, Wi (the im row's Wr IS comp 0)
-    v4i bw[NT][PAIRED ? NPC : NGC][KS];                   // general: [ct][Wr, -Wi, Wi][k-step]; paired: [pct][Wr, Wi, -Wi][k-step]
+    constexpr int NPC = kPairComps;                       // paired fragments per tile: Wr, Wi
+    constexpr int NGC = kGeneralComps;                    // general fragments per tile: Wr, -Wi, Wi (the im row's Wr IS comp 0)
+    v4i bw[NT][PAIRED ? NPC : NGC][KS];                   // general: [ct][Wr, -Wi, Wi][k-step]; paired: [pct][Wr, Wi][k-step]
     bool wave_active;
     if constexpr (PAIRED) {
         const int n_pct = a.n_ptiles;                     // pair tiles of 16 base beams = n_beams / 32
@@ -279,7 +273,7 @@ __global__ __launch_bounds__(64 * WAVES, (fused_min_waves<AIN, NIPO, WRITE_C, NS
 #pragma unroll
                 for (int h = 0; h < KS; h++)
                     bw[t][comp][h] =
-                        ok ? a.wimg[((((size_t)f * n_pct + pct0 + t) * 3 + comp) * KS + h) * 64 + lane] : v4i{0, 0, 0, 0};
+                        ok ? a.wimg[((((size_t)f * n_pct + pct0 + t) * NPC + comp) * KS + h) * 64 + lane] : v4i{0, 0, 0, 0};
         }
     } else {
         const int n_ctiles = a.n_ctiles;
@@ -328,7 +322,7 @@ __global__ __launch_bounds__(64 * WAVES, (fused_min_waves<AIN, NIPO, WRITE_C, NS
             } else {
                 const int wr = colsum(bw[t][0]), nwi = colsum(bw[t][1]), wi = colsum(bw[t][2]);
                 s0 = (int)kMagicBits - 8 * (wr + nwi);
-                s1 = (int)kMagicBits - 8 * (wi + (DSABF_GEN3 ? wr : colsum(bw[t][NGC - 1])));
+                s1 = (int)kMagicBits - 8 * (wi + wr);
             }
             sd[t][0] = v4i{s0, s0, s0, s0};
             sd[t][1] = v4i{s1, s1, s1, s1};
@@ -351,7 +345,7 @@ __global__ __launch_bounds__(64 * WAVES, (fused_min_waves<AIN, NIPO, WRITE_C, NS
     // per-lane part (row and piece) is a constant 32-bit offset: no vector integer arithmetic (the generic
     // path costs ~17 VALU ops, 6 of them quarter-rate 32-bit multiplies, per load).
     constexpr unsigned SPAN = (NIPO == 64) ? 256u : 128u;
-    const bool fast_addr = DSABF_FASTADDR && !RTW && ((unsigned)a.T % SPAN) == 0;
+    const bool fast_addr = !RTW && ((unsigned)a.T % SPAN) == 0;
     // Piece k of this thread is piece pc = tid + 256 k of the chunk: row pc / PPR, position pc % PPR.  Its byte offset
     // from the chunk's first sample is PB * pc (rows are PPR * PB bytes and consecutive) -- except for n_ipo = 64, whose
     // chunk rows are four runs of 32 samples, 64 apart.  The 16*im image sits 4 pieces away from the 16*re image (after it
@@ -428,9 +422,6 @@ __global__ __launch_bounds__(64 * WAVES, (fused_min_waves<AIN, NIPO, WRITE_C, NS
                     const unsigned x = w ^ 0x88888888u;
                     *reinterpret_cast<int*>(buf + lds_re[k]) = (int)((x >> 4) & 0x0F0F0F0Fu);
                     *reinterpret_cast<int*>(buf + (lds_re[k] ^ 64)) = (int)(x & 0x0F0F0F0Fu);
-                } else if constexpr (TRUE_NIB) {
-                    *reinterpret_cast<int*>(buf + lds_re[k]) = (int)(((((w >> 4) & 0x0F0F0F0Fu) ^ 0x88888888u) - 0x08080808u) ^ 0x80808080u);
-                    *reinterpret_cast<int*>(buf + (lds_re[k] ^ 64)) = (int)((((w & 0x0F0F0F0Fu) ^ 0x88888888u) - 0x08080808u) ^ 0x80808080u);
                 } else {
                     *reinterpret_cast<int*>(buf + lds_re[k]) = (int)(w & 0xF0F0F0F0u);
                     *reinterpret_cast<int*>(buf + (lds_re[k] ^ 64)) = (int)((w << 4) & 0xF0F0F0F0u);
@@ -444,9 +435,6 @@ __global__ __launch_bounds__(64 * WAVES, (fused_min_waves<AIN, NIPO, WRITE_C, NS
                         const unsigned x = w ^ 0x88888888u;
                         re[d] = (int)((x >> 4) & 0x0F0F0F0Fu);
                         im[d] = (int)(x & 0x0F0F0F0Fu);
-                    } else if constexpr (TRUE_NIB) {   // sign-extend the nibbles inside their bytes: ((v ^ 8) - 8) without a borrow across bytes
-                        re[d] = (int)(((((w >> 4) & 0x0F0F0F0Fu) ^ 0x88888888u) - 0x08080808u) ^ 0x80808080u);
-                        im[d] = (int)((((w & 0x0F0F0F0Fu) ^ 0x88888888u) - 0x08080808u) ^ 0x80808080u);
                     } else {
                         re[d] = (int)(w & 0xF0F0F0F0u);
                         im[d] = (int)((w << 4) & 0xF0F0F0F0u);
@@ -702,46 +690,27 @@ __global__ __launch_bounds__(64 * WAVES, (fused_min_waves<AIN, NIPO, WRITE_C, NS
                 if constexpr (PAIRED) {
                     const v4i p1 = dot(a0, bw[t][0], k0);     // Wr*Vr + K
                     const v4i p3 = dot(a1, bw[t][0], k0);     // Wr*Vi + K
-                    if constexpr (DSABF_PAIR_MFMA >= 5) {   // +-P2 chained on the MFMA pipe (bw[t][2] = -Wi)
-                        re[0] = dot(a1, bw[t][2], p1);
-                        re[1] = dot(a1, bw[t][1], p1);
-                    } else {
-                        const v4i p2 = dot(a1, bw[t][1], k1);  // Wi*Vi
-                        re[0] = p1 - p2;
-                        re[1] = p1 + p2;
-                    }
-                    if constexpr (DSABF_PAIR_MFMA >= 6) {
-                        im[0] = dot(a0, bw[t][1], p3);
-                        im[1] = dot(a0, bw[t][2], p3);
-                    } else {
-                        const v4i p4 = dot(a0, bw[t][1], k1);  // Wi*Vr
-                        im[0] = p3 + p4;
-                        im[1] = p3 - p4;
-                    }
+                    const v4i p2 = dot(a1, bw[t][1], k1);     // Wi*Vi   (+-P2, +-P4 on the VALU: chaining them on the MFMA
+                    const v4i p4 = dot(a0, bw[t][1], k1);     // Wi*Vr    pipe -- 5 or 6 MFMAs per pair tile -- lost, r03_ab_c3_pairmfma)
+                    re[0] = p1 - p2;
+                    re[1] = p1 + p2;
+                    im[0] = p3 + p4;
+                    im[1] = p3 - p4;
                 } else {
                     re[0] = dot(a1, bw[t][1], dot(a0, bw[t][0], k0));              // Wr*Vr - Wi*Vi
-                    im[0] = dot(a1, bw[t][DSABF_GEN3 ? 0 : 3], dot(a0, bw[t][2], k1));   // Wi*Vr + Wr*Vi
+                    im[0] = dot(a1, bw[t][0], dot(a0, bw[t][2], k1));              // Wi*Vr + Wr*Vi
                 }
             };
-#ifndef DSABF_ABL16
-#define DSABF_ABL16 0   // timing-only ablations (results invalid): 1 no detect (one add per accumulator keeps it alive), 2 no LDS staging writes, 4 no per-chunk barrier
-#endif
             auto consume = [&](const int t8, const int t, const v4i (&re)[SPS], const v4i (&im)[SPS]) {
 #pragma unroll
                 for (int e = 0; e < SPS; e++) {  // paired: slot 2t = beam b, slot 2t+1 = beam B-1-b
-                    if constexpr (DSABF_ABL16 & 1) {
-                        const v4i x = re[e] + im[e];
-                        sum[SPS * t + e] += __builtin_bit_cast(float, x[0] ^ x[1] ^ x[2] ^ x[3]);
-                        if (t8 == 7) { pend[0][SPS * t + e] = sum[SPS * t + e]; pend_chunk[0] = c; }
-                    } else {
-                        detect(t8, __builtin_bit_cast(v4f, re[e]), __builtin_bit_cast(v4f, im[e]), SPS * t + e);
-                    }
+                    detect(t8, __builtin_bit_cast(v4f, re[e]), __builtin_bit_cast(v4f, im[e]), SPS * t + e);
                 }
             };
             // staging work in the shadow of the MFMA stream: the next chunk's LDS image after tile 1, the parked stores
             // of the previous chunk and the prefetch of chunk c+2 after tile 3
             auto staging = [&](const int t8) {
-                if (t8 == 1 && c + 1 < c_end && !(DSABF_ABL16 & 2)) write_chunk(nxt);
+                if (t8 == 1 && c + 1 < c_end) write_chunk(nxt);
                 if (t8 == 3) {
                     flush_pending();
                     if (c + 2 < c_end) load_chunk(c + 2);
@@ -782,7 +751,7 @@ __global__ __launch_bounds__(64 * WAVES, (fused_min_waves<AIN, NIPO, WRITE_C, NS
                 staging(t8);
             }
         }
-        if (!(DSABF_ABL16 & 4)) __syncthreads();
+        __syncthreads();
     }
     flush_pending();
 #if DSABF_CLOCKPROBE
@@ -822,13 +791,16 @@ using fused_launch_fn = hipError_t (*)(const FusedArgs&, const LaunchShape&, hip
 struct FusedVariant {
     const void* fn = nullptr;
     fused_launch_fn launch = nullptr;
+    // the instantiation's template arguments, in the kernel's own order: what the census (bf_variant_key, tests/test_census_cpu.py,
+    // profiles/r06_instantiations.txt) compares with the kernel symbols of the shipped library
+    int ain = 0, nipo = 0, write_c = 0, mode = 0, paired = 0, waves = 0, ns = 0;
 };
 
 template <int AIN, int NIPO, bool WRITE_C, int MODE, bool PAIRED, int WAVES, int NS = kColTiles16>
 FusedVariant make_variant()
 {
     return FusedVariant{reinterpret_cast<const void*>(fused16_kernel<AIN, NIPO, WRITE_C, MODE, PAIRED, WAVES, NS>),
-                        launch_fused16_t<AIN, NIPO, WRITE_C, MODE, PAIRED, WAVES, NS>};
+                        launch_fused16_t<AIN, NIPO, WRITE_C, MODE, PAIRED, WAVES, NS>, AIN, NIPO, WRITE_C, MODE, PAIRED, WAVES, NS};
 }
 
 template <int AIN, int NIPO, int WAVES>
@@ -868,7 +840,7 @@ FusedVariant fused16_variant(int n_ipo, bool write_c, int mode, bool paired)
 // ... where its 236-256 registers hold without a spill: not the run-time dword-staged class (13 staging pieces per thread:
 // 60-412 bytes of scratch per lane) and not 100 antennas at n_ipo 64 (140); those keep 4 slots on 8-wave workgroups.
 template <int AIN, int NIPO>
-constexpr bool ns8_fits() { return AIN == 128 || AIN == kAntK2P16 || (AIN == 100 && NIPO < 64); }
+constexpr bool ns8_fits() { return AIN == kAntK2P16 || (AIN == 100 && NIPO < 64); }
 
 template <int AIN, int NIPO>
 FusedVariant fused16_variant_ns8_nipo(int mode)
@@ -952,32 +924,25 @@ FusedVariant fused16_variant_deep(int n_ipo, int mode, bool paired, int ns)
     }
 }
 // ns: output slots per wave (general 2; conjugate-pair 4 where the beams come in groups of 512, else 2)
-FusedVariant fused16_variant_a192(int n_ipo, int mode, bool paired, int ns);
-FusedVariant fused16_variant_a256(int n_ipo, int mode, bool paired, int ns);
 FusedVariant fused16_variant_k4p16(int n_ipo, int mode, bool paired, int ns);
 FusedVariant fused16_variant_k3p16(int n_ipo, int mode, bool paired, int ns);
 FusedVariant fused16_variant_k4p4(int n_ipo, int mode, bool paired, int ns);
 FusedVariant fused16_variant_k3p4(int n_ipo, int mode, bool paired, int ns);
 
 // One definition per antenna class, each in its own translation unit (bf_fused16_*.hip).
-FusedVariant fused16_variant_a64(int n_ipo, bool write_c, int mode, bool paired);
 FusedVariant fused16_variant_a100(int n_ipo, bool write_c, int mode, bool paired);
-FusedVariant fused16_variant_a128(int n_ipo, bool write_c, int mode, bool paired);
 FusedVariant fused16_variant_k1p16(int n_ipo, bool write_c, int mode, bool paired);
 FusedVariant fused16_variant_k1p4(int n_ipo, bool write_c, int mode, bool paired);
 FusedVariant fused16_variant_k2p16(int n_ipo, bool write_c, int mode, bool paired);
 FusedVariant fused16_variant_k2p4(int n_ipo, bool write_c, int mode, bool paired);
 // ... and three per two-k-step class for its wide launches (bf_fused16_*_w8.hip, bf_fused16_*_w8p.hip, bf_fused16_*_s8.hip)
 FusedVariant fused16_variant_a100_w8(int n_ipo, int mode);
-FusedVariant fused16_variant_a128_w8(int n_ipo, int mode);
 FusedVariant fused16_variant_k2p16_w8(int n_ipo, int mode);
 FusedVariant fused16_variant_k2p4_w8(int n_ipo, int mode);
 FusedVariant fused16_variant_a100_w8p(int n_ipo, int mode);
-FusedVariant fused16_variant_a128_w8p(int n_ipo, int mode);
 FusedVariant fused16_variant_k2p16_w8p(int n_ipo, int mode);
 FusedVariant fused16_variant_k2p4_w8p(int n_ipo, int mode);
 FusedVariant fused16_variant_a100_s8(int n_ipo, int mode);
-FusedVariant fused16_variant_a128_s8(int n_ipo, int mode);
 FusedVariant fused16_variant_k2p16_s8(int n_ipo, int mode);
 FusedVariant fused16_variant_k2p4_s8(int n_ipo, int mode);
 

@@ -36,20 +36,13 @@
 
 #include <cstdio>
 
-#ifndef DSABF_G_ORDER
-#define DSABF_G_ORDER 1   // 0: the four accumulators of a row tile round robin (A fragment by A fragment)
-#endif
 namespace dsabf {
 
 namespace {
 
-#ifndef DSABF_G_ABL
-#define DSABF_G_ABL 0   // timing-only ablations (results invalid): 1 no detect, 2 no staging writes, 4 B fragments loaded once, 8 no barrier
-#endif
-#ifndef DSABF_G_WAVES
-#define DSABF_G_WAVES 4
-#endif
-constexpr int kGWaves = DSABF_G_WAVES;                 // waves per workgroup: TWO workgroups are resident per CU (204-235 registers), unsynchronised --
+// (no compile-time switches: the round-robin accumulator order and the timing ablations of round 4 -- profiles/r04_generic_ablate.txt --
+//  were measurement arms and are gone)
+constexpr int kGWaves = 4;                 // waves per workgroup: TWO workgroups are resident per CU (204-235 registers), unsynchronised --
                                            // one's barriers, B-fragment waits and detect phases overlap the other's MFMAs
 constexpr int kGThreads = 64 * kGWaves;
 constexpr int kGNT = 2;                    // 16-beam column tiles per wave: 4 waves x 32 beams = 128 beams per workgroup
@@ -255,7 +248,7 @@ __global__ __launch_bounds__(kGThreads, 2) void fusedg_kernel(GenArgs a)
     auto plane = [&](const v4i (&bc)[kGNT][3], v4i (&bn)[kGNT][3], stage_t (&stage)[PPT]) {
         char* cur = smem + (p & 1) * kGPlane;
         char* nxt = smem + ((p + 1) & 1) * kGPlane;
-        if (!(DSABF_G_ABL & 4)) load_b(bn, h + 1 == KS ? 0 : h + 1);   // one plane ahead: lands behind this plane's MFMAs (behind the last plane: unused)
+        load_b(bn, h + 1 == KS ? 0 : h + 1);   // one plane ahead: lands behind this plane's MFMAs (behind the last plane: unused)
         // A fragments one row tile ahead (two register sets), the order pinned: the scheduler otherwise either reads every
         // tile's fragments at the top of the plane (64 registers beside 128 accumulators: spills) or each tile's just in time
         // (its LDS latency in front of every 8 MFMAs).
@@ -273,7 +266,6 @@ __global__ __launch_bounds__(kGThreads, 2) void fusedg_kernel(GenArgs a)
                 __builtin_amdgcn_sched_barrier(0);
                 {   // (a wave behind the last beam computes too, on its first tile's weights: no branch around the MFMAs)
                     const v4i a0 = fa[t8 & 1][0], a1 = fa[t8 & 1][1];
-#if DSABF_G_ORDER
                     // chain by chain: an accumulator's two MFMAs of this plane back to back -- the second continues the first inside
                     // the matrix unit instead of reading the accumulator back from the VGPRs (tools/ubench_chains.hip: 16 chains of
                     // 2 at two waves per SIMD, 0.585 round robin -> 0.676 chain by chain)
@@ -288,26 +280,12 @@ __global__ __launch_bounds__(kGThreads, 2) void fusedg_kernel(GenArgs a)
                         acc[t8][t][1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, bc[t][0], acc[t8][t][1], 0, 0, 0);   // + Wr Vi
                         __builtin_amdgcn_sched_barrier(0x7F6);
                     }
-#else
-#pragma unroll
-                    for (int t = 0; t < kGNT; t++) {
-                        acc[t8][t][0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, bc[t][0], acc[t8][t][0], 0, 0, 0);   // + Wr Vr
-                        acc[t8][t][1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, bc[t][2], acc[t8][t][1], 0, 0, 0);   // + Wi Vr
-                    }
-#pragma unroll
-                    for (int t = 0; t < kGNT; t++) {
-                        acc[t8][t][0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, bc[t][1], acc[t8][t][0], 0, 0, 0);   // - Wi Vi
-                        acc[t8][t][1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, bc[t][0], acc[t8][t][1], 0, 0, 0);   // + Wr Vi
-                    }
-#endif
                 }
                 // plane p + 1 goes to LDS one piece per row tile (behind the last plane: a copy nobody reads), then plane p + 2
                 // is requested into the registers just emptied
-                if (!(DSABF_G_ABL & 2)) {
-                    if (t8 == 1) write_piece(nxt, stage, 0);
-                    if constexpr (PPT > 1)
-                        if (t8 == 2) write_piece(nxt, stage, 1);
-                }
+                if (t8 == 1) write_piece(nxt, stage, 0);
+                if constexpr (PPT > 1)
+                    if (t8 == 2) write_piece(nxt, stage, 1);
                 if (t8 == 3) load_plane(stage);     // plane p + 2
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -324,14 +302,7 @@ __global__ __launch_bounds__(kGThreads, 2) void fusedg_kernel(GenArgs a)
                 }
         }
         tiles();
-        if ((DSABF_G_ABL & 1) && h + 1 == KS) {   // keep the accumulators alive: one store of their sum
-            v4i x = kzero4;
-#pragma unroll
-            for (int t8 = 0; t8 < 8; t8++)
-#pragma unroll
-                for (int t = 0; t < kGNT; t++) x = x + acc[t8][t][0] + acc[t8][t][1];
-            if (x[0] + x[1] + x[2] + x[3] == 0x12345) a.out[tid] = 1.0f;
-        } else if (h + 1 == KS && wave_active) {
+        if (h + 1 == KS && wave_active) {
             // ---- detect: the chunk's 128 rows x 32 beams are complete ------------------------------------------------
             const unsigned grp = (unsigned)(c / a.cpg), cc = (unsigned)(c % a.cpg);
             const unsigned sigma = 4u * grp + (unsigned)g4;          // this lane's stream
@@ -400,7 +371,7 @@ __global__ __launch_bounds__(kGThreads, 2) void fusedg_kernel(GenArgs a)
                 }
             }
         }
-        if (!(DSABF_G_ABL & 8)) __syncthreads();
+        __syncthreads();
         p++;
         if (++h == KS) {
             h = 0;
@@ -562,6 +533,13 @@ hipError_t launch_fused_generic(const Geometry& g, const void* d_image, const vo
         }
     }
     return g.n_ant % 16 == 0 ? launch_g_mode<true>(mode, write_c, a, ls, s) : launch_g_mode<false>(mode, write_c, a, ls, s);
+}
+
+const char* generic_variant_key(const Geometry& g, bool write_c, char* buf, size_t n)
+{
+    snprintf(buf, n, "fusedg_kernel<%s, %d, %s>", g.n_ant % 16 == 0 ? "true" : "false", write_c ? kDetCanonical : generic_mode(g),
+             write_c ? "true" : "false");
+    return buf;
 }
 
 int generic_vgprs(const Geometry& g)

@@ -7,4 +7,8 @@ namespace dsabf {
 void parallel_for(long n, const std::function<void(long, long)>& body);
 // Sets the calling thread's bf_last_error() text; returns `code` (bf_runtime.cpp).
 int set_error(int code, const char* msg);
+// getenv(name) in a process that says DSABF_LAB=1, NULL anywhere else (bf_kernels.hip): the measurement / test switches.  The
+// production allow-list read with plain getenv is DSABF_RCCL_LIB, DSABF_THREADS, DSABF_COALESCE, DSABF_PAIRED.
+bool lab_mode();
+const char* lab_getenv(const char* name);
 }  // namespace dsabf

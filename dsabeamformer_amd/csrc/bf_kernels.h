@@ -9,12 +9,6 @@
 namespace dsabf {
 
 constexpr int kRowsPerChunk = 128;   // time samples per LDS buffer
-#ifndef DSABF_WAVES
-#define DSABF_WAVES 4    // waves per workgroup of fused16_kernel
-#endif
-#ifndef DSABF_NS
-#define DSABF_NS 4       // 16-beam output slots per wave
-#endif
 
 struct Geometry {
     int n_beams, n_ant, n_freq, n_ipo, n_out, n_time;  // n_time = n_out * n_ipo (per gemm-unit)
@@ -26,7 +20,6 @@ struct Geometry {
     // the layout of the weight images as well as the kernel, so a handle must not see them change between two calls:
     bool plain_wg_waves = false;                        // DSABF_WG_WAVES=4: 4-wave workgroups everywhere
     bool plain_col_tiles = false;                       // DSABF_COL_TILES=4: 4 output slots per wave everywhere
-    bool runtime_ant = false;                           // DSABF_RUNTIME_ANT=1: the run-time antenna classes everywhere
     // ... and three that only pick among launches of the same kernels; bf_set_switch changes them per handle for A/B runs
     int rtw_kout = 0;                                   // windows per stream of the run-time-window launch (0: fused_launch_shape decides)
     int tsplit = 0;                                     // DSABF_TSPLIT=n: time splits per frequency (0: fused_launch_shape decides)
@@ -38,6 +31,10 @@ struct Geometry {
 };
 constexpr int kLdsPerCuBytes = 160 * 1024;
 void read_env_switches(Geometry& g);
+// getenv(name) in a process that says DSABF_LAB=1, NULL anywhere else: every measurement / test switch of the library reads the
+// environment through this (the production allow-list -- DSABF_RCCL_LIB, DSABF_THREADS, DSABF_COALESCE, DSABF_PAIRED -- does not)
+bool lab_mode();
+const char* lab_getenv(const char* name);
 
 // Bytes of the MFMA-fragment weight image: [freq][16-beam tile][re|im row][re|im operand][k-step][lane] x 16 B.
 size_t weight_image_bytes(const Geometry& g);
@@ -97,10 +94,8 @@ hipError_t launch_dedisperse_units(const Geometry& g, const float* d_out_units, 
 // kernel alone).  Groups whose delays fit run dedisperse_dm_wide_kernel (bf_dm_wide.hip), the rest dedisperse_dm_kernel.
 hipError_t launch_dedisperse_dm(const Geometry& g, const float* d_series, int n_t, const int* d_delays, int n_dm,
                                 int n_t_out, float* d_out, int* d_flags, hipStream_t s);
-#ifndef DSABF_DW_WAVES
-#define DSABF_DW_WAVES 16   // waves per workgroup of the shared-window DM kernel (8: two workgroups per CU)
-#endif
-constexpr int kDwTrials = 2 * DSABF_DW_WAVES;   // trials per tile of the wide kernel (two per wave)
+constexpr int kDwWavesPerWg = 16;            // waves per workgroup of the shared-window DM kernel
+constexpr int kDwTrials = 2 * kDwWavesPerWg;   // trials per tile of the wide kernel (two per wave)
 constexpr int kDwMaxGroups = 4096;   // flag ints a caller provides ...
 constexpr size_t kDmScratchBytes = kDwMaxGroups * sizeof(int) + 512;   // ... followed by a 512-byte row of zeros (zero-filled by the caller)
 constexpr int kDwMaxFreq = 1024;     // channels the wide kernel's LDS tables hold
@@ -122,6 +117,10 @@ size_t generic_image_extra_bytes(const Geometry& g);     // the offset-nibble co
 hipError_t launch_generic_colsum(const Geometry& g, const int8_t* d_w, void* d_image, hipStream_t s);
 
 int fused_vgprs(const Geometry& g);  // from hipFuncGetAttributes, for reports
+// The kernel instantiation a geometry runs (write_c: its stage-parity launch), spelled as the demangled kernel symbol spells it:
+// "fused16_kernel<-1, 32, false, 0, true, 4, 4>" / "fusedg_kernel<true, 0, false>"; "" if there is none.  Host arithmetic only.
+const char* fused_variant_key(const Geometry& g, bool write_c, char* buf, size_t n);
+const char* generic_variant_key(const Geometry& g, bool write_c, char* buf, size_t n);
 const char* fused_kernel_name(const Geometry& g, char* buf, size_t n);
 
 }  // namespace dsabf

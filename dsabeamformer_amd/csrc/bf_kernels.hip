@@ -36,13 +36,6 @@
 #include <cstdio>
 #include <cstdlib>
 
-#ifndef DSABF_PAIRED
-#define DSABF_PAIRED 1    // build the conjugate-pair variants of fused16_kernel (used when the weights allow it)
-#endif
-#ifndef DSABF_INTERLEAVE
-#define DSABF_INTERLEAVE 1 // deal beams to a wave's column tiles 4 (pairs: 2) at a time -> 16- / 8-byte stores (beam_of_tile)
-#endif
-
 namespace dsabf {
 
 namespace {
@@ -312,20 +305,20 @@ __global__ void pair_check_kernel(const int8_t* __restrict__ w, size_t n_fa, int
     if (bad) *flag = 1;
 }
 
-// Paired weight image: image[f][pct][comp][h][lane] (16 bytes): lane = 16*kb + c; byte i = Wr (comp 0), Wi (comp 1) or
-// -Wi (comp 2) of antenna 64*h + 16*kb + i (zero behind the last antenna) for base beam beam_of_tile(pct, c) (< n_beams / 2).
+// Paired weight image: image[f][pct][comp][h][lane] (16 bytes): lane = 16*kb + c; byte i = Wr (comp 0) or Wi (comp 1) of
+// antenna 64*h + 16*kb + i (zero behind the last antenna) for base beam beam_of_tile(pct, c) (< n_beams / 2).
 __global__ void weight_relayout16p_kernel(const int8_t* __restrict__ w, v4i* __restrict__ image, int n_freq, int n_ant,
                                           int n_beams, int ks, int interleave)
 {
     const int n_pct = n_beams / 32;
-    const size_t total = (size_t)n_freq * n_pct * 3 * ks * 64;
+    const size_t total = (size_t)n_freq * n_pct * kPairComps * ks * 64;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
         const int lane = (int)(idx & 63);
         size_t r = idx >> 6;
         const int h = (int)(r % ks);
         r /= ks;
-        const int comp = (int)(r % 3);
-        r /= 3;
+        const int comp = (int)(r % kPairComps);
+        r /= kPairComps;
         const int pct = (int)(r % n_pct);
         const int f = (int)(r / n_pct);
         const int kb = lane >> 4, b = beam_of_tile(interleave, pct, lane & 15);
@@ -334,7 +327,6 @@ __global__ void weight_relayout16p_kernel(const int8_t* __restrict__ w, v4i* __r
             const int ant = 64 * h + kb * 16 + i;
             int v = 0;
             if (ant < n_ant) v = w[2 * (((size_t)f * n_ant + ant) * n_beams + b) + (comp ? 1 : 0)];
-            if (comp == 2) v = -v;
             d[i >> 2] |= ((unsigned)v & 0xFFu) << (8 * (i & 3));
         }
         image[idx] = v4i{(int)d[0], (int)d[1], (int)d[2], (int)d[3]};
@@ -348,7 +340,7 @@ __global__ void weight_relayout16_kernel(const int8_t* __restrict__ w, v4i* __re
                                          int n_beams, int ks, int interleave, int* __restrict__ bad)
 {
     const int n_ct = (n_beams + 15) / 16;   // the last tile may be partly filled: zero weights behind the last beam
-    constexpr int NGC = DSABF_GEN3 ? 3 : 4;
+    constexpr int NGC = kGeneralComps;
     const size_t total = (size_t)n_freq * n_ct * NGC * ks * 64;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
         const int lane = (int)(idx & 63);
@@ -393,7 +385,7 @@ int interleaved(const Geometry& g, bool paired)
 {
     if (use_generic(g)) return paired ? 0 : generic_interleave(g);
     const int ns = fused_col_tiles(g, paired);
-    if (!DSABF_INTERLEAVE || g.n_beams % (16 * ns)) return 0;
+    if (g.n_beams % (16 * ns)) return 0;
     return paired ? ns / 2 : ns;
 }
 bool nipo_supported(int n_ipo) { return n_ipo == 2 || n_ipo == 4 || n_ipo == 8 || n_ipo == 16 || n_ipo == 32 || n_ipo == 64; }
@@ -405,8 +397,10 @@ bool rtw_class(const Geometry& g)
 }
 int detect_mode_of(const Geometry& g) { return g.fast_detect ? kDetFast : g.contracted_detect ? kDetContracted : kDetCanonical; }
 
-// 64, 100 and 128 antennas (the reference, BASELINE config 5 and the full k-step) have compile-time instantiations; every
-// other multiple of 4 up to 128 runs the run-time-count class of its k-step count and row alignment.
+// 100 antennas (BASELINE config 5) have compile-time instantiations: 3 - 7 % faster than the dword-staged run-time class that covers
+// the count.  Every other multiple of 4 up to 256 -- the reference's 64 included -- runs the run-time-count class of its k-step count
+// and row alignment: the compile-time classes of 64 / 128 / 192 / 256 antennas that rounds 1-5 carried measured inside the box noise
+// of the run-time ones (-1.4 ... +1.9 %, one geometry nobody names excepted: profiles/r06_class_fold_ab.txt) and were folded into them.
 FusedVariant select_variant(const Geometry& g, bool write_c)
 {
     if (use_generic(g)) return FusedVariant{};
@@ -415,8 +409,6 @@ FusedVariant select_variant(const Geometry& g, bool write_c)
         const bool paired = g.paired;
         const int mode = detect_mode_of(g);
         const int ns = fused_col_tiles(g, paired);
-        if (!g.runtime_ant && g.n_ant == 192) return fused16_variant_a192(g.n_ipo, mode, paired, ns);
-        if (!g.runtime_ant && g.n_ant == 256) return fused16_variant_a256(g.n_ipo, mode, paired, ns);
         if (g.n_ant % 16) return g.n_ant > 192 ? fused16_variant_k4p4(g.n_ipo, mode, paired, ns) : fused16_variant_k3p4(g.n_ipo, mode, paired, ns);
         return g.n_ant > 192 ? fused16_variant_k4p16(g.n_ipo, mode, paired, ns) : fused16_variant_k3p16(g.n_ipo, mode, paired, ns);
     }
@@ -424,28 +416,19 @@ FusedVariant select_variant(const Geometry& g, bool write_c)
     const bool paired = g.paired && !write_c;
     const int sel_ipo = rtw_class(g) ? 0 : g.n_ipo;     // 0: the run-time-window instantiations (every fused16_variant's default)
     const int mode = (detect_mode_of(g) == kDetFast && g.n_ipo < 16) ? kDetCanonical : detect_mode_of(g);   // fast: from 16 samples on
-    const bool rt = g.runtime_ant;
-    const bool ns8 = kColTiles16 != kColTilesWide16 && fused_col_tiles(g, paired) == kColTilesWide16;   // (a -DDSABF_NS=8 build: every kernel)
-    if (ns8) {
-        if (!rt && g.n_ant == 100) return fused16_variant_a100_s8(g.n_ipo, mode);
-        if (!rt && g.n_ant == 128) return fused16_variant_a128_s8(g.n_ipo, mode);
+    if (fused_col_tiles(g, paired) == kColTilesWide16) {
+        if (g.n_ant == 100) return fused16_variant_a100_s8(g.n_ipo, mode);
         return g.n_ant % 16 == 0 ? fused16_variant_k2p16_s8(g.n_ipo, mode) : fused16_variant_k2p4_s8(g.n_ipo, mode);
     }
     if (fused_wg_waves(g, write_c) == kWavesWide16) {
         if (paired) {
-            if (!rt && g.n_ant == 100) return fused16_variant_a100_w8p(g.n_ipo, mode);
-            if (!rt && g.n_ant == 128) return fused16_variant_a128_w8p(g.n_ipo, mode);
+            if (g.n_ant == 100) return fused16_variant_a100_w8p(g.n_ipo, mode);
             return g.n_ant % 16 == 0 ? fused16_variant_k2p16_w8p(g.n_ipo, mode) : fused16_variant_k2p4_w8p(g.n_ipo, mode);
         }
-        if (!rt && g.n_ant == 100) return fused16_variant_a100_w8(g.n_ipo, mode);
-        if (!rt && g.n_ant == 128) return fused16_variant_a128_w8(g.n_ipo, mode);
+        if (g.n_ant == 100) return fused16_variant_a100_w8(g.n_ipo, mode);
         return g.n_ant % 16 == 0 ? fused16_variant_k2p16_w8(g.n_ipo, mode) : fused16_variant_k2p4_w8(g.n_ipo, mode);
     }
-    if (!rt) {
-        if (g.n_ant == 64) return fused16_variant_a64(sel_ipo, write_c, mode, paired);
-        if (g.n_ant == 100) return fused16_variant_a100(sel_ipo, write_c, mode, paired);
-        if (g.n_ant == 128) return fused16_variant_a128(sel_ipo, write_c, mode, paired);
-    }
+    if (g.n_ant == 100) return fused16_variant_a100(sel_ipo, write_c, mode, paired);
     if (g.n_ant <= 64)
         return g.n_ant % 16 == 0 ? fused16_variant_k1p16(sel_ipo, write_c, mode, paired) : fused16_variant_k1p4(sel_ipo, write_c, mode, paired);
     return g.n_ant % 16 == 0 ? fused16_variant_k2p16(sel_ipo, write_c, mode, paired) : fused16_variant_k2p4(sel_ipo, write_c, mode, paired);
@@ -478,18 +461,18 @@ bool use_generic(const Geometry& g)
 
 size_t weight_image_bytes(const Geometry& g)
 {
-    return (size_t)g.n_freq * g.n_ctiles * (DSABF_GEN3 ? 3 : 4) * ksteps16(g) * 64 * 16 +   // [f][ct16][Wr, -Wi, Wi][k-step][lane] x 16 B
+    return (size_t)g.n_freq * g.n_ctiles * kGeneralComps * ksteps16(g) * 64 * 16 +   // [f][ct16][Wr, -Wi, Wi][k-step][lane] x 16 B
            ((use_generic(g) || deep_class(g)) ? generic_image_extra_bytes(g) : 0);
 }
 
 // the conjugate-pair kernel works on tiles of 16 base beams + their 16 mirror images
 bool pairing_supported(const Geometry& g)
 {
-    return DSABF_PAIRED && !use_generic(g) && g.n_beams % 32 == 0 && select_variant(g, false).launch != nullptr;
+    return !use_generic(g) && g.n_beams % 32 == 0 && select_variant(g, false).launch != nullptr;
 }
 size_t weight_pair_image_bytes(const Geometry& g)
 {
-    return pairing_supported(g) ? (size_t)g.n_freq * (g.n_beams / 32) * 3 * ksteps16(g) * 64 * 16 : 0;
+    return pairing_supported(g) ? (size_t)g.n_freq * (g.n_beams / 32) * kPairComps * ksteps16(g) * 64 * 16 : 0;
 }
 
 bool fused_supported(const Geometry& g, const char** why)
@@ -502,26 +485,34 @@ bool fused_supported(const Geometry& g, const char** why)
     return true;
 }
 
+// Measurement / test switches from the ENVIRONMENT: honoured only in a process that says DSABF_LAB=1 (tools/, the A/B tests).  A
+// production host's stray DSABF_* variable selects nothing (tests/test_abi_cpu.py greps csrc/ for getenv against the allow-list
+// of INTEGRATION.md); inside one process bf_set_switch (dsabf_bench.h) does the same per handle.
+bool lab_mode()
+{
+    const char* lab = getenv("DSABF_LAB");
+    return lab && lab[0] == '1' && !lab[1];
+}
+const char* lab_getenv(const char* name) { return lab_mode() ? getenv(name) : nullptr; }
+
 void read_env_switches(Geometry& g)
 {
-    const char* w = getenv("DSABF_WG_WAVES");
-    const char* t = getenv("DSABF_COL_TILES");
-    const char* r = getenv("DSABF_RUNTIME_ANT");
+    const char* w = lab_getenv("DSABF_WG_WAVES");
+    const char* t = lab_getenv("DSABF_COL_TILES");
     g.plain_wg_waves = w && atoi(w) == kWaves16;
     g.plain_col_tiles = t && atoi(t) == kColTiles16;
-    g.runtime_ant = r && r[0] == '1';
-    const char* ts = getenv("DSABF_TSPLIT");
-    const char* pad = getenv("DSABF_LDS_PAD");
-    const char* dw = getenv("DSABF_DM_WIDE");
+    const char* ts = lab_getenv("DSABF_TSPLIT");
+    const char* pad = lab_getenv("DSABF_LDS_PAD");
+    const char* dw = lab_getenv("DSABF_DM_WIDE");
     g.tsplit = ts ? atoi(ts) : 0;
     if (g.tsplit < 0) g.tsplit = 0;
     g.lds_pad = pad ? atoi(pad) : 0;       // (clamped to what the CU has left where it is applied, fused_launch_shape)
     g.dm_wide = !(dw && dw[0] == '0');
-    const char* gen = getenv("DSABF_GENERIC");
+    const char* gen = lab_getenv("DSABF_GENERIC");
     g.force_generic = gen && gen[0] == '1';
-    const char* nd = getenv("DSABF_DEEP");
+    const char* nd = lab_getenv("DSABF_DEEP");
     g.no_deep = nd && nd[0] == '0';
-    const char* nr = getenv("DSABF_RTW");
+    const char* nr = lab_getenv("DSABF_RTW");
     g.no_rtw = nr && nr[0] == '0';
 }
 
@@ -535,11 +526,9 @@ void read_env_switches(Geometry& g)
 int fused_col_tiles(const Geometry& g, bool paired)
 {
     if (deep_class(g)) return (paired && g.n_beams % 512 == 0 && !g.plain_col_tiles) ? 4 : 2;   // pair: 2 pair tiles per wave where 8 waves x 64 beams fill
-    const bool rt = g.runtime_ant;
     // the instantiations that fit their registers (ns8_fits, bf_fused16.hpp): 16-byte-staged rows, or the compile-time 100 antennas
-    const bool fits = g.n_ant % 16 == 0 || (!rt && g.n_ant == 100 && g.n_ipo < 64);
-    const bool can = paired && fits && kColTiles16 == 4 && kWaves16 == 4 && ksteps16(g) == 2 && g.n_ipo >= 16 && nipo_supported(g.n_ipo) &&
-                     g.n_beams % 512 == 0;
+    const bool fits = g.n_ant % 16 == 0 || (g.n_ant == 100 && g.n_ipo < 64);
+    const bool can = paired && fits && ksteps16(g) == 2 && g.n_ipo >= 16 && nipo_supported(g.n_ipo) && g.n_beams % 512 == 0;
     return (can && !g.plain_col_tiles) ? kColTilesWide16 : kColTiles16;
 }
 
@@ -551,8 +540,8 @@ int fused_col_tiles(const Geometry& g, bool paired)
 int fused_wg_waves(const Geometry& g, bool write_c)
 {
     if (deep_class(g) && !write_c) return kWavesWide16;
-    const bool can = !write_c && ksteps16(g) == 2 && g.n_ipo >= 16 && nipo_supported(g.n_ipo) && kWaves16 == 4 && kColTiles16 == 4 &&
-                     ((g.n_beams + 255) / 256) % 2 == 0 && fused_col_tiles(g, g.paired) == kColTiles16;
+    const bool can = !write_c && ksteps16(g) == 2 && g.n_ipo >= 16 && nipo_supported(g.n_ipo) && ((g.n_beams + 255) / 256) % 2 == 0 &&
+                     fused_col_tiles(g, g.paired) == kColTiles16;
     return (can && !g.plain_wg_waves) ? kWavesWide16 : kWaves16;
 }
 
@@ -874,11 +863,24 @@ const char* fused_kernel_name(const Geometry& g, char* buf, size_t n)
                  generic_ksteps(g), g.n_ant % 16 ? 4 : 16, g.n_ipo, g.fast_detect ? ",FAST" : g.contracted_detect ? ",CONTRACTED" : "");
         return buf;
     }
-    const bool rt = !(g.n_ant == 64 || g.n_ant == 100 || g.n_ant == 128 || g.n_ant == 192 || g.n_ant == 256);   // (the geometry's class; DSABF_RUNTIME_ANT is not shown)
-    snprintf(buf, n, "dsabf::fused16_kernel<ANT=%d%s,NIPO=%d%s%s%s%s> (v_mfma_i32_16x16x64_i8)", g.n_ant, rt ? "(run-time)" : "",
-             g.n_ipo, rtw_class(g) ? "(run-time)" : "", (g.fast_detect && g.n_ipo >= 16) ? ",FAST" : g.contracted_detect ? ",CONTRACTED" : "",
+    // (the geometry in words; which template instantiation that is -- antenna CLASS, run-time or compile-time -- fused_variant_key says)
+    snprintf(buf, n, "dsabf::fused16_kernel<ANT=%d,NIPO=%d%s%s%s%s> (v_mfma_i32_16x16x64_i8)", g.n_ant, g.n_ipo, rtw_class(g) ? "(run-time)" : "", (g.fast_detect && g.n_ipo >= 16) ? ",FAST" : g.contracted_detect ? ",CONTRACTED" : "",
              g.paired ? ",PAIRED" : "",
              fused_col_tiles(g, g.paired) == kColTilesWide16 ? ",SLOTS=8" : fused_wg_waves(g) == kWavesWide16 ? ",WAVES=8" : "");
+    return buf;
+}
+
+const char* fused_variant_key(const Geometry& g, bool write_c, char* buf, size_t n)
+{
+    if (!n) return buf;
+    buf[0] = 0;
+    Geometry gg = g;
+    if (write_c) gg.paired = false;   // (launch_gemm_only: the stage-parity path always runs the general kernel)
+    if (use_generic(gg) || (write_c && deep_class(gg))) return generic_variant_key(gg, write_c, buf, n);
+    const FusedVariant v = select_variant(gg, write_c);
+    if (v.launch)
+        snprintf(buf, n, "fused16_kernel<%d, %d, %s, %d, %s, %d, %d>", v.ain, v.nipo, v.write_c ? "true" : "false", v.mode,
+                 v.paired ? "true" : "false", v.waves, v.ns);
     return buf;
 }
 

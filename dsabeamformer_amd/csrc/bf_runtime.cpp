@@ -954,8 +954,7 @@ static hipError_t dm_scratch(bf_handle* h, hipStream_t s, int** out)
     if (h->dm_scratch.size() >= 64) {   // a caller that keeps creating streams: nothing of ours may still be in flight
         hipError_t e = hipDeviceSynchronize();
         if (e != hipSuccess) return e;
-        for (auto* ds : h->dm_streams) dm_stream_release(ds);   // a DM stage that outlives its handle is left empty, not dangling
-    for (auto& sc : h->dm_scratch) (void)hipFree(sc.second);
+        for (auto& sc : h->dm_scratch) (void)hipFree(sc.second);   // (the handle's bf_dm_streams own their scratch: untouched)
         h->dm_scratch.clear();
     }
     int* p = nullptr;
@@ -1247,6 +1246,25 @@ int bf_kernel_name(const bf_handle* h, char* buf, size_t buflen)
 {
     if (!h || !buf || !buflen) return fail(BF_ERR_INVALID, "NULL argument");
     dsabf::fused_kernel_name(h->geom, buf, buflen);
+    return BF_OK;
+}
+
+int bf_variant_key(const bf_config* cfg, int paired, int write_c, char* buf, size_t buflen)
+{
+    if (!buf || !buflen) return fail(BF_ERR_INVALID, "NULL argument");
+    if (int rc = check_cfg(cfg)) return rc;
+    dsabf::Geometry g = make_geom(*cfg);
+    const char* why = nullptr;
+    if (!dsabf::fused_supported(g, &why)) return fail(BF_ERR_INVALID, "unsupported geometry: %s", why);
+    g.paired = paired && dsabf::pairing_supported(g);
+    dsabf::fused_variant_key(g, write_c != 0, buf, buflen);
+    return BF_OK;
+}
+
+int bf_handle_variant_key(const bf_handle* h, int write_c, char* buf, size_t buflen)
+{
+    if (!h || !buf || !buflen) return fail(BF_ERR_INVALID, "NULL argument");
+    dsabf::fused_variant_key(h->geom, write_c != 0, buf, buflen);
     return BF_OK;
 }
 

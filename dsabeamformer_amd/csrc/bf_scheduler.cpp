@@ -491,17 +491,17 @@ int run_observation(const bf_config& cfg, const observation_options& opt, block_
         log << "Done Burn in" << std::endl;
     }
     uint64_t sink_committed = 0;
-    const char* unit_env = getenv("DSABF_UNIT_LAUNCH");   // measurement / test switch: the reference's per-gemm-unit launches
+    const char* unit_env = lab_getenv("DSABF_UNIT_LAUNCH");   // measurement / test switch (DSABF_LAB=1): the reference's per-gemm-unit launches
     const bool block_launch = opt.block_launch && !(unit_env && unit_env[0] == '1');
     if (opt.comm && !block_launch) return set_error(BF_ERR_INVALID, "run_observation: the sharded gather needs block-granular launches");
     int upl = opt.units_per_launch;                                // gemm-units per launch of the block path
-    if (const char* e = getenv("DSABF_UNITS_PER_LAUNCH")) upl = atoi(e);
+    if (const char* e = lab_getenv("DSABF_UNITS_PER_LAUNCH")) upl = atoi(e);
     if (upl <= 0 || upl > cfg.n_gemms_per_block || opt.comm) upl = cfg.n_gemms_per_block;   // 0 / sharded: the whole block
     while (cfg.n_gemms_per_block % upl) upl--;                    // whole launches only
     uint64_t launch_seq = 0;
     const int n_queues_used = upl == cfg.n_gemms_per_block ? std::min(n_streams, 2) : n_streams;   // (the rotation below)
     bool staged = opt.gather_staged;
-    if (const char* e = getenv("DSABF_GATHER_STAGED")) staged = e[0] == '1';
+    if (const char* e = lab_getenv("DSABF_GATHER_STAGED")) staged = e[0] == '1';
     // ---- the DM stage: where the reference's loop has its frequency collapse, src/beamformer.cu:492-511 ----
     const bool dm_here = opt.dm_delays && is_root;   // a sharded run dedisperses the gathered band
     // dm_split_trials: every rank holds the whole band (one all-gather instead of a gather) and takes ITS share of the trial ladder --

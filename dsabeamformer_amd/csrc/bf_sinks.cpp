@@ -137,7 +137,7 @@ file_sink::file_sink(const bf_config& cfg, const char* path, int gpu, uint64_t s
         ::close(fd);
         fd = -1;
     }
-    if (const char* e = getenv("DSABF_SINK_THREADS")) write_threads = std::max(1, atoi(e));
+    if (const char* e = lab_getenv("DSABF_SINK_THREADS")) write_threads = std::max(1, atoi(e));
 }
 
 file_sink::~file_sink()

@@ -54,6 +54,15 @@ int bf_kernel_name(const bf_handle *h, char *buf, size_t buflen); /* which fused
  * conjugate-pair kernel exists).  Pure host arithmetic -- for planning, and so that the launch logic is testable anywhere. */
 int bf_launch_plan(const bf_config *cfg, int paired, int n_units, int n_cus, int *grid, int *block, int *lds_bytes, char *name,
                    size_t name_len);
+/* The instantiation census (tests/test_census_cpu.py, tests/test_gpu_census.py, profiles/r06_instantiations.txt): which COMPILED kernel
+ * a configuration selects, spelled as its demangled symbol spells the template arguments -- "fused16_kernel<-1, 32, false, 0, true,
+ * 4, 4>" = <antenna class, window (0: run-time), stage-parity store, detect mode, conjugate-pair, waves per workgroup, output slots
+ * per wave>, "fusedg_kernel<true, 0, false>" = <16-byte rows, detect mode, stage-parity store>.  write_c != 0: the kernel of
+ * bf_gemm_device (the stage-parity launch).  bf_variant_key is host arithmetic (no device); bf_handle_variant_key answers for a
+ * live handle -- after bf_set_weights, which decides `paired` -- so a test can assert that the launch it checked against the oracle
+ * WAS the instantiation it meant to cover. */
+int bf_variant_key(const bf_config *cfg, int paired, int write_c, char *buf, size_t buflen);
+int bf_handle_variant_key(const bf_handle *h, int write_c, char *buf, size_t buflen);
 
 #ifdef __cplusplus
 }

@@ -263,6 +263,34 @@ def beamform_exact(g: Geom, w: np.ndarray, packed: np.ndarray) -> np.ndarray:
     return out
 
 
+def beamform_fast(g: Geom, w: np.ndarray, packed: np.ndarray) -> np.ndarray:
+    """The PRODUCT's optional BF_DETECT_FAST reading (include/dsabf.h; not a reading of the reference) restated in numpy, so that
+    its kernels can be held to the bit too: d = 16 n exact; acc = fma(d, d, acc) for re then im, in time order, from +0; one
+    (alpha/16)^2 scale per output.  The fma is emulated exactly: d^2 < 2^43 and acc + d^2 < 2^53 are exact in float64, so
+    float32(float64 sum) is the single rounding.  (The deep classes and fusedg_kernel count in n instead of 16 n: the same bits,
+    every intermediate is the same value times a power of two.)  float32 [unit][o][f][b].  Small cases only."""
+    packed = np.ascontiguousarray(packed, np.uint8).reshape(-1, g.n_freq, g.n_time, g.n_ant)
+    # (float64 matrix products: every partial sum is an integer below 2^53, so BLAS's summation order cannot matter)
+    v = expand(packed).astype(np.float64)                     # [unit][f][t][a][2]
+    W = np.ascontiguousarray(w, np.int8).astype(np.float64)   # [f][a][b][2]
+    Wr, Wi = np.ascontiguousarray(W[..., 0]), np.ascontiguousarray(W[..., 1])
+    a16 = np.float32(np.float32(1.0 / 127) * np.float32(0.0625))
+    scale = np.float32(a16 * a16)
+    outs = []
+    for u in range(packed.shape[0]):
+        vr, vi = np.ascontiguousarray(v[u, ..., 0]), np.ascontiguousarray(v[u, ..., 1])   # [f][t][a]
+        re = np.matmul(vr, Wr) - np.matmul(vi, Wi)                                          # [f][t][b]
+        im = np.matmul(vi, Wr) + np.matmul(vr, Wi)
+        dr = (16.0 * re).reshape(g.n_freq, g.n_out_per_gemm, g.n_ipo, g.n_beams)
+        di = (16.0 * im).reshape(g.n_freq, g.n_out_per_gemm, g.n_ipo, g.n_beams)
+        acc = np.zeros((g.n_freq, g.n_out_per_gemm, g.n_beams), np.float32)
+        for i in range(g.n_ipo):
+            acc = (acc.astype(np.float64) + dr[:, :, i] * dr[:, :, i]).astype(np.float32)
+            acc = (acc.astype(np.float64) + di[:, :, i] * di[:, :, i]).astype(np.float32)
+        outs.append((acc * scale).transpose(1, 0, 2))
+    return np.stack(outs)
+
+
 def dedisperse(g: Geom, out_unit: np.ndarray) -> np.ndarray:
     """a8: float32 [o][f][b] (one unit) -> float32 [b] (sum over f of output 0)."""
     ded = np.empty((g.n_beams,), np.float32)

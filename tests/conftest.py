@@ -11,6 +11,17 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 CFG = os.path.join(GOLDEN, "config")
 
 
+# The library's measurement / test switches are read from the environment only in a process that says DSABF_LAB=1 (round 6: a
+# production host's stray DSABF_* variable selects nothing).  The A/B tests set them with monkeypatch; whatever the CALLER's
+# environment held is dropped first, so that only what a test sets takes effect.  tests/test_abi_cpu.py checks the gate itself.
+LAB_SWITCHES = ("DSABF_WG_WAVES", "DSABF_COL_TILES", "DSABF_TSPLIT", "DSABF_LDS_PAD", "DSABF_DM_WIDE", "DSABF_GENERIC", "DSABF_DEEP",
+                "DSABF_RTW", "DSABF_UNIT_LAUNCH", "DSABF_UNITS_PER_LAUNCH", "DSABF_GATHER_STAGED", "DSABF_SINK_THREADS",
+                "DSABF_GATHER_SELF_RCCL")
+for _k in LAB_SWITCHES:
+    os.environ.pop(_k, None)
+os.environ["DSABF_LAB"] = "1"
+
+
 # ---- the GPU suite runs on a budget (<= 300 s on a fresh driver box) -------------------------------------
 # The default `-m gpu` run keeps a spread of at most SWEEP_CAP cases of every parametrised GPU test (first, last and evenly
 # between, in collection order -- every kernel family, antenna class and config keeps its representatives; tests/README.md maps

@@ -56,7 +56,7 @@ def test_every_export_of_the_boundary_header_cites_the_reference_call_site_it_re
     assert sorted(set(checked)) == _declared_symbols(("dsabf.h",)) and len(checked) >= 45
     bench_only = set(_declared_symbols(("dsabf_bench.h",))) - set(_declared_symbols(("dsabf.h",)))
     assert bench_only == {"bf_set_switch", "bf_get_counter", "bf_mfma_peak_device", "bf_launch_plan", "bf_kernel_info", "bf_rtw_plan", "bf_kernel_name",
-                          "bf_gather_relayout_device"}
+                          "bf_gather_relayout_device", "bf_variant_key", "bf_handle_variant_key"}
     assert not bench_only & set(checked)
     integ = open(os.path.join(ROOT, "INTEGRATION.md")).read()
     for name in bench_only:                                   # the call-site map binds the boundary, not the lab bench
@@ -113,9 +113,9 @@ def test_error_convention_without_gpu(lib):
     # which kernel a geometry runs is host arithmetic (bf_launch_plan): the reference's whole contract has one
     name = C.create_string_buffer(200)
     for n_ant, n_avg, expect in ((64, 16, b"fused16_kernel"), (100, 16, b"fused16_kernel"), (64, 3, b"fused16_kernel<ANT=64,NIPO=6(run-time)>"),
-                                 (132, 16, b"fused16_kernel<ANT=132(run-time),NIPO=32,WAVES=8>"), (132, 32, b"fusedg_kernel<ANT=132 (3 k-steps, 4-byte staging)"),
+                                 (132, 16, b"fused16_kernel<ANT=132,NIPO=32,WAVES=8>"), (132, 32, b"fusedg_kernel<ANT=132 (3 k-steps, 4-byte staging)"),
                                  (324, 16, b"(6 k-steps, 4-byte staging)"), (320, 16, b"(5 k-steps, 16-byte staging)"),
-                                 (256, 16, b"fused16_kernel<ANT=256,NIPO=32,WAVES=8>"), (144, 8, b"fused16_kernel<ANT=144(run-time),NIPO=16,WAVES=8>")):
+                                 (256, 16, b"fused16_kernel<ANT=256,NIPO=32,WAVES=8>"), (144, 8, b"fused16_kernel<ANT=144,NIPO=16,WAVES=8>")):
         cfg.n_ant, cfg.n_avg = n_ant, n_avg
         assert lib.bf_launch_plan(C.byref(cfg), 0, 4, 256, None, None, None, name, 200) == 0
         assert expect in name.value, name.value

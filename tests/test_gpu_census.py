@@ -1,0 +1,156 @@
+"""The instantiation census on the GPU: EVERY fused kernel compiled into libdsabf.so is launched once, on the
+smallest geometry of the reference's contract that selects it (tools/census.py), and held to the oracle:
+
+  * the handle says which instantiation it launches (bf_handle_variant_key) -- it must be the one the case is meant to cover;
+  * canonical reading: np.array_equal with orc.beamform (the g++ reading of src/beamformer.cuh:150-152);
+  * contracted reading: np.array_equal with orc.beamform under ORC_CONTRACT_NVCC;
+  * fast detect (the product's own option): np.array_equal with the oracle's restatement of it AND inside the stated tolerance
+    (n_ipo + 1) * 2^-23 of the exact value;
+  * stage-parity store (bf_gemm_device): np.array_equal with orc.gemm.
+
+A wrong bit in any one of the 382 instantiations -- the reference has ONE kernel per stage (src/beamformer.cuh:66-155), every one
+of these replaces them for some geometry and is selected silently -- fails here, in the driver-observed run.  CPU side of the same
+census: tests/test_census_cpu.py (compiled set == reachable set)."""
+import os
+import sys
+import time
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+pytestmark = pytest.mark.gpu
+
+
+def _conj_symmetric(w):
+    w = w.copy()
+    nb = w.shape[2]
+    w[:, :, nb // 2:, 0] = w[:, :, :nb // 2, 0][:, :, ::-1]
+    w[:, :, nb // 2:, 1] = -w[:, :, :nb // 2, 1][:, :, ::-1]
+    return w
+
+
+def run_case(torch, bfm, orc, key, rec, n_freq):
+    """One instantiation on its smallest geometry; returns a failure text or None."""
+    g = orc.Geom(n_beams=rec["n_beams"], n_ant=rec["n_ant"], n_freq=n_freq, n_pol=rec["n_pol"], n_avg=rec["n_avg"],
+                 n_out_per_gemm=rec["n_out"])
+    seed = sum(ord(c) * (i + 1) for i, c in enumerate(key)) % (1 << 31)
+    rng = np.random.default_rng(seed)
+    w = rng.integers(-127, 128, size=(g.n_freq, g.n_ant, g.n_beams, 2), dtype=np.int8)
+    if rec["paired"]:
+        w = _conj_symmetric(w)
+    cfg = bfm.production_config(n_beams=g.n_beams, n_ant=g.n_ant, n_freq=g.n_freq, n_pol=g.n_pol, n_avg=g.n_avg,
+                                n_out_per_gemm=g.n_out_per_gemm, n_gemms_per_block=1, n_blocks_on_gpu=1, n_streams=1,
+                                detect_mode=rec["mode"])
+    stream = torch.cuda.current_stream().cuda_stream
+    with bfm.Beamformer(cfg) as bf:
+        bf.set_weights(w)
+        ran = bf.variant_key(bool(rec["write_c"]))
+        if ran != key:
+            return "the handle launches %s" % ran
+        if rec["write_c"]:
+            packed = rng.integers(0, 256, size=(g.n_freq, g.n_time, g.n_ant), dtype=np.uint8)
+            d_in = torch.from_numpy(packed).cuda()
+            d_c = torch.full((g.n_freq * g.n_time * g.n_beams * 2,), float("nan"), dtype=torch.float32, device="cuda")
+            bf.gemm(d_in, d_c, stream)
+            torch.cuda.synchronize()
+            want = orc.gemm(g, w, orc.expand(packed))
+            got = d_c.cpu().numpy().reshape(want.shape)
+            return None if np.array_equal(got, want) else "bf_gemm_device differs from orc.gemm in %d of %d values" % ((got != want).sum(), want.size)
+        n_units = 3
+        packed = rng.integers(0, 256, size=(n_units, g.n_freq, g.n_time, g.n_ant), dtype=np.uint8)
+        packed[0, 0, :, :] = 0x88            # the extremes: all (-8, -8) ...
+        packed[1, 0, 0, :] = 0x77            # ... and (7, 7)
+        d_in = torch.from_numpy(packed).cuda()
+        d_out = torch.full((n_units * g.out_per_gemm + 64,), float("nan"), dtype=torch.float32, device="cuda")
+        bf.beamform(d_in, n_units, d_out, stream)
+        torch.cuda.synchronize()
+        got = d_out.cpu().numpy()
+        if not np.isnan(got[n_units * g.out_per_gemm:]).all():
+            return "wrote behind the last output"
+        got = got[:n_units * g.out_per_gemm].reshape(n_units, g.n_out_per_gemm, g.n_freq, g.n_beams)
+        if rec["mode"] == 1 and g.n_ipo >= 16:     # BF_DETECT_FAST (below 16 samples the library runs the canonical detect)
+            want = orc.beamform_fast(g, w, packed)
+            exact = orc.beamform_exact(g, w, packed)
+            ok = exact > 0
+            if ok.any() and np.abs(got[ok] / exact[ok] - 1).max() > (g.n_ipo + 1) * 2.0 ** -23:
+                return "fast detect outside its stated tolerance"
+        else:
+            with orc.detect_contract(orc.CONTRACT_NVCC if rec["mode"] == 2 else orc.CONTRACT_NONE):
+                want = orc.beamform(g, w, packed)
+        if not np.array_equal(got, want):
+            return "differs from the oracle in %d of %d values" % ((got != want).sum(), want.size)
+    return None
+
+
+def test_every_compiled_instantiation_against_the_oracle():
+    import torch
+
+    import census
+    import dsabeamformer_amd as bfm
+    import oracle as orc
+
+    assert torch.cuda.is_available(), "these tests need a GPU"
+    comp, reach = census.compiled(), census.reachable()
+    assert comp == set(reach), (sorted(comp - set(reach)), sorted(set(reach) - comp))
+    failures, lines, t_all = [], [], time.perf_counter()
+    for i, key in enumerate(sorted(reach)):
+        t0 = time.perf_counter()
+        # two frequency counts: 3 (a frequency per block index) and 8 (the XCD-aware block map, decode_block)
+        err = run_case(torch, bfm, orc, key, reach[key], 8 if i % 4 == 0 else 3)
+        lines.append("%-54s %6.1f ms  %s" % (key, (time.perf_counter() - t0) * 1e3, err or "ok"))
+        if err:
+            failures.append((key, reach[key], err))
+    total = time.perf_counter() - t_all
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "census_gpu.txt"), "w") as fp:
+        fp.write("# tests/test_gpu_census.py: %d instantiations, %d failures, %.1f s\n" % (len(reach), len(failures), total))
+        fp.write("\n".join(lines) + "\n")
+    assert not failures, failures[:10]
+    assert len(reach) >= 300                     # (the walk really found the library's kernels)
+
+
+def test_a_dm_stage_survives_more_than_64_streams_on_its_handle(orc):
+    """the 65th distinct HIP stream passed to bf_dedisperse_dm_device used to release every live bf_dm_stream of
+    the handle (a stray line in the scratch cache's eviction).  A DM stage created before, pushed after, destroyed in both orders."""
+    import torch
+
+    import dsabeamformer_amd as bfm
+    from dsabeamformer_amd.api import DmStream
+
+    n_freq, n_beams, n_dm = 8, 64, 4
+    rng = np.random.default_rng(65)
+    delays = np.sort(rng.integers(0, 6, size=(n_dm, n_freq)), axis=1)[:, ::-1].astype(np.int32).copy()
+    series = rng.random((40, n_freq, n_beams), dtype=np.float32)
+    for order in ("stream first", "handle first"):
+        bf = bfm.Beamformer(bfm.production_config(n_freq=n_freq, n_beams=n_beams, n_gemms_per_block=1, n_blocks_on_gpu=1, n_streams=1))
+        ds = DmStream(bf, delays, n_freq, 16)
+        d_series = torch.from_numpy(series).cuda()
+        d_delays = torch.from_numpy(delays).cuda()
+        d_out = torch.empty(n_dm * 30 * n_beams, dtype=torch.float32, device="cuda")
+        host = np.empty(n_dm * 16 * n_beams, np.float32)     # a push's chunk arrives as [n_dm][n_t_out][beam], contiguous
+        first, n0 = ds.push(d_series[:16], 16, host)
+        torch.cuda.synchronize()
+        got = [host[:n_dm * n0 * n_beams].reshape(n_dm, n0, n_beams).copy()]
+        streams = [torch.cuda.Stream() for _ in range(70)]
+        for s in streams:                             # 70 distinct streams: the cache of 64 is evicted on the way
+            bf.dedisperse_dm(d_series, 40, d_delays, n_dm, 30, d_out, s.cuda_stream)
+        torch.cuda.synchronize()
+        want_whole = orc.dedisperse_dm(series, delays, 30)
+        assert np.array_equal(d_out.cpu().numpy().reshape(want_whole.shape), want_whole)
+        first2, n1 = ds.push(d_series[16:32], 16, host)   # the stage is still alive ...
+        torch.cuda.synchronize()
+        got.append(host[:n_dm * n1 * n_beams].reshape(n_dm, n1, n_beams).copy())
+        chunks = np.concatenate(got, axis=1)
+        assert first == 0 and first2 == n0
+        assert np.array_equal(chunks, orc.dedisperse_dm(series[:32], delays, n0 + n1))   # ... and still right
+        if order == "stream first":
+            ds.close()
+            bf.close()
+        else:
+            bf.close()
+            ds.close()

@@ -172,22 +172,22 @@ def test_any_beam_count_divisible_by_four_bit_exact(torch, bfmod, orc, n_beams, 
     bf.close()
 
 
-def test_run_time_antenna_classes_equal_the_compile_time_ones(torch, bfmod, orc, monkeypatch):
-    """DSABF_RUNTIME_ANT=1 routes 64 / 100 / 128 antennas through the run-time-count classes: same bits."""
-    for n_ant in (64, 100, 128):
+def test_antenna_classes_by_their_instantiation(torch, bfmod, orc):
+    """64 and 128 antennas run the run-time-count classes since round 6 (the compile-time ones measured inside the box noise
+    and were folded, profiles/r06_class_fold_ab.txt), 100 antennas -- BASELINE config 5 -- keep theirs: the handle says which
+    instantiation it launches, and the bits are the oracle's."""
+    for n_ant, cls in ((64, -1), (100, 100), (128, -3), (96, -3), (48, -1), (52, -2), (108, -4)):
         g = orc.Geom(n_beams=64, n_ant=n_ant, n_freq=2, n_avg=16, n_out_per_gemm=4)
         rng = np.random.default_rng(8000 + n_ant)
         w = rng.integers(-127, 128, size=(g.n_freq, g.n_ant, g.n_beams, 2), dtype=np.int8)
         packed = rng.integers(0, 256, size=(2, g.n_freq, g.n_time, g.n_ant), dtype=np.uint8)
         want = orc.beamform(g, w, packed)
-        monkeypatch.setenv("DSABF_RUNTIME_ANT", "1")
         bf = bfmod.Beamformer(_cfg(bfmod, g))
         bf.set_weights(w)
-        assert "(run-time)" not in bf.kernel_info(2)["kernel"]   # the NAME reports the geometry; the env switch is internal
+        assert bf.variant_key() == "fused16_kernel<%d, 32, false, 0, false, 4, 4>" % cls
         got = _run(torch, bf, packed, want.size).reshape(want.shape)
         assert np.array_equal(got, want)
         bf.close()
-        monkeypatch.delenv("DSABF_RUNTIME_ANT")
 
 
 def test_geometry_fuzz_over_the_whole_contract(torch, bfmod, orc):

@@ -39,31 +39,35 @@ def fused(ant, nipo, mode, paired, waves, ns, write_c=False):
 #   MFMAs per 128-sample chunk and wave: 8 row tiles x column tiles x (general: 4 = 2 chains x re | im; pair: 4 real products
 #   per PAIR tile) x k-steps
 HOT = [
-    ("bf_fused16_a64", fused(64, 32, 0, True, 4, 4), 128, 8 * 2 * 4 * 1),       # C3 headline: conjugate-pair kernel, 4 waves / SIMD
-    ("bf_fused16_a64", fused(64, 32, 0, False, 4, 4), 128, 8 * 4 * 4 * 1),      # C3 general kernel (calibrated weights), 4 waves / SIMD
-    ("bf_fused16_a64", fused(64, 32, 2, True, 4, 4), 128, 8 * 2 * 4 * 1),       # contracted readings
-    ("bf_fused16_a64", fused(64, 32, 2, False, 4, 4), 128, 8 * 4 * 4 * 1),
-    ("bf_fused16_a64", fused(64, 2, 0, True, 4, 4), 168, 8 * 2 * 4 * 1),        # C2 DEBUG geometry: 3 waves / SIMD
+    # (round 6: 64 antennas run the run-time class k1p16 = template argument -1, profiles/r06_class_fold_ab.txt)
+    ("bf_fused16_k1p16", fused(-1, 32, 0, True, 4, 4), 128, 8 * 2 * 4 * 1),       # C3 headline: conjugate-pair kernel, 4 waves / SIMD
+    ("bf_fused16_k1p16", fused(-1, 32, 0, False, 4, 4), 128, 8 * 4 * 4 * 1),      # C3 general kernel (calibrated weights), 4 waves / SIMD
+    ("bf_fused16_k1p16", fused(-1, 32, 2, True, 4, 4), 128, 8 * 2 * 4 * 1),       # contracted readings
+    ("bf_fused16_k1p16", fused(-1, 32, 2, False, 4, 4), 128, 8 * 4 * 4 * 1),
+    ("bf_fused16_k1p16", fused(-1, 2, 0, True, 4, 4), 168, 8 * 2 * 4 * 1),        # C2 DEBUG geometry: 3 waves / SIMD
     ("bf_fused16_a100_s8", fused(100, 32, 0, True, 4, 8), 256, 8 * 4 * 4 * 2),  # C5 headline: 8 output slots per wave, 2 waves / SIMD
     ("bf_fused16_a100_w8", fused(100, 32, 0, False, 8, 4), 256, 8 * 4 * 4 * 2),  # C5 general kernel on 8-wave workgroups
-    ("bf_fused16_a128_s8", fused(128, 32, 0, True, 4, 8), 256, 8 * 4 * 4 * 2),
-    ("bf_fused16_a128_w8", fused(128, 32, 0, False, 8, 4), 256, 8 * 4 * 4 * 2),
-    ("bf_fused16_a256", fused(256, 32, 0, False, 8, 2), 256, 8 * 2 * 4 * 4),      # deep general: 2 slots per wave, 4 k-steps
-    ("bf_fused16_a256", fused(256, 32, 0, True, 8, 4), 256, 8 * 2 * 4 * 4),       # deep pair: 2 pair tiles per wave
-    ("bf_fused16_a192", fused(192, 32, 0, False, 8, 2), 256, 8 * 2 * 4 * 3),
+    ("bf_fused16_k2p16_s8", fused(-3, 32, 0, True, 4, 8), 256, 8 * 4 * 4 * 2, 16),   # 128 antennas x 512 beams, pair: 3 dwords of scratch at 256
+                                                                                      # registers, and as fast as the compile-time class was
+    ("bf_fused16_k2p16_w8", fused(-3, 32, 0, False, 8, 4), 256, 8 * 4 * 4 * 2),
+    ("bf_fused16_k4p16", fused(-5, 32, 0, False, 8, 2), 256, 8 * 2 * 4 * 4),      # deep general: 2 slots per wave, 4 k-steps
+    ("bf_fused16_k4p16", fused(-5, 32, 0, True, 8, 4), 256, 8 * 2 * 4 * 4),       # deep pair: 2 pair tiles per wave
+    ("bf_fused16_k3p16", fused(-6, 32, 0, False, 8, 2), 256, 8 * 2 * 4 * 3),
 ]
 
 
-@pytest.mark.parametrize("unit,name,budget,mfmas", HOT, ids=[h[1][25:60] for h in HOT])
-def test_hot_instantiations_keep_their_registers_no_scratch_and_their_mfma_count(objects, unit, name, budget, mfmas):
+@pytest.mark.parametrize("hot", HOT, ids=[h[1][25:60] for h in HOT])
+def test_hot_instantiations_keep_their_registers_no_scratch_and_their_mfma_count(objects, hot):
+    unit, name, budget, mfmas = hot[:4]
+    scratch_ok = hot[4] if len(hot) > 4 else 0        # bytes of scratch per lane this instantiation is known to carry (0: none)
     co, ks = objects[unit]
     assert name in ks, "instantiation missing from %s: %s" % (unit, name)
     k = ks[name]
-    assert k["private_segment_fixed_size"] == 0, "scratch (a spill) in %s" % name
-    assert k.get("vgpr_spill_count", 0) == 0 and k.get("sgpr_spill_count", 0) == 0
+    assert k["private_segment_fixed_size"] <= scratch_ok, "scratch (a spill) in %s" % name
+    assert k.get("sgpr_spill_count", 0) == 0 and (scratch_ok or k.get("vgpr_spill_count", 0) == 0)
     assert k["vgpr_count"] + k["agpr_count"] <= budget, (name, k)
     ops = isa_report.disassembly(co, name)
-    assert isa_report.count(ops, "scratch_") == 0
+    assert scratch_ok or isa_report.count(ops, "scratch_") == 0
     assert isa_report.count(ops, "v_mfma_i32_16x16x64_i8") == mfmas, "the unrolled chunk loop holds %d MFMAs" % isa_report.count(ops, "v_mfma")
     assert isa_report.count(ops, "v_mfma") == mfmas                    # ... and no other matrix instruction
     # the detect stays on plain fp32 VALU ops: packed f32 issues beside MFMAs at twice the price (MI355X_MICROARCH.md), and
@@ -74,15 +78,13 @@ def test_hot_instantiations_keep_their_registers_no_scratch_and_their_mfma_count
 
 
 def test_spills_stay_where_they_are_known(objects):
-    """No fused kernel of the compile-time 64- and 128-antenna classes, of the 16-byte-staged one-k-step run-time class or of
-    the wide (8-slot / 8-wave) 100-antenna launches carries scratch.  The classes that do are listed: the dword-staged run-time
+    """No fused kernel of the 16-byte-staged run-time classes (64, 128, 192, 256 antennas among them) or of the wide (8-slot /
+    8-wave) 100-antenna launches carries scratch.  The classes that do are listed: the dword-staged run-time
     classes (13 staging pieces per thread), 100 antennas on 4-wave workgroups at n_ipo 2 / 4 / 64 (general kernel; the wide
     launches replace it from n_ipo 16 on), one 8-slot run-time instantiation -- a few dwords each, bounded here so that growth
     shows."""
-    clean_units = ("bf_fused16_a64", "bf_fused16_a128", "bf_fused16_a128_s8", "bf_fused16_a128_w8", "bf_fused16_a128_w8p",
-                   "bf_fused16_a100_s8", "bf_fused16_a100_w8", "bf_fused16_a100_w8p", "bf_fused16_k1p16", "bf_fused16_k2p16",
-                   "bf_fused16_k2p16_w8", "bf_fused16_k2p16_w8p", "bf_fused16_k2p4_w8p", "bf_fused16_a192", "bf_fused16_a256",
-                   "bf_fused16_k3p16", "bf_fused16_k4p16")
+    clean_units = ("bf_fused16_a100_s8", "bf_fused16_a100_w8", "bf_fused16_a100_w8p", "bf_fused16_k1p16", "bf_fused16_k2p16",
+                   "bf_fused16_k2p16_w8", "bf_fused16_k2p16_w8p", "bf_fused16_k2p4_w8p", "bf_fused16_k3p16", "bf_fused16_k4p16")
     bad, worst = [], 0
     for unit, (co, ks) in objects.items():
         for name, k in ks.items():

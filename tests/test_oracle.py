@@ -262,28 +262,6 @@ def test_executed_notebook_pins_weights_and_generator(orc, linear_inputs, linear
     assert np.array_equal(sig, nb["nb2d_signal_src1023_f255"])
 
 
-def _fast_restatement(g, w, packed):
-    """BF_DETECT_FAST (include/dsabf.h) restated: d = 16 n exact; acc = fma(d, d, acc) for re then im, in time order;
-    one (alpha/16)^2 scale per output.  fma is emulated exactly: d^2 < 2^43 and acc + d^2 < 2^53 are exact in float64."""
-    pb = packed.astype(np.int8)
-    v = np.stack([pb >> 4, (packed << 4).astype(np.uint8).astype(np.int8) >> 4], -1).astype(np.int64)
-    W = w.astype(np.int64)
-    a16 = np.float32(np.float32(1.0 / 127) * np.float32(0.0625))
-    scale = np.float32(a16 * a16)
-    outs = []
-    for u in range(packed.shape[0]):
-        re = np.einsum("fab,fta->ftb", W[..., 0], v[u, ..., 0]) - np.einsum("fab,fta->ftb", W[..., 1], v[u, ..., 1])
-        im = np.einsum("fab,fta->ftb", W[..., 0], v[u, ..., 1]) + np.einsum("fab,fta->ftb", W[..., 1], v[u, ..., 0])
-        dr = (16 * re).astype(np.float64).reshape(g.n_freq, g.n_out_per_gemm, g.n_ipo, g.n_beams)
-        di = (16 * im).astype(np.float64).reshape(g.n_freq, g.n_out_per_gemm, g.n_ipo, g.n_beams)
-        acc = np.zeros((g.n_freq, g.n_out_per_gemm, g.n_beams), np.float32)
-        for i in range(g.n_ipo):
-            acc = (acc.astype(np.float64) + dr[:, :, i] * dr[:, :, i]).astype(np.float32)
-            acc = (acc.astype(np.float64) + di[:, :, i] * di[:, :, i]).astype(np.float32)
-        outs.append((acc * scale).transpose(1, 0, 2))
-    return np.stack(outs)
-
-
 @pytest.mark.parametrize("n_avg,n_out", [(1, 8), (4, 2), (16, 2), (32, 1)])
 def test_every_detect_reading_within_stated_tolerance_of_exact(orc, n_avg, n_out):
     """Nobody here can run nvcc: whether the reference's device code evaluates `x*x + y*y` (src/beamformer.cuh:151) as
@@ -306,7 +284,7 @@ def test_every_detect_reading_within_stated_tolerance_of_exact(orc, n_avg, n_out
         assert np.abs(readings[name] / exact - 1).max() <= tol, name
     assert orc.get_detect_contract() == orc.CONTRACT_NONE
     assert np.array_equal(readings["g++"], _np_beamform(g, w, packed))
-    fast = _fast_restatement(g, w, packed)
+    fast = orc.beamform_fast(g, w, packed)
     assert np.abs(fast / exact - 1).max() <= (g.n_ipo + 1) * 2.0 ** -23
     # the readings are different functions (this is why "bit-identical to the reference's GPU" is not claimed) ...
     assert (readings["g++"] != readings["nvcc"]).any()
