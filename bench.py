@@ -226,6 +226,59 @@ def time_launches(torch, fn, n, stream):
     return sum(ms) / len(ms), ms[len(ms) // 2], ms[0]
 
 
+def dm_stage_record(torch, bfm, device, n_dm=64, trial_share=(0, 1), pushes=24, warm=6, blocks_per_push=1):
+    """The DM-trial stage of the observation loop by itself: kernel-only time per PRODUCTION
+    block -- 32 gemm-units x 8 outputs = 256 beam-blocks of 256 x 256 floats, 64 MiB -- for `n_dm` trials of the notebook's ladder to
+    DM 250, the delay window carried over on the device.  Zero-copy feed: bf_dm_stream_reserve hands out the rows' place inside the
+    stage's buffer (in the loop the beamformer or the gather writes them there; here they hold what a first fill left), the push only
+    launches -- so what is timed is the stage's own work: the dedispersion kernels over [carry | new rows] (the buffer is a ring
+    mapped twice back to back: nothing slides).  trial_share = (r, R): rank r's share of the ladder when a sharded run splits
+    the trials (`beam -X`; R = 1: the whole ladder on one GPU).  blocks_per_push > 1: the stage fed every few blocks -- a block's
+    64 trials x 256 times x 256 beams are 64 workgroups of the shared-window kernel, a quarter of the chip."""
+    import ctypes as C
+
+    import numpy as np
+
+    from dsabeamformer_amd import _lib, api, host
+
+    hip = _lib._preload_hip_runtime()
+    pc = bfm.production_config()
+    rows = pc.n_gemms_per_block * pc.n_out_per_gemm * blocks_per_push
+    freq = [host.channel_frequency(0, c) for c in range(pc.n_freq)]
+    ladder = host.dm_trials(dm_max=250.0)
+    dms = ladder[:: max(1, len(ladder) // n_dm)][:n_dm]
+    delays = host.dm_delays(dms, freq, freq[0], 0.131)
+    first, count = host.dm_trial_share(len(dms), trial_share[1], trial_share[0]) if trial_share[1] > 1 else (0, len(dms))
+    delays = np.ascontiguousarray(delays[first:first + count])
+    D = int(delays.max())
+    stream = torch.cuda.current_stream()
+    sptr = stream.cuda_stream
+    b = bfm.Beamformer(pc, device=device)
+    dm = api.DmStream(b, delays, pc.n_freq, rows)
+    row_floats = pc.n_freq * pc.n_beams
+    fill = torch.rand(rows * row_floats, device="cuda")
+
+    def one(i):
+        dst = dm.reserve(rows, sptr)
+        if i < n_fill:       # (first pass over the buffer: real values in every row the kernels will read)
+            hip.hipMemcpyAsync(C.c_void_p(dst), C.c_void_p(fill.data_ptr()), C.c_size_t(rows * row_floats * 4), 3, C.c_void_p(sptr))
+        dm.push(dst, rows, None, sptr)
+
+    n_fill = 2 * ((D + rows) // rows + 2)
+    for i in range(n_fill + warm):
+        one(i)
+    torch.cuda.synchronize()
+    avg, med, mn = time_launches(torch, lambda i: one(n_fill + warm + i), pushes, stream)
+    dm.close()
+    b.close()
+    window = D + rows                                           # rows the kernels read per push: [carry | new]
+    alg = 4 * (window * row_floats + count * rows * pc.n_beams)   # read once + the chunk [dm][t][b] written once
+    adds = float(count) * rows * pc.n_freq * pc.n_beams
+    return {"us_per_block": avg * 1e3 / blocks_per_push, "us_per_push": avg * 1e3, "us_per_push_median": med * 1e3, "us_per_beam_block": avg * 1e3 / rows,
+            "dm_trials": count, "rows_per_push": rows, "blocks_per_push": blocks_per_push, "max_delay_rows": D, "algorithmic_bytes_per_push": alg,
+            "hbm_gbs_algorithmic": alg / (avg * 1e-3) / 1e9, "gadds_per_s": adds / (avg * 1e-3) / 1e9}
+
+
 def cpu_baselines(n_avg, n_out, seconds, full=True):
     """Host-side baselines, on a bounded sample (full=False, the N > 1 line: record (1) alone, on all host cores): (1) the oracle's beamform port (expand + GEMM + detect, OpenMP, all cores)
     on gemm-units of the bench workload; (2) the reference's only CPU code on the path, generate_test_data
@@ -1379,6 +1432,19 @@ def main():
                                 "(tests/golden/make_dispersion_golden.py)"})
             out["dedisperse_dm"] = rec
 
+        def extras_dm_stage():
+            # the stage as the loop runs it (bf_dm_stream, zero-copy feed): per production block, beside a rank's beamforming time
+            rec = {"whole_band_one_gpu": dm_stage_record(torch, bfm, local, 64, (0, 1)),
+                   "whole_band_one_gpu_4_blocks_per_push": dm_stage_record(torch, bfm, local, 64, (0, 1), pushes=12, blocks_per_push=4),
+                   "trial_share_1_of_8": dm_stage_record(torch, bfm, local, 64, (0, 8)),
+                   "note": "kernel-only, rows already in the stage's buffer (bf_dm_stream_reserve: the beamformer / the gather writes them "
+                           "there, bf_dm_stream_push only launches -- round 5 copied every row device-to-device first); 64 trials of the "
+                           "notebook's ladder to DM 250 on a production block (256 beam-blocks); trial_share_1_of_8 = one rank's 8 trials "
+                           "over the whole band when a sharded run splits the ladder (`beam -X`).  A rank's beamforming at N = 8: c4_shard.  "
+                           "A production block gives the shared-window kernel 64 workgroups (2 trial groups x 16 time tiles x 2 beam tiles) "
+                           "for 256 CUs: ..._4_blocks_per_push shows the same stage fed every four blocks (real time: 33.5 ms per block)"}
+            out["dm_stage"] = rec
+
         def extras_relayout():
             # the device pass of the staged gather transport by itself, at the shape one receiver of BASELINE configs[3] sees in
             # the distributed-owner gather: 8 ranks, 2048 / 8 = 256 rows held, 32 channels x 256 beams per row and sender
@@ -1436,6 +1502,7 @@ def main():
             guarded("debug_geometry", extras_geometries)
             guarded("streaming", extras_streaming)
             guarded("dedisperse_dm", extras_dm)
+            guarded("dm_stage", extras_dm_stage)
         if not args.no_cpu_baseline:
             # N = 1: the full set.  N > 1: the same key, the beamform port alone on a shorter sample (the other ranks have
             # finished; the whole-band beam-block is the unit at every N, so the number is comparable across the lines)

@@ -136,6 +136,13 @@ class Beamformer:
             arr = (C.c_void_p * n_units)(*[_ptr(p).value for p in host_outs])
         check(self._lib.bf_enqueue_block(self._h, stream_idx, slot, first_unit, n_units, arr))
 
+    def enqueue_block_to(self, stream_idx: int, slot: int, first_unit: int, n_units: int, d_dst, host_outs=None) -> None:
+        """enqueue_block with the powers written to the device address d_dst ([unit][o][f][b]) instead of the queue's buffer."""
+        arr = None
+        if host_outs is not None:
+            arr = (C.c_void_p * n_units)(*[_ptr(p).value for p in host_outs])
+        check(self._lib.bf_enqueue_block_to(self._h, stream_idx, slot, first_unit, n_units, _ptr(d_dst), arr))
+
     def enqueue_block_dedisperse(self, stream_idx: int, first_unit: int, n_units: int, host_rows=None) -> None:
         check(self._lib.bf_enqueue_block_dedisperse(self._h, stream_idx, first_unit, n_units, _ptr(host_rows)))
 
@@ -248,6 +255,13 @@ class DmStream:
         first, n = C.c_uint64(), C.c_int()
         check(self._lib.bf_dm_stream_push(self._s, _ptr(d_rows), n_rows, _ptr(host_out), C.byref(first), C.byref(n), C.c_void_p(stream)))
         return int(first.value), int(n.value)
+
+    def reserve(self, n_rows: int, stream: int = 0) -> int:
+        """Device address of the next n_rows rows' place inside the stage's buffer (bf_dm_stream_reserve): write them there on
+        ``stream``, then push(that address, n_rows) -- no copy."""
+        p = C.c_void_p()
+        check(self._lib.bf_dm_stream_reserve(self._s, n_rows, C.byref(p), C.c_void_p(stream)))
+        return p.value or 0
 
     def output_device(self) -> int:
         p = C.c_void_p()

@@ -393,3 +393,34 @@ int bf_gather_detected_staged(bf_comm* c, const float* d_local, size_t n_rows, s
 }
 
 }  // extern "C"
+
+namespace dsabf {
+int comm_all_ok(bf_comm* c, bool ok, bool* all)
+{
+    *all = ok;
+    if (!c || c->world == 1) return BF_OK;
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    if (prev != c->device && hipSetDevice(c->device) != hipSuccess) return comm_fail(BF_ERR_DEVICE, "hipSetDevice failed");
+    float* d = nullptr;   // [0, 4): this rank's flag (one 16-byte row), [4, 4 + 4 world): everybody's
+    int rc = BF_OK;
+    std::vector<float> got((size_t)4 * c->world, 0.0f);
+    const float mine[4] = {ok ? 1.0f : 0.0f, 0.0f, 0.0f, 0.0f};
+    hipError_t e = hipMalloc((void**)&d, sizeof(float) * (4 + got.size()));
+    if (e == hipSuccess) e = hipMemcpy(d, mine, sizeof mine, hipMemcpyHostToDevice);
+    if (e != hipSuccess) rc = comm_fail(BF_ERR_DEVICE, std::string("comm_all_ok: ") + hipGetErrorString(e));
+    // (a rank whose device calls failed still takes part if it can: its flag is false either way)
+    if (d) {
+        const int g = bf_gather_detected(c, d, 1, 4, BF_GATHER_ROOT_ALL, BF_GATHER_LAYOUT_RANK_MAJOR, d + 4, nullptr);
+        if (g != BF_OK) rc = g;
+        if (rc == BF_OK && (e = hipMemcpy(got.data(), d + 4, sizeof(float) * got.size(), hipMemcpyDeviceToHost)) != hipSuccess)
+            rc = comm_fail(BF_ERR_DEVICE, std::string("comm_all_ok: ") + hipGetErrorString(e));
+        (void)hipFree(d);
+    }
+    bool every = rc == BF_OK;
+    for (int r = 0; every && r < c->world; r++) every = got[(size_t)4 * r] == 1.0f;
+    *all = every;
+    if (prev >= 0 && prev != c->device) (void)hipSetDevice(prev);
+    return rc;
+}
+}  // namespace dsabf

@@ -402,10 +402,16 @@ int bfh_run_observation_junk_sharded(const bf_config* cfg, uint64_t n_blocks, in
     const bool holds_band = gather_root == BF_GATHER_ROOT_ALL || gather_root == rank;
     bf_config full = *cfg;
     full.n_freq = cfg->n_freq * world;
+    // (a failed preparation of THIS rank does not return here: the other ranks would wait for it in the first gather.  It is
+    //  reported to run_observation, which lets every shard know before anything starts -- observation_options::local_setup_ok)
+    bool setup_ok = true;
     std::unique_ptr<file_sink> fs;
     if (detected_path && holds_band) {
         fs.reset(new file_sink(full, detected_path, gpu));
-        if (!fs->ok() || !fs->is_open()) return BF_ERR_INVALID;
+        if (!fs->ok() || !fs->is_open()) {
+            setup_ok = false;
+            fs.reset();
+        }
     }
     int first = 0, count = n_dm;
     if (split_trials) dm_trial_share(n_dm, world, rank, &first, &count);
@@ -414,10 +420,13 @@ int bfh_run_observation_junk_sharded(const bf_config* cfg, uint64_t n_blocks, in
         int dmax = 0;
         for (size_t i = (size_t)first * full.n_freq; i < (size_t)(first + count) * full.n_freq; i++) dmax = delays[i] > dmax ? delays[i] : dmax;
         dms.reset(new dm_file_sink(*cfg, full.n_freq, count, dmax, dm_path, gpu, first));
-        if (!dms->is_open()) return BF_ERR_INVALID;
+        if (!dms->is_open()) {
+            setup_ok = false;
+            dms.reset();
+        }
     }
     junk_block_source src(*cfg, n_blocks, ring_blocks, seed);
-    if (!src.ok()) return BF_ERR_DEVICE;
+    if (!src.ok()) setup_ok = false;
     std::vector<antenna> pos((size_t)cfg->n_ant);
     std::vector<beam_direction> dir((size_t)cfg->n_beams);
     default_positions(cfg->n_ant, pos.data());
@@ -435,6 +444,7 @@ int bfh_run_observation_junk_sharded(const bf_config* cfg, uint64_t n_blocks, in
     opt.n_dm = delays ? n_dm : 0;
     opt.dm_split_trials = split_trials != 0;
     opt.dm_sink = dms.get();
+    opt.local_setup_ok = setup_ok;
     observation_result res;
     std::ostringstream quiet;
     std::streambuf* keep = std::cout.rdbuf();

@@ -2,6 +2,8 @@
 #pragma once
 #include <functional>
 
+struct bf_comm;
+
 namespace dsabf {
 // Splits [0, n) over the machine's hardware threads (std::thread; OpenMP is not assumed in the product build).
 void parallel_for(long n, const std::function<void(long, long)>& body);
@@ -11,4 +13,7 @@ int set_error(int code, const char* msg);
 // production allow-list read with plain getenv is DSABF_RCCL_LIB, DSABF_THREADS, DSABF_COALESCE, DSABF_PAIRED.
 bool lab_mode();
 const char* lab_getenv(const char* name);
+// Control plane of a sharded run (bf_comm.cpp): every rank contributes a flag, every rank learns whether ALL are set -- one tiny
+// all-gather on the communicator (16 bytes per rank), blocking.  world 1 / NULL: *all = ok.
+int comm_all_ok(bf_comm* c, bool ok, bool* all);
 }  // namespace dsabf

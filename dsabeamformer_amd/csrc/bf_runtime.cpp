@@ -42,6 +42,7 @@ struct bf_handle {
     // them later on the same stream: calls on one stream are ordered by the stream, calls on different streams must not share.
     std::vector<std::pair<hipStream_t, int*>> dm_scratch;
     bool force_general = false;   // bf_set_switch("paired", 0): never select the conjugate-pair kernel
+    bool dm_ring = true;          // bf_set_switch("dm_ring", 0): the next bf_dm_stream_create takes the linear buffer (test switch)
     // bf_enqueue_gemm_unit coalesces (see flush_units): the caller keeps the reference's one-unit-per-call loop
     // (src/beamformer.cu:454-519), the device sees one launch per run of consecutive gemm-units.
     struct pending_unit {
@@ -652,7 +653,8 @@ int bf_enqueue_gemm_unit(bf_handle* h, int stream_idx, int slot, int time_slice,
     return BF_OK;
 }
 
-int bf_enqueue_block(bf_handle* h, int stream_idx, int slot, int first_unit, int n_units, float* const* host_out)
+// d_dst: where the launch's powers go ([unit][o][f][b] of its n_units gemm-units); NULL: this queue's block buffer
+static int enqueue_block_impl(bf_handle* h, int stream_idx, int slot, int first_unit, int n_units, float* d_dst, float* const* host_out)
 {
     if (!h) return fail(BF_ERR_INVALID, "handle is NULL");
     if (!h->weights_set) return fail(BF_ERR_STATE, "bf_set_weights has not been called");
@@ -665,18 +667,21 @@ int bf_enqueue_block(bf_handle* h, int stream_idx, int slot, int first_unit, int
     FLUSH_UNITS(h);
     const size_t per_gemm = bf_bytes_per_gemm(&h->cfg);
     const size_t per_det = bf_floats_per_detect(&h->cfg);
-    if (h->d_out_blk.empty()) h->d_out_blk.assign((size_t)h->cfg.n_streams, nullptr);
-    if (h->blk_ran.empty()) h->blk_ran.assign((size_t)h->cfg.n_streams, 0);
-    // This queue's block buffer, at first use.  A hipMalloc in the middle of a stream of blocks stalls the device (measured: 9.4 ->
-    // 10.9 us per beam-block), so a caller that rotates over queues reserves them BEFORE its loop with bf_block_output_device
-    // (run_observation does, for the queues it will use) -- the library does not guess and allocate all n_streams of them
-    // (8 x 128 MiB at the production geometry, six of them dead for a two-queue loop).
-    if (!h->d_out_blk[stream_idx])
-        HIP_TRY(hipMalloc((void**)&h->d_out_blk[stream_idx], per_det * sizeof(float) * (size_t)h->cfg.n_gemms_per_block));
-    h->blk_ran[stream_idx] = 1;
-    if (int rc = preserve_last_units(h, stream_idx, (size_t)first_unit, (size_t)first_unit + (size_t)n_units, nullptr)) return rc;
+    float* out = d_dst;
+    if (!d_dst) {
+        if (h->d_out_blk.empty()) h->d_out_blk.assign((size_t)h->cfg.n_streams, nullptr);
+        if (h->blk_ran.empty()) h->blk_ran.assign((size_t)h->cfg.n_streams, 0);
+        // This queue's block buffer, at first use.  A hipMalloc in the middle of a stream of blocks stalls the device (measured: 9.4 ->
+        // 10.9 us per beam-block), so a caller that rotates over queues reserves them BEFORE its loop with bf_block_output_device
+        // (run_observation does, for the queues it will use; include/dsabf.h says so at bf_enqueue_block) -- the library does not
+        // guess and allocate all n_streams of them (8 x 128 MiB at the production geometry, six of them dead for a two-queue loop).
+        if (!h->d_out_blk[stream_idx])
+            HIP_TRY(hipMalloc((void**)&h->d_out_blk[stream_idx], per_det * sizeof(float) * (size_t)h->cfg.n_gemms_per_block));
+        h->blk_ran[stream_idx] = 1;
+        if (int rc = preserve_last_units(h, stream_idx, (size_t)first_unit, (size_t)first_unit + (size_t)n_units, nullptr)) return rc;
+        out = h->d_out_blk[stream_idx] + per_det * (size_t)first_unit;
+    }
     const uint8_t* in = h->d_data + per_gemm * ((size_t)h->cfg.n_gemms_per_block * slot + first_unit);
-    float* out = h->d_out_blk[stream_idx] + per_det * (size_t)first_unit;
     hipStream_t s = h->streams[stream_idx];
     h->n_fused_launches++;
     HIP_TRY(dsabf::launch_fused(h->geom, h->d_wimage, h->d_wimage_p, in, n_units, out, h->n_cus, s));
@@ -693,6 +698,17 @@ int bf_enqueue_block(bf_handle* h, int stream_idx, int slot, int first_unit, int
             u += run;
         }
     return BF_OK;
+}
+
+int bf_enqueue_block(bf_handle* h, int stream_idx, int slot, int first_unit, int n_units, float* const* host_out)
+{
+    return enqueue_block_impl(h, stream_idx, slot, first_unit, n_units, nullptr, host_out);
+}
+
+int bf_enqueue_block_to(bf_handle* h, int stream_idx, int slot, int first_unit, int n_units, float* d_dst, float* const* host_out)
+{
+    if (!d_dst) return fail(BF_ERR_INVALID, "d_dst is NULL");
+    return enqueue_block_impl(h, stream_idx, slot, first_unit, n_units, d_dst, host_out);
 }
 
 int bf_enqueue_block_dedisperse(bf_handle* h, int stream_idx, int first_unit, int n_units, float* host_rows)
@@ -1017,17 +1033,109 @@ int bf_dedisperse_dm_band_device(bf_handle* h, const float* d_series, int n_t, i
 struct bf_dm_stream {
     bf_handle* h = nullptr;
     int n_dm = 0, n_freq = 0, max_delay = 0, max_rows = 0;
-    size_t row_floats = 0, cap_rows = 0;
-    size_t fill = 0;              // rows of d_buf in use: [fill - carry, fill) are the newest rows of the series
+    size_t row_floats = 0;
+    // The rows live in a RING of cap_rows rows whose physical memory is mapped TWICE, back to back, into one virtual range (HIP's
+    // virtual-memory API): row i is also row i + cap_rows, so every window of <= cap_rows consecutive rows -- the carried-over
+    // delay window in front of a push's rows -- is contiguous for the kernels wherever it starts, and nothing ever moves.  (Rounds
+    // 5's linear buffer slid the carry back to its start every few pushes: at the production block, 31 MiB read and written again
+    // every 2.5 blocks.)  ring == false: that linear buffer -- for a device without VMM support, and bf_set_switch("dm_ring", 0).
+    bool ring = false;
+    size_t cap_rows = 0;          // ring: rows of physical memory (>= max_delay + 3 max_rows); linear: 2 (max_delay + max_rows)
+    size_t wpos = 0;              // ring: physical row the next pushed row goes to (< cap_rows)
+    size_t fill = 0;              // linear: rows of d_buf in use, [fill - carry, fill) are the newest rows of the series
+    hipMemGenericAllocationHandle_t phys{};
+    size_t phys_bytes = 0;
+    bool phys_created = false, va_reserved = false, mapped0 = false, mapped1 = false;
     uint64_t pushed = 0;          // rows the stream has been given
-    float* d_buf = nullptr;       // cap_rows x [freq][beam]
+    uint64_t n_push = 0;          // pushes so far
+    float* d_buf = nullptr;       // ring: the double mapping (2 x phys_bytes of address space); linear: cap_rows x [freq][beam]
     float* d_out = nullptr;       // [n_dm][max_rows][beam]: the most recent push's chunk
     int32_t* d_delays = nullptr;  // [n_dm][freq]
     int* d_flags = nullptr;       // the wide kernel's scratch (dsabf::kDmScratchBytes), this stream's own
     bool flags_zeroed = false;
-    hipEvent_t done = nullptr;    // end of the previous push (its host copy included): pushes are ordered, whatever queue they use
-    bool done_recorded = false;
+    // end of push j (its host copy included) = done[j % 3].  Push j waits for push j - 1 (they share d_out); the producer of push
+    // j's rows overwrites what only pushes <= j - 3 can still be reading (cap_rows >= max_delay + 3 max_rows) and waits for push j - 3.
+    hipEvent_t done[3] = {nullptr, nullptr, nullptr};
+    bool done_recorded[3] = {false, false, false};
+    float* reserved = nullptr;    // bf_dm_stream_reserve: where the NEXT push's rows are being written by their producer ...
+    int reserved_rows = 0;        // ... and how many (0: no reservation outstanding)
 };
+
+// device side of a DM stage (its handle's device must be current); the object itself stays, detached from the handle
+static void dm_stream_release(bf_dm_stream* s)
+{
+    for (int k = 0; k < 3; k++) {
+        if (!s->done[k]) continue;
+        if (s->done_recorded[k]) (void)hipEventSynchronize(s->done[k]);
+        (void)hipEventDestroy(s->done[k]);
+        s->done[k] = nullptr;
+        s->done_recorded[k] = false;
+    }
+    if (s->ring || s->va_reserved || s->phys_created) {
+        if (s->mapped0) (void)hipMemUnmap(s->d_buf, s->phys_bytes);
+        if (s->mapped1) (void)hipMemUnmap(reinterpret_cast<char*>(s->d_buf) + s->phys_bytes, s->phys_bytes);
+        if (s->va_reserved) (void)hipMemAddressFree(s->d_buf, 2 * s->phys_bytes);
+        if (s->phys_created) (void)hipMemRelease(s->phys);
+        s->mapped0 = s->mapped1 = s->va_reserved = s->phys_created = false;
+    } else {
+        (void)hipFree(s->d_buf);
+    }
+    (void)hipFree(s->d_out);
+    (void)hipFree(s->d_delays);
+    (void)hipFree(s->d_flags);
+    s->d_buf = s->d_out = nullptr;
+    s->d_delays = nullptr;
+    s->d_flags = nullptr;
+    s->h = nullptr;
+}
+
+// The ring: one physical allocation, mapped at va and at va + phys_bytes.  False (and nothing left behind): no VMM here.
+static bool dm_ring_create(bf_dm_stream* s, int device, size_t want_rows)
+{
+    int vmm = 0;
+    if (hipDeviceGetAttribute(&vmm, hipDeviceAttributeVirtualMemoryManagementSupported, device) != hipSuccess || !vmm) return false;
+    hipMemAllocationProp prop{};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = device;
+    size_t gran = 0;
+    if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) != hipSuccess || !gran) return false;
+    const size_t row_bytes = s->row_floats * sizeof(float);
+    size_t g = gran, r = row_bytes;          // rows per granule-aligned stretch: gran / gcd(row_bytes, gran)
+    while (r) {
+        const size_t t = g % r;
+        g = r;
+        r = t;
+    }
+    const size_t step = gran / g;
+    const size_t rows = (want_rows + step - 1) / step * step;
+    s->phys_bytes = rows * row_bytes;
+    void* va = nullptr;
+    bool ok = hipMemCreate(&s->phys, s->phys_bytes, &prop, 0) == hipSuccess;
+    s->phys_created = ok;
+    ok = ok && hipMemAddressReserve(&va, 2 * s->phys_bytes, gran, nullptr, 0) == hipSuccess;
+    s->va_reserved = ok;
+    s->d_buf = static_cast<float*>(va);
+    ok = ok && (s->mapped0 = hipMemMap(va, s->phys_bytes, 0, s->phys, 0) == hipSuccess);
+    ok = ok && (s->mapped1 = hipMemMap(static_cast<char*>(va) + s->phys_bytes, s->phys_bytes, 0, s->phys, 0) == hipSuccess);
+    hipMemAccessDesc acc{};
+    acc.location = prop.location;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    ok = ok && hipMemSetAccess(va, 2 * s->phys_bytes, &acc, 1) == hipSuccess;
+    if (!ok) {
+        if (s->mapped0) (void)hipMemUnmap(va, s->phys_bytes);
+        if (s->mapped1) (void)hipMemUnmap(static_cast<char*>(va) + s->phys_bytes, s->phys_bytes);
+        if (s->va_reserved) (void)hipMemAddressFree(va, 2 * s->phys_bytes);
+        if (s->phys_created) (void)hipMemRelease(s->phys);
+        s->mapped0 = s->mapped1 = s->va_reserved = s->phys_created = false;
+        s->d_buf = nullptr;
+        (void)hipGetLastError();
+        return false;
+    }
+    s->ring = true;
+    s->cap_rows = rows;
+    return true;
+}
 
 int bf_dm_stream_create(bf_handle* h, const int32_t* delays, int n_dm, int n_freq_total, int max_rows_per_push, bf_dm_stream** out)
 {
@@ -1049,14 +1157,18 @@ int bf_dm_stream_create(bf_handle* h, const int32_t* delays, int n_dm, int n_fre
     s->max_delay = dmax;
     s->max_rows = max_rows_per_push;
     s->row_floats = (size_t)n_freq_total * h->cfg.n_beams;
-    // room for the carry and a push twice over: when the end is reached the carry moves to the start without overlapping itself
-    s->cap_rows = 2 * ((size_t)dmax + (size_t)max_rows_per_push);
-    hipError_t e = hipMalloc((void**)&s->d_buf, s->cap_rows * s->row_floats * sizeof(float));
+    hipError_t e = hipSuccess;
+    // the ring: the window of a push (<= max_delay + max_rows rows) + two more pushes' rows that may be written while it is read
+    if (!h->dm_ring || !dm_ring_create(s, h->device, (size_t)dmax + 3 * (size_t)max_rows_per_push)) {
+        // linear: room for the carry and a push twice over -- when the end is reached the carry moves to the start without overlapping itself
+        s->cap_rows = 2 * ((size_t)dmax + (size_t)max_rows_per_push);
+        e = hipMalloc((void**)&s->d_buf, s->cap_rows * s->row_floats * sizeof(float));
+    }
     if (e == hipSuccess) e = hipMalloc((void**)&s->d_out, (size_t)n_dm * max_rows_per_push * h->cfg.n_beams * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void**)&s->d_delays, (size_t)n_dm * n_freq_total * sizeof(int32_t));
     if (e == hipSuccess) e = hipMalloc((void**)&s->d_flags, dsabf::kDmScratchBytes);
     if (e == hipSuccess) e = hipMemcpy(s->d_delays, delays, (size_t)n_dm * n_freq_total * sizeof(int32_t), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&s->done, hipEventDisableTiming);
+    for (int k = 0; k < 3 && e == hipSuccess; k++) e = hipEventCreateWithFlags(&s->done[k], hipEventDisableTiming);
     h->dm_streams.push_back(s);
     if (e != hipSuccess) {
         const int rc = fail(BF_ERR_DEVICE, "bf_dm_stream_create: %s", hipGetErrorString(e));
@@ -1067,24 +1179,6 @@ int bf_dm_stream_create(bf_handle* h, const int32_t* delays, int n_dm, int n_fre
     }
     *out = s;
     return BF_OK;
-}
-
-// device side of a DM stage (its handle's device must be current); the object itself stays, detached from the handle
-static void dm_stream_release(bf_dm_stream* s)
-{
-    if (s->done) {
-        if (s->done_recorded) (void)hipEventSynchronize(s->done);
-        (void)hipEventDestroy(s->done);
-    }
-    (void)hipFree(s->d_buf);
-    (void)hipFree(s->d_out);
-    (void)hipFree(s->d_delays);
-    (void)hipFree(s->d_flags);
-    s->done = nullptr;
-    s->d_buf = s->d_out = nullptr;
-    s->d_delays = nullptr;
-    s->d_flags = nullptr;
-    s->h = nullptr;
 }
 
 int bf_dm_stream_destroy(bf_dm_stream* s)
@@ -1114,50 +1208,106 @@ int bf_dm_stream_output_device(bf_dm_stream* s, float** d_out)
     return BF_OK;
 }
 
+// Where the next n_rows rows go, with everything the writer of those rows must wait for queued on q first.
+//   ring: behind the previous rows, wherever that is -- they overwrite rows that only pushes <= j - 3 can still be reading;
+//   linear: behind the previous rows too, unless the buffer's end is reached: then the carry slides back to the start first, behind
+//           the previous push's kernels (which read what the slide and the new rows overwrite).
+static int dm_place_rows(bf_dm_stream* s, int n_rows, hipStream_t q, float** dst)
+{
+    const size_t D = (size_t)s->max_delay;
+    const size_t carry = s->pushed < D ? (size_t)s->pushed : D;
+    if (s->ring) {
+        const int old = (int)(s->n_push % 3);        // the slot push j will record into: last recorded by push j - 3
+        if (s->done_recorded[old]) HIP_TRY(hipStreamWaitEvent(q, s->done[old], 0));
+        *dst = s->d_buf + s->wpos * s->row_floats;   // (wpos + n_rows may pass cap_rows: the second mapping continues the first)
+        return BF_OK;
+    }
+    if (s->fill + (size_t)n_rows > s->cap_rows) {    // slide: fill - carry >= carry here (cap = 2 (D + max_rows))
+        const int prev = (int)((s->n_push + 2) % 3);
+        if (s->n_push && s->done_recorded[prev]) HIP_TRY(hipStreamWaitEvent(q, s->done[prev], 0));
+        if (carry)
+            HIP_TRY(hipMemcpyAsync(s->d_buf, s->d_buf + (s->fill - carry) * s->row_floats, carry * s->row_floats * sizeof(float),
+                                   hipMemcpyDeviceToDevice, q));
+        s->fill = carry;                              // (the carry HAS moved: committed here, not at the push)
+    }
+    *dst = s->d_buf + s->fill * s->row_floats;
+    return BF_OK;
+}
+
+// Zero-copy feed (round 6): the place of the next n_rows rows in the stage's own buffer, directly behind the carried-over window.
+// The producer -- bf_enqueue_block_to, bf_gather_detected -- writes them there, ordered on (or behind) hip_stream; the push that
+// follows finds them in place and only launches.  The reference's collapse sits directly behind detect, no copy in between
+// (src/beamformer.cu:492-511); round 5's push copied every row device-to-device first (64 MiB read + 64 MiB written per production
+// block).
+int bf_dm_stream_reserve(bf_dm_stream* s, int n_rows, float** d_dst, void* hip_stream)
+{
+    if (!s || !d_dst) return fail(BF_ERR_INVALID, "NULL argument");
+    *d_dst = nullptr;
+    if (n_rows <= 0 || n_rows > s->max_rows) return fail(BF_ERR_INVALID, "n_rows must be 1 .. %d (max_rows_per_push)", s->max_rows);
+    if (!s->h) return fail(BF_ERR_STATE, "the handle of this DM stage has been destroyed");
+    if (s->reserved_rows) return fail(BF_ERR_STATE, "bf_dm_stream_reserve: the previous reservation has not been pushed");
+    bf_handle* h = s->h;
+    ON_DEVICE(h);
+    float* dst = nullptr;
+    if (int rc = dm_place_rows(s, n_rows, as_stream(hip_stream), &dst)) return rc;
+    s->reserved = dst;
+    s->reserved_rows = n_rows;
+    *d_dst = dst;
+    return BF_OK;
+}
+
 int bf_dm_stream_push(bf_dm_stream* s, const float* d_rows, int n_rows, float* host_out, uint64_t* first_t, int* n_t_out,
                       void* hip_stream)
 {
     if (!s || !d_rows) return fail(BF_ERR_INVALID, "NULL argument");
     if (n_rows <= 0 || n_rows > s->max_rows) return fail(BF_ERR_INVALID, "n_rows must be 1 .. %d (max_rows_per_push)", s->max_rows);
     if (!s->h) return fail(BF_ERR_STATE, "the handle of this DM stage has been destroyed");
+    const bool in_place = s->reserved_rows != 0;
+    if (in_place && (d_rows != s->reserved || n_rows != s->reserved_rows))
+        return fail(BF_ERR_STATE, "bf_dm_stream_push: %d rows are reserved at %p (bf_dm_stream_reserve); push exactly those", s->reserved_rows,
+                    (void*)s->reserved);
     bf_handle* h = s->h;
     ON_DEVICE(h);
     hipStream_t q = as_stream(hip_stream);
-    if (s->done_recorded) HIP_TRY(hipStreamWaitEvent(q, s->done, 0));   // behind the previous push, whatever queue that ran on
+    const int prev = (int)((s->n_push + 2) % 3), mine = (int)(s->n_push % 3);
+    if (s->n_push && s->done_recorded[prev]) HIP_TRY(hipStreamWaitEvent(q, s->done[prev], 0));   // behind the previous push, whatever queue that ran on
     if (!s->flags_zeroed) {
         HIP_TRY(hipMemsetAsync(s->d_flags, 0, dsabf::kDmScratchBytes, q));
         s->flags_zeroed = true;
     }
-    // (the stream's bookkeeping -- fill, pushed -- is committed at the end: a call that fails on the way leaves it as it found it)
+    // (the stream's bookkeeping -- wpos / fill, pushed -- is committed at the end: a call that fails on the way leaves it as it found it)
     const size_t D = (size_t)s->max_delay;
-    const size_t carry = s->pushed < D ? (size_t)s->pushed : D;          // rows [fill - carry, fill) = series rows [pushed - carry, pushed)
-    size_t fill = s->fill;
-    if (fill + (size_t)n_rows > s->cap_rows) {                            // slide: fill - carry >= carry here (cap = 2 (D + max_rows))
-        if (carry)
-            HIP_TRY(hipMemcpyAsync(s->d_buf, s->d_buf + (fill - carry) * s->row_floats, carry * s->row_floats * sizeof(float),
-                                   hipMemcpyDeviceToDevice, q));
-        fill = carry;
+    const size_t carry = s->pushed < D ? (size_t)s->pushed : D;          // the rows in front of the new ones = series rows [pushed - carry, pushed)
+    if (!in_place) {                                                      // rows that live elsewhere: brought behind the carry first
+        float* dst = nullptr;
+        if (int rc = dm_place_rows(s, n_rows, q, &dst)) return rc;
+        HIP_TRY(hipMemcpyAsync(dst, d_rows, (size_t)n_rows * s->row_floats * sizeof(float), hipMemcpyDeviceToDevice, q));
     }
-    HIP_TRY(hipMemcpyAsync(s->d_buf + fill * s->row_floats, d_rows, (size_t)n_rows * s->row_floats * sizeof(float),
-                           hipMemcpyDeviceToDevice, q));
-    fill += (size_t)n_rows;
     const uint64_t emitted = s->pushed > D ? s->pushed - D : 0;          // output times [0, emitted) have been produced
     const uint64_t after = s->pushed + (uint64_t)n_rows;
     const uint64_t complete = after > D ? after - D : 0;                   // ... and [0, complete) can be now
     const int n_out = (int)(complete - emitted);
     const size_t n_t = carry + (size_t)n_rows;                            // the series the kernels see: starts at output time `emitted`
+    // first row of [carry | new rows]: linear: fill - carry; ring: wpos - carry, through the second mapping when that is negative
+    const size_t start = s->ring ? (s->wpos >= carry ? s->wpos - carry : s->wpos + s->cap_rows - carry) : s->fill - carry;
     if (n_out > 0) {
         dsabf::Geometry g = h->geom;
         g.n_freq = s->n_freq;
-        HIP_TRY(dsabf::launch_dedisperse_dm(g, s->d_buf + (fill - n_t) * s->row_floats, (int)n_t, s->d_delays, s->n_dm, n_out, s->d_out,
+        HIP_TRY(dsabf::launch_dedisperse_dm(g, s->d_buf + start * s->row_floats, (int)n_t, s->d_delays, s->n_dm, n_out, s->d_out,
                                             s->d_flags, q));
         if (host_out)
             HIP_TRY(hipMemcpyAsync(host_out, s->d_out, (size_t)s->n_dm * n_out * h->cfg.n_beams * sizeof(float), hipMemcpyDeviceToHost, q));
     }
-    HIP_TRY(hipEventRecord(s->done, q));
-    s->done_recorded = true;
-    s->fill = fill;
+    HIP_TRY(hipEventRecord(s->done[mine], q));
+    s->done_recorded[mine] = true;
+    if (s->ring)
+        s->wpos = (s->wpos + (size_t)n_rows) % s->cap_rows;
+    else
+        s->fill += (size_t)n_rows;
     s->pushed = after;
+    s->n_push++;
+    s->reserved = nullptr;
+    s->reserved_rows = 0;
     if (first_t) *first_t = emitted;
     if (n_t_out) *n_t_out = n_out;
     return BF_OK;
@@ -1183,8 +1333,10 @@ int bf_set_switch(bf_handle* h, const char* name, int value)
         h->coalesce = value != 0;
     } else if (!strcmp(name, "paired")) {
         h->force_general = value == 0;   // takes effect at the next bf_set_weights (the kernel is chosen per weight set)
+    } else if (!strcmp(name, "dm_ring")) {
+        h->dm_ring = value != 0;         // takes effect at the next bf_dm_stream_create
     } else {
-        return fail(BF_ERR_INVALID, "unknown switch \"%s\" (tsplit, rtw_kout, lds_pad, dm_wide, paired, coalesce)", name);
+        return fail(BF_ERR_INVALID, "unknown switch \"%s\" (tsplit, rtw_kout, lds_pad, dm_wide, dm_ring, paired, coalesce)", name);
     }
     return BF_OK;
 }

@@ -414,24 +414,40 @@ int run_debug_observation(const bf_config& cfg, const debug_run_options& opt, de
 int run_observation(const bf_config& cfg, const observation_options& opt, block_source& source, const antenna* pos,
                     const beam_direction* dir, observation_result* res, std::ostream& log)
 {
+    // A sharded run enters its first collective -- the gather behind block 0 -- only if EVERY shard got through its setup: each rank
+    // takes part in ONE exchange of "ready" flags before the loop, whichever way its setup went (a rank that bailed out alone would
+    // leave the others waiting in that gather for ever: ADVICE r05).  The caller's own preparations count too (local_setup_ok).
+    struct setup_gate {
+        bf_comm* comm;
+        bool done = false;
+        int fail(int rc)
+        {
+            if (comm && !done) {
+                done = true;
+                bool all = false;
+                (void)comm_all_ok(comm, false, &all);
+            }
+            return rc;
+        }
+    } gate{opt.comm};
     const int n_streams = cfg.n_streams;
-    if (cfg.n_gemms_per_block % n_streams) return BF_ERR_INVALID;
+    if (cfg.n_gemms_per_block % n_streams) return gate.fail(BF_ERR_INVALID);
     if (opt.world < 1 || opt.rank < 0 || opt.rank >= opt.world || opt.gather_root < BF_GATHER_ROOT_ALL || opt.gather_root >= opt.world)
-        return set_error(BF_ERR_INVALID, "run_observation: need 0 <= rank < world and gather_root a rank or BF_GATHER_ROOT_ALL");
+        return gate.fail(set_error(BF_ERR_INVALID, "run_observation: need 0 <= rank < world and gather_root a rank or BF_GATHER_ROOT_ALL"));
     // who holds the gathered band after every block: one rank, or (BF_GATHER_ROOT_ALL) every rank
     const bool is_root = !opt.comm || opt.gather_root == BF_GATHER_ROOT_ALL || opt.rank == opt.gather_root;
     if (opt.comm && (bf_comm_rank(opt.comm) != opt.rank || bf_comm_world(opt.comm) != opt.world))
-        return set_error(BF_ERR_INVALID, "run_observation: the communicator's rank / world differ from the options'");
+        return gate.fail(set_error(BF_ERR_INVALID, "run_observation: the communicator's rank / world differ from the options'"));
     if (opt.comm && !opt.block_launch)
-        return set_error(BF_ERR_INVALID, "run_observation: the sharded gather needs block-granular launches");
+        return gate.fail(set_error(BF_ERR_INVALID, "run_observation: the sharded gather needs block-granular launches"));
     if (opt.comm && opt.sink && !is_root)
-        return set_error(BF_ERR_INVALID, "run_observation: only the gather root may have a sink");
-    if (opt.dm_delays && opt.n_dm <= 0) return set_error(BF_ERR_INVALID, "run_observation: dm_delays without n_dm");
-    if (opt.dm_sink && !opt.dm_delays) return set_error(BF_ERR_INVALID, "run_observation: a dm_sink needs dm_delays");
+        return gate.fail(set_error(BF_ERR_INVALID, "run_observation: only the gather root may have a sink"));
+    if (opt.dm_delays && opt.n_dm <= 0) return gate.fail(set_error(BF_ERR_INVALID, "run_observation: dm_delays without n_dm"));
+    if (opt.dm_sink && !opt.dm_delays) return gate.fail(set_error(BF_ERR_INVALID, "run_observation: a dm_sink needs dm_delays"));
     if (opt.comm && opt.dm_sink && !is_root)
-        return set_error(BF_ERR_INVALID, "run_observation: only the gather root may have a dm_sink");
+        return gate.fail(set_error(BF_ERR_INVALID, "run_observation: only the gather root may have a dm_sink"));
     if (opt.dm_split_trials && (!opt.comm || opt.gather_root != BF_GATHER_ROOT_ALL))
-        return set_error(BF_ERR_INVALID, "run_observation: dm_split_trials needs a sharded run gathered to every rank (BF_GATHER_ROOT_ALL)");
+        return gate.fail(set_error(BF_ERR_INVALID, "run_observation: dm_split_trials needs a sharded run gathered to every rank (BF_GATHER_ROOT_ALL)"));
     source.read_headers();  // :334 (before the device exists here: the block-size check below needs no GPU)
     const size_t block_bytes = bf_bytes_per_block(&cfg);
     if (source.get_block_size() != block_bytes) {
@@ -439,14 +455,14 @@ int run_observation(const bf_config& cfg, const observation_options& opt, block_
         // GEOMETRY's size: a smaller ring block is read past its end (past the mapping on the last one), a larger one is
         // silently truncated.  Neither can produce a meaningful beam: refuse.
         log << "ERROR: block size " << source.get_block_size() << ", Should also be " << block_bytes << std::endl;
-        return set_error(BF_ERR_INVALID, "run_observation: the source's block size does not match bf_bytes_per_block(cfg)");
+        return gate.fail(set_error(BF_ERR_INVALID, "run_observation: the source's block size does not match bf_bytes_per_block(cfg)"));
     }
 
     bf_handle* h = nullptr;
     int rc = bf_create(&cfg, opt.device, &h);
     if (rc != BF_OK) {
         log << "GPUassert: " << bf_last_error() << std::endl;
-        return rc;
+        return gate.fail(rc);
     }
     struct guard {
         bf_handle* h;
@@ -466,14 +482,14 @@ int run_observation(const bf_config& cfg, const observation_options& opt, block_
     const size_t n_f_per_detect = bf_floats_per_detect(&cfg);
     // beam_out: the reference's pinned D2H destination (:249); the root of a sharded run receives the whole band there
     const size_t beam_out_stride = n_f_per_detect * (size_t)(opt.comm ? opt.world : 1);
-    if ((rc = bf_alloc_pinned(&g.pinned, beam_out_stride * n_streams * sizeof(float))) != BF_OK) return rc;
+    if ((rc = bf_alloc_pinned(&g.pinned, beam_out_stride * n_streams * sizeof(float))) != BF_OK) return gate.fail(rc);
     float* beam_out = static_cast<float*>(g.pinned);
     ::memset(beam_out, 0, beam_out_stride * n_streams * sizeof(float));
     {
         std::vector<int8_t> fourier_coefficients((size_t)cfg.n_freq * cfg.n_ant * cfg.n_beams * 2);
         generate_fourier_coefficients(cfg.n_beams, cfg.n_ant, cfg.n_freq, opt.rank * cfg.n_freq, opt.gpu, pos, dir,
                                       fourier_coefficients.data());
-        if ((rc = bf_set_weights(h, fourier_coefficients.data())) != BF_OK) return rc;
+        if ((rc = bf_set_weights(h, fourier_coefficients.data())) != BF_OK) return gate.fail(rc);
     }
     std::vector<int> timeSlice((size_t)n_streams);
     for (int i = 0; i < n_streams; i++) timeSlice[i] = i;  // :319
@@ -493,7 +509,7 @@ int run_observation(const bf_config& cfg, const observation_options& opt, block_
     uint64_t sink_committed = 0;
     const char* unit_env = lab_getenv("DSABF_UNIT_LAUNCH");   // measurement / test switch (DSABF_LAB=1): the reference's per-gemm-unit launches
     const bool block_launch = opt.block_launch && !(unit_env && unit_env[0] == '1');
-    if (opt.comm && !block_launch) return set_error(BF_ERR_INVALID, "run_observation: the sharded gather needs block-granular launches");
+    if (opt.comm && !block_launch) return gate.fail(set_error(BF_ERR_INVALID, "run_observation: the sharded gather needs block-granular launches"));
     int upl = opt.units_per_launch;                                // gemm-units per launch of the block path
     if (const char* e = lab_getenv("DSABF_UNITS_PER_LAUNCH")) upl = atoi(e);
     if (upl <= 0 || upl > cfg.n_gemms_per_block || opt.comm) upl = cfg.n_gemms_per_block;   // 0 / sharded: the whole block
@@ -519,18 +535,18 @@ int run_observation(const bf_config& cfg, const observation_options& opt, block_
     std::deque<dm_chunk> dm_pending;            // pushed, not yet delivered (their block's analysis event has not fired)
     std::vector<float*> dm_host;                // pinned chunk buffers, used round robin
     uint64_t dm_seq = 0, dm_times = 0, dm_chunks = 0;
-    if (opt.dm_delays && !block_launch) return set_error(BF_ERR_INVALID, "run_observation: the DM stage needs block-granular launches");
+    if (opt.dm_delays && !block_launch) return gate.fail(set_error(BF_ERR_INVALID, "run_observation: the DM stage needs block-granular launches"));
     const bool dm_run = dm_here && dm_count > 0;      // (more ranks than trials: the surplus ranks only beamform)
     if (dm_run) {
         if ((rc = bf_dm_stream_create(h, opt.dm_delays + (size_t)dm_first * n_freq_band, dm_count, n_freq_band, dm_rows, &g.dm)) != BF_OK) {
             log << "GPUassert: " << bf_last_error() << std::endl;
-            return rc;
+            return gate.fail(rc);
         }
         // chunks in flight: the launches of MAX_TOTAL_SEP blocks queued + the one being delivered
         const size_t n_buf = (size_t)(kMaxTotalSep + 2) * (size_t)(cfg.n_gemms_per_block / upl);
         for (size_t i = 0; i < n_buf; i++) {
             void* pb = nullptr;
-            if ((rc = bf_alloc_pinned(&pb, (size_t)dm_count * dm_rows * cfg.n_beams * sizeof(float))) != BF_OK) return rc;
+            if ((rc = bf_alloc_pinned(&pb, (size_t)dm_count * dm_rows * cfg.n_beams * sizeof(float))) != BF_OK) return gate.fail(rc);
             g.more_pinned.push_back(pb);
             dm_host.push_back(static_cast<float*>(pb));
         }
@@ -539,10 +555,20 @@ int run_observation(const bf_config& cfg, const observation_options& opt, block_
     if (block_launch)   // the per-queue block buffers are allocated on first use: do that here, not inside the timed loop
         for (int q = 0; q < n_queues_used; q++) {
             float* unused = nullptr;
-            if ((rc = bf_block_output_device(h, q, &unused)) != BF_OK) return rc;
-            if (opt.comm && is_root && (rc = bf_block_gather_device(h, q, opt.world, &unused)) != BF_OK) return rc;
-            if (opt.comm && staged && is_root && (rc = bf_block_gather_stage_device(h, q, opt.world, &unused)) != BF_OK) return rc;
+            if ((!dm_run || opt.comm) && (rc = bf_block_output_device(h, q, &unused)) != BF_OK) return gate.fail(rc);   // (a DM stage takes the rows itself)
+            if (opt.comm && is_root && !dm_run && (rc = bf_block_gather_device(h, q, opt.world, &unused)) != BF_OK) return gate.fail(rc);
+            if (opt.comm && staged && is_root && (rc = bf_block_gather_stage_device(h, q, opt.world, &unused)) != BF_OK) return gate.fail(rc);
         }
+    if (opt.comm) {
+        gate.done = true;
+        bool all = false;
+        if ((rc = comm_all_ok(opt.comm, opt.local_setup_ok, &all)) != BF_OK) return rc;
+        if (!all)
+            return set_error(BF_ERR_STATE, opt.local_setup_ok ? "run_observation: another shard of this run failed its setup; nothing was started"
+                                                              : "run_observation: this shard's caller reported a failed setup (local_setup_ok = false)");
+    } else if (!opt.local_setup_ok) {
+        return set_error(BF_ERR_STATE, "run_observation: the caller reported a failed setup (local_setup_ok = false)");
+    }
     bf_timer_start(h);  // :358
     while (!obs_state.check_observations_complete()) {  // :364
         if (opt.verbose) {
@@ -591,9 +617,17 @@ int run_observation(const bf_config& cfg, const observation_options& opt, block_
                         }
                         last_gemm[q] = block_index * n_units + u;
                     }
-                    rc = bf_enqueue_block(h, q, (int)obs_state.get_next_gpu_analysis_block(), first, upl,
-                                          opt.comm ? nullptr : &unit_dst[first]);
+                    // The DM stage owns the place its rows belong in -- directly behind its carried-over delay window: the beamformer
+                    // (one GPU) or the gather (a holder of a sharded run) writes them THERE, and the push below only launches.  The
+                    // reference's collapse reads what detect wrote, no copy in between (src/beamformer.cu:481,492-511).
                     float* d_rows = nullptr;     // where this launch's beam-blocks are on the device, [row][freq (over the band)][beam]
+                    void* dm_qs = nullptr;
+                    if (dm_run && (rc = bf_queue_stream(h, q, &dm_qs)) == BF_OK) rc = bf_dm_stream_reserve(g.dm, dm_rows, &d_rows, dm_qs);
+                    if (rc == BF_OK)
+                        rc = (dm_run && !opt.comm) ? bf_enqueue_block_to(h, q, (int)obs_state.get_next_gpu_analysis_block(), first, upl, d_rows,
+                                                                         &unit_dst[first])
+                                                   : bf_enqueue_block(h, q, (int)obs_state.get_next_gpu_analysis_block(), first, upl,
+                                                                      opt.comm ? nullptr : &unit_dst[first]);
                     if (rc == BF_OK && opt.comm) {
                         // sharded (upl == n_units): bring the shards' powers together on the root, in [unit][o][f over the
                         // band][b], behind the launch on the same queue; only the root copies to the host
@@ -601,8 +635,9 @@ int run_observation(const bf_config& cfg, const observation_options& opt, block_
                         void* qs = nullptr;
                         const size_t full_det = n_f_per_detect * (size_t)opt.world;
                         const bool root = is_root;
+                        if (dm_run) d_full = d_rows;     // (a holder with a DM stage receives straight into the stage's buffer)
                         if ((rc = bf_block_output_device(h, q, &d_blk)) == BF_OK && (rc = bf_queue_stream(h, q, &qs)) == BF_OK &&
-                            (!root || (rc = bf_block_gather_device(h, q, opt.world, &d_full)) == BF_OK) &&
+                            (!root || dm_run || (rc = bf_block_gather_device(h, q, opt.world, &d_full)) == BF_OK) &&
                             (!root || !staged || (rc = bf_block_gather_stage_device(h, q, opt.world, &d_stage)) == BF_OK))
                             rc = staged ? bf_gather_detected_staged(opt.comm, d_blk, (size_t)n_units * cfg.n_out_per_gemm,
                                                                     (size_t)cfg.n_freq * cfg.n_beams, opt.gather_root, d_full, d_stage, qs)
@@ -611,19 +646,15 @@ int run_observation(const bf_config& cfg, const observation_options& opt, block_
                                                              BF_GATHER_LAYOUT_FREQ_MAJOR, d_full, qs);
                         for (int u = 0; rc == BF_OK && root && u < n_units; u++)
                             rc = bf_enqueue_d2h(h, q, d_full + full_det * (size_t)u, unit_dst[u], full_det);
-                        d_rows = d_full;
-                    } else if (rc == BF_OK && dm_run) {
-                        if ((rc = bf_block_output_device(h, q, &d_rows)) == BF_OK) d_rows += n_f_per_detect * (size_t)first;
                     }
                     if (rc == BF_OK && dm_run) {
                         // the DM stage, where the reference's loop collapses frequency (src/beamformer.cu:492-511): this launch's rows
-                        // into the stream on the launch's own queue; the chunk that becomes complete travels to a pinned buffer
-                        void* qs = nullptr;
+                        // are in the stream's buffer already; its kernels run on the launch's own queue, the chunk that becomes complete
+                        // travels to a pinned buffer
                         uint64_t first_t = 0;
                         int n_t = 0;
                         float* chunk = dm_host[(size_t)(dm_seq++ % dm_host.size())];
-                        if ((rc = bf_queue_stream(h, q, &qs)) == BF_OK)
-                            rc = bf_dm_stream_push(g.dm, d_rows, dm_rows, chunk, &first_t, &n_t, qs);
+                        rc = bf_dm_stream_push(g.dm, d_rows, dm_rows, chunk, &first_t, &n_t, dm_qs);
                         if (rc == BF_OK && n_t > 0) dm_pending.push_back({(uint64_t)block_index, first_t, n_t, chunk});
                     }
                     if (rc != BF_OK) {

@@ -1,7 +1,9 @@
 /* dm_stream.c -- the DM-trial stage of the observation loop from plain C (C99): what a maintainer puts where the reference's
  * loop has its DM-0 collapse (src/beamformer.cu:492-511).  Four PSRDADA-sized blocks of the DEBUG geometry go through
- *   bf_submit_block -> bf_enqueue_block (one fused launch per block, powers copied to the host)
- *   -> bf_block_output_device + bf_queue_stream + bf_dm_stream_push (the block's rows into the DM stream, on the same queue)
+ *   bf_submit_block -> bf_queue_stream + bf_dm_stream_reserve (the place of the block's rows INSIDE the DM stage's buffer)
+ *   -> bf_enqueue_block_to (one fused launch per block writes its powers there; they are also copied to the host)
+ *   -> bf_dm_stream_push (the rows are in place: the stage only launches its kernels, on the same queue -- no copy in between,
+ *      as the reference's collapse reads what detect wrote)
  * and every chunk [dm][t][beam] the stream emits is checked, bit for bit, against the same ascending-f float sum computed
  * here from the detected powers -- across the block boundaries: the largest delay is longer than one block.
  * Build:  hipcc -x c -std=c99 -Iinclude examples/dm_stream.c -o dm_stream -Ldsabeamformer_amd -ldsabf -Wl,-rpath,$PWD/dsabeamformer_amd */
@@ -79,7 +81,7 @@ int main(void)
 
     for (b = 0; b < N_BLOCKS; b++) {
         float *host_ptrs[64];
-        float *d_blk = NULL;
+        float *d_rows = NULL;
         void *queue = NULL;
         const int q = b % 2;    /* whole blocks alternate between two queues */
         uint64_t first_t = 0;
@@ -92,11 +94,11 @@ int main(void)
             host_ptrs[i] = (float *)det + ((size_t)b * cfg.n_gemms_per_block + i) * per_unit;
         CHECK(bf_submit_block(h, b % cfg.n_blocks_on_gpu, block, block_bytes, NULL));
         CHECK(bf_stream_sync(h, -1));   /* (this example reuses one host block; the loop proper waits on the transfer event) */
-        CHECK(bf_enqueue_block(h, q, b % cfg.n_blocks_on_gpu, 0, cfg.n_gemms_per_block, host_ptrs));
-        /* the DM stage: this block's rows, [unit][o][f][b] = [row][f][b], behind the launch on the same queue */
-        CHECK(bf_block_output_device(h, q, &d_blk));
+        /* the DM stage owns the place of this block's rows ([unit][o][f][b] = [row][f][b]): the launch writes them there */
         CHECK(bf_queue_stream(h, q, &queue));
-        CHECK(bf_dm_stream_push(dm, d_blk, rows_per_block, (float *)chunk, &first_t, &n_t, queue));
+        CHECK(bf_dm_stream_reserve(dm, rows_per_block, &d_rows, queue));
+        CHECK(bf_enqueue_block_to(h, q, b % cfg.n_blocks_on_gpu, 0, cfg.n_gemms_per_block, d_rows, host_ptrs));
+        CHECK(bf_dm_stream_push(dm, d_rows, rows_per_block, (float *)chunk, &first_t, &n_t, queue));
         CHECK(bf_stream_sync(h, q));
         if (first_t != next_t) {
             fprintf(stderr, "block %d: chunk starts at %llu, expected %llu\n", b, (unsigned long long)first_t, (unsigned long long)next_t);
@@ -125,11 +127,11 @@ int main(void)
         fprintf(stderr, "emitted %llu output times, expected %d\n", (unsigned long long)next_t, n_rows - max_delay);
         return 1;
     }
-    CHECK(bf_dm_stream_destroy(dm));
+    CHECK(bf_dm_stream_destroy(dm));   /* the stage before its handle, pinned memory after it (include/dsabf.h) */
+    CHECK(bf_destroy(h));
     CHECK(bf_free_pinned(block));
     CHECK(bf_free_pinned(det));
     CHECK(bf_free_pinned(chunk));
-    CHECK(bf_destroy(h));
     free(pos);
     free(dir);
     free(w);

@@ -74,10 +74,10 @@ int main(void)
             return 1;
         }
     }
+    CHECK(bf_destroy(h));           /* drains the queues; the host buffers of enqueued units outlive it (include/dsabf.h) */
     CHECK(bf_free_pinned(block));
     CHECK(bf_free_pinned(out));
     CHECK(bf_free_pinned(ded));
-    CHECK(bf_destroy(h));
     free(pos);
     free(dir);
     free(w);

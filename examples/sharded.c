@@ -158,11 +158,11 @@ int main(int argc, char **argv)
             return 1;
         }
         free(ded);
-        CHECK(bf_free_pinned(host_full));
     }
-    CHECK(bf_free_pinned(block));
     CHECK(bf_comm_destroy(comm));
-    CHECK(bf_destroy(h));
+    CHECK(bf_destroy(h));           /* pinned memory after the handle (include/dsabf.h) */
+    if (rank == 0) CHECK(bf_free_pinned(host_full));
+    CHECK(bf_free_pinned(block));
     free(pos);
     free(dir);
     free(w);

@@ -100,7 +100,11 @@ int bf_device_count(int *count);
 int bf_device_name(int device, char *buf, size_t buflen);
 
 /* Replaces: allocations src/beamformer.cu:249-266, memsets :291-298, streams/handles :305-320 and the
- * teardown :560-605.  d_B and d_C of the reference do not exist here (expand, GEMM and detect are fused). */
+ * teardown :560-605.  d_B and d_C of the reference do not exist here (expand, GEMM and detect are fused).
+ * bf_destroy drains the handle's queues first, as the reference's teardown does (cudaStreamSynchronize of every stream,
+ * src/beamformer.cu:560-562): gemm-units that bf_enqueue_gemm_unit accepted and nothing has launched yet are launched, and their
+ * host copies land -- so the host_out / host_out_row buffers of every enqueued unit must stay valid until bf_destroy has
+ * returned (free pinned memory AFTER the handle, as the reference frees beam_out after its streams, :605,613). */
 int bf_create(const bf_config *cfg, int device, bf_handle **out);
 int bf_destroy(bf_handle *h);
 int bf_get_config(const bf_handle *h, bf_config *cfg); /* the geometry the handle was built for (the #defines of src/beamformer.hh:45-152) */
@@ -172,8 +176,15 @@ int bf_enqueue_gemm_unit(bf_handle *h, int stream_idx, int slot, int time_slice,
  * src/beamformer.cu:454-519; a whole PSRDADA block of 32 units keeps the chip filled where one unit cannot).  The detected
  * powers land in a per-queue device buffer of n_gemms_per_block units; host_out, if not NULL, is an array of n_units host
  * pointers (pinned; NULL entries are skipped): unit first_unit + i is copied to host_out[i] asynchronously, behind the
- * launch, on the same queue.  Results are identical to n_units calls of bf_enqueue_gemm_unit. */
+ * launch, on the same queue.  Results are identical to n_units calls of bf_enqueue_gemm_unit.
+ * The per-queue buffer is allocated when a queue is first used: a caller that rotates over queues reserves them BEFORE its loop
+ * with bf_block_output_device(h, q, &p) for every queue it will use (a hipMalloc in the middle of a stream of blocks stalls the
+ * device: 9.4 -> 10.9 us per beam-block measured; run_observation and examples/ do).
+ * bf_enqueue_block_to: the same launch with the powers written to d_dst (device, room for n_units * bf_floats_per_detect floats,
+ * [unit][o][f][b]) instead of the queue's buffer -- for a consumer that owns the place the rows belong in (bf_dm_stream_reserve:
+ * the frequency collapse directly behind detect, src/beamformer.cu:481,492-511, with no copy in between). */
 int bf_enqueue_block(bf_handle *h, int stream_idx, int slot, int first_unit, int n_units, float *const *host_out);
+int bf_enqueue_block_to(bf_handle *h, int stream_idx, int slot, int first_unit, int n_units, float *d_dst, float *const *host_out);
 
 /* Replaces K5, the DEBUG dedisperse, src/beamformer.cu:498-510: sums output 0 of the unit last enqueued on
  * `stream_idx` over frequency (ascending f, fp32) and copies the n_beams floats to host_out_row. */
@@ -250,12 +261,21 @@ int bf_dedisperse_dm_device(bf_handle *h, const float *d_series, int n_t, const 
  * ordered by the stream itself, whichever queues they are issued on.  host_out (optional, pinned, room for n_dm * n_rows *
  * n_beams floats) receives the chunk; first_t / n_t_out are known to the host at once (pure arithmetic).  The device copy of
  * the most recent chunk: bf_dm_stream_output_device.  Destroy the stream before its handle (a handle that goes first releases the
- * stage's device memory; the stage then only answers BF_ERR_STATE and can still be destroyed). */
+ * stage's device memory; the stage then only answers BF_ERR_STATE and can still be destroyed).
+ * Zero-copy feed (what run_observation uses): bf_dm_stream_reserve(s, n_rows, &d_dst, hip_stream) hands out the place of the next
+ * n_rows rows INSIDE the stage's buffer, directly behind the carried-over window; the producer writes them there ON hip_stream (or
+ * ordered behind it) -- bf_enqueue_block_to(h, q, ..., d_dst, ...), or bf_gather_detected(..., d_full = d_dst, stream) on a gather
+ * root -- and bf_dm_stream_push(s, d_dst, n_rows, ...) then launches the kernels without moving a row (a push of rows that live
+ * elsewhere copies them in first: one more read and write of every row).  One reservation at a time; it must be pushed as
+ * reserved (same pointer, same n_rows).  The stage's buffer is a ring of max_delay + 3 max_rows_per_push rows whose memory is
+ * mapped twice, back to back (hipMemCreate / hipMemMap): the delay window in front of a push is contiguous wherever it starts, and
+ * no row is ever moved or read twice by anything but the dedispersion itself. */
 typedef struct bf_dm_stream bf_dm_stream;
 int bf_dm_stream_create(bf_handle *h, const int32_t *delays, int n_dm, int n_freq_total, int max_rows_per_push,
                         bf_dm_stream **out);
 int bf_dm_stream_destroy(bf_dm_stream *s);
 int bf_dm_stream_max_delay(const bf_dm_stream *s);
+int bf_dm_stream_reserve(bf_dm_stream *s, int n_rows, float **d_dst, void *hip_stream);
 int bf_dm_stream_push(bf_dm_stream *s, const float *d_rows, int n_rows, float *host_out, uint64_t *first_t, int *n_t_out,
                       void *hip_stream);
 int bf_dm_stream_output_device(bf_dm_stream *s, float **d_out);

@@ -42,6 +42,9 @@ int bf_rtw_plan(const bf_config *cfg, int n_units, int n_cus, int *windows_per_s
  *                       compile-time instantiation; 0: the library picks the one with the least padding that still fills the chip)
  *   "lds_pad"  bytes    extra dynamic LDS per workgroup (fewer resident workgroups per CU); clamped to what a CU has
  *   "dm_wide"  0 / 1    0: bf_dedisperse_dm*_device runs the per-thread-window kernel alone
+ *   "dm_ring"  0 / 1    0: the next bf_dm_stream_create keeps its rows in a linear buffer whose carried-over window slides back to the
+ *                       start when the end is reached (what a device without virtual-memory management gets), instead of the ring
+ *                       that is mapped twice back to back (nothing ever moves); same chunks
  *   "paired"   0 / 1    0: the next bf_set_weights selects the general kernel even for conjugate-symmetric weights
  *   "coalesce" 0 / 1    0: bf_enqueue_gemm_unit launches one kernel per call (the reference's literal launch pattern) */
 int bf_set_switch(bf_handle *h, const char *name, int value);

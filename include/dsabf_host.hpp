@@ -558,8 +558,13 @@ struct observation_options {
     int gather_root = 0;
     // Transport of that gather (both give the same [unit][o][f over the band][b] on the root): false = every (row, sender) run
     // received in place (bf_gather_detected), true = one message per sender + one device re-layout pass
-    // (bf_gather_detected_staged).  DSABF_GATHER_STAGED=1 / 0 in the environment overrides (measurement switch).
+    // (bf_gather_detected_staged).
     bool gather_staged = false;
+    // Sharded run: false if THIS rank's caller failed its own preparations (a sink that did not open, a source that is not there).
+    // Every shard exchanges one "ready" flag before the loop; if any is false, all of them return BF_ERR_STATE and nothing is started
+    // -- a rank that bails out alone would leave the others waiting in the first gather for ever.  A caller that detects such a
+    // failure therefore still CALLS run_observation (with this flag cleared) instead of returning on its own.
+    bool local_setup_ok = true;
     // DM-trial dedispersion of the detected stream (needs block_launch): int32 [n_dm][cfg.n_freq * world] sample delays, all >= 0
     // (dm_delays()).  Every analysed block is pushed into a bf_dm_stream behind its launch -- on a sharded run by the gather
     // root, on the gathered band -- and the chunks go to dm_sink (may be NULL: the stage still runs, e.g. for timing).

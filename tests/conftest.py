@@ -23,13 +23,17 @@ os.environ["DSABF_LAB"] = "1"
 
 
 # ---- the GPU suite runs on a budget (<= 300 s on a fresh driver box) -------------------------------------
-# The default `-m gpu` run keeps a spread of at most SWEEP_CAP cases of every parametrised GPU test (first, last and evenly
-# between, in collection order -- every kernel family, antenna class and config keeps its representatives; tests/README.md maps
-# SURVEY.md section 8's rows and BASELINE's configs to the tests that stay); DSABF_LONG_TESTS=1 runs every case (tools/
-# refresh_profiles_r05.sh does, and commits the tail under profiles/).  A test that must always run in full says
-# @pytest.mark.sweep_cap(n) with its own number.  CPU tests are never thinned.
+# The default `-m gpu` run keeps at most SWEEP_CAP cases of every parametrised GPU test: FIRST the cases on BASELINE.json's own
+# geometries -- 64 / 100 / 128 antennas x the DEBUG and the production window (n_avg 1 and 16: n_ipo 2 and 32) -- every one of
+# them, whatever the cap ("explicitly, rather than first, last, evenly between"); then an even spread of the
+# others, first and last included, up to the cap.  tests/README.md maps SURVEY.md section 8's rows and BASELINE's configs to the
+# tests that stay; DSABF_LONG_TESTS=1 runs every case (tools/refresh_profiles_r06.sh does, and commits the tail under profiles/);
+# the number of cases a budgeted run leaves out is printed at the end of the run.  A test that must always run in full says
+# @pytest.mark.sweep_cap(n) with its own number.  CPU tests are never thinned.  Every compiled kernel instantiation is launched
+# against the oracle by ONE test whatever the cap (tests/test_gpu_census.py).
 LONG = os.environ.get("DSABF_LONG_TESTS") == "1"
-SWEEP_CAP = 4
+SWEEP_CAP = 8
+BASELINE_ANT, BASELINE_AVG = (64, 100, 128), (1, 16)
 
 
 def sweep(every, default):
@@ -40,6 +44,33 @@ def sweep(every, default):
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "sweep_cap(n): cases of this parametrised GPU test kept in the budgeted run (default %d)" % SWEEP_CAP)
+
+
+def baseline_case(item) -> bool:
+    """A parametrised case on one of BASELINE.json's geometries: named parameters n_ant / n_avg, or a `shape` tuple (n_ant, n_avg, ...)."""
+    cs = getattr(item, "callspec", None)
+    if cs is None:
+        return False
+    p = cs.params
+    n_ant, n_avg = p.get("n_ant"), p.get("n_avg")
+    shape = p.get("shape")
+    if isinstance(shape, tuple) and len(shape) >= 2 and all(isinstance(v, int) for v in shape[:2]):
+        n_ant, n_avg = shape[0], shape[1]
+    return n_ant in BASELINE_ANT and n_avg in BASELINE_AVG and p.get("n_pol", 2) == 2
+
+
+def thin(group, cap):
+    """Indices of `group` the budgeted run keeps: every BASELINE case, then an even spread of the rest up to `cap`."""
+    base = [k for k, it in enumerate(group) if baseline_case(it)]
+    rest = [k for k in range(len(group)) if k not in base]
+    room = max(cap - len(base), 2 if not base else 0)
+    if len(rest) <= room:
+        return set(base) | set(rest)
+    spread = {rest[round(i * (len(rest) - 1) / max(room - 1, 1))] for i in range(room)} if room else set()
+    return set(base) | spread
+
+
+_deselected = [0]
 
 
 def pytest_collection_modifyitems(config, items):
@@ -56,12 +87,21 @@ def pytest_collection_modifyitems(config, items):
         cap = int(m.args[0]) if m and m.args else SWEEP_CAP
         if len(group) <= cap:
             continue
-        keep = {round(i * (len(group) - 1) / max(cap - 1, 1)) for i in range(cap)}
+        keep = thin(group, cap)
         drop.update(id(it) for k, it in enumerate(group) if k not in keep)
     if drop:
         gone = [it for it in items if id(it) in drop]
         items[:] = [it for it in items if id(it) not in drop]
+        _deselected[0] = len(gone)
         config.hook.pytest_deselected(items=gone)
+
+
+def pytest_terminal_summary(terminalreporter):
+    if _deselected[0] and terminalreporter.config.getoption("-m") and "gpu" in terminalreporter.config.getoption("-m") \
+            and "not gpu" not in terminalreporter.config.getoption("-m"):
+        terminalreporter.write_line("BUDGETED GPU RUN: %d parametrised cases left out (at most %d per test + every BASELINE geometry); "
+                                    "DSABF_LONG_TESTS=1 runs them all -- required before a kernel change is merged" % (_deselected[0], SWEEP_CAP),
+                                    yellow=True, bold=True)
 
 
 @pytest.fixture(scope="session")

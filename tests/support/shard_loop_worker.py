@@ -37,9 +37,12 @@ cfg = bfm.production_config(n_beams=p["n_beams"], n_freq=p["n_freq_local"], n_av
 cfg.n_gemms_per_block, cfg.n_streams = p["n_units"], p["n_streams"]
 delays = np.load(os.path.join(work, "delays.npy")) if p["n_dm"] else None
 holds = p["gather_root"] < 0 or p["gather_root"] == rank
+det_path = os.path.join(work, "det.%d" % rank)
+if p.get("bad_rank", -1) == rank:       # this shard's own preparations fail: its sink cannot be opened
+    det_path = os.path.join(work, "no_such_directory", "det.%d" % rank)
 r = host.run_observation_junk_sharded(
     cfg, p["n_blocks"], rank, world, uid, gather_root=p["gather_root"], staged=p["staged"], delays=delays,
-    split_trials=p["split"], detected_path=os.path.join(work, "det.%d" % rank) if holds else None,
+    split_trials=p["split"], detected_path=det_path if holds else None,
     dm_path=os.path.join(work, "dm.%d" % rank) if (holds and delays is not None) else None,
     ring_blocks=p["ring_blocks"], seed=p["seed"], gpu=p["gpu"])
 np.savez(os.path.join(work, "rank%d.npz" % rank), ring=r["ring"], dm_times=r["dm_times"])

@@ -343,6 +343,31 @@ def test_plain_c_sharded_example(fake_rccl, tmp_path, world):
     (tmp_path / ("peak%d.txt" % world)).write_text(seen[0])
 
 
+def test_a_shard_whose_setup_fails_stops_every_shard_before_the_first_gather(fake_rccl, tmp_path):
+    """one rank of a sharded observation cannot open its sink.  It used to return on its own -- and the others waited
+    for it in the gather behind block 0, with no timeout.  Now every shard exchanges a "ready" flag before the loop
+    (observation_options::local_setup_ok, dsabf::comm_all_ok): all three processes end, promptly, with an error that says whose
+    setup failed, and nobody wrote a detected file."""
+    import json
+
+    prob = dict(world=3, n_beams=64, n_freq_local=4, n_avg=16, n_out=2, n_units=4, n_streams=2, n_blocks=3, ring_blocks=2,
+                gather_root=-1, staged=False, n_dm=0, split=False, seed=1, gpu=0, env={}, bad_rank=1)
+    json.dump(prob, open(tmp_path / "problem.json", "w"))
+    env = dict(os.environ, DSABF_RCCL_LIB=fake_rccl, FAKERCCL_MAILBOX_MB="8")
+    procs = [subprocess.Popen([sys.executable, os.path.join(SUPPORT, "shard_loop_worker.py"), str(r), str(tmp_path)],
+                              env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(3)]
+    try:
+        outs = [p.communicate(timeout=120)[0] for p in procs]
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    assert all(p.returncode not in (0, None) for p in procs), outs
+    assert "this shard's caller reported a failed setup" in outs[1], outs[1]
+    assert "another shard of this run failed its setup" in outs[0] and "another shard of this run failed its setup" in outs[2], outs
+    assert not any(os.path.getsize(tmp_path / f) > 4096 for f in os.listdir(tmp_path) if f.startswith("det."))   # (a header at most)
+
+
 # (soak: DSABF_LONG_TESTS=1 DSABF_SHARD_SEEDS=16:200 walks other seeds)
 @pytest.mark.parametrize("seed", sweep(range(*(int(v) for v in os.environ.get("DSABF_SHARD_SEEDS", "0:16").split(":"))), [6]))
 def test_sharded_observation_loop_under_random_shapes(orc, fake_rccl, tmp_path, seed):

@@ -141,8 +141,13 @@ def test_dm_stream_chunks_are_the_whole_series_call_bit_for_bit(torch, bfmod, or
     the last max_delay rows carried over on the device.  The chunks, joined along t, are bit-equal to orc.dedisperse_dm over
     the whole series -- with the shared-window kernel and with the per-thread-window kernel alone -- chunk k starts where chunk
     k - 1 ended, nothing is emitted before max_delay rows have been seen, and a dispersed pulse that straddles push boundaries
-    comes out at its own trial and time."""
-    from dsabeamformer_amd import api
+    comes out at its own trial and time.  Round 6: the same with the ZERO-COPY feed (bf_dm_stream_reserve: the producer writes the
+    rows into the stage's own buffer, the push only launches) and with both feeds mixed in one stream."""
+    import ctypes as C
+
+    from dsabeamformer_amd import _lib, api
+
+    hip = _lib._preload_hip_runtime()
 
     rng = np.random.default_rng(77)
     if shape == "fine_ladder":
@@ -163,8 +168,11 @@ def test_dm_stream_chunks_are_the_whole_series_call_bit_for_bit(torch, bfmod, or
     d_series = torch.from_numpy(series).cuda()
     streams = [torch.cuda.Stream(), torch.cuda.Stream()]
     row_bytes = n_f * n_b * 4
-    for wide in (1, 0):
+    # ring: the stage's buffer mapped twice back to back (nothing ever moves; the ring here holds 141 / 173 rows: a window wraps
+    # around its end every few pushes) -- or the linear buffer whose carry slides (what a device without VMM gets)
+    for wide, feed, ring in ((1, "copy", 1), (0, "copy", 0), (1, "reserve", 1), (0, "mixed", 1), (1, "mixed", 0), (0, "reserve", 0)):
         bf.set_switch("dm_wide", wide)
+        bf.set_switch("dm_ring", ring)
         dm = api.DmStream(bf, delays, n_f, max_rows)
         assert dm.max_delay == D
         host = torch.full((n_dm * max_rows * n_b,), float("nan"), dtype=torch.float32).pin_memory()
@@ -173,7 +181,18 @@ def test_dm_stream_chunks_are_the_whole_series_call_bit_for_bit(torch, bfmod, or
         while pushed < n_t:
             n = min(sizes[k % len(sizes)], n_t - pushed)
             st = streams[k % 2]
-            first, n_out = dm.push(d_series.data_ptr() + pushed * row_bytes, n, host, st.cuda_stream)
+            src = d_series.data_ptr() + pushed * row_bytes
+            if feed == "reserve" or (feed == "mixed" and k % 3):
+                # the producer (here: a device copy standing in for the beamformer / the gather) writes the rows where the stage
+                # wants them, on the stream the reservation was made on; the push finds them in place
+                dst = dm.reserve(n, st.cuda_stream)
+                with pytest.raises(bfmod.DsabfError, match="previous reservation"):
+                    dm.reserve(n, st.cuda_stream)                                   # one at a time
+                with pytest.raises(bfmod.DsabfError, match="push exactly those"):
+                    dm.push(src, n, host, st.cuda_stream)                           # ... and pushed as reserved
+                assert hip.hipMemcpyAsync(C.c_void_p(dst), C.c_void_p(src), C.c_size_t(n * row_bytes), 3, C.c_void_p(st.cuda_stream)) == 0
+                src = dst
+            first, n_out = dm.push(src, n, host, st.cuda_stream)
             assert first == at and n_out == max(0, pushed + n - D) - max(0, pushed - D)
             st.synchronize()
             if n_out:
@@ -183,10 +202,11 @@ def test_dm_stream_chunks_are_the_whole_series_call_bit_for_bit(torch, bfmod, or
             k += 1
         got = np.concatenate(parts, axis=1)
         assert got.shape == want.shape and at == n_t - D
-        assert np.array_equal(got, want), (shape, wide)
+        assert np.array_equal(got, want), (shape, wide, feed, ring)
         assert int(got[:, :, 0].max(axis=1).argmax()) == k_true and int(got[k_true, :, 0].argmax()) == t0
         dm.close()
     bf.set_switch("dm_wide", 1)
+    bf.set_switch("dm_ring", 1)
     bf.close()
 
 
