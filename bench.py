@@ -156,9 +156,39 @@ def calibrated_weights(w, seed=7):
     return out
 
 
-def pmc_summary(name):
+def pmc_key(kernels, variant, workload, units, paired, detect):
+    """What identifies a counter pass: the device code (build.kernel_build_id(), also the tail of bf_version()), the kernel
+    instantiation and the launch.  bench.py prints it on stderr at start (tools/pmc.sh copies that line into the summary's first
+    line); pmc_for_launch() accepts a committed summary only if its key is THIS run's."""
+    return "kernels=%s variant=%s workload=%s units=%d paired=%d detect=%s" % (kernels, variant.replace(" ", ""), workload, units, int(bool(paired)), detect)
+
+
+def pmc_for_launch(key, profiles_dir=None):
+    """(counter means, file name, stale) of the committed rocprofv3 PMC summary (profiles/*pmc_summary*.txt, tools/pmc.sh) whose first
+    line carries exactly `key` -- the counters of THIS kernel build and launch (a kernel change without a profile
+    refresh must not pair new timings with old counters).  No such file: ({}, the newest summary of the same workload and launch
+    if there is one, True) -- the bench line then says traffic: null, pmc_stale: true and names what it did not use."""
+    profiles_dir = profiles_dir or os.path.join(ROOT, "profiles")
+    launch = key.split(" ", 2)[2]                      # workload= units= paired= detect=
+    near = None
+    for path in sorted(glob.glob(os.path.join(profiles_dir, "*pmc_summary*.txt")), reverse=True):
+        try:
+            first = open(path).readline().strip()
+        except OSError:
+            continue
+        if not first.startswith("# pmc_key "):
+            continue
+        have = first[len("# pmc_key "):]
+        if have == key:
+            return pmc_summary(os.path.basename(path), profiles_dir), os.path.basename(path), False
+        if near is None and have.split(" ", 2)[2:] == [launch]:
+            near = os.path.basename(path)
+    return {}, near, True
+
+
+def pmc_summary(name, profiles_dir=None):
     """Counter means of one committed rocprofv3 PMC summary (tools/pmc.sh), {} if absent."""
-    path = os.path.join(ROOT, "profiles", name)
+    path = os.path.join(profiles_dir or os.path.join(ROOT, "profiles"), name)
     vals = {}
     if os.path.exists(path):
         fused = True        # sections are headed by a kernel name; only the fused kernel's counters are wanted (the streaming
@@ -402,6 +432,25 @@ def count_gpus():
     return n
 
 
+def count_gpus_in_child(timeout_s=120.0):
+    """What a short-lived CHILD process says torch.cuda.device_count() is (counting devices does not initialise the GPU on this image;
+    the parent still never loads HIP).  The second opinion when the sysfs walk of count_gpus() comes up short: a container that exposes
+    /dev/kfd without that sysfs tree, or render nodes under another permission model, must not lose the whole run to it.  None: the
+    child failed or did not answer in time (first `import torch` on a fresh box can take a minute or two).  DSABF_BENCH_CHILD_COUNT:
+    tests (the child's answer, without a child)."""
+    import subprocess
+
+    fake = os.environ.get("DSABF_BENCH_CHILD_COUNT")
+    if fake is not None:
+        return int(fake) if fake.strip().lstrip("-").isdigit() else None
+    try:
+        r = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True, text=True,
+                           timeout=timeout_s, start_new_session=True)
+        return int(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 and r.stdout.strip() else None
+    except Exception:
+        return None
+
+
 def self_launch(args):
     """`python bench.py --gpus N` with N > 1 and no launcher around it: run torch.distributed.run as a CHILD process and exit
     with its status.  This process never initialises the GPU -- the device count comes from sysfs (count_gpus), torch is not
@@ -415,8 +464,24 @@ def self_launch(args):
     one_gpu = os.environ.get("DSABF_BENCH_ONE_GPU") == "1"     # test mode: the ranks time-share GPU 0
     if not one_gpu:
         have = count_gpus()
+        have_child = None
         if have < args.gpus:
-            sys.exit("bench.py --gpus %d: this node shows %d GPU(s)" % (args.gpus, have))
+            # the sysfs walk can be wrong (no topology tree in this container, another permission model on the render nodes): ask a
+            # child before refusing
+            have_child = count_gpus_in_child()
+        if have < args.gpus and (have_child is None or have_child < args.gpus):
+            # refused -- as ONE JSON line on stdout like every other outcome of this command (value null + error), both counts in it
+            msg = ("bench.py --gpus %d: this node shows %d GPU(s) in sysfs (%s) and %s to a child process's torch.cuda.device_count()"
+                   % (args.gpus, have, os.environ.get("DSABF_KFD_TOPOLOGY", "/sys/class/kfd/kfd/topology/nodes"),
+                      "no answer" if have_child is None else "%d" % have_child))
+            print(json.dumps({"metric": METRIC_NAME, "value": None, "unit": "beam-blocks/s", "n_gpus": args.gpus, "error": msg,
+                              "stage": "counting the GPUs (no rank was started)", "rank": None,
+                              "gpus_seen": {"sysfs": have, "child_device_count": have_child}}), flush=True)
+            print(msg, file=sys.stderr, flush=True)
+            sys.exit(6)
+        if have < args.gpus:
+            print("bench.py: sysfs shows %d GPU(s), a child process's torch.cuda.device_count() %d: going by the child"
+                  % (have, have_child), file=sys.stderr, flush=True)
     port = os.environ.get("MASTER_PORT")
     if not port:
         with socket.socket() as s:                              # a free port of the loopback interface
@@ -875,6 +940,12 @@ def main():
 
     info = bf.kernel_info(units)
     paired = "PAIRED" in info["kernel"]
+    # the key a committed counter pass must carry to be quoted beside this run's timings: the device code the LIBRARY says it holds
+    # (bf_version() ends in "kernels <id>"), the instantiation this handle launches, the launch
+    kernels_id = bfm.load().bf_version().decode().rsplit("kernels ", 1)[-1].rstrip(")")
+    this_pmc_key = pmc_key(kernels_id, bf.variant_key(), args.workload, units, paired, args.detect)
+    if rank == 0:
+        print("bench.py: pmc_key %s" % this_pmc_key, file=sys.stderr, flush=True)
     peak_cache = {}        # the micro-benchmarks behind roofline.peak_measured run once per process
 
     def build_record(elapsed, events, extra_warm):
@@ -891,12 +962,9 @@ def main():
         launch_ops = ops_per_block * blocks_per_step / world    # per launch (this rank's kernel)
         launch_bytes = bytes_per_block * blocks_per_step / world
         mfma_bound = args.workload != "c2"
-        # committed rocprofv3 PMC summaries of exactly this launch (tools/pmc.sh), if any
-        pmc_name = {("c3", 128, True): "r05_c3_paired_pmc_summary.txt", ("c3", 128, False): "r05_c3_general_pmc_summary.txt",
-                    ("c5", 16, True): "r05_c5_pmc_summary.txt", ("c5", 16, False): "r05_c5_general_pmc_summary.txt",
-                    ("c2", 128, True): "r05_c2_pmc_summary.txt"}.get(
-            (args.workload, units, paired))
-        pmc = pmc_summary(pmc_name) if (pmc_name and world == 1 and args.detect == "canonical") else {}
+        # the committed rocprofv3 PMC summary of exactly this kernel build and launch (tools/pmc.sh), if there is one: resolved by the
+        # key stored IN the summary, never by a file name
+        pmc, pmc_name, pmc_stale = pmc_for_launch(this_pmc_key) if world == 1 else ({}, None, False)
         if mfma_bound:
             achieved = launch_ops / (kern_avg_ms * 1e-3) / 1e12
             roof = {"bound": "mfma", "achieved": achieved, "peak": INT8_DENSE_PEAK_TOPS, "unit": "TOP/s",
@@ -970,6 +1038,10 @@ def main():
                      "executed_frac": (executed / (kern_avg_ms * 1e-3) / 1e12 / INT8_DENSE_PEAK_TOPS) if mfma_bound else None,
                      "mfma_busy_frac": pmc_mfma_busy(pmc),
                      "pmc_source": ("profiles/" + pmc_name) if pmc else None,
+                     # true: no committed counter pass carries this run's key (kernel build id + instantiation + launch) -- the
+                     # counters of an OLDER build (pmc_not_used) are not paired with these timings; traffic etc. stay null
+                     "pmc_stale": bool(pmc_stale and world == 1), "pmc_key": this_pmc_key,
+                     "pmc_not_used": ("profiles/" + pmc_name) if (pmc_stale and pmc_name) else None,
                      # traffic and mfma_busy_frac are read from the committed rocprofv3 summary named above -- measured
                      # on an earlier box with the same kernel, NOT observed in this run (everything else in this object is)
                      "from_committed_profile": (["traffic", "mfma_busy_frac"] + (["valu_per_mfma", "issue_occupancy", "bound_measured",
@@ -1231,7 +1303,8 @@ def main():
             # supplementary, never the headline, same inputs:
             if paired:
                 g = variant(0, "0")
-                gp = pmc_summary("r05_c3_general_pmc_summary.txt") if args.workload == "c3" and units == 128 else {}
+                gkey = pmc_key(kernels_id, bf.variant_key().replace("true, 4, 4>", "false, 4, 4>"), args.workload, units, False, "canonical")
+                gp, gp_name, gp_stale = pmc_for_launch(gkey)
                 g.update({"mfma_busy_frac": pmc_mfma_busy(gp), "note": "DSABF_PAIRED=0: the kernel any weight set without the "
                           "conjugate symmetry runs; every algorithmic int8 op executes on the MFMA pipe; same bits"})
                 out["general_kernel"] = g
@@ -1281,7 +1354,7 @@ def main():
             s5 = variant(0, wl="c5", n_units=16, reps=30)
             s5["workload"] = ("C5 shard: one of 8 ranks of BASELINE configs[4] = 128 freq x 512 beams x 100 ant x 2 pol, "
                               "N_TIME 256, 16 gemm-units per launch; beam-blocks here are 512 beams x 128 freq")
-            s5["pmc_source"] = "profiles/r05_c5_pmc_summary.txt is the whole-band launch (16 gemm-units x 1024 freq), not this shard"
+            s5["pmc_source"] = "the committed C5 counter pass is the whole-band launch (16 gemm-units x 1024 freq), not this shard"
             out["c5_shard"] = s5
             # the same C3 shape with 256 antennas (four k-steps: the deep classes of fused16_kernel) -- the
             # detect is amortised over 4 x the MACs.  The linear fan is conjugate-symmetric (pair kernel); the calibrated set is not.

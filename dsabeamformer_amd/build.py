@@ -68,6 +68,22 @@ def sources() -> list[str]:
 
 
 STAMP = os.path.join(PKG, "build", "flags.stamp")   # the flag set the in-tree library was built with
+KID_STAMP = os.path.join(PKG, "build", "kernel_id.stamp")   # the kernel build id compiled into bf_version()
+RUNTIME_SRC = os.path.join(CSRC, "bf_runtime.cpp")
+
+
+def kernel_build_id() -> str:
+    """Identity of the device code: a hash over every kernel source (csrc/*.hip, *.hpp, *.h, *.inc) and the flag set they are compiled
+    with.  Compiled into the library (bf_version() ends in "kernels <id>") and written into every rocprofv3 counter summary under
+    profiles/ (tools/pmc.sh), so that bench.py pairs live timings only with counters of THE SAME kernels."""
+    import hashlib
+
+    h = hashlib.sha256(_stamp().encode())
+    for p in sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.hpp")) + glob.glob(os.path.join(CSRC, "*.h")) +
+                    glob.glob(os.path.join(CSRC, "*.inc"))):
+        h.update(os.path.basename(p).encode())
+        h.update(open(p, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def _stamp() -> str:
@@ -80,6 +96,8 @@ def _stale() -> bool:
     # a library built with other flags (an experiment's DSABF_EXTRA_FLAGS, tools/variants.sh) is stale even if it is newer
     # than every source: never let tests / bench / profiles silently run a variant build
     if not os.path.exists(STAMP) or open(STAMP).read() != _stamp():
+        return True
+    if not os.path.exists(KID_STAMP) or open(KID_STAMP).read() != kernel_build_id():
         return True
     t = os.path.getmtime(LIB)
     if not all(os.path.exists(b) for b in MAINS):
@@ -97,16 +115,19 @@ def build(force: bool = False, verbose: bool = False) -> str:
     objdir = os.path.join(PKG, "build")
     os.makedirs(objdir, exist_ok=True)
     procs = []
+    kid = kernel_build_id()
+    kid_same = os.path.exists(KID_STAMP) and open(KID_STAMP).read() == kid
     for src in sources():
         obj = os.path.join(objdir, os.path.basename(src) + ".o")
         objs.append(obj)
         flags_same = os.path.exists(STAMP) and open(STAMP).read() == _stamp()
-        if not force and flags_same and os.path.exists(obj) and os.path.getmtime(obj) > max(
+        is_runtime = os.path.abspath(src) == os.path.abspath(RUNTIME_SRC)   # carries the kernel build id: rebuilt whenever that changes
+        if not force and flags_same and (kid_same or not is_runtime) and os.path.exists(obj) and os.path.getmtime(obj) > max(
                 [os.path.getmtime(src)] + [os.path.getmtime(p) for p in glob.glob(os.path.join(CSRC, "*.h*"))] +
                 [os.path.getmtime(p) for p in glob.glob(os.path.join(ROOT, "include", "*.h*"))]):
             continue
         # .hip: device + host; .cpp: plain host C++ (HIP host API only), also through hipcc for the include paths
-        cmd = [HIPCC] + flags_for(src) + ["-c", src, "-o", obj]
+        cmd = [HIPCC] + flags_for(src) + (['-DDSABF_KERNEL_BUILD_ID="%s"' % kid] if is_runtime else []) + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
@@ -132,6 +153,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
     subprocess.check_call(cmd)
     with open(STAMP, "w") as fp:
         fp.write(_stamp())
+    with open(KID_STAMP, "w") as fp:
+        fp.write(kid)
     # the CLI programs are ordinary HIP applications: they link libdsabf.so AND the HIP runtime
     for exe, src in MAINS.items():
         if src == REPLICAS_SRC:   # a plain launcher: no HIP, no libdsabf (it must not initialise a GPU before exec)

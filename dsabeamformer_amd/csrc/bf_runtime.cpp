@@ -13,6 +13,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -159,7 +160,10 @@ int set_error(int code, const char* msg)
 extern "C" {
 
 const char* bf_last_error(void) { return g_err.c_str(); }
-const char* bf_version(void) { return "dsabf 0.2 (gfx950, fused expand+int8 MFMA+detect)"; }
+#ifndef DSABF_KERNEL_BUILD_ID
+#define DSABF_KERNEL_BUILD_ID "unknown"   // build.py: a hash over the kernel sources and their flags (build.kernel_build_id())
+#endif
+const char* bf_version(void) { return "dsabf 0.3 (gfx950, fused expand+int8 MFMA+detect; kernels " DSABF_KERNEL_BUILD_ID ")"; }
 
 int bf_config_default(bf_config* cfg, int debug)
 {
@@ -1045,7 +1049,7 @@ struct bf_dm_stream {
     size_t fill = 0;              // linear: rows of d_buf in use, [fill - carry, fill) are the newest rows of the series
     hipMemGenericAllocationHandle_t phys{};
     size_t phys_bytes = 0;
-    bool phys_created = false, va_reserved = false, mapped0 = false, mapped1 = false;
+    bool phys_created = false, mapped0 = false, mapped1 = false;
     uint64_t pushed = 0;          // rows the stream has been given
     uint64_t n_push = 0;          // pushes so far
     float* d_buf = nullptr;       // ring: the double mapping (2 x phys_bytes of address space); linear: cap_rows x [freq][beam]
@@ -1071,12 +1075,11 @@ static void dm_stream_release(bf_dm_stream* s)
         s->done[k] = nullptr;
         s->done_recorded[k] = false;
     }
-    if (s->ring || s->va_reserved || s->phys_created) {
+    if (s->ring || s->phys_created) {
         if (s->mapped0) (void)hipMemUnmap(s->d_buf, s->phys_bytes);
         if (s->mapped1) (void)hipMemUnmap(reinterpret_cast<char*>(s->d_buf) + s->phys_bytes, s->phys_bytes);
-        if (s->va_reserved) (void)hipMemAddressFree(s->d_buf, 2 * s->phys_bytes);
-        if (s->phys_created) (void)hipMemRelease(s->phys);
-        s->mapped0 = s->mapped1 = s->va_reserved = s->phys_created = false;
+        if (s->phys_created) (void)hipMemRelease(s->phys);   // (the addresses go back to nobody: ring_address_space)
+        s->mapped0 = s->mapped1 = s->phys_created = false;
     } else {
         (void)hipFree(s->d_buf);
     }
@@ -1087,6 +1090,38 @@ static void dm_stream_release(bf_dm_stream* s)
     s->d_delays = nullptr;
     s->d_flags = nullptr;
     s->h = nullptr;
+}
+
+// Address space for the rings: taken from arenas that are reserved once per process and NEVER given back or handed out twice.
+// On this stack (ROCm 7.2, gfx950) a virtual range that is unmapped and mapped again to other physical memory keeps stale
+// translations: kernels and copies then disagree about where the rows are (tools/vmm_probe.cpp modes 0-4: wrong from the second
+// ring on, whatever is freed, synchronised or allocated in between; modes 5-6, fresh addresses every time: always right --
+// profiles/r06_vmm_probe.txt).  Addresses cost nothing (47 bits of them); a stage takes 2 x its ring's bytes.
+static void* ring_address_space(size_t bytes, size_t gran)
+{
+    static std::mutex mu;
+    static char* base = nullptr;
+    static size_t size = 0, used = 0;
+    std::lock_guard<std::mutex> lock(mu);
+    used = (used + gran - 1) / gran * gran;
+    if (!base || used + bytes > size) {
+        void* va = nullptr;
+        for (size_t want : {(size_t)256 << 30, (size_t)32 << 30, (size_t)4 << 30, bytes}) {
+            if (want < bytes) continue;
+            if (hipMemAddressReserve(&va, want, gran, nullptr, 0) == hipSuccess && va) {
+                base = static_cast<char*>(va);
+                size = want;
+                used = 0;
+                break;
+            }
+            (void)hipGetLastError();
+            va = nullptr;
+        }
+        if (!va) return nullptr;
+    }
+    void* out = base + used;
+    used += bytes;
+    return out;
 }
 
 // The ring: one physical allocation, mapped at va and at va + phys_bytes.  False (and nothing left behind): no VMM here.
@@ -1110,11 +1145,9 @@ static bool dm_ring_create(bf_dm_stream* s, int device, size_t want_rows)
     const size_t step = gran / g;
     const size_t rows = (want_rows + step - 1) / step * step;
     s->phys_bytes = rows * row_bytes;
-    void* va = nullptr;
-    bool ok = hipMemCreate(&s->phys, s->phys_bytes, &prop, 0) == hipSuccess;
+    void* va = ring_address_space(2 * s->phys_bytes, gran);
+    bool ok = va != nullptr && hipMemCreate(&s->phys, s->phys_bytes, &prop, 0) == hipSuccess;
     s->phys_created = ok;
-    ok = ok && hipMemAddressReserve(&va, 2 * s->phys_bytes, gran, nullptr, 0) == hipSuccess;
-    s->va_reserved = ok;
     s->d_buf = static_cast<float*>(va);
     ok = ok && (s->mapped0 = hipMemMap(va, s->phys_bytes, 0, s->phys, 0) == hipSuccess);
     ok = ok && (s->mapped1 = hipMemMap(static_cast<char*>(va) + s->phys_bytes, s->phys_bytes, 0, s->phys, 0) == hipSuccess);
@@ -1125,9 +1158,8 @@ static bool dm_ring_create(bf_dm_stream* s, int device, size_t want_rows)
     if (!ok) {
         if (s->mapped0) (void)hipMemUnmap(va, s->phys_bytes);
         if (s->mapped1) (void)hipMemUnmap(static_cast<char*>(va) + s->phys_bytes, s->phys_bytes);
-        if (s->va_reserved) (void)hipMemAddressFree(va, 2 * s->phys_bytes);
         if (s->phys_created) (void)hipMemRelease(s->phys);
-        s->mapped0 = s->mapped1 = s->va_reserved = s->phys_created = false;
+        s->mapped0 = s->mapped1 = s->phys_created = false;
         s->d_buf = nullptr;
         (void)hipGetLastError();
         return false;

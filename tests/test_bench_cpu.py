@@ -4,6 +4,8 @@ import os
 import subprocess
 import sys
 
+import pytest
+
 from conftest import ROOT
 
 sys.path.insert(0, ROOT)
@@ -43,6 +45,33 @@ def test_committed_pmc_summaries_give_the_quoted_traffic_and_mfma_busy():
     assert abs(c3["SQ_INSTS_VALU_MFMA_I8"] * 32768 / (8 * 256 * 64 * 32 * 256 * 2048 / 2) - 1) < 0.01
     assert abs(gen["SQ_INSTS_VALU_MFMA_I8"] * 32768 / (8 * 256 * 64 * 32 * 256 * 2048) - 1) < 0.01
     assert bench.pmc_summary("no_such_file.txt") == {} and bench.pmc_traffic({}) is None and bench.pmc_mfma_busy({}) is None
+
+
+def test_counters_are_quoted_only_for_the_build_they_were_taken_from(tmp_path):
+    """the line's counters (traffic, mfma_busy_frac, ...) come from a committed rocprofv3 pass -- resolved by the
+    key stored IN the summary (kernel build id = the tail of bf_version(), the instantiation, the launch), not by a per-round file
+    name.  A summary of another build is not used: traffic null, pmc_stale true, and the line names what it left aside."""
+    body = ("void dsabf::fused16_kernel<-1, 32, false, 0, true, 4, 4>\n  FETCH_SIZE                       mean 526739  (n=752)\n"
+            "  WRITE_SIZE                       mean 524288  (n=731)\ndsabf::expand_kernel\n  FETCH_SIZE                       mean 1  (n=3)\n")
+    key = bench.pmc_key("0123456789abcdef", "fused16_kernel<-1, 32, false, 0, true, 4, 4>", "c3", 128, True, "canonical")
+    assert key == "kernels=0123456789abcdef variant=fused16_kernel<-1,32,false,0,true,4,4> workload=c3 units=128 paired=1 detect=canonical"
+    (tmp_path / "r09_c3_paired_pmc_summary.txt").write_text("# pmc_key %s\n%s" % (key, body))
+    (tmp_path / "r08_c3_paired_pmc_summary.txt").write_text("# pmc_key %s\n%s" % (key.replace("0123456789abcdef", "an_older_build_id"), body))
+    (tmp_path / "r05_c3_paired_pmc_summary.txt").write_text(body)                       # no key: a summary from before round 6
+    vals, name, stale = bench.pmc_for_launch(key, str(tmp_path))
+    assert not stale and name == "r09_c3_paired_pmc_summary.txt" and vals["FETCH_SIZE"] == 526739 and vals["WRITE_SIZE"] == 524288
+    assert bench.pmc_traffic(vals) == (2 * 526739 + 524288) * 1024
+    # the kernels changed and nobody refreshed the profile: a doctored key = a stale summary
+    vals, name, stale = bench.pmc_for_launch(key.replace("0123456789abcdef", "fedcba9876543210"), str(tmp_path))
+    assert stale and vals == {} and name == "r09_c3_paired_pmc_summary.txt" and bench.pmc_traffic(vals) is None
+    # another launch of the same build: nothing to fall back to by name
+    vals, name, stale = bench.pmc_for_launch(key.replace("units=128", "units=32"), str(tmp_path))
+    assert stale and vals == {} and name is None
+    # ... and the committed summaries of THIS tree carry keys (the refresh script writes them; bf_version() reports the same id)
+    from dsabeamformer_amd import build
+    import dsabeamformer_amd as bfm
+
+    assert bfm.load().bf_version().decode().endswith("kernels %s)" % build.kernel_build_id())
 
 
 def test_watchdog_prints_exactly_one_line(capsys):
@@ -145,17 +174,46 @@ def test_gpu_count_comes_from_sysfs_not_from_the_hip_runtime(tmp_path, monkeypat
     assert "import torch" not in inspect.getsource(bench.self_launch) and "import torch" not in inspect.getsource(bench.count_gpus)
 
 
-def test_multi_gpu_request_on_a_box_with_fewer_gpus_says_so(tmp_path):
-    """`python bench.py --gpus 2` on a box that shows one GPU (an 8-GPU host, one render node in the container): a message, a
-    non-zero status, NO child process, no line -- whatever hardware the test itself runs on (the topology is a fixture)."""
-    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "DSABF_BENCH_ONE_GPU",
-                                                             "HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES")}
-    env.update(_fake_topology(tmp_path, 8, {3}))
+def _clean_env():
+    return {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "DSABF_BENCH_ONE_GPU", "HIP_VISIBLE_DEVICES",
+                                                              "ROCR_VISIBLE_DEVICES", "DSABF_BENCH_CHILD_COUNT")}
+
+
+@pytest.mark.parametrize("child", ["1", "none"])
+def test_multi_gpu_request_on_a_box_with_fewer_gpus_says_so(tmp_path, child):
+    """`python bench.py --gpus 2` on a box that shows one GPU (an 8-GPU host, one render node in the container) -- and a child
+    process's torch.cuda.device_count() agrees, or does not answer: refused with ONE JSON line on stdout like every other outcome
+    (value null, the error, BOTH counts), a non-zero status, no launcher -- whatever hardware the test itself runs on (the
+    topology is a fixture, the child's answer too: DSABF_BENCH_CHILD_COUNT)."""
+    env = _clean_env()
+    env.update(_fake_topology(tmp_path, 8, {3}), DSABF_BENCH_CHILD_COUNT=child)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
                        timeout=300, env=env)
-    assert r.returncode != 0 and "this node shows 1 GPU(s)" in (r.stderr + r.stdout)
+    assert r.returncode == 6 and "this node shows 1 GPU(s)" in r.stderr
     assert "starting" not in r.stderr                                   # no launcher was started
-    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["value"] is None and d["n_gpus"] == 2 and "this node shows 1 GPU(s)" in d["error"] and d["rank"] is None
+    assert d["gpus_seen"] == {"sysfs": 1, "child_device_count": 1 if child == "1" else None}
+
+
+def test_a_container_without_the_sysfs_tree_goes_by_the_childs_count(tmp_path):
+    """/dev/kfd without /sys/class/kfd/kfd/topology (or render nodes under another permission model) made the
+    sysfs walk see 0 GPUs and the run was lost to a hard refusal.  Now a short-lived child's torch.cuda.device_count() is the
+    second opinion: if IT sees enough GPUs the launcher starts (here a stand-in that answers at once)."""
+    code = ("import sys; sys.path.insert(0, %r); import bench\n"
+            "bench.launcher_command = lambda n, argv, port: [sys.executable, '-c', 'print(\"LAUNCHED %%d\" %% ' + str(n) + ')']\n"
+            "sys.argv = ['bench.py', '--gpus', '4']\n"
+            "bench.main()\n" % ROOT)
+    env = _clean_env()
+    env.update(DSABF_KFD_TOPOLOGY=str(tmp_path / "no_such_tree"), DSABF_DRI_DIR=str(tmp_path), DSABF_BENCH_CHILD_COUNT="8")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "LAUNCHED 4" in r.stdout and "going by the child" in r.stderr and "sysfs shows 0 GPU(s)" in r.stderr
+    import inspect
+    import re
+    assert not re.search(r"^\s*(import|from) torch", inspect.getsource(bench.count_gpus_in_child), re.M)   # the PARENT never imports torch
 
 
 def test_a_launcher_that_never_returns_is_killed_and_reported(tmp_path):

@@ -4,6 +4,7 @@ GPU 0 and their point-to-point messages travel through tests/support/fake_rccl.c
 RCCL entry points csrc/bf_comm.cpp binds (selected with DSABF_RCCL_LIB; same matching rules: per-pair issue order,
 concurrent progress inside a group, sizes must agree).  Everything else is the product: bf_comm_create,
 bf_gather_detected's plan walk and grouping, `beam -R world -r rank`, the gather inside run_observation."""
+import json
 import os
 import subprocess
 import sys
@@ -148,26 +149,32 @@ def test_beam_sharded_over_two_ranks_gathers_the_whole_band(orc, fake_rccl, tmp_
             assert np.array_equal(raw[gemm][:, 128 * r:128 * (r + 1)], want), (gemm, r)
 
 
-@pytest.mark.parametrize("gather,n", sweep([("alltoall", 2), ("root", 2), ("alltoall", 8)], [("alltoall", 8)]))
-def test_bench_with_two_ranks_on_one_gpu(fake_rccl, gather, n):
+@pytest.mark.parametrize("gather,n,wl", sweep([("alltoall", 2, "c3"), ("root", 2, "c3"), ("alltoall", 8, "c3"), ("alltoall", 8, "c5")],
+                                               [("alltoall", 8, "c3"), ("alltoall", 8, "c5")]))
+def test_bench_with_two_ranks_on_one_gpu(fake_rccl, gather, n, wl):
     """bench.py as the driver launches it for N = 2 (torch.distributed.run, one process per rank) -- with both ranks on
     GPU 0, gloo for the barrier / max-over-ranks / id broadcast and the loopback stand-in under bf_gather_detected: the
     N > 1 control flow (sharded weights and inputs, double-buffered gather on the side stream, every gather mode side by
-    side) runs end to end and rank 0 prints one well-formed line.  The numbers mean nothing (two ranks on one GPU)."""
+    side) runs end to end and rank 0 prints one well-formed line.  The numbers mean nothing (two ranks on one GPU).
+    wl = c5: BASELINE configs[4] "on 8 MI355X" -- 100 antennas, 512 beams, 1024 channels = 128 per rank, 256-KiB rows -- as the
+    driver would launch it (the committed shape of that line: profiles/r06_bench_c5_n8_loopback.json, --units 16)."""
     import json
+
+    F, B = (1024, 512) if wl == "c5" else (256, 256)
 
     # (n = 8: the driver's largest launch, 32 channels per rank; 64 rings of 4 MiB keep the shared memory small)
     env = dict(os.environ, DSABF_RCCL_LIB=fake_rccl, DSABF_BENCH_ONE_GPU="1", FAKERCCL_MAILBOX_MB="64" if n == 2 else "4")
     port = str(29700 + os.getpid() % 200)
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
                         "127.0.0.1", "--master-port", port, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "3",
-                        "--warmup", "1", "--units", "4" if n == 2 else "8", "--gather", gather, "--dist-backend", "gloo", "--min-warm-seconds", "0.1",
-                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env)
+                        "--warmup", "1", "--units", "2" if wl == "c5" else "4" if n == 2 else "8", "--workload", wl, "--gather", gather,
+                        "--dist-backend", "gloo", "--min-warm-seconds", "0.1", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, (r.stdout + r.stderr)[-4000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1                                   # rank 0 only
     d = json.loads(lines[0])
-    assert d["n_gpus"] == n and d["config"]["freq_per_gpu"] == 256 // n and d["scaling"] == "strong"
+    assert d["n_gpus"] == n and d["config"]["freq_per_gpu"] == F // n and d["scaling"] == "strong"
+    assert ("100 ant" in d["config"]["workload"]) == (wl == "c5")
     assert d["config"]["gather"].startswith(gather) and "C-ABI" in d["config"]["gather"] and "gather_note" not in d["config"]
     # what the LIBRARY says about the communicator (bf_comm_info): as many ranks as the launcher started, and which file
     assert d["rccl"]["ranks"] == n and d["rccl"]["lib"].endswith("libfakerccl.so") and d["rccl"]["version"] == 0
@@ -183,9 +190,9 @@ def test_bench_with_two_ranks_on_one_gpu(fake_rccl, gather, n):
     assert modes["alltoall_freq_major"]["messages_sent_per_rank_per_step"] == (n - 1) * (n_rows // n)
     assert modes["alltoall_freq_major_staged"]["messages_sent_per_rank_per_step"] == modes["alltoall_rank_major"]["messages_sent_per_rank_per_step"] == n - 1
     assert modes["root_freq_major"]["messages_sent_per_rank_per_step"] == n_rows and modes["root_freq_major_staged"]["messages_sent_per_rank_per_step"] == 1
-    assert modes["alltoall_rank_major"]["bytes_sent_per_rank_per_step"] == n_rows * (256 // n) * 256 * 4 * (n - 1) / n
+    assert modes["alltoall_rank_major"]["bytes_sent_per_rank_per_step"] == n_rows * (F // n) * B * 4 * (n - 1) / n
     # the link model beside it: alltoall loads every link with 1 / n of a rank's powers per direction, root the root's with all of them
-    shard = n_rows * (256 // n) * 256 * 4
+    shard = n_rows * (F // n) * B * 4
     lm_a, lm_r = modes["alltoall_rank_major"]["link_model"], modes["root_rank_major"]["link_model"]
     assert lm_a["bytes_on_the_busiest_link_per_step"] == shard / n and lm_r["bytes_on_the_busiest_link_per_step"] == shard
     assert abs(lm_a["ms_at_75_gbs"] - shard / n / 75e9 * 1e3) < 1e-9 and lm_a["measured_gbs_per_link"] > 0 and "link_model" not in modes["none"]
@@ -291,7 +298,9 @@ def test_plain_multi_gpu_request_on_this_one_gpu_box_is_refused_without_starting
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "DSABF_BENCH_ONE_GPU")}
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode != 0 and "this node shows 1 GPU(s)" in r.stderr and "starting" not in r.stderr
-    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]       # refused as a line (value null), both counts in it: the
+    d = json.loads(lines[0])                                               # sysfs walk and a child's torch.cuda.device_count() agree
+    assert len(lines) == 1 and d["value"] is None and d["gpus_seen"] == {"sysfs": 1, "child_device_count": 1}
 
 
 def test_bench_exits_nonzero_when_the_communicator_cannot_be_created():

@@ -123,9 +123,19 @@ def test_plain_bench_prints_its_one_line(torch):
     d = json.loads(lines[0])
     roof = d["roofline"]
     assert d["value"] > 0 and d["n_gpus"] == 1 and roof["bound"] == "mfma" and 0.3 < roof["frac"] < 0.7
-    assert roof["bound_measured"] == "simd-issue" and 15 < roof["valu_per_mfma"] < 19 and 0.9 < roof["issue_occupancy"] < 1.1
-    assert abs(roof["issue_model_cycles_per_mfma"] - (13 + 2.45 * roof["valu_per_mfma"])) < 1e-6 and 1.8 < roof["clock_ghz_under_load"] < 2.5
-    assert {"valu_per_mfma", "issue_occupancy", "bound_measured", "clock_ghz_under_load"} <= set(roof["from_committed_profile"])
+    # the counters beside the timings are those of THIS build (the key stored in the committed summary = the library's own build id
+    # + instantiation + launch; tests/test_bench_cpu.py holds the committed summaries to the tree's build id) ...
+    from dsabeamformer_amd import build
+    import dsabeamformer_amd as bfm
+
+    assert ("kernels=%s " % build.kernel_build_id()) in roof["pmc_key"] and bfm.load().bf_version().decode().endswith(build.kernel_build_id() + ")")
+    if not roof["pmc_stale"]:
+        assert roof["pmc_source"].startswith("profiles/r06_") and roof["traffic"] is not None and roof["pmc_not_used"] is None
+        assert roof["bound_measured"] == "simd-issue" and 15 < roof["valu_per_mfma"] < 19 and 0.9 < roof["issue_occupancy"] < 1.1
+        assert abs(roof["issue_model_cycles_per_mfma"] - (13 + 2.45 * roof["valu_per_mfma"])) < 1e-6 and 1.8 < roof["clock_ghz_under_load"] < 2.5
+        assert {"valu_per_mfma", "issue_occupancy", "bound_measured", "clock_ghz_under_load"} <= set(roof["from_committed_profile"])
+    else:   # ... or none at all: a kernel change without a profile refresh never pairs new timings with old counters
+        assert roof["traffic"] is None and roof["mfma_busy_frac"] is None and roof["pmc_source"] is None and roof["from_committed_profile"] == []
 
 
 # ---- f4 as a pipeline stage: DM-trial dedispersion of the detected STREAM ---------------------------------

@@ -27,7 +27,18 @@ for f in glob.glob(out + "/pass*/**/*counter_collection.csv", recursive=True):
         # the dispatch's own duration in the pass that counted the cycles: clock = GRBM_GUI_ACTIVE / 8 / this
         if r["Counter_Name"] == "GRBM_GUI_ACTIVE" and r.get("Start_Timestamp") and r.get("End_Timestamp"):
             agg[k.split("(")[0][-60:]]["_KERNEL_NS_GRBM_PASS"].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
+# first line: the key of this pass -- kernel build id (bf_version()), instantiation, launch -- as bench.py printed it on stderr;
+# bench.py quotes a committed summary beside its timings only if this line is its own run's (pmc_for_launch)
+key = None
+for f in sorted(glob.glob(out + "/pass*.log")):
+    for line in open(f, errors="replace"):
+        if line.startswith("bench.py: pmc_key "):
+            key = line[len("bench.py: pmc_key "):].strip()
+            break
+    if key:
+        break
 with open(out + "/summary.txt", "w") as fp:
+    fp.write("# pmc_key %s\n" % (key or "unknown"))
     for k, d in agg.items():
         fp.write(k + "\n")
         for c, v in sorted(d.items()):
