@@ -87,7 +87,9 @@ def kernel_build_id() -> str:
 
 
 def _stamp() -> str:
-    return " ".join(FLAGS) + " | " + repr(sorted(SCHED_BY_SUFFIX.items()))
+    # (the tree's own location is not part of the flag set: the same tree under another path -- the GPU box's scratch copy, a
+    #  checkout elsewhere -- is the same build, and bf_version()'s kernel build id must not depend on where it was compiled)
+    return (" ".join(FLAGS) + " | " + repr(sorted(SCHED_BY_SUFFIX.items()))).replace(ROOT, "<root>")
 
 
 def _stale() -> bool:

@@ -28,8 +28,10 @@ constexpr int kDetCanonical = 0;   // xx = x*x; yy = y*y; p = xx + yy; acc += p 
 constexpr int kDetFast = 1;        // acc = fma(d, d, acc) on the unscaled integers        (4)
 constexpr int kDetContracted = 2;  // yy = y*y; p = fma(x, x, yy); acc += p  (nvcc -fmad)  (5)
 
-// Antenna classes (template parameter AIN).  A positive value is a compile-time antenna count (the hot geometries).
-// The negative classes take the count from FusedArgs::n_ant at run time:
+// Antenna classes (template parameter AIN).  A positive value is a compile-time antenna count: since round 6 only 100 (BASELINE
+// config 5, whose 100-byte rows are dword-staged: 3 - 7 % faster than the run-time class that covers them); the compile-time
+// classes of 64 / 128 / 192 / 256 antennas measured inside the box noise of the run-time ones and were folded into them
+// (profiles/r06_class_fold_ab.txt, r06_ab_fold_c3.txt).  The negative classes take the count from FusedArgs::n_ant at run time:
 constexpr int kAntK1P16 = -1;  // <= 64 antennas, n_ant % 16 == 0: one k-step, 16-byte staging pieces
 constexpr int kAntK1P4 = -2;   // <= 64 antennas, n_ant % 4 == 0:  one k-step, 4-byte staging pieces
 constexpr int kAntK2P16 = -3;  // 65..128 antennas, n_ant % 16 == 0: two k-steps
@@ -155,7 +157,7 @@ constexpr int kColTilesWide16 = 8;           // ... of the two-k-step conjugate-
 // C(b) = (P1 - P2) + j(P3 + P4) and C(B-1-b) = (P1 + P2) + j(P3 - P4): two beams for the MFMA work of one, exact in
 // int32 (the +-P2 / +-P4 are 4 integer VALU ops per sample pair; P1 and P3 carry the float seed, P2 and P4 start at 0).
 //
-// AIN = antennas per time sample (64, 100 or 128).  More than 64 antennas are two k-steps of 64: the LDS chunk image
+// AIN = antenna class (above).  More than 64 antennas are two k-steps of 64: the LDS chunk image
 // becomes two 128-row planes (antennas 0-63 | 64-127), every product is a chain of two MFMAs, and the detect -- whose
 // cost does not depend on the antenna count -- is amortised over twice the MACs.  100 antennas run as 128 with zero
 // weights behind antenna 99; their packed rows (100 B) are only dword-aligned, so they are staged in 4-byte pieces.
