@@ -1242,8 +1242,8 @@ int bf_dm_stream_output_device(bf_dm_stream* s, float** d_out)
 
 // Where the next n_rows rows go, with everything the writer of those rows must wait for queued on q first.
 //   ring: behind the previous rows, wherever that is -- they overwrite rows that only pushes <= j - 3 can still be reading;
-//   linear: behind the previous rows too, unless the buffer's end is reached: then the carry slides back to the start first, behind
-//           the previous push's kernels (which read what the slide and the new rows overwrite).
+//   linear: behind the previous push, then behind the previous rows -- unless the buffer's end is reached: then the carry slides
+//           back to the start first.
 static int dm_place_rows(bf_dm_stream* s, int n_rows, hipStream_t q, float** dst)
 {
     const size_t D = (size_t)s->max_delay;
@@ -1254,9 +1254,12 @@ static int dm_place_rows(bf_dm_stream* s, int n_rows, hipStream_t q, float** dst
         *dst = s->d_buf + s->wpos * s->row_floats;   // (wpos + n_rows may pass cap_rows: the second mapping continues the first)
         return BF_OK;
     }
+    // linear: the writer of the new rows runs behind the previous push, always -- after a slide the new rows walk into the area the
+    // pushes before it read (and an earlier, still pending slide copies from), and only the chain of pushes orders those
+    // (tools/fuzz_dm_stream.py without synchronisation between pushes found the version that waited only when sliding)
+    const int prev = (int)((s->n_push + 2) % 3);
+    if (s->n_push && s->done_recorded[prev]) HIP_TRY(hipStreamWaitEvent(q, s->done[prev], 0));
     if (s->fill + (size_t)n_rows > s->cap_rows) {    // slide: fill - carry >= carry here (cap = 2 (D + max_rows))
-        const int prev = (int)((s->n_push + 2) % 3);
-        if (s->n_push && s->done_recorded[prev]) HIP_TRY(hipStreamWaitEvent(q, s->done[prev], 0));
         if (carry)
             HIP_TRY(hipMemcpyAsync(s->d_buf, s->d_buf + (s->fill - carry) * s->row_floats, carry * s->row_floats * sizeof(float),
                                    hipMemcpyDeviceToDevice, q));

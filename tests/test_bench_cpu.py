@@ -24,13 +24,13 @@ def test_defaults_are_the_contract(monkeypatch):
 
 
 def test_committed_pmc_summaries_give_the_quoted_traffic_and_mfma_busy():
-    """roofline.traffic / mfma_busy_frac come from profiles/r05_*_pmc_summary.txt: the files must parse, and the derived
+    """roofline.traffic / mfma_busy_frac come from profiles/r06_*_pmc_summary.txt: the files must parse, and the derived
     numbers must be what DESIGN.md section 4 quotes (traffic within 1 % of the algorithmic bytes for C3 and C2)."""
-    c3 = bench.pmc_summary("r05_c3_paired_pmc_summary.txt")
-    gen = bench.pmc_summary("r05_c3_general_pmc_summary.txt")
-    c5 = bench.pmc_summary("r05_c5_pmc_summary.txt")
-    c5g = bench.pmc_summary("r05_c5_general_pmc_summary.txt")
-    c2 = bench.pmc_summary("r05_c2_pmc_summary.txt")
+    c3 = bench.pmc_summary("r06_c3_paired_pmc_summary.txt")
+    gen = bench.pmc_summary("r06_c3_general_pmc_summary.txt")
+    c5 = bench.pmc_summary("r06_c5_pmc_summary.txt")
+    c5g = bench.pmc_summary("r06_c5_general_pmc_summary.txt")
+    c2 = bench.pmc_summary("r06_c2_pmc_summary.txt")
     assert c3 and gen and c5 and c5g and c2
     # the general kernel of the 100-antenna geometry keeps the matrix pipe busy more than half the time (22 % of that on the
     # zero weights behind antenna 99); round 3: 3-fragment image, 8-wave workgroups, iterative-maxocc scheduling: 58 -> 63 %
@@ -71,7 +71,16 @@ def test_counters_are_quoted_only_for_the_build_they_were_taken_from(tmp_path):
     from dsabeamformer_amd import build
     import dsabeamformer_amd as bfm
 
-    assert bfm.load().bf_version().decode().endswith("kernels %s)" % build.kernel_build_id())
+    kid = build.kernel_build_id()
+    assert bfm.load().bf_version().decode().endswith("kernels %s)" % kid)
+    # A kernel edit without a profile refresh fails HERE: the five committed counter passes of the BASELINE launches are of this build
+    for name, variant in (("r06_c3_paired", "fused16_kernel<-1,32,false,0,true,4,4>"), ("r06_c3_general", "fused16_kernel<-1,32,false,0,false,4,4>"),
+                          ("r06_c5", "fused16_kernel<100,32,false,0,true,4,8>"), ("r06_c5_general", "fused16_kernel<100,32,false,0,false,8,4>"),
+                          ("r06_c2", "fused16_kernel<-1,2,false,0,true,4,4>")):
+        first = open(os.path.join(ROOT, "profiles", name + "_pmc_summary.txt")).readline().strip()
+        assert first.startswith("# pmc_key kernels=%s variant=%s " % (kid, variant)), (name, first, "run tools/refresh_profiles_r06.sh on the final kernels")
+        vals, src, stale = bench.pmc_for_launch(first[len("# pmc_key "):])
+        assert not stale and src == name + "_pmc_summary.txt" and vals
 
 
 def test_watchdog_prints_exactly_one_line(capsys):
@@ -286,15 +295,16 @@ def test_deadline_reports_a_sigterm_from_the_launcher():
 
 
 def test_issue_model_says_what_binds_the_kernel():
-    """from the committed PMC pass of the headline launch -- 17.2 VALU ops per MFMA, 13 + 2.45 K cycles of
-    issue per MFMA account for the launch's cycles (the SIMDs' instruction issue is the bound, the matrix pipe is 29 % busy),
+    """from the committed PMC pass of the headline launch -- 17.4 VALU ops per MFMA (17.2 with round 5's
+    compile-time 64-antenna class: the run-time class tests its staging pieces against the antenna count), 13 + 2.45 K cycles of
+    issue per MFMA account for the launch's cycles (the SIMDs' instruction issue is the bound, the matrix pipe is 28 % busy),
     and the clock the chip held."""
-    c3 = bench.pmc_summary("r05_c3_paired_pmc_summary.txt")
+    c3 = bench.pmc_summary("r06_c3_paired_pmc_summary.txt")
     m = bench.issue_model(c3, 0.9475)
-    assert abs(m["valu_per_mfma"] - 17.2) < 0.1 and abs(m["issue_model_cycles_per_mfma"] - (13 + 2.45 * m["valu_per_mfma"])) < 1e-9
+    assert abs(m["valu_per_mfma"] - 17.4) < 0.15 and abs(m["issue_model_cycles_per_mfma"] - (13 + 2.45 * m["valu_per_mfma"])) < 1e-9
     assert 0.9 < m["issue_occupancy"] < 1.05 and m["bound_measured"] == "simd-issue"
     assert 1.9 < m["clock_ghz_under_load"] < 2.45      # (2.04 ... 2.20 by box; nominal 2.4)
-    gen = bench.issue_model(bench.pmc_summary("r05_c3_general_pmc_summary.txt"), 1.05)
+    gen = bench.issue_model(bench.pmc_summary("r06_c3_general_pmc_summary.txt"), 1.05)
     assert 6.0 < gen["valu_per_mfma"] < 7.5 and gen["bound_measured"] in ("simd-issue", "unclear")
     assert bench.issue_model({}, 1.0) == {"bound_measured": None}
 
@@ -305,9 +315,9 @@ def test_committed_bench_lines_agree_with_the_committed_rocprof_kernel_stats():
     for rocprof, a profiled one: 5 %; 8 % for the 50-us launches of C2), and roofline.frac must follow from it."""
     import csv
 
-    for wl, stats, units_blocks in (("c3", "r05_c3_paired_kernel_stats.csv", 2048), ("c5", "r05_c5_kernel_stats.csv", 128),
-                                    ("c2", "r05_c2_kernel_stats.csv", 1024)):
-        line = [l for l in open(os.path.join(ROOT, "profiles", "r05_%s_bench.json" % wl)) if l.startswith("{")][-1]
+    for wl, stats, units_blocks in (("c3", "r06_c3_paired_kernel_stats.csv", 2048), ("c5", "r06_c5_kernel_stats.csv", 128),
+                                    ("c2", "r06_c2_kernel_stats.csv", 1024)):
+        line = [l for l in open(os.path.join(ROOT, "profiles", "r06_%s_bench.json" % wl)) if l.startswith("{")][-1]
         d = json.loads(line)
         roof = d["roofline"]
         rows = [r for r in csv.DictReader(open(os.path.join(ROOT, "profiles", stats))) if "fused16_kernel" in r["Name"]]
@@ -319,7 +329,8 @@ def test_committed_bench_lines_agree_with_the_committed_rocprof_kernel_stats():
         per_launch = roof["algorithmic_ops_per_launch"] if roof["bound"] == "mfma" else roof["algorithmic_bytes_per_launch"]
         scale = 1e12 if roof["bound"] == "mfma" else 1e9
         assert abs(per_launch / (roof["kernel_ms_avg"] * 1e-3) / scale / roof["peak"] / roof["frac"] - 1) < 1e-6
-        assert roof["traffic"] is not None and roof["pmc_source"].startswith("profiles/r0")
+        assert roof["traffic"] is not None and roof["pmc_source"].startswith("profiles/r06_") and roof["pmc_stale"] is False
+        assert open(os.path.join(ROOT, roof["pmc_source"])).readline().strip() == "# pmc_key " + roof["pmc_key"]
         # labelled: not observed in that run (round 5 adds what binds the kernel, from the same committed passes)
         assert {"traffic", "mfma_busy_frac"} <= set(roof["from_committed_profile"]) <= {"traffic", "mfma_busy_frac", "valu_per_mfma",
                                                                                         "issue_occupancy", "bound_measured", "clock_ghz_under_load"}

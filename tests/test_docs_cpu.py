@@ -7,7 +7,7 @@ import re
 from conftest import ROOT
 
 DOCS = ["DESIGN.md", "README.md", "INTEGRATION.md", os.path.join("tools", "README.md"), os.path.join("oracle", "README.md"),
-        os.path.join("docs", "LOG_r04.md"), os.path.join("docs", "LOG_r05.md"), os.path.join("docs", "PERF_MODEL.md"),
+        os.path.join("docs", "LOG_r04.md"), os.path.join("docs", "LOG_r05.md"), os.path.join("docs", "LOG_r06.md"), os.path.join("docs", "PERF_MODEL.md"),
         os.path.join("tests", "README.md")]
 PREFIXES = ("profiles/", "tools/", "tests/", "include/", "examples/", "oracle/", "dsabeamformer_amd/", "csrc/")
 
@@ -61,5 +61,5 @@ def test_design_md_stays_readable():
         if l.startswith("|"):
             for cell in l.strip("|").split("|"):
                 assert len(cell) <= 420, cell[:80]
-    for n in (1, 2, 3, 4, 5):
+    for n in (1, 2, 3, 4, 5, 6):
         assert os.path.exists(os.path.join(ROOT, "docs", "LOG_r0%d.md" % n))

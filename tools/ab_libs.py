@@ -10,6 +10,8 @@ gives the median over rounds of the per-round average kernel time (HIP events ar
 import argparse
 import json
 import os
+
+os.environ.setdefault("DSABF_LAB", "1")   # a measurement tool: the library reads its A/B switches from the environment only in lab mode
 import subprocess
 import sys
 

@@ -2,6 +2,8 @@
 """129 ... 256 antennas in rows that are only dword-aligned (n_ant % 16 != 0): fused16_kernel's deep classes with 4-byte staging
 pieces (round 5) against fusedg_kernel (DSABF_DEEP=0), which took them until round 4.  GPU box, repo root: python tools/deep_p4_perf.py"""
 import os
+
+os.environ.setdefault("DSABF_LAB", "1")   # a measurement tool: the library reads its A/B switches from the environment only in lab mode
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

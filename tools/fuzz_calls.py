@@ -4,6 +4,8 @@ seeds.  GPU box, repo root:  SEED=100 CASES=300 python tools/fuzz_calls.py
 FUZZ=loops: test_production_loop_to_file_under_random_launch_patterns (the whole observation loop to a file sink) instead;
 FUZZ=debug: test_debug_flow_with_random_catalogues_geometries_and_launch_patterns."""
 import os
+
+os.environ.setdefault("DSABF_LAB", "1")   # a measurement tool: the library reads its A/B switches from the environment only in lab mode
 import sys
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))

@@ -3,7 +3,12 @@
 random pieces on alternating HIP streams, the delay window carried over on the device, against ONE oracle call over the whole
 series.  Random series length, channels, beams (any multiple of 4), trial counts, delay tables (fine / coarse / mixed / random /
 constant: the wide kernel, the per-thread kernel and both in one call), push sizes from 1 row to the whole series; both kernel
-selections.  GPU box, repo root:  SEED=1 CASES=300 python tools/fuzz_dm_stream.py > gpurun_out/r05p/r05_fuzz_dm_stream.txt"""
+selections.  Round 6: every piece is fed either by a copying push or through bf_dm_stream_reserve (the producer -- a device copy
+here -- writes into the stage's own buffer), the buffer is the twice-mapped ring or the linear one, and in half of the problems
+NOTHING is synchronised between pushes (the chunks go to their own host buffers): the stage's own ordering -- a push behind the
+previous one, a producer behind the push three back -- is all that keeps the rows apart.
+GPU box, repo root:  SEED=1 CASES=300 python tools/fuzz_dm_stream.py > gpurun_out/r06p/r06_fuzz_dm_stream.txt"""
+import ctypes as C
 import os
 import sys
 
@@ -13,7 +18,9 @@ import torch
 sys.path.insert(0, ".")
 import dsabeamformer_amd as bfm  # noqa: E402
 import oracle as orc  # noqa: E402
-from dsabeamformer_amd import api  # noqa: E402
+from dsabeamformer_amd import _lib, api  # noqa: E402
+
+hip = _lib._preload_hip_runtime()
 
 seed, cases = int(os.environ.get("SEED", "1")), int(os.environ.get("CASES", "200"))
 rng = np.random.default_rng(seed)
@@ -47,25 +54,43 @@ for case in range(cases):
     row_bytes = n_f * n_b * 4
     for mode in ("shared", "thread"):
         bf.set_switch("dm_wide", 0 if mode == "thread" else 1)
+        ring = int(rng.integers(0, 4) != 0)
+        bf.set_switch("dm_ring", ring)
         dm = api.DmStream(bf, delays, n_f, max_rows)
-        host = torch.full((n_dm * max_rows * n_b,), float("nan"), dtype=torch.float32).pin_memory()
-        parts, at, pushed, k, ok = [], 0, 0, 0, True
+        lazy = bool(rng.integers(0, 2))            # no synchronisation between pushes: every chunk to a host buffer of its own
+        plan, pushed = [], 0
         while pushed < n_t:
             n = min(int(rng.integers(1, max_rows + 1)), n_t - pushed)
-            st = streams[int(rng.integers(0, len(streams)))]
-            first, n_out = dm.push(d_series.data_ptr() + pushed * row_bytes, n, host, st.cuda_stream)
-            ok &= first == at and n_out == max(0, pushed + n - D) - max(0, pushed - D)
-            st.synchronize()
-            if n_out:
-                parts.append(host[:n_dm * n_out * n_b].numpy().reshape(n_dm, n_out, n_b).copy())
-            at += n_out
+            plan.append((pushed, n))
             pushed += n
+        hosts = [torch.full((n_dm * n * n_b,), float("nan"), dtype=torch.float32).pin_memory() for _, n in plan] if lazy else \
+            [torch.full((n_dm * max_rows * n_b,), float("nan"), dtype=torch.float32).pin_memory()]
+        parts, at, k, ok, outs = [], 0, 0, True, []
+        for pushed, n in plan:
+            st = streams[int(rng.integers(0, len(streams)))]
+            host = hosts[k if lazy else 0]
+            src = d_series.data_ptr() + pushed * row_bytes
+            if rng.integers(0, 3):                 # the zero-copy feed: the producer writes where the stage says
+                dst = dm.reserve(n, st.cuda_stream)
+                ok &= hip.hipMemcpyAsync(C.c_void_p(dst), C.c_void_p(src), C.c_size_t(n * row_bytes), 3, C.c_void_p(st.cuda_stream)) == 0
+                src = dst
+            first, n_out = dm.push(src, n, host, st.cuda_stream)
+            ok &= first == at and n_out == max(0, pushed + n - D) - max(0, pushed - D)
+            if not lazy:
+                st.synchronize()
+                if n_out:
+                    parts.append(host[:n_dm * n_out * n_b].numpy().reshape(n_dm, n_out, n_b).copy())
+            outs.append(n_out)
+            at += n_out
             k += 1
+        if lazy:
+            torch.cuda.synchronize()
+            parts = [hosts[i][:n_dm * o * n_b].numpy().reshape(n_dm, o, n_b).copy() for i, o in enumerate(outs) if o]
         pushes_total += k
         got = np.concatenate(parts, axis=1) if parts else np.zeros((n_dm, 0, n_b), np.float32)
         if not ok or got.shape != want.shape or not np.array_equal(got, want):
             bad += 1
-            print("MISMATCH case %d mode %s kind %s n_t %d n_f %d n_b %d n_dm %d D %d max_rows %d" % (case, mode, kind, n_t, n_f, n_b, n_dm, D, max_rows))
+            print("MISMATCH case %d mode %s kind %s n_t %d n_f %d n_b %d n_dm %d D %d max_rows %d ring %d lazy %d" % (case, mode, kind, n_t, n_f, n_b, n_dm, D, max_rows, ring, lazy))
         dm.close()
     kinds[kind] = kinds.get(kind, 0) + 1
     bf.close()

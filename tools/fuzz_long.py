@@ -7,6 +7,8 @@ Round 4: FUZZ_GENERIC=1 draws antenna counts up to 636 and accumulation windows 
 FUZZ_DEEP=1: 144 ... 256 antennas in 16-byte rows, windows 16 / 32 / 64 (the deep classes).
 usage: SEED=1 CASES=150 [FUZZ_WIDE=1 | FUZZ_GENERIC=1 | FUZZ_DEEP=1] python tools/fuzz_long.py"""
 import os
+
+os.environ.setdefault("DSABF_LAB", "1")   # a measurement tool: the library reads its A/B switches from the environment only in lab mode
 import sys
 
 import numpy as np
@@ -71,7 +73,7 @@ for case in range(N):
     name = info["kernel"]
     generic = "fusedg_kernel" in name
     assert generic or ("PAIRED" in name) == paired, (name, paired)
-    key = ("generic" if generic else "rt" if "(run-time)" in name else str(n_ant), n_ipo, paired, mode,
+    key = (bf.variant_key(), n_ipo, paired, mode,      # the compiled instantiation the case ran (round 6: tools/census.py names all of them)
            "generic" if generic else "slots8" if "SLOTS=8" in name else "waves8" if "WAVES=8" in name else "plain")
     classes[key] = classes.get(key, 0) + 1
     d_in = torch.from_numpy(packed).cuda()
@@ -85,7 +87,8 @@ for case in range(N):
         bad += 1
         print("MISMATCH", case, g, n_units, paired, mode, os.environ["DSABF_TSPLIT"], "rtw_kout", kout)
     bf.close()
-print("seed", os.environ.get("SEED", "1"), "cases", N, "mismatches", bad, "distinct (antenna class, n_ipo, paired, mode, launch) combinations", len(classes),
+print("seed", os.environ.get("SEED", "1"), "cases", N, "mismatches", bad, "distinct (instantiation, n_ipo, paired, mode, launch) combinations", len(classes),
+      "distinct instantiations", len({k[0] for k in classes}),
       "cases on 8-wave workgroups", sum(v for k, v in classes.items() if k[4] == "waves8"),
       "on 8 slots per wave", sum(v for k, v in classes.items() if k[4] == "slots8"),
       "on fusedg_kernel", sum(v for k, v in classes.items() if k[4] == "generic"))

@@ -3,6 +3,8 @@
 fused16_kernel where both cover the geometry.  GPU box, repo root:  python tools/generic_perf.py > gpurun_out/generic_perf.txt
 Rates are ALGORITHMIC int8 ops (8 * beams * antennas * samples * frequencies) / kernel time, against the nominal 5.0 POP/s."""
 import os
+
+os.environ.setdefault("DSABF_LAB", "1")   # a measurement tool: the library reads its A/B switches from the environment only in lab mode
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,4 +1,6 @@
 import os, sys, traceback
+
+os.environ.setdefault("DSABF_LAB", "1")   # a measurement tool: the library reads its A/B switches from the environment only in lab mode
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
 import torch
 import dsabeamformer_amd as bfm

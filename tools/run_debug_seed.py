@@ -2,6 +2,8 @@
 """Re-runs one seed of the random DEBUG flow (tests/test_gpu_round4.py) many times and reports how often, and where, its table
 differs from the oracle's.  GPU box, repo root:  python tools/run_debug_seed.py 4036 300"""
 import os
+
+os.environ.setdefault("DSABF_LAB", "1")   # a measurement tool: the library reads its A/B switches from the environment only in lab mode
 import pathlib
 import sys
 import tempfile

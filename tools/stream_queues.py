@@ -2,6 +2,8 @@
 """run_observation end to end (PCIe included) for 8 / 4 / 2 / 1 compute queues, block launches against the coalesced per-unit loop;
 GPU box, repo root: python tools/stream_queues.py"""
 import os, sys
+
+os.environ.setdefault("DSABF_LAB", "1")   # a measurement tool: the library reads its A/B switches from the environment only in lab mode
 sys.path.insert(0, "/root/repo")
 import dsabeamformer_amd as bfm
 from dsabeamformer_amd import host

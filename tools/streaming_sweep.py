@@ -3,6 +3,8 @@
 granularities run_observation offers, interleaved rounds, best and median per configuration.
 GPU box, repo root:  python tools/streaming_sweep.py [rounds] [blocks] > gpurun_out/r02_streaming.txt"""
 import os
+
+os.environ.setdefault("DSABF_LAB", "1")   # a measurement tool: the library reads its A/B switches from the environment only in lab mode
 import sys
 
 sys.path.insert(0, ".")
