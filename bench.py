@@ -285,6 +285,7 @@ def dm_stage_record(torch, bfm, device, n_dm=64, trial_share=(0, 1), pushes=24, 
     sptr = stream.cuda_stream
     b = bfm.Beamformer(pc, device=device)
     dm = api.DmStream(b, delays, pc.n_freq, rows)
+    ring = bool(b.counter("dm_ring_stages"))     # the stage's buffer: the twice-mapped ring (nothing slides), or the linear fallback
     row_floats = pc.n_freq * pc.n_beams
     fill = torch.rand(rows * row_floats, device="cuda")
 
@@ -305,7 +306,7 @@ def dm_stage_record(torch, bfm, device, n_dm=64, trial_share=(0, 1), pushes=24, 
     alg = 4 * (window * row_floats + count * rows * pc.n_beams)   # read once + the chunk [dm][t][b] written once
     adds = float(count) * rows * pc.n_freq * pc.n_beams
     return {"us_per_block": avg * 1e3 / blocks_per_push, "us_per_push": avg * 1e3, "us_per_push_median": med * 1e3, "us_per_beam_block": avg * 1e3 / rows,
-            "dm_trials": count, "rows_per_push": rows, "blocks_per_push": blocks_per_push, "max_delay_rows": D, "algorithmic_bytes_per_push": alg,
+            "dm_trials": count, "rows_per_push": rows, "blocks_per_push": blocks_per_push, "max_delay_rows": D, "ring_buffer": ring, "algorithmic_bytes_per_push": alg,
             "hbm_gbs_algorithmic": alg / (avg * 1e-3) / 1e9, "gadds_per_s": adds / (avg * 1e-3) / 1e9}
 
 

@@ -1383,8 +1383,12 @@ int bf_get_counter(const bf_handle* h, const char* name, uint64_t* value)
         *value = h->n_fused_launches;
     else if (!strcmp(name, "queued_units"))
         *value = h->pending.size();
-    else
-        return fail(BF_ERR_INVALID, "unknown counter \"%s\" (fused_launches, queued_units)", name);
+    else if (!strcmp(name, "dm_ring_stages")) {   // live DM stages of this handle whose buffer is the twice-mapped ring (the rest: linear)
+        uint64_t n = 0;
+        for (const bf_dm_stream* s : h->dm_streams) n += s->ring ? 1 : 0;
+        *value = n;
+    } else
+        return fail(BF_ERR_INVALID, "unknown counter \"%s\" (fused_launches, queued_units, dm_ring_stages)", name);
     return BF_OK;
 }
 

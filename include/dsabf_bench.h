@@ -49,7 +49,8 @@ int bf_rtw_plan(const bf_config *cfg, int n_units, int n_cus, int *windows_per_s
  *   "coalesce" 0 / 1    0: bf_enqueue_gemm_unit launches one kernel per call (the reference's literal launch pattern) */
 int bf_set_switch(bf_handle *h, const char *name, int value);
 /* Counters of one handle: "fused_launches" = fused-kernel launches issued so far (what coalescing saves),
- * "queued_units" = gemm-units bf_enqueue_gemm_unit has queued and not launched yet. */
+ * "queued_units" = gemm-units bf_enqueue_gemm_unit has queued and not launched yet, "dm_ring_stages" = live DM stages of the handle
+ * whose buffer is the twice-mapped ring (a device without virtual-memory management gives them the linear buffer instead). */
 int bf_get_counter(const bf_handle *h, const char *name, uint64_t *value);
 int bf_kernel_name(const bf_handle *h, char *buf, size_t buflen); /* which fused kernel this geometry runs */
 /* The same answers WITHOUT a handle or a device: which kernel and launch shape a configuration would run for n_units gemm-units

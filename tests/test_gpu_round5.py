@@ -184,6 +184,7 @@ def test_dm_stream_chunks_are_the_whole_series_call_bit_for_bit(torch, bfmod, or
         bf.set_switch("dm_wide", wide)
         bf.set_switch("dm_ring", ring)
         dm = api.DmStream(bf, delays, n_f, max_rows)
+        assert bf.counter("dm_ring_stages") == ring            # an MI355X really gives the stage the twice-mapped ring
         assert dm.max_delay == D
         host = torch.full((n_dm * max_rows * n_b,), float("nan"), dtype=torch.float32).pin_memory()
         parts, at, pushed, k = [], 0, 0, 0
