@@ -154,3 +154,49 @@ def test_a_dm_stage_survives_more_than_64_streams_on_its_handle(orc):
         else:
             bf.close()
             ds.close()
+
+
+def test_real_rccl_receives_straight_into_the_dm_stages_ring(orc, monkeypatch):
+    """What a holder of a sharded run does since round 6: bf_gather_detected receives the band INTO the rows bf_dm_stream_reserve
+    handed out -- memory that is mapped twice (hipMemCreate + 2 x hipMemMap), the rows of some pushes running across the seam.
+    Here with the REAL RCCL library: a one-rank communicator whose own rows travel through grouped ncclSend / ncclRecv
+    (DSABF_GATHER_SELF_RCCL=1, the code path every message of a multi-GPU run takes).  Chunks bit-equal to the oracle over the whole
+    series; the ring is small (D + 3 pushes = 41 rows) so that 12 pushes wrap it several times."""
+    import torch
+
+    import dsabeamformer_amd as bfm
+    from dsabeamformer_amd import api
+
+    n_f, n_b, n_dm, rows = 16, 64, 6, 8
+    rng = np.random.default_rng(606)
+    delays = np.ascontiguousarray((np.arange(n_dm)[:, None] * np.linspace(17 / (n_dm - 1), 0.0, n_f)[None, :]).astype(np.int32))
+    D = int(delays.max())
+    n_t = 12 * rows
+    series = (rng.random((n_t, n_f, n_b), dtype=np.float32) * 1e3).astype(np.float32)
+    want = orc.dedisperse_dm(series, delays, n_t - D)
+    monkeypatch.setenv("DSABF_GATHER_SELF_RCCL", "1")
+    bf = bfm.Beamformer(bfm.production_config(n_freq=n_f, n_beams=n_b, n_gemms_per_block=1, n_blocks_on_gpu=1, n_streams=1))
+    comm = api.Comm(0, 1, api.comm_unique_id(), device=0)
+    assert comm.info()["lib"] and "fakerccl" not in comm.info()["lib"]
+    dm = api.DmStream(bf, delays, n_f, rows)
+    assert bf.counter("dm_ring_stages") == 1
+    d_series = torch.from_numpy(series).cuda()
+    st = torch.cuda.Stream()
+    host = torch.full((n_dm * rows * n_b,), float("nan"), dtype=torch.float32).pin_memory()
+    parts, seam = [], 0
+    lo = None
+    for k in range(12):
+        dst = dm.reserve(rows, st.cuda_stream)
+        lo = dst if lo is None else min(lo, dst)
+        seam += int(dst + rows * n_f * n_b * 4 > lo + (D + 3 * rows) * n_f * n_b * 4)     # this push's rows run past the ring's end
+        with torch.cuda.stream(st):
+            comm.gather(d_series[k * rows:(k + 1) * rows], rows, n_f * n_b, 0, api.GATHER_FREQ_MAJOR, dst, st.cuda_stream)
+        first, n_out = dm.push(dst, rows, host, st.cuda_stream)
+        st.synchronize()
+        if n_out:
+            parts.append(host[:n_dm * n_out * n_b].numpy().reshape(n_dm, n_out, n_b).copy())
+    assert seam >= 1, "no push crossed the seam of the double mapping: the test does not test what it says"
+    assert np.array_equal(np.concatenate(parts, axis=1), want)
+    dm.close()
+    comm.close()
+    bf.close()
