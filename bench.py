@@ -256,7 +256,7 @@ def time_launches(torch, fn, n, stream):
     return sum(ms) / len(ms), ms[len(ms) // 2], ms[0]
 
 
-def dm_stage_record(torch, bfm, device, n_dm=64, trial_share=(0, 1), pushes=24, warm=6, blocks_per_push=1):
+def dm_stage_record(torch, bfm, device, n_dm=64, trial_share=(0, 1), pushes=24, warm=6, blocks_per_push=1, queues=1):
     """The DM-trial stage of the observation loop by itself: kernel-only time per PRODUCTION
     block -- 32 gemm-units x 8 outputs = 256 beam-blocks of 256 x 256 floats, 64 MiB -- for `n_dm` trials of the notebook's ladder to
     DM 250, the delay window carried over on the device.  Zero-copy feed: bf_dm_stream_reserve hands out the rows' place inside the
@@ -264,7 +264,9 @@ def dm_stage_record(torch, bfm, device, n_dm=64, trial_share=(0, 1), pushes=24, 
     launches -- so what is timed is the stage's own work: the dedispersion kernels over [carry | new rows] (the buffer is a ring
     mapped twice back to back: nothing slides).  trial_share = (r, R): rank r's share of the ladder when a sharded run splits
     the trials (`beam -X`; R = 1: the whole ladder on one GPU).  blocks_per_push > 1: the stage fed every few blocks -- a block's
-    64 trials x 256 times x 256 beams are 64 workgroups of the shared-window kernel, a quarter of the chip."""
+    64 trials x 256 times x 256 beams are 64 workgroups of the shared-window kernel, a quarter of the chip.  queues > 1: consecutive
+    blocks pushed on alternating HIP streams, as run_observation's two compute queues do: up to three pushes are in flight and
+    their tiles run side by side (us_per_block is then the host-timed rate over all pushes, not one push's HIP-event time)."""
     import ctypes as C
 
     import numpy as np
@@ -283,6 +285,8 @@ def dm_stage_record(torch, bfm, device, n_dm=64, trial_share=(0, 1), pushes=24, 
     D = int(delays.max())
     stream = torch.cuda.current_stream()
     sptr = stream.cuda_stream
+    qs = [sptr] if queues <= 1 else [torch.cuda.Stream() for _ in range(queues)]
+    qptr = [q if isinstance(q, int) else q.cuda_stream for q in qs]
     b = bfm.Beamformer(pc, device=device)
     dm = api.DmStream(b, delays, pc.n_freq, rows)
     ring = bool(b.counter("dm_ring_stages"))     # the stage's buffer: the twice-mapped ring (nothing slides), or the linear fallback
@@ -290,23 +294,35 @@ def dm_stage_record(torch, bfm, device, n_dm=64, trial_share=(0, 1), pushes=24, 
     fill = torch.rand(rows * row_floats, device="cuda")
 
     def one(i):
-        dst = dm.reserve(rows, sptr)
+        q = qptr[i % len(qptr)]
+        dst = dm.reserve(rows, q)
         if i < n_fill:       # (first pass over the buffer: real values in every row the kernels will read)
-            hip.hipMemcpyAsync(C.c_void_p(dst), C.c_void_p(fill.data_ptr()), C.c_size_t(rows * row_floats * 4), 3, C.c_void_p(sptr))
-        dm.push(dst, rows, None, sptr)
+            hip.hipMemcpyAsync(C.c_void_p(dst), C.c_void_p(fill.data_ptr()), C.c_size_t(rows * row_floats * 4), 3, C.c_void_p(q))
+        dm.push(dst, rows, None, q)
 
     n_fill = 2 * ((D + rows) // rows + 2)
     for i in range(n_fill + warm):
         one(i)
     torch.cuda.synchronize()
-    avg, med, mn = time_launches(torch, lambda i: one(n_fill + warm + i), pushes, stream)
+    if len(qptr) == 1:
+        avg, med, mn = time_launches(torch, lambda i: one(n_fill + warm + i), pushes, stream)
+    else:
+        reps = []
+        for r in range(5):
+            t0 = time.perf_counter()
+            for i in range(pushes):
+                one(n_fill + warm + r * pushes + i)
+            torch.cuda.synchronize()
+            reps.append((time.perf_counter() - t0) * 1e3 / pushes)
+        reps.sort()
+        avg, med, mn = sum(reps) / len(reps), reps[len(reps) // 2], reps[0]
     dm.close()
     b.close()
     window = D + rows                                           # rows the kernels read per push: [carry | new]
     alg = 4 * (window * row_floats + count * rows * pc.n_beams)   # read once + the chunk [dm][t][b] written once
     adds = float(count) * rows * pc.n_freq * pc.n_beams
     return {"us_per_block": avg * 1e3 / blocks_per_push, "us_per_push": avg * 1e3, "us_per_push_median": med * 1e3, "us_per_beam_block": avg * 1e3 / rows,
-            "dm_trials": count, "rows_per_push": rows, "blocks_per_push": blocks_per_push, "max_delay_rows": D, "ring_buffer": ring, "algorithmic_bytes_per_push": alg,
+            "dm_trials": count, "rows_per_push": rows, "blocks_per_push": blocks_per_push, "queues": len(qptr), "max_delay_rows": D, "ring_buffer": ring, "algorithmic_bytes_per_push": alg,
             "hbm_gbs_algorithmic": alg / (avg * 1e-3) / 1e9, "gadds_per_s": adds / (avg * 1e-3) / 1e9}
 
 
@@ -1509,6 +1525,8 @@ def main():
         def extras_dm_stage():
             # the stage as the loop runs it (bf_dm_stream, zero-copy feed): per production block, beside a rank's beamforming time
             rec = {"whole_band_one_gpu": dm_stage_record(torch, bfm, local, 64, (0, 1)),
+                   "whole_band_one_gpu_two_queues": dm_stage_record(torch, bfm, local, 64, (0, 1), pushes=48, queues=2),
+                   "trial_share_1_of_8_two_queues": dm_stage_record(torch, bfm, local, 64, (0, 8), pushes=48, queues=2),
                    "whole_band_one_gpu_4_blocks_per_push": dm_stage_record(torch, bfm, local, 64, (0, 1), pushes=12, blocks_per_push=4),
                    "trial_share_1_of_8": dm_stage_record(torch, bfm, local, 64, (0, 8)),
                    "note": "kernel-only, rows already in the stage's buffer (bf_dm_stream_reserve: the beamformer / the gather writes them "

@@ -1053,14 +1053,20 @@ struct bf_dm_stream {
     uint64_t pushed = 0;          // rows the stream has been given
     uint64_t n_push = 0;          // pushes so far
     float* d_buf = nullptr;       // ring: the double mapping (2 x phys_bytes of address space); linear: cap_rows x [freq][beam]
-    float* d_out = nullptr;       // [n_dm][max_rows][beam]: the most recent push's chunk
     int32_t* d_delays = nullptr;  // [n_dm][freq]
-    int* d_flags = nullptr;       // the wide kernel's scratch (dsabf::kDmScratchBytes), this stream's own
-    bool flags_zeroed = false;
-    // end of push j (its host copy included) = done[j % 3].  Push j waits for push j - 1 (they share d_out); the producer of push
-    // j's rows overwrites what only pushes <= j - 3 can still be reading (cap_rows >= max_delay + 3 max_rows) and waits for push j - 3.
-    hipEvent_t done[3] = {nullptr, nullptr, nullptr};
-    bool done_recorded[3] = {false, false, false};
+    // Three pushes may be in flight at once (a caller that alternates queues, as run_observation does: a production block is 64
+    // tiles of the shared-window kernel, a quarter of the chip -- the tiles of consecutive blocks run side by side).  Push j works
+    // in set j % 3: its chunk [n_dm][max_rows][beam] and the wide kernel's scratch (dsabf::kDmScratchBytes).
+    //   rows_ready[j % 3]: the rows of push j -- and of every push before it -- are in the buffer (recorded on push j's queue behind
+    //                      its producer and behind rows_ready of push j - 1): what push j + 1's kernels wait for, not push j's END;
+    //   done[j % 3]:       push j and every push before it are complete, host copy included (recorded behind done of push j - 1).
+    // Push j waits for done of push j - 3 (its set's previous user); so does the producer of push j's rows, which overwrites what
+    // only pushes <= j - 3 can still be reading (cap_rows >= max_delay + 3 max_rows).  The linear buffer keeps one push at a time.
+    float* d_out[3] = {nullptr, nullptr, nullptr};
+    int* d_flags[3] = {nullptr, nullptr, nullptr};
+    bool flags_zeroed[3] = {false, false, false};
+    hipEvent_t done[3] = {nullptr, nullptr, nullptr}, rows_ready[3] = {nullptr, nullptr, nullptr};
+    bool done_recorded[3] = {false, false, false}, rows_recorded[3] = {false, false, false};
     float* reserved = nullptr;    // bf_dm_stream_reserve: where the NEXT push's rows are being written by their producer ...
     int reserved_rows = 0;        // ... and how many (0: no reservation outstanding)
 };
@@ -1069,11 +1075,13 @@ struct bf_dm_stream {
 static void dm_stream_release(bf_dm_stream* s)
 {
     for (int k = 0; k < 3; k++) {
-        if (!s->done[k]) continue;
-        if (s->done_recorded[k]) (void)hipEventSynchronize(s->done[k]);
-        (void)hipEventDestroy(s->done[k]);
-        s->done[k] = nullptr;
-        s->done_recorded[k] = false;
+        if (s->done[k]) {
+            if (s->done_recorded[k]) (void)hipEventSynchronize(s->done[k]);
+            (void)hipEventDestroy(s->done[k]);
+        }
+        if (s->rows_ready[k]) (void)hipEventDestroy(s->rows_ready[k]);
+        s->done[k] = s->rows_ready[k] = nullptr;
+        s->done_recorded[k] = s->rows_recorded[k] = false;
     }
     if (s->ring || s->phys_created) {
         if (s->mapped0) (void)hipMemUnmap(s->d_buf, s->phys_bytes);
@@ -1083,12 +1091,15 @@ static void dm_stream_release(bf_dm_stream* s)
     } else {
         (void)hipFree(s->d_buf);
     }
-    (void)hipFree(s->d_out);
+    for (int k = 0; k < 3; k++) {
+        (void)hipFree(s->d_out[k]);
+        (void)hipFree(s->d_flags[k]);
+        s->d_out[k] = nullptr;
+        s->d_flags[k] = nullptr;
+    }
     (void)hipFree(s->d_delays);
-    (void)hipFree(s->d_flags);
-    s->d_buf = s->d_out = nullptr;
+    s->d_buf = nullptr;
     s->d_delays = nullptr;
-    s->d_flags = nullptr;
     s->h = nullptr;
 }
 
@@ -1196,11 +1207,17 @@ int bf_dm_stream_create(bf_handle* h, const int32_t* delays, int n_dm, int n_fre
         s->cap_rows = 2 * ((size_t)dmax + (size_t)max_rows_per_push);
         e = hipMalloc((void**)&s->d_buf, s->cap_rows * s->row_floats * sizeof(float));
     }
-    if (e == hipSuccess) e = hipMalloc((void**)&s->d_out, (size_t)n_dm * max_rows_per_push * h->cfg.n_beams * sizeof(float));
+    const int n_sets = s->ring ? 3 : 1;   // (the linear buffer keeps one push at a time: one chunk, one scratch)
+    for (int k = 0; k < n_sets && e == hipSuccess; k++) {
+        e = hipMalloc((void**)&s->d_out[k], (size_t)n_dm * max_rows_per_push * h->cfg.n_beams * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc((void**)&s->d_flags[k], dsabf::kDmScratchBytes);
+    }
     if (e == hipSuccess) e = hipMalloc((void**)&s->d_delays, (size_t)n_dm * n_freq_total * sizeof(int32_t));
-    if (e == hipSuccess) e = hipMalloc((void**)&s->d_flags, dsabf::kDmScratchBytes);
     if (e == hipSuccess) e = hipMemcpy(s->d_delays, delays, (size_t)n_dm * n_freq_total * sizeof(int32_t), hipMemcpyHostToDevice);
-    for (int k = 0; k < 3 && e == hipSuccess; k++) e = hipEventCreateWithFlags(&s->done[k], hipEventDisableTiming);
+    for (int k = 0; k < 3 && e == hipSuccess; k++) {
+        e = hipEventCreateWithFlags(&s->done[k], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&s->rows_ready[k], hipEventDisableTiming);
+    }
     h->dm_streams.push_back(s);
     if (e != hipSuccess) {
         const int rc = fail(BF_ERR_DEVICE, "bf_dm_stream_create: %s", hipGetErrorString(e));
@@ -1236,7 +1253,7 @@ int bf_dm_stream_output_device(bf_dm_stream* s, float** d_out)
 {
     if (!s || !d_out) return fail(BF_ERR_INVALID, "NULL argument");
     if (!s->h) return fail(BF_ERR_STATE, "the handle of this DM stage has been destroyed");
-    *d_out = s->d_out;
+    *d_out = s->d_out[s->ring && s->n_push ? (s->n_push - 1) % 3 : 0];   // the most recent push's chunk
     return BF_OK;
 }
 
@@ -1305,10 +1322,16 @@ int bf_dm_stream_push(bf_dm_stream* s, const float* d_rows, int n_rows, float* h
     ON_DEVICE(h);
     hipStream_t q = as_stream(hip_stream);
     const int prev = (int)((s->n_push + 2) % 3), mine = (int)(s->n_push % 3);
-    if (s->n_push && s->done_recorded[prev]) HIP_TRY(hipStreamWaitEvent(q, s->done[prev], 0));   // behind the previous push, whatever queue that ran on
-    if (!s->flags_zeroed) {
-        HIP_TRY(hipMemsetAsync(s->d_flags, 0, dsabf::kDmScratchBytes, q));
-        s->flags_zeroed = true;
+    const int set = s->ring ? mine : 0;                                   // chunk + scratch this push works in
+    if (s->ring) {
+        // this set's previous user is push j - 3 (the producer of in-place rows waited for it too, on the stream it was given)
+        if (s->done_recorded[mine]) HIP_TRY(hipStreamWaitEvent(q, s->done[mine], 0));
+    } else if (s->n_push && s->done_recorded[prev]) {
+        HIP_TRY(hipStreamWaitEvent(q, s->done[prev], 0));                 // linear: behind the previous push, whatever queue that ran on
+    }
+    if (!s->flags_zeroed[set]) {
+        HIP_TRY(hipMemsetAsync(s->d_flags[set], 0, dsabf::kDmScratchBytes, q));
+        s->flags_zeroed[set] = true;
     }
     // (the stream's bookkeeping -- wpos / fill, pushed -- is committed at the end: a call that fails on the way leaves it as it found it)
     const size_t D = (size_t)s->max_delay;
@@ -1317,6 +1340,13 @@ int bf_dm_stream_push(bf_dm_stream* s, const float* d_rows, int n_rows, float* h
         float* dst = nullptr;
         if (int rc = dm_place_rows(s, n_rows, q, &dst)) return rc;
         HIP_TRY(hipMemcpyAsync(dst, d_rows, (size_t)n_rows * s->row_floats * sizeof(float), hipMemcpyDeviceToDevice, q));
+    }
+    if (s->ring) {
+        // the kernels read [carry | new rows]: the carry was written by the producers of the pushes before this one, possibly on
+        // other queues -- wait until THEIR rows are in place (not for their dedispersion), then say that ours are
+        if (s->n_push && s->rows_recorded[prev]) HIP_TRY(hipStreamWaitEvent(q, s->rows_ready[prev], 0));
+        HIP_TRY(hipEventRecord(s->rows_ready[mine], q));
+        s->rows_recorded[mine] = true;
     }
     const uint64_t emitted = s->pushed > D ? s->pushed - D : 0;          // output times [0, emitted) have been produced
     const uint64_t after = s->pushed + (uint64_t)n_rows;
@@ -1328,11 +1358,14 @@ int bf_dm_stream_push(bf_dm_stream* s, const float* d_rows, int n_rows, float* h
     if (n_out > 0) {
         dsabf::Geometry g = h->geom;
         g.n_freq = s->n_freq;
-        HIP_TRY(dsabf::launch_dedisperse_dm(g, s->d_buf + start * s->row_floats, (int)n_t, s->d_delays, s->n_dm, n_out, s->d_out,
-                                            s->d_flags, q));
+        HIP_TRY(dsabf::launch_dedisperse_dm(g, s->d_buf + start * s->row_floats, (int)n_t, s->d_delays, s->n_dm, n_out, s->d_out[set],
+                                            s->d_flags[set], q));
         if (host_out)
-            HIP_TRY(hipMemcpyAsync(host_out, s->d_out, (size_t)s->n_dm * n_out * h->cfg.n_beams * sizeof(float), hipMemcpyDeviceToHost, q));
+            HIP_TRY(hipMemcpyAsync(host_out, s->d_out[set], (size_t)s->n_dm * n_out * h->cfg.n_beams * sizeof(float), hipMemcpyDeviceToHost, q));
     }
+    // the end of push j implies the end of every push before it (chunks leave in order; a producer that waits for push j - 3 knows
+    // that nothing older reads the rows it overwrites)
+    if (s->ring && s->n_push && s->done_recorded[prev]) HIP_TRY(hipStreamWaitEvent(q, s->done[prev], 0));
     HIP_TRY(hipEventRecord(s->done[mine], q));
     s->done_recorded[mine] = true;
     if (s->ring)

@@ -258,7 +258,9 @@ int bf_dedisperse_dm_device(bf_handle *h, const float *d_series, int n_t, const 
  *   pushed row (cfg.n_freq, or world * cfg.n_freq on a gather root); max_rows_per_push: the largest n_rows of a push
  *   (n_gemms_per_block * n_out_per_gemm for block launches).
  * bf_dm_stream_push is asynchronous on `hip_stream` (the queue that produced d_rows: bf_queue_stream); successive pushes are
- * ordered by the stream itself, whichever queues they are issued on.  host_out (optional, pinned, room for n_dm * n_rows *
+ * ordered by the stream itself, whichever queues they are issued on: their chunks complete in push order -- but up to three
+ * pushes issued on different queues RUN side by side (each in a chunk buffer and scratch of its own; a push waits for the rows
+ * of the one before it, not for its end), so every push in flight needs a host_out of its own.  host_out (optional, pinned, room for n_dm * n_rows *
  * n_beams floats) receives the chunk; first_t / n_t_out are known to the host at once (pure arithmetic).  The device copy of
  * the most recent chunk: bf_dm_stream_output_device.  Destroy the stream before its handle (a handle that goes first releases the
  * stage's device memory; the stage then only answers BF_ERR_STATE and can still be destroyed).
