@@ -8,6 +8,11 @@ smallest geometry of the reference's contract that selects it (tools/census.py),
     (n_ipo + 1) * 2^-23 of the exact value;
   * stage-parity store (bf_gemm_device): np.array_equal with orc.gemm.
 
+Every case runs its kernel's STEADY STATE, not only its prologue: the launch is held to one workgroup per (frequency, beam group)
+(`tsplit` 1) over at least five 128-sample chunks (ten for windows of 64 samples and more) plus a ragged tail, so the LDS double
+buffer, the prefetch two chunks ahead and the parked stores of the previous chunk all happen in every instantiation; the
+stage-parity cases take the largest gemm-unit (more outputs) that still selects the same instantiation.
+
 A wrong bit in any one of the 382 instantiations -- the reference has ONE kernel per stage (src/beamformer.cuh:66-155), every one
 of these replaces them for some geometry and is selected silently -- fails here, in the driver-observed run.  CPU side of the same
 census: tests/test_census_cpu.py (compiled set == reachable set)."""
@@ -42,15 +47,28 @@ def run_case(torch, bfm, orc, key, rec, n_freq):
     w = rng.integers(-127, 128, size=(g.n_freq, g.n_ant, g.n_beams, 2), dtype=np.int8)
     if rec["paired"]:
         w = _conj_symmetric(w)
-    cfg = bfm.production_config(n_beams=g.n_beams, n_ant=g.n_ant, n_freq=g.n_freq, n_pol=g.n_pol, n_avg=g.n_avg,
-                                n_out_per_gemm=g.n_out_per_gemm, n_gemms_per_block=1, n_blocks_on_gpu=1, n_streams=1,
-                                detect_mode=rec["mode"])
+    def config(geom):
+        return bfm.production_config(n_beams=geom.n_beams, n_ant=geom.n_ant, n_freq=geom.n_freq, n_pol=geom.n_pol, n_avg=geom.n_avg,
+                                     n_out_per_gemm=geom.n_out_per_gemm, n_gemms_per_block=1, n_blocks_on_gpu=1, n_streams=1,
+                                     detect_mode=rec["mode"])
+
+    if rec["write_c"]:
+        # bf_gemm_device takes ONE gemm-unit: the longest one (more outputs per unit) that still selects this instantiation
+        for n_out in (max(1, -(-640 // g.n_ipo)), max(1, -(-384 // g.n_ipo))):
+            if n_out % 2 != rec["n_out"] % 2:
+                n_out += 1                   # (short windows: whether a unit is whole 16-sample runs decides the class)
+            big = orc.Geom(n_beams=g.n_beams, n_ant=g.n_ant, n_freq=g.n_freq, n_pol=g.n_pol, n_avg=g.n_avg, n_out_per_gemm=n_out)
+            if n_out > g.n_out_per_gemm and bfm.variant_key(config(big), bool(rec["paired"]), True) == key:
+                g = big
+                break
+    cfg = config(g)
     stream = torch.cuda.current_stream().cuda_stream
     with bfm.Beamformer(cfg) as bf:
         bf.set_weights(w)
         ran = bf.variant_key(bool(rec["write_c"]))
         if ran != key:
             return "the handle launches %s" % ran
+        bf.set_switch("tsplit", 1)           # one workgroup per (frequency, beam group) walks every chunk of the launch
         if rec["write_c"]:
             packed = rng.integers(0, 256, size=(g.n_freq, g.n_time, g.n_ant), dtype=np.uint8)
             d_in = torch.from_numpy(packed).cuda()
@@ -60,7 +78,7 @@ def run_case(torch, bfm, orc, key, rec, n_freq):
             want = orc.gemm(g, w, orc.expand(packed))
             got = d_c.cpu().numpy().reshape(want.shape)
             return None if np.array_equal(got, want) else "bf_gemm_device differs from orc.gemm in %d of %d values" % ((got != want).sum(), want.size)
-        n_units = 3
+        n_units = -(-(1280 if g.n_ipo >= 64 else 640) // g.n_time) + 1     # >= 5 (10) chunks of 128 samples and a ragged tail
         packed = rng.integers(0, 256, size=(n_units, g.n_freq, g.n_time, g.n_ant), dtype=np.uint8)
         packed[0, 0, :, :] = 0x88            # the extremes: all (-8, -8) ...
         packed[1, 0, 0, :] = 0x77            # ... and (7, 7)
