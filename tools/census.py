@@ -51,7 +51,20 @@ def other_kernels(lib_path: str | None = None) -> list[str]:
     return sorted({m.group(1) for m in re.finditer(r"__device_stub__([a-z_0-9]+)\(", txt)})
 
 
-def reachable() -> dict[str, dict]:
+def interleaved(key: str, n_beams: int) -> bool:
+    """Does a launch of instantiation `key` over n_beams deal the beams to a wave's column tiles round robin (16- / 8-byte vector
+    stores, whole 128-byte lines) or tile by tile (scalar stores, the last tile partly filled)?  A run-time argument of the kernel
+    (FusedArgs::interleave; bf_kernels.hip interleaved(), bf_fusedg.hip generic_interleave()): both store paths live in every
+    instantiation, and which one runs depends on the beam count alone."""
+    if key.startswith("fusedg_kernel"):
+        return n_beams % 32 == 0
+    ns = int(key.rstrip(">").split(",")[-1])
+    return n_beams % (16 * ns) == 0
+
+
+def reachable(both_store_paths: bool = False) -> dict:
+    """{instantiation: smallest geometry that selects it}; both_store_paths: {(instantiation, interleaved stores?): smallest geometry}
+    -- an instantiation appears once or twice, as the contract reaches one or both of its store paths."""
     import ctypes as C
 
     import dsabeamformer_amd as bfm
@@ -82,6 +95,8 @@ def reachable() -> dict[str, dict]:
                                     continue   # outside the product's contract (e.g. beyond 2048 antennas): bf_create refuses too
                                 key = buf.value.decode()
                                 assert key, (n_ant, n_beams, n_pol, n_avg, n_out, mode, paired, write_c)
+                                if both_store_paths:
+                                    key = (key, interleaved(key, n_beams))
                                 rec = best.get(key)
                                 if rec is None or cost < rec["cost"]:
                                     best[key] = dict(n_ant=n_ant, n_beams=n_beams, n_pol=n_pol, n_avg=n_avg, n_out=n_out, mode=mode,
