@@ -38,10 +38,12 @@ def _conj_symmetric(w):
     return w
 
 
-def run_case(torch, bfm, orc, key, rec, n_freq):
-    """One instantiation on its smallest geometry; returns a failure text or None."""
+def run_case(torch, bfm, orc, key, rec, n_freq, whole_spans=False):
+    """One instantiation on its smallest geometry; returns a failure text or None.  whole_spans: gemm-units of 256 samples instead
+    -- a chunk's sample span then never straddles a gemm-unit and the kernel takes its scalar chunk addressing (fused16_kernel's
+    `fast_addr`, a run-time branch of every compile-time-window instantiation: the path every production geometry runs)."""
     g = orc.Geom(n_beams=rec["n_beams"], n_ant=rec["n_ant"], n_freq=n_freq, n_pol=rec["n_pol"], n_avg=rec["n_avg"],
-                 n_out_per_gemm=rec["n_out"])
+                 n_out_per_gemm=(256 // (rec["n_pol"] * rec["n_avg"])) if whole_spans else rec["n_out"])
     seed = sum(ord(c) * (i + 1) for i, c in enumerate(key)) % (1 << 31)
     rng = np.random.default_rng(seed)
     w = rng.integers(-127, 128, size=(g.n_freq, g.n_ant, g.n_beams, 2), dtype=np.int8)
@@ -116,7 +118,7 @@ def test_every_compiled_instantiation_against_the_oracle():
     # wave's column tiles: vector stores of whole lines; or tile by tile: scalar stores, a partly filled last tile)
     comp, reach = census.compiled(), census.reachable(both_store_paths=True)
     assert comp == {k for k, _ in reach}, (sorted(comp - {k for k, _ in reach}), sorted({k for k, _ in reach} - comp))
-    failures, lines, t_all = [], [], time.perf_counter()
+    failures, lines, t_all, n_spans = [], [], time.perf_counter(), 0
     for i, (key, inter) in enumerate(sorted(reach)):
         t0 = time.perf_counter()
         # two frequency counts: 3 (a frequency per block index) and 8 (the XCD-aware block map, decode_block)
@@ -124,12 +126,22 @@ def test_every_compiled_instantiation_against_the_oracle():
         lines.append("%-54s %-11s %6.1f ms  %s" % (key, "interleaved" if inter else "by tile", (time.perf_counter() - t0) * 1e3, err or "ok"))
         if err:
             failures.append((key, reach[(key, inter)], err))
+        # ... and once more with gemm-units of whole 256-sample spans (the scalar chunk addressing of the compile-time windows)
+        targs = [t.strip() for t in key[key.index("<") + 1:-1].split(",")]          # fused16_kernel<AIN, NIPO, WRITE_C, ...>
+        compile_time_window = key.startswith("fused16_kernel") and int(targs[1]) != 0 and targs[2] == "false"
+        if compile_time_window and (not inter or (key, False) not in reach):
+            t0 = time.perf_counter()
+            err = run_case(torch, bfm, orc, key, reach[(key, inter)], 3, whole_spans=True)
+            lines.append("%-54s %-11s %6.1f ms  %s" % (key, "whole spans", (time.perf_counter() - t0) * 1e3, err or "ok"))
+            n_spans += 1
+            if err:
+                failures.append((key, "whole spans", err))
     total = time.perf_counter() - t_all
     out = os.path.join(ROOT, "gpurun_out")
     os.makedirs(out, exist_ok=True)
     with open(os.path.join(out, "census_gpu.txt"), "w") as fp:
-        fp.write("# tests/test_gpu_census.py: %d instantiations, %d (instantiation, store path) cases, %d failures, %.1f s\n"
-                 % (len({k for k, _ in reach}), len(reach), len(failures), total))
+        fp.write("# tests/test_gpu_census.py: %d instantiations, %d (instantiation, store path) cases + %d with whole-span gemm-units, %d failures, %.1f s\n"
+                 % (len({k for k, _ in reach}), len(reach), n_spans, len(failures), total))
         fp.write("\n".join(lines) + "\n")
     assert not failures, failures[:10]
     assert len(reach) >= 300                     # (the walk really found the library's kernels)
