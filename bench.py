@@ -1494,6 +1494,23 @@ def main():
                     fn(i)
                 avg, med, mn = time_launches(torch, fn, 30, stream)
                 rec[label] = {"ms_avg": avg, "ms_median": med}
+            # the same kernel on a launch that FILLS the chip: 64 trials x 901 times are 2 x 57 x 2 = 228 tiles of the shared-window
+            # kernel for 256 CUs (one tile per CU: a single, incomplete round); 256 trials of the same ladder are 912
+            b2.set_switch("dm_wide", 1)
+            dms4 = ladder[:: max(1, len(ladder) // 256)][:256]
+            delays4 = host.dm_delays(dms4, freq, freq[0], 0.131)
+            n_t_out4 = n_t - int(delays4.max())
+            d_delays4 = torch.from_numpy(delays4).cuda()
+            d_dd4 = torch.empty(len(dms4) * n_t_out4 * 256, device="cuda")
+            fn4 = lambda i: b2.dedisperse_dm(d_series, n_t, d_delays4, len(dms4), n_t_out4, d_dd4, sptr)  # noqa: E731
+            for i in range(3):
+                fn4(i)
+            avg4, med4, _ = time_launches(torch, fn4, 15, stream)
+            adds4 = float(len(dms4)) * n_t_out4 * 256 * 256
+            rec["shared_window_256_trials"] = {"ms_avg": avg4, "ms_median": med4, "dm_trials": len(dms4), "tiles": ((len(dms4) + 31) // 32) * ((n_t_out4 + 15) // 16) * 2,
+                                               "gadds_per_s": adds4 / (avg4 * 1e-3) / 1e9, "frac": adds4 / (avg4 * 1e-3) / 1e9 / (256 * 64 * 2.4e9 / 1e9),
+                                               "note": "the same kernel and ladder, four times as dense: a launch of several rounds of tiles per CU instead of 228 tiles for 256 CUs"}
+            del d_dd4
             b2.close()
             alg = 4 * (n_t * 256 * 256 + len(dms) * n_t_out * 256)
             ms = rec["shared_window"]["ms_avg"]
